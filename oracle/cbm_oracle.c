@@ -1,0 +1,670 @@
+/* cbm_oracle.c — CPU restatement of cleanba's rollout+update hot path.
+ *
+ * TEST INFRASTRUCTURE.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * leg may load this library; the product (cleanba_amd/) never does and fails loudly when
+ * its HIP library is missing.
+ *
+ * PARITY UNPINNED against JAX: the reference (/root/reference, vwxyzjn/cleanba @2024-10-08)
+ * is pure Python on jax 0.4.8 / flax 0.6.8 / optax 0.1.4 / rlax 0.1.5 (poetry.lock), none of
+ * which can be imported here, and the reference ships no tests or golden vectors.  This file
+ * is a line-by-line restatement of the reference scripts plus the documented semantics of
+ * those library versions.  What pins it instead (tests/): Random123 / JAX-documented threefry
+ * known answers, analytic identities (GAE geometric series, V-trace at rho=1, PPO at ratio=1),
+ * and a cross-implementation check of every forward/backward against torch-CPU autograd.
+ *
+ * Citations are file:line under /root/reference/cleanba/ ("ppo" = cleanba_ppo.py,
+ * "impala" = cleanba_impala.py, "naturecnn" = legacy_scripts/..._naturecnn.py).
+ *
+ * NUMERICS SPEC shared with the HIP kernels: every forward dot
+ * product is a k-ascending fp32 fmaf chain from 0 (that is what v_mfma_f32_32x32x2_f32
+ * computes), bias added afterwards; k order is (c,kh,kw) for the uint8 conv1 and
+ * (kh,kw,ci) for the fp32 convs (= flax HWIO flattening); the 3136->512 dense may be cut
+ * in `ksplit` contiguous K segments whose partial chains are added in ascending order.
+ * XLA's own reduction order is unspecified, so any fixed order is an equally valid
+ * restatement; fixing it lets logits — and therefore sampled actions — match bit for bit.
+ * Backward reductions accumulate in f64 (tolerance 1e-5 applies there).
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include <float.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+#include "../include/cbm_math.h"
+
+#define EXPORT __attribute__((visibility("default")))
+
+static int g_threads = 1;
+EXPORT void cbo_set_threads(int n) { g_threads = n > 0 ? n : 1; }
+EXPORT int cbo_get_threads(void) { return g_threads; }
+
+/* ============================================================ PRNG (jax.random) */
+EXPORT void cbo_threefry2x32(const uint32_t key[2], const uint32_t ctr[2], uint32_t out[2]) {
+  cbm_threefry2x32(key[0], key[1], ctr[0], ctr[1], &out[0], &out[1]);
+}
+/* jax.random.PRNGKey(seed): [seed >> 32, seed & 0xffffffff]  (ppo:468) */
+EXPORT void cbo_prng_key(uint64_t seed, uint32_t key[2]) {
+  key[0] = (uint32_t)(seed >> 32); key[1] = (uint32_t)(seed & 0xffffffffu);
+}
+/* jax.random.split(key, n) -> out[n][2]  (ppo:256, 469, 599) */
+EXPORT void cbo_split(const uint32_t key[2], int n, uint32_t* out) {
+  for (int r = 0; r < n; ++r) cbm_split_at(key[0], key[1], (uint32_t)n, (uint32_t)r, &out[2 * r], &out[2 * r + 1]);
+}
+EXPORT void cbo_random_bits(const uint32_t key[2], int64_t n, uint32_t* out) {
+  for (int64_t i = 0; i < n; ++i) out[i] = cbm_random_bits_at(key[0], key[1], (uint32_t)n, (uint32_t)i);
+}
+/* jax.random.uniform(key, shape) float32 in [0,1)  (ppo:257) */
+EXPORT void cbo_uniform(const uint32_t key[2], int64_t n, float* out) {
+  for (int64_t i = 0; i < n; ++i) out[i] = cbm_bits_to_uniform(cbm_random_bits_at(key[0], key[1], (uint32_t)n, (uint32_t)i));
+}
+
+/* jax.random.permutation(key, N) = _shuffle(arange(N)): rounds = ceil(3 ln N / ln(2^32-1));
+ * per round: key, sub = split(key); stable sort by random_bits(sub, [N])  (ppo:606). */
+typedef struct { uint32_t k; int32_t v; } kv_t;
+static void merge_sort_kv(kv_t* a, kv_t* tmp, int n) {
+  for (int w = 1; w < n; w *= 2) {
+    for (int lo = 0; lo < n; lo += 2 * w) {
+      int mid = lo + w < n ? lo + w : n, hi = lo + 2 * w < n ? lo + 2 * w : n;
+      int i = lo, j = mid, o = lo;
+      while (i < mid && j < hi) tmp[o++] = (a[j].k < a[i].k) ? a[j++] : a[i++]; /* stable */
+      while (i < mid) tmp[o++] = a[i++];
+      while (j < hi) tmp[o++] = a[j++];
+    }
+    memcpy(a, tmp, sizeof(kv_t) * (size_t)n);
+  }
+}
+EXPORT int cbo_shuffle_rounds(int n) {
+  double sz = n > 1 ? (double)n : 1.0;
+  return (int)ceil(3.0 * log(sz) / log(4294967295.0));
+}
+EXPORT void cbo_permutation(const uint32_t key_in[2], int n, int32_t* perm) {
+  uint32_t key[2] = {key_in[0], key_in[1]};
+  kv_t* a = (kv_t*)malloc(sizeof(kv_t) * (size_t)n);
+  kv_t* t = (kv_t*)malloc(sizeof(kv_t) * (size_t)n);
+  for (int i = 0; i < n; ++i) a[i].v = i;
+  int rounds = cbo_shuffle_rounds(n);
+  for (int r = 0; r < rounds; ++r) {
+    uint32_t ks[4];
+    cbo_split(key, 2, ks);
+    key[0] = ks[0]; key[1] = ks[1];
+    for (int i = 0; i < n; ++i) a[i].k = cbm_random_bits_at(ks[2], ks[3], (uint32_t)n, (uint32_t)i);
+    merge_sort_kv(a, t, n);
+  }
+  for (int i = 0; i < n; ++i) perm[i] = a[i].v;
+  free(a); free(t);
+}
+
+/* ============================================================ parameter layout
+ * Flat fp32 blob, flax shapes: conv kernels HWIO, dense [in,out].
+ * kind 0 = Nature-CNN (naturecnn:143-178), kind 1 = IMPALA ResNet (ppo:149-189). */
+#define MAXL 32
+typedef struct {
+  int kind, A;
+  int64_t n_layers;
+  int64_t w_off[MAXL], b_off[MAXL];
+  int64_t total;
+} cbo_layout;
+
+/* Nature layer ids: 0 conv1, 1 conv2, 2 conv3, 3 dense, 4 actor, 5 critic */
+EXPORT void cbo_nature_layout(int A, cbo_layout* L) {
+  memset(L, 0, sizeof(*L));
+  L->kind = 0; L->A = A; L->n_layers = 6;
+  int64_t o = 0;
+  const int64_t wsz[6] = {8 * 8 * 4 * 32, 4 * 4 * 32 * 64, 3 * 3 * 64 * 64, 3136 * 512, 512 * (int64_t)A, 512};
+  const int64_t bsz[6] = {32, 64, 64, 512, A, 1};
+  for (int i = 0; i < 6; ++i) { L->w_off[i] = o; o += wsz[i]; L->b_off[i] = o; o += bsz[i]; }
+  L->total = o;
+}
+EXPORT int64_t cbo_nature_param_count(int A) { cbo_layout L; cbo_nature_layout(A, &L); return L.total; }
+
+/* ============================================================ Nature-CNN forward
+ * naturecnn:143-178 + Actor/Critic ppo:192-203, on B frames obs[idx[b]] (idx NULL = b).
+ * obs is [*,4,84,84] uint8 NCHW; transpose+/255 (ppo:180-181) folded into conv1. */
+#define IH 84
+#define IW 84
+#define C0 4
+#define O1 20
+#define C1 32
+#define O2 9
+#define C2 64
+#define O3 7
+#define C3 64
+#define FL 3136
+#define HD 512
+#define FRAME (C0 * IH * IW)
+
+static void nature_fwd_frame(const float* P, const cbo_layout* L, const uint8_t* x, int ksplit,
+                             float* a1, float* a2, float* a3, float* hid, float* logits, float* value) {
+  const int A = L->A;
+  /* conv1 8x8 s4 VALID, k order (c,kh,kw) */
+  {
+    const float* W = P + L->w_off[0]; const float* b = P + L->b_off[0];
+    for (int oh = 0; oh < O1; ++oh) for (int ow = 0; ow < O1; ++ow) {
+      float acc[C1];
+      for (int co = 0; co < C1; ++co) acc[co] = 0.0f;
+      for (int c = 0; c < C0; ++c) for (int kh = 0; kh < 8; ++kh) for (int kw = 0; kw < 8; ++kw) {
+        const float a = cbm_u8_unit(x[(c * IH + oh * 4 + kh) * IW + ow * 4 + kw]);
+        const float* w = W + ((kh * 8 + kw) * C0 + c) * C1;
+        for (int co = 0; co < C1; ++co) acc[co] = fmaf(a, w[co], acc[co]);
+      }
+      float* o = a1 + (oh * O1 + ow) * C1;
+      for (int co = 0; co < C1; ++co) { float v = acc[co] + b[co]; o[co] = v > 0.0f ? v : 0.0f; }
+    }
+  }
+  /* conv2 4x4 s2 VALID, k order (kh,kw,ci) */
+  {
+    const float* W = P + L->w_off[1]; const float* b = P + L->b_off[1];
+    for (int oh = 0; oh < O2; ++oh) for (int ow = 0; ow < O2; ++ow) {
+      float acc[C2];
+      for (int co = 0; co < C2; ++co) acc[co] = 0.0f;
+      for (int kh = 0; kh < 4; ++kh) for (int kw = 0; kw < 4; ++kw) {
+        const float* in = a1 + ((oh * 2 + kh) * O1 + ow * 2 + kw) * C1;
+        const float* w0 = W + (kh * 4 + kw) * C1 * C2;
+        for (int ci = 0; ci < C1; ++ci) {
+          const float a = in[ci]; const float* w = w0 + ci * C2;
+          for (int co = 0; co < C2; ++co) acc[co] = fmaf(a, w[co], acc[co]);
+        }
+      }
+      float* o = a2 + (oh * O2 + ow) * C2;
+      for (int co = 0; co < C2; ++co) { float v = acc[co] + b[co]; o[co] = v > 0.0f ? v : 0.0f; }
+    }
+  }
+  /* conv3 3x3 s1 VALID */
+  {
+    const float* W = P + L->w_off[2]; const float* b = P + L->b_off[2];
+    for (int oh = 0; oh < O3; ++oh) for (int ow = 0; ow < O3; ++ow) {
+      float acc[C3];
+      for (int co = 0; co < C3; ++co) acc[co] = 0.0f;
+      for (int kh = 0; kh < 3; ++kh) for (int kw = 0; kw < 3; ++kw) {
+        const float* in = a2 + ((oh + kh) * O2 + ow + kw) * C2;
+        const float* w0 = W + (kh * 3 + kw) * C2 * C3;
+        for (int ci = 0; ci < C2; ++ci) {
+          const float a = in[ci]; const float* w = w0 + ci * C3;
+          for (int co = 0; co < C3; ++co) acc[co] = fmaf(a, w[co], acc[co]);
+        }
+      }
+      float* o = a3 + (oh * O3 + ow) * C3;   /* flatten order (h,w,c), ppo:185 */
+      for (int co = 0; co < C3; ++co) { float v = acc[co] + b[co]; o[co] = v > 0.0f ? v : 0.0f; }
+    }
+  }
+  /* dense 3136->512 (+relu), optional K split */
+  {
+    const float* W = P + L->w_off[3]; const float* b = P + L->b_off[3];
+    float tot[HD], acc[HD];
+    const int seg = FL / ksplit;
+    for (int s = 0; s < ksplit; ++s) {
+      for (int n = 0; n < HD; ++n) acc[n] = 0.0f;
+      for (int k = s * seg; k < (s + 1) * seg; ++k) {
+        const float a = a3[k]; const float* w = W + (int64_t)k * HD;
+        for (int n = 0; n < HD; ++n) acc[n] = fmaf(a, w[n], acc[n]);
+      }
+      if (s == 0) for (int n = 0; n < HD; ++n) tot[n] = acc[n];
+      else for (int n = 0; n < HD; ++n) tot[n] = tot[n] + acc[n];
+    }
+    for (int n = 0; n < HD; ++n) { float v = tot[n] + b[n]; hid[n] = v > 0.0f ? v : 0.0f; }
+  }
+  /* heads */
+  {
+    const float* Wa = P + L->w_off[4]; const float* ba = P + L->b_off[4];
+    const float* Wc = P + L->w_off[5]; const float* bc = P + L->b_off[5];
+    for (int a = 0; a < A; ++a) {
+      float acc = 0.0f;
+      for (int k = 0; k < HD; ++k) acc = fmaf(hid[k], Wa[k * A + a], acc);
+      logits[a] = acc + ba[a];
+    }
+    float acc = 0.0f;
+    for (int k = 0; k < HD; ++k) acc = fmaf(hid[k], Wc[k], acc);
+    value[0] = acc + bc[0];
+  }
+}
+
+#define A1SZ (O1 * O1 * C1)
+#define A2SZ (O2 * O2 * C2)
+#define A3SZ FL
+
+/* acts: NULL or B*(A1SZ+A2SZ+A3SZ+HD) floats laid out [act1 | act2 | act3 | hid] blocks. */
+EXPORT void cbo_nature_forward(const float* P, int A, const uint8_t* obs, const int32_t* idx, int B,
+                               int ksplit, float* acts, float* logits, float* value) {
+  cbo_layout L; cbo_nature_layout(A, &L);
+  if (ksplit < 1) ksplit = 1;
+  float* a1 = acts; float* a2 = acts ? a1 + (int64_t)B * A1SZ : NULL;
+  float* a3 = acts ? a2 + (int64_t)B * A2SZ : NULL; float* hd = acts ? a3 + (int64_t)B * A3SZ : NULL;
+#pragma omp parallel num_threads(g_threads)
+  {
+    float* t = (float*)malloc(sizeof(float) * (A1SZ + A2SZ + A3SZ + HD));
+#pragma omp for schedule(static)
+    for (int b = 0; b < B; ++b) {
+      const uint8_t* x = obs + (int64_t)(idx ? idx[b] : b) * FRAME;
+      float* p1 = acts ? a1 + (int64_t)b * A1SZ : t;
+      float* p2 = acts ? a2 + (int64_t)b * A2SZ : t + A1SZ;
+      float* p3 = acts ? a3 + (int64_t)b * A3SZ : t + A1SZ + A2SZ;
+      float* ph = acts ? hd + (int64_t)b * HD : t + A1SZ + A2SZ + A3SZ;
+      nature_fwd_frame(P, &L, x, ksplit, p1, p2, p3, ph, logits + (int64_t)b * A, value + b);
+    }
+    free(t);
+  }
+}
+
+/* ============================================================ Nature-CNN backward
+ * Given dL/dlogits [B,A] and dL/dvalue [B] and the saved activations, accumulate dL/dparams
+ * (what jax.value_and_grad produces at ppo:590,619 / impala:607).  f64 accumulation. */
+static void nature_bwd_frame(const float* P, const cbo_layout* L, const uint8_t* x,
+                             const float* a1, const float* a2, const float* a3, const float* hid,
+                             const float* dlog, float dval, double* G, float* scratch) {
+  const int A = L->A;
+  float* dh = scratch;              /* HD   */
+  float* d3 = dh + HD;              /* A3SZ */
+  float* d2 = d3 + A3SZ;            /* A2SZ */
+  float* d1 = d2 + A2SZ;            /* A1SZ */
+  const float* Wa = P + L->w_off[4]; const float* Wc = P + L->w_off[5];
+  /* heads */
+  for (int k = 0; k < HD; ++k) {
+    double s = 0.0;
+    for (int a = 0; a < A; ++a) { s += (double)dlog[a] * Wa[k * A + a]; G[L->w_off[4] + k * A + a] += (double)hid[k] * dlog[a]; }
+    s += (double)dval * Wc[k];
+    G[L->w_off[5] + k] += (double)hid[k] * dval;
+    dh[k] = hid[k] > 0.0f ? (float)s : 0.0f;
+  }
+  for (int a = 0; a < A; ++a) G[L->b_off[4] + a] += dlog[a];
+  G[L->b_off[5]] += dval;
+  /* dense */
+  {
+    const float* W = P + L->w_off[3];
+    for (int n = 0; n < HD; ++n) G[L->b_off[3] + n] += dh[n];
+    for (int k = 0; k < FL; ++k) {
+      const float* w = W + (int64_t)k * HD; double* g = G + L->w_off[3] + (int64_t)k * HD;
+      const float a = a3[k];
+      double s = 0.0;
+      if (a != 0.0f) { for (int n = 0; n < HD; ++n) { s += (double)w[n] * dh[n]; g[n] += (double)a * dh[n]; } }
+      d3[k] = a > 0.0f ? (float)s : 0.0f;
+    }
+  }
+  /* conv3: dW3, dact2 */
+  {
+    const float* W = P + L->w_off[2];
+    for (int i = 0; i < A2SZ; ++i) d2[i] = 0.0f;
+    for (int oh = 0; oh < O3; ++oh) for (int ow = 0; ow < O3; ++ow) {
+      const float* dy = d3 + (oh * O3 + ow) * C3;
+      for (int co = 0; co < C3; ++co) G[L->b_off[2] + co] += dy[co];
+      for (int kh = 0; kh < 3; ++kh) for (int kw = 0; kw < 3; ++kw) {
+        const int pos = ((oh + kh) * O2 + ow + kw) * C2;
+        for (int ci = 0; ci < C2; ++ci) {
+          const float a = a2[pos + ci];
+          const float* w = W + ((kh * 3 + kw) * C2 + ci) * C3;
+          double* g = G + L->w_off[2] + ((kh * 3 + kw) * C2 + ci) * C3;
+          float s = 0.0f;
+          for (int co = 0; co < C3; ++co) { s += w[co] * dy[co]; g[co] += (double)a * dy[co]; }
+          d2[pos + ci] += s;
+        }
+      }
+    }
+    for (int i = 0; i < A2SZ; ++i) if (!(a2[i] > 0.0f)) d2[i] = 0.0f;
+  }
+  /* conv2: dW2, dact1 */
+  {
+    const float* W = P + L->w_off[1];
+    for (int i = 0; i < A1SZ; ++i) d1[i] = 0.0f;
+    for (int oh = 0; oh < O2; ++oh) for (int ow = 0; ow < O2; ++ow) {
+      const float* dy = d2 + (oh * O2 + ow) * C2;
+      for (int co = 0; co < C2; ++co) G[L->b_off[1] + co] += dy[co];
+      for (int kh = 0; kh < 4; ++kh) for (int kw = 0; kw < 4; ++kw) {
+        const int pos = ((oh * 2 + kh) * O1 + ow * 2 + kw) * C1;
+        for (int ci = 0; ci < C1; ++ci) {
+          const float a = a1[pos + ci];
+          const float* w = W + ((kh * 4 + kw) * C1 + ci) * C2;
+          double* g = G + L->w_off[1] + ((kh * 4 + kw) * C1 + ci) * C2;
+          float s = 0.0f;
+          for (int co = 0; co < C2; ++co) { s += w[co] * dy[co]; g[co] += (double)a * dy[co]; }
+          d1[pos + ci] += s;
+        }
+      }
+    }
+    for (int i = 0; i < A1SZ; ++i) if (!(a1[i] > 0.0f)) d1[i] = 0.0f;
+  }
+  /* conv1: dW1 only */
+  {
+    for (int oh = 0; oh < O1; ++oh) for (int ow = 0; ow < O1; ++ow) {
+      const float* dy = d1 + (oh * O1 + ow) * C1;
+      for (int co = 0; co < C1; ++co) G[L->b_off[0] + co] += dy[co];
+      for (int c = 0; c < C0; ++c) for (int kh = 0; kh < 8; ++kh) for (int kw = 0; kw < 8; ++kw) {
+        const uint8_t px = x[(c * IH + oh * 4 + kh) * IW + ow * 4 + kw];
+        if (!px) continue;
+        const float a = cbm_u8_unit(px);
+        double* g = G + L->w_off[0] + ((kh * 8 + kw) * C0 + c) * C1;
+        for (int co = 0; co < C1; ++co) g[co] += (double)a * dy[co];
+      }
+    }
+  }
+}
+
+EXPORT void cbo_nature_backward(const float* P, int A, const uint8_t* obs, const int32_t* idx, int B,
+                                const float* acts, const float* dlogits, const float* dvalue, float* grads) {
+  cbo_layout L; cbo_nature_layout(A, &L);
+  const float* a1 = acts; const float* a2 = a1 + (int64_t)B * A1SZ;
+  const float* a3 = a2 + (int64_t)B * A2SZ; const float* hd = a3 + (int64_t)B * A3SZ;
+  int nt = g_threads;
+  double** Gs = (double**)calloc((size_t)nt, sizeof(double*));
+#pragma omp parallel num_threads(nt)
+  {
+    int tid = 0;
+#ifdef _OPENMP
+    tid = omp_get_thread_num();
+#endif
+    double* G = (double*)calloc((size_t)L.total, sizeof(double));
+    Gs[tid] = G;
+    float* scratch = (float*)malloc(sizeof(float) * (HD + A3SZ + A2SZ + A1SZ));
+#pragma omp for schedule(static)
+    for (int b = 0; b < B; ++b) {
+      const uint8_t* x = obs + (int64_t)(idx ? idx[b] : b) * FRAME;
+      nature_bwd_frame(P, &L, x, a1 + (int64_t)b * A1SZ, a2 + (int64_t)b * A2SZ, a3 + (int64_t)b * A3SZ,
+                       hd + (int64_t)b * HD, dlogits + (int64_t)b * A, dvalue[b], G, scratch);
+    }
+    free(scratch);
+  }
+  for (int64_t i = 0; i < L.total; ++i) {
+    double s = 0.0;
+    for (int t = 0; t < nt; ++t) if (Gs[t]) s += Gs[t][i];
+    grads[i] = (float)s;
+  }
+  for (int t = 0; t < nt; ++t) free(Gs[t]);
+  free(Gs);
+}
+
+/* ============================================================ action sampling
+ * get_action_and_value ppo:256-261 / get_action impala:296-300:
+ *   key, subkey = split(key); u = uniform(subkey, [B,A]);
+ *   action = argmax(logits - log(-log(u)), axis=1)  (first max wins)
+ *   logprob = log_softmax(logits)[b, action]                                    */
+static float log_softmax_at(const float* z, int A, int a) {
+  /* jax.nn.log_softmax: shifted = x - max; shifted - log(sum(exp(shifted))) */
+  float mx = z[0];
+  for (int i = 1; i < A; ++i) mx = z[i] > mx ? z[i] : mx;
+  float s = 0.0f;
+  for (int i = 0; i < A; ++i) s += cbm_expf(z[i] - mx);
+  return (z[a] - mx) - cbm_logf(s);
+}
+EXPORT void cbo_sample_actions(const float* logits, int B, int A, const uint32_t key_in[2],
+                               uint32_t key_out[2], int32_t* actions, float* logprobs) {
+  uint32_t ks[4];
+  cbo_split(key_in, 2, ks);
+  key_out[0] = ks[0]; key_out[1] = ks[1];
+  const uint32_t n = (uint32_t)(B * A);
+  for (int b = 0; b < B; ++b) {
+    int best = 0; float bestv = 0.0f;
+    for (int a = 0; a < A; ++a) {
+      const float u = cbm_bits_to_uniform(cbm_random_bits_at(ks[2], ks[3], n, (uint32_t)(b * A + a)));
+      const float g = logits[b * A + a] - cbm_logf(-cbm_logf(u));
+      if (a == 0 || g > bestv) { best = a; bestv = g; }
+    }
+    actions[b] = best;
+    if (logprobs) logprobs[b] = log_softmax_at(logits + b * A, A, best);
+  }
+}
+
+/* ============================================================ GAE  (ppo:532-560)
+ * dones/values/rewards [T,B]; next_done/next_value [B]; reverse scan. */
+EXPORT void cbo_gae(const float* rewards, const float* values, const uint8_t* dones,
+                    const float* next_value, const uint8_t* next_done, int T, int B,
+                    float gamma, float gae_lambda, float* adv, float* target) {
+  const float gl = (float)((double)gamma * (double)gae_lambda); /* python float product, then f32 */
+  for (int b = 0; b < B; ++b) {
+    float a = 0.0f;
+    for (int t = T - 1; t >= 0; --t) {
+      const float nd = (t == T - 1) ? (float)next_done[b] : (float)dones[(t + 1) * B + b];
+      const float nv = (t == T - 1) ? next_value[b] : values[(t + 1) * B + b];
+      const float nnt = 1.0f - nd;
+      const float delta = (rewards[t * B + b] + (gamma * nv) * nnt) - values[t * B + b];
+      a = delta + ((gl * nnt) * a);
+      adv[t * B + b] = a;
+      target[t * B + b] = a + values[t * B + b];
+    }
+  }
+}
+
+/* ============================================================ advantage normalisation
+ * ppo:592-595: reshape [T, G, B/G]; (x - mean(0,2)) / (std(0,2) + 1e-8), population std. */
+EXPORT void cbo_advnorm(float* adv, int T, int B, int groups) {
+  const int w = B / groups;
+  for (int g = 0; g < groups; ++g) {
+    double s = 0.0;
+    for (int t = 0; t < T; ++t) for (int j = 0; j < w; ++j) s += adv[t * B + g * w + j];
+    const float mean = (float)(s / ((double)T * w));
+    double v = 0.0;
+    for (int t = 0; t < T; ++t) for (int j = 0; j < w; ++j) { const float d = adv[t * B + g * w + j] - mean; v += (double)d * d; }
+    const float sd = sqrtf((float)(v / ((double)T * w)));
+    for (int t = 0; t < T; ++t) for (int j = 0; j < w; ++j) adv[t * B + g * w + j] = (adv[t * B + g * w + j] - mean) / (sd + 1e-8f);
+  }
+}
+
+/* ============================================================ PPO loss head  (ppo:516-577)
+ * From logits/value of a minibatch: the 5 statistics and dL/dlogits, dL/dvalue.
+ * stats = [loss, pg_loss, v_loss, entropy, approx_kl]. */
+EXPORT void cbo_ppo_loss_head(const float* logits, const float* value, int N, int A,
+                              const int32_t* actions, const float* old_logprob, const float* adv,
+                              const float* target, float clip_coef, float ent_coef, float vf_coef,
+                              float* stats, float* dlogits, float* dvalue) {
+  double s_pg = 0, s_v = 0, s_ent = 0, s_kl = 0;
+  const float invN = 1.0f / (float)N;
+  for (int i = 0; i < N; ++i) {
+    const float* z = logits + (int64_t)i * A;
+    const int a = actions[i];
+    float mx = z[0];
+    for (int j = 1; j < A; ++j) mx = z[j] > mx ? z[j] : mx;
+    float se = 0.0f;
+    for (int j = 0; j < A; ++j) se += cbm_expf(z[j] - mx);
+    const float lse_shift = cbm_logf(se);
+    const float newlp = (z[a] - mx) - lse_shift;               /* log_softmax[a]  ppo:524 */
+    const float lse = lse_shift + mx;                          /* logsumexp       ppo:525 */
+    float zn[64], p[64];
+    float mx2 = -INFINITY;
+    for (int j = 0; j < A; ++j) { zn[j] = z[j] - lse; if (zn[j] < -FLT_MAX) zn[j] = -FLT_MAX; mx2 = zn[j] > mx2 ? zn[j] : mx2; }
+    float s2 = 0.0f;
+    for (int j = 0; j < A; ++j) { p[j] = cbm_expf(zn[j] - mx2); s2 += p[j]; }
+    float ent = 0.0f;
+    for (int j = 0; j < A; ++j) { p[j] = p[j] / s2; ent += zn[j] * p[j]; }
+    ent = -ent;                                                /* ppo:527-528 */
+    const float logratio = newlp - old_logprob[i];
+    const float ratio = cbm_expf(logratio);
+    const float ad = adv[i];
+    const float lo = 1.0f - clip_coef, hi = 1.0f + clip_coef;
+    const float rc = ratio < lo ? lo : (ratio > hi ? hi : ratio);
+    const float pg1 = -ad * ratio, pg2 = -ad * rc;
+    const float pg = pg1 > pg2 ? pg1 : pg2;
+    const float dv = value[i] - target[i];
+    s_pg += pg; s_v += (double)dv * dv; s_ent += ent; s_kl += (double)((ratio - 1.0f) - logratio);
+    if (dlogits) {
+      /* d max(pg1,pg2)/d ratio with jax tie rules (lax.max / clip split ties 0.5/0.5) */
+      const float w1 = pg1 > pg2 ? 1.0f : (pg1 == pg2 ? 0.5f : 0.0f);
+      const float dclip = (ratio > lo && ratio < hi) ? 1.0f : ((ratio == lo || ratio == hi) ? 0.5f : 0.0f);
+      const float dpg_dratio = w1 * (-ad) + (1.0f - w1) * (-ad) * dclip;
+      const float c_lp = dpg_dratio * ratio * invN;            /* dL/d newlogprob */
+      float* dz = dlogits + (int64_t)i * A;
+      for (int j = 0; j < A; ++j) {
+        const float dlp = (j == a ? 1.0f : 0.0f) - p[j];
+        dz[j] = c_lp * dlp + ent_coef * invN * p[j] * (zn[j] + ent);
+      }
+      dvalue[i] = vf_coef * dv * invN;
+    }
+  }
+  const float pgm = (float)(s_pg / N), vm = (float)(0.5 * s_v / N), em = (float)(s_ent / N);
+  stats[1] = pgm; stats[2] = vm; stats[3] = em; stats[4] = (float)(s_kl / N);
+  stats[0] = pgm - ent_coef * em + vm * vf_coef;
+}
+
+/* full PPO minibatch: forward + loss + backward -> grads (value_and_grad(ppo_loss) ppo:619) */
+EXPORT void cbo_ppo_loss_grad(const float* P, int A, const uint8_t* obs, const int32_t* idx, int N,
+                              const int32_t* actions, const float* old_logprob, const float* adv,
+                              const float* target, float clip_coef, float ent_coef, float vf_coef,
+                              int ksplit, float* stats, float* grads, float* logits_out, float* value_out) {
+  float* acts = (float*)malloc(sizeof(float) * (size_t)N * (A1SZ + A2SZ + A3SZ + HD));
+  float* logits = (float*)malloc(sizeof(float) * (size_t)N * A);
+  float* value = (float*)malloc(sizeof(float) * (size_t)N);
+  float* dlog = (float*)malloc(sizeof(float) * (size_t)N * A);
+  float* dval = (float*)malloc(sizeof(float) * (size_t)N);
+  cbo_nature_forward(P, A, obs, idx, N, ksplit, acts, logits, value);
+  cbo_ppo_loss_head(logits, value, N, A, actions, old_logprob, adv, target, clip_coef, ent_coef, vf_coef, stats, dlog, dval);
+  if (grads) cbo_nature_backward(P, A, obs, idx, N, acts, dlog, dval, grads);
+  if (logits_out) memcpy(logits_out, logits, sizeof(float) * (size_t)N * A);
+  if (value_out) memcpy(value_out, value, sizeof(float) * (size_t)N);
+  free(acts); free(logits); free(value); free(dlog); free(dval);
+}
+
+/* ============================================================ optimizers
+ * optax.chain(clip_by_global_norm(c), adam(lr, eps=1e-5))  (ppo:492-500), MultiSteps k=1.
+ * lr and the bias corrections bc1 = 1-b1^t, bc2 = 1-b2^t are computed by the caller
+ * (host python, float32) so both sides consume identical scalars. */
+EXPORT float cbo_global_norm(const float* g, int64_t n) {
+  double s = 0.0;
+  for (int64_t i = 0; i < n; ++i) s += (double)g[i] * g[i];
+  return sqrtf((float)s);
+}
+EXPORT void cbo_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float max_norm,
+                          float lr, float b1, float b2, float eps, float bc1, float bc2) {
+  const float gn = cbo_global_norm(g, n);
+  const int clip = !(gn < max_norm);
+  for (int64_t i = 0; i < n; ++i) {
+    const float gi = clip ? (g[i] / gn) * max_norm : g[i];
+    m[i] = (1.0f - b1) * gi + b1 * m[i];
+    v[i] = (1.0f - b2) * (gi * gi) + b2 * v[i];
+    const float mh = m[i] / bc1, vh = v[i] / bc2;
+    const float u = mh / (sqrtf(vh) + eps);
+    p[i] = p[i] + (-lr) * u;
+  }
+}
+/* rmsprop_pytorch_style impala:152-188: nu = (1-d)g^2 + d nu; u = g/(sqrt(nu)+eps); p -= lr u */
+EXPORT void cbo_rmsprop_step(float* p, const float* g, float* nu, int64_t n, float max_norm,
+                             float lr, float decay, float eps) {
+  const float gn = cbo_global_norm(g, n);
+  const int clip = !(gn < max_norm);
+  for (int64_t i = 0; i < n; ++i) {
+    const float gi = clip ? (g[i] / gn) * max_norm : g[i];
+    nu[i] = (1.0f - decay) * (gi * gi) + decay * nu[i];
+    const float u = gi / (sqrtf(nu[i]) + eps);
+    p[i] = p[i] + (-lr) * u;
+  }
+}
+
+/* ============================================================ V-trace / IMPALA loss head
+ * impala:569-597 with rlax 0.1.5 vtrace_td_error_and_advantage (lambda=1, clips=1).
+ * Inputs are the network outputs on all T1=T+1 steps of Bm env columns, [T1,Bm,...]
+ * time-major; behaviour logits `mu`, actions, rewards, dones, firststeps likewise.
+ * stats = [total, pg_loss, baseline_loss, ent_loss]; grads wrt logits/value of all T1 rows. */
+EXPORT void cbo_impala_loss_head(const float* logits, const float* value, const float* mu_logits,
+                                 const int32_t* actions, const float* rewards, const uint8_t* dones,
+                                 const uint8_t* firststeps, int T1, int Bm, int A, float gamma,
+                                 float vf_coef, float ent_coef, float* stats, float* dlogits, float* dvalue) {
+  const int T = T1 - 1;
+  double s_pg = 0, s_bl = 0, s_ent = 0;
+  if (dlogits) memset(dlogits, 0, sizeof(float) * (size_t)T1 * Bm * A);
+  if (dvalue) memset(dvalue, 0, sizeof(float) * (size_t)T1 * Bm);
+  float* rho = (float*)malloc(sizeof(float) * (size_t)T);
+  float* err = (float*)malloc(sizeof(float) * (size_t)T);
+  float* lpa = (float*)malloc(sizeof(float) * (size_t)T);
+  for (int b = 0; b < Bm; ++b) {
+    /* rhos = exp(log pi(a) - log mu(a))  (rlax.categorical_importance_sampling_ratios) */
+    for (int t = 0; t < T; ++t) {
+      const int64_t r = (int64_t)t * Bm + b;
+      const int a = actions[r];
+      lpa[t] = log_softmax_at(logits + r * A, A, a);
+      const float lm = log_softmax_at(mu_logits + r * A, A, a);
+      rho[t] = cbm_expf(lpa[t] - lm);
+    }
+    /* vtrace errors: err_t = crho_t (r_t + disc_t v_{t+1} - v_t) + disc_t c_t err_{t+1} */
+    float e = 0.0f;
+    for (int t = T - 1; t >= 0; --t) {
+      const int64_t r = (int64_t)t * Bm + b;
+      const float disc = (1.0f - (float)dones[r]) * gamma;
+      const float cr = rho[t] < 1.0f ? rho[t] : 1.0f;
+      const float td = cr * ((rewards[r] + disc * value[r + Bm]) - value[r]);
+      e = td + (disc * cr) * e;
+      err[t] = e;
+    }
+    for (int t = 0; t < T; ++t) {
+      const int64_t r = (int64_t)t * Bm + b;
+      const float disc = (1.0f - (float)dones[r]) * gamma;
+      const float mask = 1.0f - (float)firststeps[r];
+      const float cr = rho[t] < 1.0f ? rho[t] : 1.0f;
+      /* errors = stopgrad(err + v_tm1) - v_tm1 */
+      const float errors = (err[t] + value[r]) - value[r];
+      /* targets_tm1[t+1] = errors[t+1] + v_tm1[t+1]; last step bootstraps from v_t[-1] */
+      const float qboot = (t == T - 1) ? value[r + Bm]
+                                       : (((err[t + 1] + value[r + Bm]) - value[r + Bm]) + value[r + Bm]);
+      const float q = rewards[r] + disc * qboot;
+      const float pgadv = cr * (q - value[r]);
+      s_pg += (double)(-lpa[t] * pgadv * mask);
+      s_bl += (double)(errors * errors * mask);
+      /* entropy of softmax(logits) (distrax): -sum p log p */
+      const float* z = logits + r * A;
+      float mx = z[0];
+      for (int j = 1; j < A; ++j) mx = z[j] > mx ? z[j] : mx;
+      float se = 0.0f, p[64], lp[64];
+      for (int j = 0; j < A; ++j) { p[j] = cbm_expf(z[j] - mx); se += p[j]; }
+      const float lse = cbm_logf(se);
+      float H = 0.0f;
+      for (int j = 0; j < A; ++j) { lp[j] = (z[j] - mx) - lse; p[j] = p[j] / se; H += p[j] * lp[j]; }
+      H = -H;
+      s_ent += (double)(-H * mask);
+      if (dlogits) {
+        float* dz = dlogits + r * A;
+        const int a = actions[r];
+        for (int j = 0; j < A; ++j) {
+          const float dlp = (j == a ? 1.0f : 0.0f) - p[j];
+          /* pg: -adv*mask*dlogpi ; ent_loss = -H*mask -> d(-H)/dz_j = p_j (lp_j + H) */
+          dz[j] = (-pgadv * mask) * dlp + ent_coef * mask * p[j] * (lp[j] + H);
+        }
+        dvalue[r] += vf_coef * (-errors) * mask;   /* 0.5*errors^2, d errors/d v_tm1 = -1 */
+      }
+    }
+  }
+  free(rho); free(err); free(lpa);
+  stats[1] = (float)s_pg; stats[2] = (float)(0.5 * s_bl); stats[3] = (float)s_ent;
+  stats[0] = stats[1] + vf_coef * stats[2] + ent_coef * stats[3];
+}
+
+/* V-trace alone (rlax.vtrace_td_error_and_advantage, one env column set): for analytic pins. */
+EXPORT void cbo_vtrace(const float* v_tm1, const float* v_t, const float* r_t, const float* disc_t,
+                       const float* rho_tm1, int T, int B, float* errors, float* pg_adv, float* q_est) {
+  for (int b = 0; b < B; ++b) {
+    float e = 0.0f;
+    for (int t = T - 1; t >= 0; --t) {
+      const int i = t * B + b;
+      const float cr = rho_tm1[i] < 1.0f ? rho_tm1[i] : 1.0f;
+      const float td = cr * ((r_t[i] + disc_t[i] * v_t[i]) - v_tm1[i]);
+      e = td + (disc_t[i] * cr) * e;
+      errors[i] = (e + v_tm1[i]) - v_tm1[i];
+      q_est[i] = e; /* raw recursion value, overwritten below */
+    }
+    for (int t = 0; t < T; ++t) {
+      const int i = t * B + b;
+      const float cr = rho_tm1[i] < 1.0f ? rho_tm1[i] : 1.0f;
+      const float qb = (t == T - 1) ? v_t[i] : (errors[i + B] + v_tm1[i + B]);
+      q_est[i] = r_t[i] + disc_t[i] * qb;
+      pg_adv[i] = cr * (q_est[i] - v_tm1[i]);
+    }
+  }
+}
+
+/* full IMPALA minibatch: T1*Bm frames forward, loss, backward (impala:569-620) */
+EXPORT void cbo_impala_loss_grad(const float* P, int A, const uint8_t* obs, const int32_t* idx, int T1, int Bm,
+                                 const float* mu_logits, const int32_t* actions, const float* rewards,
+                                 const uint8_t* dones, const uint8_t* firststeps, float gamma, float vf_coef,
+                                 float ent_coef, float* stats, float* grads) {
+  const int N = T1 * Bm;
+  float* acts = (float*)malloc(sizeof(float) * (size_t)N * (A1SZ + A2SZ + A3SZ + HD));
+  float* logits = (float*)malloc(sizeof(float) * (size_t)N * A);
+  float* value = (float*)malloc(sizeof(float) * (size_t)N);
+  float* dlog = (float*)malloc(sizeof(float) * (size_t)N * A);
+  float* dval = (float*)malloc(sizeof(float) * (size_t)N);
+  cbo_nature_forward(P, A, obs, idx, N, 1, acts, logits, value);
+  cbo_impala_loss_head(logits, value, mu_logits, actions, rewards, dones, firststeps, T1, Bm, A, gamma,
+                       vf_coef, ent_coef, stats, dlog, dval);
+  if (grads) cbo_nature_backward(P, A, obs, idx, N, acts, dlog, dval, grads);
+  free(acts); free(logits); free(value); free(dlog); free(dval);
+}
+
+/* scalar helpers exported for tests of the shared header */
+EXPORT float cbo_logf(float x) { return cbm_logf(x); }
+EXPORT float cbo_expf(float x) { return cbm_expf(x); }
+EXPORT float cbo_u8_unit(uint32_t x) { return cbm_u8_unit(x); }
