@@ -1,0 +1,633 @@
+// api.hip — the C ABI of libcleanba_mi.so (include/cleanba_mi.h): context, HBM rollout ring,
+// actor / learner orchestration on HIP streams, and the pure-function entry points used by tests.
+//
+// Hand-off design (replaces the two queue.Queue(maxsize=1) per actor thread, ppo:662-686):
+//   - rollouts live in an HBM ring of `ring_depth` entries; every field is [T+1][B_dev] (t-major,
+//     env columns of slot s at [s*E,(s+1)*E)), exactly the hstack/flatten order of ppo:587,601.
+//   - producer (actor slot) and consumer (learner) exchange only sequence numbers on the host
+//     (committed[s], updates_done) and HIP events on the device (ready / consumed / params_ready);
+//     the GPU never waits for the host and the host never copies rollout data.
+//   - parameters are published by the learner into a 3-deep versioned buffer; an actor rollout
+//     `u` reads version max(0,u-2) with --concurrency (the `update != 2` skew, ppo:287-304) or
+//     u-1 without.
+#include "cbm_internal.h"
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <mutex>
+#include <condition_variable>
+#include <vector>
+
+static thread_local char g_err[512] = "";
+void cbm_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* cbm_last_error(void) { return g_err; }
+extern "C" const char* cbm_build_info(void) { return "cleanba-mi gfx950 f32-mfma abi=1 built " __DATE__ " " __TIME__; }
+
+#define MAX_SLOTS 16
+#define MAX_RING 4
+#define NPV 3
+
+struct RingEntry {
+  uint8_t* obs = nullptr;
+  int32_t* actions = nullptr;
+  float *logprobs = nullptr, *values = nullptr, *rewards = nullptr, *logits = nullptr;
+  uint8_t *dones = nullptr, *firststeps = nullptr;
+  hipEvent_t ready[MAX_SLOTS];
+  hipEvent_t consumed;
+};
+struct Slot {
+  hipStream_t stream = nullptr;
+  NatureWs ws;
+  uint32_t key[2] = {0, 0};
+  int t = 0, rollout = 0, ring = 0, pver = 0;
+  cbm_env_state* env_state = nullptr;
+  uint32_t env_seed = 0;
+  bool env_inited = false;
+  float* stats_dev = nullptr;
+};
+struct cbm_ctx {
+  cbm_config cfg;
+  NatureLayout L;
+  int E, S, Bdev, T, T1, A, MB, nmb, epochs;
+  int64_t P;
+  float *params = nullptr, *grads = nullptr, *opt_m = nullptr, *opt_v = nullptr;
+  float* actor_params[NPV] = {nullptr, nullptr, nullptr};
+  hipEvent_t params_ready[NPV];
+  RingEntry ring[MAX_RING];
+  Slot slots[MAX_SLOTS];
+  hipStream_t lstream = nullptr;
+  NatureWs lws;
+  float *adv = nullptr, *target = nullptr, *next_value = nullptr, *stats_dev = nullptr, *loss_partials = nullptr, *norm_partials = nullptr;
+  int32_t *perm = nullptr, *perm_tmp = nullptr, *impala_idx = nullptr;
+  uint64_t* ckeys = nullptr;
+  std::mutex mu;
+  std::condition_variable cv;
+  int committed[MAX_SLOTS];
+  int updates_done = 0;
+  int stat_rows = 0;
+};
+
+static bool is_ppo(const cbm_ctx* c) { return c->cfg.algo == CBM_ALGO_PPO; }
+
+extern "C" int cbm_default_config(int32_t algo, cbm_config* cfg) {
+  memset(cfg, 0, sizeof(*cfg));
+  cfg->abi_version = CBM_ABI_VERSION;
+  cfg->network = CBM_NET_NATURE;
+  cfg->algo = algo;
+  cfg->num_actions = 18;
+  cfg->local_num_envs = 64;
+  cfg->num_actor_slots = 2;
+  cfg->num_minibatches = 4;
+  cfg->ring_depth = 3;
+  cfg->gamma = 0.99f;
+  cfg->gae_lambda = 0.95f;
+  cfg->ent_coef = 0.01f;
+  cfg->vf_coef = 0.5f;
+  cfg->adam_b1 = 0.9f; cfg->adam_b2 = 0.999f; cfg->adam_eps = 1e-5f;
+  cfg->rms_decay = 0.99f; cfg->rms_eps = 0.01f;
+  cfg->actor_dense_ksplit = 14;
+  if (algo == CBM_ALGO_PPO) {
+    cfg->num_steps = 128; cfg->update_epochs = 4; cfg->norm_adv = 1; cfg->clip_coef = 0.1f; cfg->max_grad_norm = 0.5f;
+  } else {
+    cfg->num_steps = 20; cfg->update_epochs = 1; cfg->norm_adv = 0; cfg->clip_coef = 0.0f; cfg->max_grad_norm = 40.0f;
+  }
+  return 0;
+}
+
+extern "C" int64_t cbm_param_count(int32_t network, int32_t num_actions) {
+  if (network != CBM_NET_NATURE) return -1;
+  return nature_layout(num_actions).total;
+}
+
+template <class Tp>
+static int dalloc(Tp** p, size_t n) {
+  if (hipMalloc((void**)p, n * sizeof(Tp)) != hipSuccess) { cbm_set_error("hipMalloc(%zu bytes) failed", n * sizeof(Tp)); return -1; }
+  return 0;
+}
+
+extern "C" int cbm_ctx_create(const cbm_config* cfg, cbm_ctx** out) {
+  if (!cfg || cfg->abi_version != CBM_ABI_VERSION) { cbm_set_error("bad config / abi version"); return -1; }
+  if (cfg->network != CBM_NET_NATURE) { cbm_set_error("network kind %d not built into this library yet", cfg->network); return -2; }
+  if (cfg->num_actor_slots < 1 || cfg->num_actor_slots > MAX_SLOTS || cfg->ring_depth < 2 || cfg->ring_depth > MAX_RING) {
+    cbm_set_error("num_actor_slots in [1,%d], ring_depth in [2,%d]", MAX_SLOTS, MAX_RING); return -1;
+  }
+  if (cfg->num_actions < 2 || cfg->num_actions > 28) { cbm_set_error("num_actions must be in [2,28]"); return -1; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { cbm_set_error("no HIP device visible: libcleanba_mi needs an MI355X"); return -3; }
+  CBM_HIP(hipSetDevice(cfg->device));
+  cbm_ctx* c = new cbm_ctx();
+  c->cfg = *cfg;
+  c->A = cfg->num_actions; c->E = cfg->local_num_envs; c->S = cfg->num_actor_slots;
+  c->Bdev = c->E * c->S; c->T = cfg->num_steps; c->T1 = c->T + 1;
+  c->nmb = cfg->num_minibatches; c->epochs = is_ppo(c) ? cfg->update_epochs : 1;
+  if (c->Bdev % c->nmb) { cbm_set_error("local_num_envs*slots must be divisible by num_minibatches (ppo:416-418)"); delete c; return -1; }
+  c->MB = is_ppo(c) ? (c->T * c->Bdev) / c->nmb : c->T1 * (c->Bdev / c->nmb);
+  if (3136 % cfg->actor_dense_ksplit || (3136 / cfg->actor_dense_ksplit) % 4) { cbm_set_error("actor_dense_ksplit must divide 3136 into multiples of 4"); delete c; return -1; }
+  c->L = nature_layout(c->A);
+  c->P = c->L.total;
+  const size_t P = (size_t)c->P, B = (size_t)c->Bdev, T1 = (size_t)c->T1;
+  if (dalloc(&c->params, P) || dalloc(&c->grads, P) || dalloc(&c->opt_m, P) || dalloc(&c->opt_v, P)) return -1;
+  hipMemset(c->params, 0, P * 4); hipMemset(c->grads, 0, P * 4); hipMemset(c->opt_m, 0, P * 4); hipMemset(c->opt_v, 0, P * 4);
+  for (int i = 0; i < NPV; ++i) { if (dalloc(&c->actor_params[i], P)) return -1; CBM_HIP(hipEventCreateWithFlags(&c->params_ready[i], hipEventDisableTiming)); }
+  for (int r = 0; r < cfg->ring_depth; ++r) {
+    RingEntry& R = c->ring[r];
+    if (dalloc(&R.obs, T1 * B * CBM_FRAME) || dalloc(&R.actions, T1 * B) || dalloc(&R.logprobs, T1 * B) || dalloc(&R.values, T1 * B) ||
+        dalloc(&R.rewards, T1 * B) || dalloc(&R.logits, T1 * B * c->A) || dalloc(&R.dones, T1 * B) || dalloc(&R.firststeps, T1 * B)) return -1;
+    hipMemset(R.dones, 0, T1 * B); hipMemset(R.firststeps, 0, T1 * B); hipMemset(R.rewards, 0, T1 * B * 4);
+    for (int s = 0; s < c->S; ++s) CBM_HIP(hipEventCreateWithFlags(&R.ready[s], hipEventDisableTiming));
+    CBM_HIP(hipEventCreateWithFlags(&R.consumed, hipEventDisableTiming));
+  }
+  for (int s = 0; s < c->S; ++s) {
+    Slot& sl = c->slots[s];
+    CBM_HIP(hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
+    if (nature_ws_alloc(sl.ws, c->E, false, cfg->actor_dense_ksplit)) return -1;
+    if (dalloc(&sl.env_state, (size_t)c->E) || dalloc(&sl.stats_dev, 2)) return -1;
+    c->committed[s] = 0;
+  }
+  CBM_HIP(hipStreamCreateWithFlags(&c->lstream, hipStreamNonBlocking));
+  const int lmax = c->MB > c->Bdev ? c->MB : c->Bdev;
+  if (nature_ws_alloc(c->lws, lmax, true, cfg->actor_dense_ksplit)) return -1;
+  c->stat_rows = c->epochs * c->nmb;
+  if (dalloc(&c->adv, T1 * B) || dalloc(&c->target, T1 * B) || dalloc(&c->next_value, B) || dalloc(&c->stats_dev, (size_t)c->stat_rows * 8) ||
+      dalloc(&c->loss_partials, (size_t)4 * (lmax / 256 + 2) + 3 * B) || dalloc(&c->norm_partials, CBM_NORM_PARTS) ||
+      dalloc(&c->perm, T1 * B) || dalloc(&c->perm_tmp, T1 * B) || dalloc(&c->ckeys, T1 * B)) return -1;
+  if (!is_ppo(c)) {  // static minibatch index table: contiguous env-column chunks, all T+1 rows (impala:623-634)
+    const int Bm = c->Bdev / c->nmb;
+    std::vector<int32_t> h((size_t)c->nmb * c->MB);
+    for (int mb = 0; mb < c->nmb; ++mb)
+      for (int t = 0; t < c->T1; ++t)
+        for (int j = 0; j < Bm; ++j) h[(size_t)mb * c->MB + t * Bm + j] = t * c->Bdev + mb * Bm + j;
+    if (dalloc(&c->impala_idx, h.size())) return -1;
+    CBM_HIP(hipMemcpy(c->impala_idx, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+  }
+  CBM_HIP(hipDeviceSynchronize());
+  *out = c;
+  return 0;
+}
+
+extern "C" int cbm_ctx_destroy(cbm_ctx* c) {
+  if (!c) return 0;
+  hipSetDevice(c->cfg.device);
+  hipDeviceSynchronize();
+  void* ps[] = {c->params, c->grads, c->opt_m, c->opt_v, c->adv, c->target, c->next_value, c->stats_dev, c->loss_partials, c->norm_partials,
+                c->perm, c->perm_tmp, c->ckeys, c->impala_idx};
+  for (void* p : ps) if (p) hipFree(p);
+  for (int i = 0; i < NPV; ++i) { if (c->actor_params[i]) hipFree(c->actor_params[i]); hipEventDestroy(c->params_ready[i]); }
+  for (int r = 0; r < c->cfg.ring_depth; ++r) {
+    RingEntry& R = c->ring[r];
+    void* qs[] = {R.obs, R.actions, R.logprobs, R.values, R.rewards, R.logits, R.dones, R.firststeps};
+    for (void* p : qs) if (p) hipFree(p);
+    for (int s = 0; s < c->S; ++s) hipEventDestroy(R.ready[s]);
+    hipEventDestroy(R.consumed);
+  }
+  for (int s = 0; s < c->S; ++s) {
+    nature_ws_free(c->slots[s].ws);
+    if (c->slots[s].env_state) hipFree(c->slots[s].env_state);
+    if (c->slots[s].stats_dev) hipFree(c->slots[s].stats_dev);
+    hipStreamDestroy(c->slots[s].stream);
+  }
+  nature_ws_free(c->lws);
+  hipStreamDestroy(c->lstream);
+  delete c;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------ params / buffers
+extern "C" int cbm_params_set(cbm_ctx* c, const float* h, int64_t n) {
+  if (n != c->P) { cbm_set_error("param count %lld != %lld", (long long)n, (long long)c->P); return -1; }
+  CBM_HIP(hipSetDevice(c->cfg.device));
+  CBM_HIP(hipDeviceSynchronize());
+  CBM_HIP(hipMemcpy(c->params, h, (size_t)n * 4, hipMemcpyHostToDevice));
+  for (int i = 0; i < NPV; ++i) CBM_HIP(hipMemcpy(c->actor_params[i], h, (size_t)n * 4, hipMemcpyHostToDevice));
+  CBM_HIP(hipMemset(c->opt_m, 0, (size_t)n * 4));
+  CBM_HIP(hipMemset(c->opt_v, 0, (size_t)n * 4));
+  return 0;
+}
+extern "C" int cbm_params_get(cbm_ctx* c, float* h, int64_t n) {
+  if (n != c->P) { cbm_set_error("param count mismatch"); return -1; }
+  CBM_HIP(hipStreamSynchronize(c->lstream));
+  CBM_HIP(hipMemcpy(h, c->params, (size_t)n * 4, hipMemcpyDeviceToHost));
+  return 0;
+}
+extern "C" int cbm_actor_params_get(cbm_ctx* c, float* h, int64_t n) {
+  if (n != c->P) { cbm_set_error("param count mismatch"); return -1; }
+  CBM_HIP(hipDeviceSynchronize());
+  CBM_HIP(hipMemcpy(h, c->actor_params[c->slots[0].pver % NPV], (size_t)n * 4, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+extern "C" int cbm_buffer(cbm_ctx* c, const char* name, int32_t ri, void** p, int64_t* nbytes) {
+  const size_t TB = (size_t)c->T1 * c->Bdev;
+  std::string n(name);
+  if (ri < 0 || ri >= c->cfg.ring_depth) ri = 0;
+  RingEntry& R = c->ring[ri];
+  struct { const char* k; void* ptr; size_t sz; } tab[] = {
+      {"params", c->params, (size_t)c->P * 4}, {"grads", c->grads, (size_t)c->P * 4}, {"opt_m", c->opt_m, (size_t)c->P * 4},
+      {"opt_v", c->opt_v, (size_t)c->P * 4}, {"actor_params", c->actor_params[c->slots[0].pver % NPV], (size_t)c->P * 4},
+      {"adv", c->adv, TB * 4}, {"target", c->target, TB * 4}, {"perm", c->perm, TB * 4}, {"next_value", c->next_value, (size_t)c->Bdev * 4},
+      {"stats", c->stats_dev, (size_t)c->stat_rows * 8 * 4}, {"obs", R.obs, TB * CBM_FRAME}, {"actions", R.actions, TB * 4},
+      {"logprobs", R.logprobs, TB * 4}, {"values", R.values, TB * 4}, {"rewards", R.rewards, TB * 4}, {"logits", R.logits, TB * c->A * 4},
+      {"dones", R.dones, TB}, {"firststeps", R.firststeps, TB}, {"lws_logits", c->lws.logits, (size_t)c->lws.maxB * 32 * 4},
+      {"lws_value", c->lws.value, (size_t)c->lws.maxB * 4}};
+  for (auto& e : tab)
+    if (n == e.k) { *p = e.ptr; if (nbytes) *nbytes = (int64_t)e.sz; return 0; }
+  cbm_set_error("unknown buffer '%s'", name);
+  return -1;
+}
+extern "C" int cbm_copy_to_host(cbm_ctx* c, void* dst, const void* src, int64_t n) {
+  CBM_HIP(hipDeviceSynchronize());
+  CBM_HIP(hipMemcpy(dst, src, (size_t)n, hipMemcpyDeviceToHost));
+  return 0;
+}
+extern "C" int cbm_copy_to_device(cbm_ctx* c, void* dst, const void* src, int64_t n) {
+  CBM_HIP(hipDeviceSynchronize());
+  CBM_HIP(hipMemcpy(dst, src, (size_t)n, hipMemcpyHostToDevice));
+  return 0;
+}
+extern "C" int cbm_dev_alloc(int64_t nbytes, void** p) { CBM_HIP(hipMalloc(p, (size_t)nbytes)); return 0; }
+extern "C" int cbm_dev_free(void* p) { CBM_HIP(hipFree(p)); return 0; }
+extern "C" void* cbm_learner_stream(cbm_ctx* c) { return (void*)c->lstream; }
+extern "C" int cbm_sync(cbm_ctx* c) { CBM_HIP(hipSetDevice(c->cfg.device)); CBM_HIP(hipDeviceSynchronize()); return 0; }
+
+// ------------------------------------------------------------------------------------------ actor
+extern "C" int cbm_actor_set_key(cbm_ctx* c, int32_t s, const uint32_t key[2]) { c->slots[s].key[0] = key[0]; c->slots[s].key[1] = key[1]; return 0; }
+extern "C" int cbm_actor_get_key(cbm_ctx* c, int32_t s, uint32_t key[2]) { key[0] = c->slots[s].key[0]; key[1] = c->slots[s].key[1]; return 0; }
+
+extern "C" int cbm_actor_env_reset_device(cbm_ctx* c, int32_t s, uint32_t seed) {
+  Slot& sl = c->slots[s];
+  CBM_HIP(hipSetDevice(c->cfg.device));
+  RingEntry& R = c->ring[0];
+  sl.env_seed = seed;
+  launch_env_reset(seed, c->E, sl.env_state, R.obs + (size_t)s * c->E * CBM_FRAME, CBM_FRAME, R.dones + s * c->E, R.firststeps + s * c->E, sl.stream);
+  sl.env_inited = true;
+  return 0;
+}
+
+static size_t row_off(const cbm_ctx* c, int t, int s) { return (size_t)t * c->Bdev + (size_t)s * c->E; }
+
+extern "C" int cbm_actor_begin_rollout(cbm_ctx* c, int32_t s, int32_t concurrency, int32_t* policy_version) {
+  Slot& sl = c->slots[s];
+  CBM_HIP(hipSetDevice(c->cfg.device));
+  const int u = ++sl.rollout;
+  const int need = concurrency ? (u >= 2 ? u - 2 : 0) : u - 1;
+  const int depth = c->cfg.ring_depth;
+  const int need_free = u - depth;  // ring entry reused: its previous rollout must be consumed
+  {
+    std::unique_lock<std::mutex> lk(c->mu);
+    c->cv.wait(lk, [&] { return c->updates_done >= need && c->updates_done >= need_free; });
+  }
+  const int ri = (u - 1) % depth;
+  if (need > 0) CBM_HIP(hipStreamWaitEvent(sl.stream, c->params_ready[need % NPV], 0));
+  if (need_free > 0) CBM_HIP(hipStreamWaitEvent(sl.stream, c->ring[ri].consumed, 0));
+  sl.pver = need;
+  sl.ring = ri;
+  sl.t = 0;
+  if (u >= 2) {
+    // carry the last row of the previous rollout to the head of this one: PPO next_obs/next_done (ppo:308-310),
+    // IMPALA the whole bootstrap transition (impala:416)
+    RingEntry& Pv = c->ring[(u - 2) % depth];
+    RingEntry& R = c->ring[ri];
+    const size_t so = row_off(c, c->T, s), d0 = row_off(c, 0, s);
+    const size_t E = (size_t)c->E;
+    CBM_HIP(hipMemcpyAsync(R.obs + d0 * CBM_FRAME, Pv.obs + so * CBM_FRAME, E * CBM_FRAME, hipMemcpyDeviceToDevice, sl.stream));
+    CBM_HIP(hipMemcpyAsync(R.dones + d0, Pv.dones + so, E, hipMemcpyDeviceToDevice, sl.stream));
+    CBM_HIP(hipMemcpyAsync(R.firststeps + d0, Pv.firststeps + so, E, hipMemcpyDeviceToDevice, sl.stream));
+    if (!is_ppo(c)) {
+      CBM_HIP(hipMemcpyAsync(R.actions + d0, Pv.actions + so, E * 4, hipMemcpyDeviceToDevice, sl.stream));
+      CBM_HIP(hipMemcpyAsync(R.rewards + d0, Pv.rewards + so, E * 4, hipMemcpyDeviceToDevice, sl.stream));
+      CBM_HIP(hipMemcpyAsync(R.logits + d0 * c->A, Pv.logits + so * c->A, E * c->A * 4, hipMemcpyDeviceToDevice, sl.stream));
+      sl.t = 1;
+    }
+  }
+  if (policy_version) *policy_version = need + 1;
+  return 0;
+}
+
+// get_action_and_value on ring row t of slot s + Gumbel sampling, results stored into the row
+static void actor_infer_row(cbm_ctx* c, int s, int t) {
+  Slot& sl = c->slots[s];
+  RingEntry& R = c->ring[sl.ring];
+  const size_t o = row_off(c, t, s);
+  nature_forward(c->L, c->actor_params[sl.pver % NPV], R.obs + o * CBM_FRAME, nullptr, c->E, c->cfg.actor_dense_ksplit, sl.ws, sl.stream);
+  uint32_t n0, n1, s0, s1;  // key, subkey = jax.random.split(key)  (ppo:256)
+  cbm_split_at(sl.key[0], sl.key[1], 2, 0, &n0, &n1);
+  cbm_split_at(sl.key[0], sl.key[1], 2, 1, &s0, &s1);
+  sl.key[0] = n0; sl.key[1] = n1;
+  if (is_ppo(c))
+    launch_sample(sl.ws.logits, c->E, c->A, s0, s1, R.actions + o, R.logprobs + o, sl.ws.value, R.values + o, nullptr, sl.stream);
+  else
+    launch_sample(sl.ws.logits, c->E, c->A, s0, s1, R.actions + o, nullptr, nullptr, nullptr, R.logits + o * c->A, sl.stream);
+}
+
+extern "C" int cbm_actor_step_host(cbm_ctx* c, int32_t s, const uint8_t* obs, const uint8_t* done, const uint8_t* firststep,
+                                   const float* reward_with_obs, int32_t* actions_out) {
+  Slot& sl = c->slots[s];
+  CBM_HIP(hipSetDevice(c->cfg.device));
+  if (sl.t > c->T) { cbm_set_error("rollout overrun: t=%d", sl.t); return -1; }
+  RingEntry& R = c->ring[sl.ring];
+  const size_t o = row_off(c, sl.t, s);
+  const size_t E = (size_t)c->E;
+  CBM_HIP(hipMemcpyAsync(R.obs + o * CBM_FRAME, obs, E * CBM_FRAME, hipMemcpyHostToDevice, sl.stream));
+  if (done) CBM_HIP(hipMemcpyAsync(R.dones + o, done, E, hipMemcpyHostToDevice, sl.stream));
+  if (firststep) CBM_HIP(hipMemcpyAsync(R.firststeps + o, firststep, E, hipMemcpyHostToDevice, sl.stream));
+  if (reward_with_obs) CBM_HIP(hipMemcpyAsync(R.rewards + o, reward_with_obs, E * 4, hipMemcpyHostToDevice, sl.stream));
+  actor_infer_row(c, s, sl.t);
+  CBM_HIP(hipMemcpyAsync(actions_out, R.actions + o, E * 4, hipMemcpyDeviceToHost, sl.stream));
+  CBM_HIP(hipStreamSynchronize(sl.stream));  // the per-step D2H sync of ppo:317
+  sl.t += 1;
+  return 0;
+}
+extern "C" int cbm_actor_record_host(cbm_ctx* c, int32_t s, const float* reward) {
+  Slot& sl = c->slots[s];
+  CBM_HIP(hipSetDevice(c->cfg.device));
+  RingEntry& R = c->ring[sl.ring];
+  const size_t o = row_off(c, sl.t - 1, s);
+  CBM_HIP(hipMemcpyAsync(R.rewards + o, reward, (size_t)c->E * 4, hipMemcpyHostToDevice, sl.stream));
+  return 0;
+}
+
+extern "C" int cbm_actor_rollout_device(cbm_ctx* c, int32_t s, int32_t nsteps) {
+  Slot& sl = c->slots[s];
+  CBM_HIP(hipSetDevice(c->cfg.device));
+  if (!sl.env_inited) { cbm_set_error("device env not reset: call cbm_actor_env_reset_device first"); return -1; }
+  RingEntry& R = c->ring[sl.ring];
+  const int max_steps = 27000;  // ATARI_MAX_FRAMES ppo:121-123
+  if (is_ppo(c)) {
+    for (int i = 0; i < nsteps; ++i) {
+      const int t = sl.t;
+      if (t >= c->T) { cbm_set_error("rollout overrun"); return -1; }
+      actor_infer_row(c, s, t);
+      const size_t o = row_off(c, t, s), o1 = row_off(c, t + 1, s);
+      launch_env_step(sl.env_seed, c->E, max_steps, R.actions + o, sl.env_state, R.obs + o * CBM_FRAME, R.obs + o1 * CBM_FRAME, R.rewards + o,
+                      R.dones + o1, R.firststeps + o1, sl.stream);
+      sl.t += 1;
+    }
+  } else {
+    // IMPALA: row t holds what arrived with obs_t; stepping with action_t fills row t+1 (impala:352-384).
+    if (sl.t == 1 && sl.rollout >= 2) {  // carried transition: its action has not been sent to the env yet
+      const size_t o = row_off(c, 0, s), o1 = row_off(c, 1, s);
+      launch_env_step(sl.env_seed, c->E, max_steps, R.actions + o, sl.env_state, R.obs + o * CBM_FRAME, R.obs + o1 * CBM_FRAME, R.rewards + o1,
+                      R.dones + o1, R.firststeps + o1, sl.stream);
+    }
+    for (int i = 0; i < nsteps; ++i) {
+      const int t = sl.t;
+      if (t > c->T) { cbm_set_error("rollout overrun"); return -1; }
+      actor_infer_row(c, s, t);
+      if (t < c->T) {
+        const size_t o = row_off(c, t, s), o1 = row_off(c, t + 1, s);
+        launch_env_step(sl.env_seed, c->E, max_steps, R.actions + o, sl.env_state, R.obs + o * CBM_FRAME, R.obs + o1 * CBM_FRAME, R.rewards + o1,
+                        R.dones + o1, R.firststeps + o1, sl.stream);
+      }
+      sl.t += 1;
+    }
+  }
+  return 0;
+}
+
+extern "C" int cbm_actor_commit(cbm_ctx* c, int32_t s, const uint8_t* next_obs, const uint8_t* next_done) {
+  Slot& sl = c->slots[s];
+  CBM_HIP(hipSetDevice(c->cfg.device));
+  RingEntry& R = c->ring[sl.ring];
+  if (next_obs) {
+    const size_t o = row_off(c, c->T, s);
+    CBM_HIP(hipMemcpyAsync(R.obs + o * CBM_FRAME, next_obs, (size_t)c->E * CBM_FRAME, hipMemcpyHostToDevice, sl.stream));
+    if (next_done) CBM_HIP(hipMemcpyAsync(R.dones + o, next_done, (size_t)c->E, hipMemcpyHostToDevice, sl.stream));
+    CBM_HIP(hipStreamSynchronize(sl.stream));  // host buffers may be reused by the caller
+  }
+  CBM_HIP(hipEventRecord(R.ready[s], sl.stream));
+  {
+    std::lock_guard<std::mutex> lk(c->mu);
+    c->committed[s] = sl.rollout;
+  }
+  c->cv.notify_all();
+  return 0;
+}
+
+extern "C" int cbm_actor_episode_stats(cbm_ctx* c, int32_t s, float* avg_return, float* avg_length) {
+  Slot& sl = c->slots[s];
+  CBM_HIP(hipSetDevice(c->cfg.device));
+  float h[2] = {0, 0};
+  launch_env_stats(sl.env_state, c->E, sl.stats_dev, sl.stream);
+  CBM_HIP(hipMemcpyAsync(h, sl.stats_dev, 8, hipMemcpyDeviceToHost, sl.stream));
+  CBM_HIP(hipStreamSynchronize(sl.stream));
+  if (avg_return) *avg_return = h[0];
+  if (avg_length) *avg_length = h[1];
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------ learner
+extern "C" int cbm_learner_wait(cbm_ctx* c) {
+  CBM_HIP(hipSetDevice(c->cfg.device));
+  const int v = c->updates_done + 1;
+  {
+    std::unique_lock<std::mutex> lk(c->mu);
+    c->cv.wait(lk, [&] { for (int s = 0; s < c->S; ++s) if (c->committed[s] < v) return false; return true; });
+  }
+  RingEntry& R = c->ring[(v - 1) % c->cfg.ring_depth];
+  for (int s = 0; s < c->S; ++s) CBM_HIP(hipStreamWaitEvent(c->lstream, R.ready[s], 0));
+  return 0;
+}
+
+static RingEntry& cur_ring(cbm_ctx* c) { return c->ring[c->updates_done % c->cfg.ring_depth]; }
+
+extern "C" int cbm_learner_prepare(cbm_ctx* c, uint32_t key[2]) {
+  (void)key;
+  CBM_HIP(hipSetDevice(c->cfg.device));
+  if (!is_ppo(c)) return 0;
+  RingEntry& R = cur_ring(c);
+  const int B = c->Bdev, T = c->T;
+  // compute_gae ppo:543-560: bootstrap value with the LEARNER's params on next_obs (row T)
+  nature_forward(c->L, c->params, R.obs + (size_t)T * B * CBM_FRAME, nullptr, B, c->cfg.actor_dense_ksplit, c->lws, c->lstream);
+  CBM_HIP(hipMemcpyAsync(c->next_value, c->lws.value, (size_t)B * 4, hipMemcpyDeviceToDevice, c->lstream));
+  launch_gae(R.rewards, R.values, R.dones, c->next_value, R.dones + (size_t)T * B, T, B, c->cfg.gamma, c->cfg.gae_lambda, c->adv, c->target, c->lstream);
+  if (c->cfg.norm_adv) launch_advnorm(c->adv, T, B, c->nmb, c->lstream);
+  return 0;
+}
+
+static int learner_epoch_perm(cbm_ctx* c, uint32_t key[2]) {
+  // key, subkey = split(key); perm = permutation(subkey, N)   (ppo:599,606)
+  uint32_t n0, n1, s0, s1;
+  cbm_split_at(key[0], key[1], 2, 0, &n0, &n1);
+  cbm_split_at(key[0], key[1], 2, 1, &s0, &s1);
+  key[0] = n0; key[1] = n1;
+  const uint32_t sub[2] = {s0, s1};
+  launch_permutation(sub, c->T * c->Bdev, c->perm, c->perm_tmp, c->ckeys, c->lstream);
+  return 0;
+}
+
+extern "C" int cbm_learner_minibatch_grad(cbm_ctx* c, int32_t epoch, int32_t mb) {
+  CBM_HIP(hipSetDevice(c->cfg.device));
+  RingEntry& R = cur_ring(c);
+  float* stats = c->stats_dev + (size_t)(epoch * c->nmb + mb) * 8;
+  if (is_ppo(c)) {
+    const int32_t* idx = c->perm + (size_t)mb * c->MB;
+    nature_forward(c->L, c->params, R.obs, idx, c->MB, 1, c->lws, c->lstream);
+    launch_ppo_loss(c->lws.logits, c->lws.value, c->MB, c->A, idx, R.actions, R.logprobs, c->adv, c->target, c->cfg.clip_coef, c->cfg.ent_coef,
+                    c->cfg.vf_coef, c->lws.dzv, c->loss_partials, stats, c->lstream);
+    nature_backward(c->L, c->params, R.obs, idx, c->MB, c->lws, c->grads, c->lstream);
+  } else {
+    const int Bm = c->Bdev / c->nmb;
+    const int32_t* idx = c->impala_idx + (size_t)mb * c->MB;
+    nature_forward(c->L, c->params, R.obs, idx, c->MB, 1, c->lws, c->lstream);
+    launch_impala_loss(c->lws.logits, c->lws.value, R.logits, R.actions, R.rewards, R.dones, R.firststeps, c->T1, Bm, c->A, mb * Bm, c->Bdev,
+                       c->cfg.gamma, c->cfg.vf_coef, c->cfg.ent_coef, c->lws.dzv, c->loss_partials, stats, c->lstream);
+    nature_backward(c->L, c->params, R.obs, idx, c->MB, c->lws, c->grads, c->lstream);
+  }
+  return 0;
+}
+
+extern "C" int cbm_learner_optimizer_step(cbm_ctx* c, float lr, float bc1, float bc2, float grad_div) {
+  CBM_HIP(hipSetDevice(c->cfg.device));
+  if (is_ppo(c))
+    launch_adam(c->params, c->grads, c->opt_m, c->opt_v, c->P, c->cfg.max_grad_norm, lr, c->cfg.adam_b1, c->cfg.adam_b2, c->cfg.adam_eps, bc1, bc2,
+                grad_div, c->norm_partials, c->lstream);
+  else
+    launch_rmsprop(c->params, c->grads, c->opt_m, c->P, c->cfg.max_grad_norm, lr, c->cfg.rms_decay, c->cfg.rms_eps, grad_div, c->norm_partials,
+                   c->lstream);
+  return 0;
+}
+
+extern "C" int cbm_learner_finish(cbm_ctx* c, float* stats_out) {
+  CBM_HIP(hipSetDevice(c->cfg.device));
+  const int v = c->updates_done + 1;
+  RingEntry& R = cur_ring(c);
+  // publish params version v to the actors (ppo:721-725): D2D copy + event, no host sync
+  CBM_HIP(hipMemcpyAsync(c->actor_params[v % NPV], c->params, (size_t)c->P * 4, hipMemcpyDeviceToDevice, c->lstream));
+  CBM_HIP(hipEventRecord(c->params_ready[v % NPV], c->lstream));
+  CBM_HIP(hipEventRecord(R.consumed, c->lstream));
+  if (stats_out) {
+    const int w = is_ppo(c) ? 5 : 4;
+    std::vector<float> h((size_t)c->stat_rows * 8);
+    CBM_HIP(hipMemcpyAsync(h.data(), c->stats_dev, h.size() * 4, hipMemcpyDeviceToHost, c->lstream));
+    CBM_HIP(hipStreamSynchronize(c->lstream));
+    for (int r = 0; r < c->stat_rows; ++r) for (int q = 0; q < w; ++q) stats_out[r * w + q] = h[(size_t)r * 8 + q];
+  }
+  {
+    std::lock_guard<std::mutex> lk(c->mu);
+    c->updates_done = v;
+  }
+  c->cv.notify_all();
+  return 0;
+}
+
+extern "C" int cbm_learner_update(cbm_ctx* c, uint32_t key[2], const float* lrs, const float* bc1, const float* bc2, int32_t n_opt_steps,
+                                  float* stats_out) {
+  if (n_opt_steps != c->epochs * c->nmb) { cbm_set_error("n_opt_steps must be epochs*minibatches = %d", c->epochs * c->nmb); return -1; }
+  if (cbm_learner_prepare(c, key)) return -1;
+  int step = 0;
+  for (int e = 0; e < c->epochs; ++e) {
+    if (is_ppo(c)) learner_epoch_perm(c, key);
+    for (int mb = 0; mb < c->nmb; ++mb, ++step) {
+      if (cbm_learner_minibatch_grad(c, e, mb)) return -1;
+      if (cbm_learner_optimizer_step(c, lrs[step], bc1 ? bc1[step] : 1.0f, bc2 ? bc2[step] : 1.0f, 1.0f)) return -1;
+    }
+  }
+  return cbm_learner_finish(c, stats_out);
+}
+
+// epoch permutation for the split (data-parallel) form
+extern "C" int cbm_learner_epoch_begin(cbm_ctx* c, uint32_t key[2]) {
+  CBM_HIP(hipSetDevice(c->cfg.device));
+  if (is_ppo(c)) return learner_epoch_perm(c, key);
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------ pure functions
+static int check_B(cbm_ctx* c, int B) {
+  if (B > c->lws.maxB) { cbm_set_error("B=%d exceeds the learner workspace (%d frames)", B, c->lws.maxB); return -1; }
+  return 0;
+}
+extern "C" int cbm_forward(cbm_ctx* c, const float* params, const uint8_t* obs, const int32_t* idx, int32_t B, int32_t ksplit, float* logits,
+                           float* value) {
+  CBM_HIP(hipSetDevice(c->cfg.device));
+  if (check_B(c, B)) return -1;
+  if (ksplit > 1 && (B > 512 || ksplit != c->lws.dense_part_ksplit || !c->lws.dense_part)) {
+    // a split-K plan needs its partial buffer; allocate on demand for tests
+    if (c->lws.dense_part) hipFree(c->lws.dense_part);
+    CBM_HIP(hipMalloc((void**)&c->lws.dense_part, (size_t)ksplit * c->lws.maxB * 512 * 4));
+    c->lws.dense_part_ksplit = ksplit;
+  }
+  nature_forward(c->L, params, obs, idx, B, ksplit, c->lws, c->lstream);
+  if (logits) CBM_HIP(hipMemcpyAsync(logits, c->lws.logits, (size_t)B * c->A * 4, hipMemcpyDeviceToDevice, c->lstream));
+  if (value) CBM_HIP(hipMemcpyAsync(value, c->lws.value, (size_t)B * 4, hipMemcpyDeviceToDevice, c->lstream));
+  CBM_HIP(hipStreamSynchronize(c->lstream));
+  return 0;
+}
+extern "C" int cbm_sample(cbm_ctx* c, const float* logits, int32_t B, const uint32_t sub[2], int32_t* actions, float* logprobs) {
+  CBM_HIP(hipSetDevice(c->cfg.device));
+  launch_sample(logits, B, c->A, sub[0], sub[1], actions, logprobs, nullptr, nullptr, nullptr, c->lstream);
+  CBM_HIP(hipStreamSynchronize(c->lstream));
+  return 0;
+}
+extern "C" int cbm_gae(cbm_ctx* c, const float* rewards, const float* values, const uint8_t* dones, const float* next_value,
+                       const uint8_t* next_done, int32_t T, int32_t B, float* adv, float* target) {
+  CBM_HIP(hipSetDevice(c->cfg.device));
+  launch_gae(rewards, values, dones, next_value, next_done, T, B, c->cfg.gamma, c->cfg.gae_lambda, adv, target, c->lstream);
+  CBM_HIP(hipStreamSynchronize(c->lstream));
+  return 0;
+}
+extern "C" int cbm_advnorm(cbm_ctx* c, float* adv, int32_t T, int32_t B, int32_t groups) {
+  CBM_HIP(hipSetDevice(c->cfg.device));
+  launch_advnorm(adv, T, B, groups, c->lstream);
+  CBM_HIP(hipStreamSynchronize(c->lstream));
+  return 0;
+}
+extern "C" int cbm_permutation(cbm_ctx* c, const uint32_t key[2], int32_t n, int32_t* perm) {
+  CBM_HIP(hipSetDevice(c->cfg.device));
+  int32_t* tmp = nullptr; uint64_t* ck = nullptr;
+  CBM_HIP(hipMalloc((void**)&tmp, (size_t)n * 4));
+  CBM_HIP(hipMalloc((void**)&ck, (size_t)n * 8));
+  launch_permutation(key, n, perm, tmp, ck, c->lstream);
+  CBM_HIP(hipStreamSynchronize(c->lstream));
+  hipFree(tmp); hipFree(ck);
+  return 0;
+}
+extern "C" int cbm_ppo_loss_grad(cbm_ctx* c, const float* params, const uint8_t* obs, const int32_t* idx, int32_t N, const int32_t* actions,
+                                 const float* old_logprob, const float* adv, const float* target, float* stats5, float* grads, float* logits_out,
+                                 float* value_out) {
+  CBM_HIP(hipSetDevice(c->cfg.device));
+  if (check_B(c, N)) return -1;
+  nature_forward(c->L, params, obs, idx, N, 1, c->lws, c->lstream);
+  launch_ppo_loss(c->lws.logits, c->lws.value, N, c->A, nullptr, actions, old_logprob, adv, target, c->cfg.clip_coef, c->cfg.ent_coef,
+                  c->cfg.vf_coef, c->lws.dzv, c->loss_partials, stats5, c->lstream);
+  if (grads) nature_backward(c->L, params, obs, idx, N, c->lws, grads, c->lstream);
+  if (logits_out) CBM_HIP(hipMemcpyAsync(logits_out, c->lws.logits, (size_t)N * c->A * 4, hipMemcpyDeviceToDevice, c->lstream));
+  if (value_out) CBM_HIP(hipMemcpyAsync(value_out, c->lws.value, (size_t)N * 4, hipMemcpyDeviceToDevice, c->lstream));
+  CBM_HIP(hipStreamSynchronize(c->lstream));
+  return 0;
+}
+extern "C" int cbm_impala_loss_grad(cbm_ctx* c, const float* params, const uint8_t* obs, const int32_t* idx, int32_t T1, int32_t Bm,
+                                    const float* mu_logits, const int32_t* actions, const float* rewards, const uint8_t* dones,
+                                    const uint8_t* firststeps, float* stats4, float* grads) {
+  CBM_HIP(hipSetDevice(c->cfg.device));
+  const int N = T1 * Bm;
+  if (check_B(c, N)) return -1;
+  nature_forward(c->L, params, obs, idx, N, 1, c->lws, c->lstream);
+  float* partials = nullptr;
+  CBM_HIP(hipMalloc((void**)&partials, (size_t)Bm * 3 * 4 + 64));
+  launch_impala_loss(c->lws.logits, c->lws.value, mu_logits, actions, rewards, dones, firststeps, T1, Bm, c->A, 0, Bm, c->cfg.gamma, c->cfg.vf_coef,
+                     c->cfg.ent_coef, c->lws.dzv, partials, stats4, c->lstream);
+  if (grads) nature_backward(c->L, params, obs, idx, N, c->lws, grads, c->lstream);
+  CBM_HIP(hipStreamSynchronize(c->lstream));
+  hipFree(partials);
+  return 0;
+}
+extern "C" int cbm_adam_step(cbm_ctx* c, float* p, const float* g, float* m, float* v, int64_t n, float max_norm, float lr, float bc1, float bc2,
+                             float grad_div) {
+  CBM_HIP(hipSetDevice(c->cfg.device));
+  launch_adam(p, g, m, v, n, max_norm, lr, c->cfg.adam_b1, c->cfg.adam_b2, c->cfg.adam_eps, bc1, bc2, grad_div, c->norm_partials, c->lstream);
+  CBM_HIP(hipStreamSynchronize(c->lstream));
+  return 0;
+}
+extern "C" int cbm_rmsprop_step(cbm_ctx* c, float* p, const float* g, float* nu, int64_t n, float max_norm, float lr, float grad_div) {
+  CBM_HIP(hipSetDevice(c->cfg.device));
+  launch_rmsprop(p, g, nu, n, max_norm, lr, c->cfg.rms_decay, c->cfg.rms_eps, grad_div, c->norm_partials, c->lstream);
+  CBM_HIP(hipStreamSynchronize(c->lstream));
+  return 0;
+}

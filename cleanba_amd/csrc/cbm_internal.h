@@ -1,0 +1,81 @@
+// cbm_internal.h — internal C++ interfaces between the translation units of libcleanba_mi.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/cleanba_mi.h"
+#include "../../include/cbm_math.h"
+
+#define CBM_FRAME 28224  // 4*84*84 uint8
+
+// ---- parameter layout (flax shapes): Nature-CNN ------------------------------
+struct NatureLayout {
+  int A;
+  int64_t w[6], b[6];  // 0 conv1, 1 conv2, 2 conv3, 3 dense, 4 actor, 5 critic
+  int64_t total;
+};
+NatureLayout nature_layout(int A);
+
+// ---- workspace for running the network on up to maxB frames ----------------------------
+struct NatureWs {
+  int maxB = 0;
+  bool with_grad = false;
+  float *act1 = nullptr, *act2 = nullptr, *act3 = nullptr, *hid = nullptr;
+  float *logits = nullptr, *value = nullptr;
+  float* dense_part = nullptr;  // [ksplit][maxB][512] when maxB is small
+  int dense_part_ksplit = 0;
+  // backward
+  float *dzv = nullptr, *dhid = nullptr, *dact3pad = nullptr, *dact2pad = nullptr, *dact1 = nullptr;
+  float *wg_part = nullptr, *bias_part = nullptr;
+  int64_t wg_part_floats = 0, bias_part_floats = 0;
+};
+int nature_ws_alloc(NatureWs& ws, int maxB, bool with_grad, int dense_ksplit_small);
+void nature_ws_free(NatureWs& ws);
+
+// forward: obs[idx[b]] (idx may be null) -> ws.logits [B,A], ws.value [B]; activations kept in ws.
+void nature_forward(const NatureLayout& L, const float* P, const uint8_t* obs, const int32_t* idx, int B,
+                    int dense_ksplit, NatureWs& ws, hipStream_t st);
+// backward from ws.dzv ([B][32]: dlogits | dvalue | 0) -> grads (flat, same layout as params).
+void nature_backward(const NatureLayout& L, const float* P, const uint8_t* obs, const int32_t* idx, int B,
+                     NatureWs& ws, float* grads, hipStream_t st);
+
+// ---- pointwise / scan kernels -----------------------------------------------------------
+void launch_sample(const float* logits, int B, int A, uint32_t sk0, uint32_t sk1, int32_t* actions, float* logprobs,
+                   const float* value_in, float* value_out, float* logits_out, hipStream_t st);
+void launch_gae(const float* rewards, const float* values, const uint8_t* dones, const float* next_value,
+                const uint8_t* next_done, int T, int B, float gamma, float lambda, float* adv, float* target,
+                hipStream_t st);
+void launch_advnorm(float* adv, int T, int B, int groups, hipStream_t st);
+// perm = jax.random.permutation(key, n): host does the key splits, device the bits + stable sorts.
+void launch_permutation(const uint32_t key[2], int n, int32_t* perm, int32_t* tmp, uint64_t* ckeys, hipStream_t st);
+void launch_ppo_loss(const float* logits, const float* value, int N, int A, const int32_t* idx, const int32_t* actions,
+                     const float* old_logprob, const float* adv, const float* target, float clip_coef, float ent_coef,
+                     float vf_coef, float* dzv, float* partials, float* stats5, hipStream_t st);
+void launch_impala_loss(const float* logits, const float* value, const float* mu_logits, const int32_t* actions,
+                        const float* rewards, const uint8_t* dones, const uint8_t* firststeps, int T1, int Bm, int A,
+                        int col0, int ld, float gamma, float vf_coef, float ent_coef, float* dzv, float* partials,
+                        float* stats4, hipStream_t st);
+void launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float max_norm, float lr, float b1, float b2,
+                 float eps, float bc1, float bc2, float grad_div, float* norm_partials, hipStream_t st);
+void launch_rmsprop(float* p, const float* g, float* nu, int64_t n, float max_norm, float lr, float decay, float eps,
+                    float grad_div, float* norm_partials, hipStream_t st);
+#define CBM_NORM_PARTS 512
+
+// ---- synthetic env ------------------------------------------------------------------------
+void launch_env_reset(uint32_t seed, int E, cbm_env_state* st_dev, uint8_t* obs, int64_t obs_stride, uint8_t* done,
+                      uint8_t* firststep, hipStream_t st);
+void launch_env_step(uint32_t seed, int E, int max_episode_steps, const int32_t* actions, cbm_env_state* st_dev,
+                     const uint8_t* obs_prev, uint8_t* obs_next, float* reward, uint8_t* done_next,
+                     uint8_t* firststep_next, hipStream_t st);
+void launch_env_stats(const cbm_env_state* st_dev, int E, float* out2, hipStream_t st);
+
+// error plumbing
+void cbm_set_error(const char* fmt, ...);
+#define CBM_HIP(call)                                                                      \
+  do {                                                                                     \
+    hipError_t e_ = (call);                                                                \
+    if (e_ != hipSuccess) {                                                                \
+      cbm_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return -1;                                                                           \
+    }                                                                                      \
+  } while (0)

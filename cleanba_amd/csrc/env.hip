@@ -1,0 +1,209 @@
+// env.hip — synthetic Atari-shaped vector environment (stands in for envpool.make(...), ppo:128-139).
+//
+// Breakout-shaped 84x84 frames, 4-frame stacks, pure-integer dynamics keyed by (seed, env_id, episode,
+// step, action): the same functions are compiled for the GPU (device env: frames are rendered straight
+// into the HBM rollout ring, no host round trip) and for the CPU (host env with envpool's numpy API), so
+// the two produce identical bytes (tests/test_env.py).
+//
+// envpool semantics kept: auto-reset on the step after `done` (that step returns the first
+// observation of the new episode with reward 0 and elapsed_step 0), `terminated` w.p. ~1/800 per step,
+// clipped reward in {0,1} w.p. ~0.02, truncation at max_episode_steps (ppo:121-123,328).
+#include "cbm_internal.h"
+#include <string.h>
+
+#define PADDLE_W 12
+#define NBRICK 84  // 6 rows x 14 columns, 28 bits per state word
+
+CBM_HD uint32_t env_hash(uint32_t seed, uint32_t env_id, uint32_t a, uint32_t b) {
+  uint32_t o0, o1;
+  cbm_threefry2x32(seed, env_id, a, b, &o0, &o1);
+  return o0 ^ (o1 >> 3);
+}
+
+CBM_HD void env_new_episode(cbm_env_state* s, uint32_t seed, uint32_t env_id) {
+  s->episode += 1u;
+  const uint32_t h = env_hash(seed, env_id, s->episode, 0x9E3779B9u);
+  s->elapsed = 0;
+  s->needs_reset = 0;
+  s->paddle_x = 36;
+  s->ball_x = 4 + (int32_t)(h % 72u);
+  s->ball_y = 40;
+  s->ball_dx = (h >> 8) & 1u ? 2 : -2;
+  s->ball_dy = 2;
+  s->bricks[0] = s->bricks[1] = s->bricks[2] = 0x0FFFFFFFu;
+}
+
+// one env.step(action); returns clipped reward, sets *terminated / *truncated
+CBM_HD float env_advance(cbm_env_state* s, uint32_t seed, uint32_t env_id, int32_t action, int32_t max_steps, int* terminated,
+                         int* truncated) {
+  s->elapsed += 1;
+  const int dir = action % 3;
+  int px = s->paddle_x + (dir == 1 ? 4 : (dir == 2 ? -4 : 0));
+  s->paddle_x = px < 1 ? 1 : (px > 83 - PADDLE_W ? 83 - PADDLE_W : px);
+  int bx = s->ball_x + s->ball_dx, by = s->ball_y + s->ball_dy;
+  if (bx < 1) { bx = 1; s->ball_dx = -s->ball_dx; }
+  if (bx > 81) { bx = 81; s->ball_dx = -s->ball_dx; }
+  if (by < 12) { by = 12; s->ball_dy = -s->ball_dy; }
+  if (by > 75) { by = 75; s->ball_dy = -s->ball_dy; }
+  s->ball_x = bx; s->ball_y = by;
+  // events depend on the action through the paddle position: nothing can be precomputed
+  const uint32_t h = env_hash(seed ^ (s->episode * 0x85EBCA6Bu), env_id, (uint32_t)s->elapsed, (uint32_t)s->paddle_x);
+  float reward = 0.0f;
+  if ((h & 0xFFFFu) < 1311u) {  // ~0.02
+    reward = 1.0f;
+    uint32_t k = (h >> 7) % NBRICK;
+    for (int tries = 0; tries < NBRICK; ++tries) {  // clear the next standing brick
+      const uint32_t w = k / 28u, bit = k % 28u;
+      if (s->bricks[w] & (1u << bit)) { s->bricks[w] &= ~(1u << bit); break; }
+      k = (k + 1u) % NBRICK;
+    }
+    if ((s->bricks[0] | s->bricks[1] | s->bricks[2]) == 0u) s->bricks[0] = s->bricks[1] = s->bricks[2] = 0x0FFFFFFFu;
+  }
+  *terminated = ((h >> 16) & 0xFFFFu) < 82u ? 1 : 0;  // ~1/800
+  *truncated = s->elapsed >= max_steps ? 1 : 0;
+  return reward;
+}
+
+CBM_HD uint8_t env_pixel(const cbm_env_state* s, int y, int x) {
+  if (y >= 17 && y < 35) {  // six brick rows, 2 px tall + 1 px gap; 14 bricks of 5 px + 1 px gap
+    const int row = (y - 17) / 3, ry = (y - 17) % 3, col = x / 6, rx = x % 6;
+    if (ry < 2 && rx < 5) {
+      const int k = row * 14 + col;
+      if (s->bricks[k / 28] & (1u << (k % 28))) return (uint8_t)(200 - 24 * row);
+    }
+    return 0;
+  }
+  if (y >= 78 && y < 80 && x >= s->paddle_x && x < s->paddle_x + PADDLE_W) return 200;
+  if (y >= s->ball_y && y < s->ball_y + 2 && x >= s->ball_x && x < s->ball_x + 2) return 255;
+  if (y >= 10 && y < 12) return 142;
+  if (y >= 12 && (x == 0 || x == 83)) return 142;
+  return 0;
+}
+
+// full transition of one env given its previous frame stack; pixel work done by the caller's threads
+struct EnvOut { float reward; uint8_t done, terminated, firststep, was_reset; int32_t elapsed; };
+
+CBM_HD EnvOut env_transition(cbm_env_state* s, uint32_t seed, uint32_t env_id, int32_t action, int32_t max_steps) {
+  EnvOut o;
+  if (s->needs_reset) {
+    env_new_episode(s, seed, env_id);
+    o.reward = 0.0f; o.done = 0; o.terminated = 0; o.firststep = 1; o.was_reset = 1; o.elapsed = 0;
+    return o;
+  }
+  int term = 0, trunc = 0;
+  o.reward = env_advance(s, seed, env_id, action, max_steps, &term, &trunc);
+  o.terminated = (uint8_t)term;
+  o.done = (uint8_t)(term | trunc);
+  o.firststep = 0; o.was_reset = 0; o.elapsed = s->elapsed;
+  s->ep_return += o.reward;
+  s->ep_length += 1.0f;
+  if (o.done) {
+    s->ret_return = s->ep_return; s->ret_length = s->ep_length;
+    s->ep_return = 0.0f; s->ep_length = 0.0f;
+    s->needs_reset = 1;
+  }
+  return o;
+}
+
+// ------------------------------------------------------------------------------------------ device
+__global__ __launch_bounds__(256) void env_reset_kernel(uint32_t seed, int E, cbm_env_state* st, uint8_t* obs, int64_t stride,
+                                                         uint8_t* done, uint8_t* firststep) {
+  __shared__ cbm_env_state s;
+  const int e = blockIdx.x;
+  if (threadIdx.x == 0) {
+    s = cbm_env_state();
+    s.episode = 0;
+    env_new_episode(&s, seed, (uint32_t)e);
+    st[e] = s;
+    if (done) done[e] = 0;
+    if (firststep) firststep[e] = 1;
+  }
+  __syncthreads();
+  uint8_t* o = obs + (size_t)e * stride;
+  for (int i = threadIdx.x; i < 7056; i += 256) {
+    const uint8_t v = env_pixel(&s, i / 84, i % 84);
+    o[i] = v; o[7056 + i] = v; o[2 * 7056 + i] = v; o[3 * 7056 + i] = v;
+  }
+}
+void launch_env_reset(uint32_t seed, int E, cbm_env_state* st_dev, uint8_t* obs, int64_t obs_stride, uint8_t* done, uint8_t* firststep,
+                      hipStream_t st) {
+  hipLaunchKernelGGL(env_reset_kernel, dim3(E), dim3(256), 0, st, seed, E, st_dev, obs, obs_stride, done, firststep);
+}
+
+__global__ __launch_bounds__(256) void env_step_kernel(uint32_t seed, int E, int max_steps, const int32_t* actions, cbm_env_state* st,
+                                                        const uint8_t* obs_prev, uint8_t* obs_next, float* reward, uint8_t* done_next,
+                                                        uint8_t* firststep_next) {
+  __shared__ cbm_env_state s;
+  __shared__ EnvOut out;
+  const int e = blockIdx.x;
+  if (threadIdx.x == 0) {
+    s = st[e];
+    out = env_transition(&s, seed, (uint32_t)e, actions[e], max_steps);
+    st[e] = s;
+    reward[e] = out.reward;
+    done_next[e] = out.done;
+    if (firststep_next) firststep_next[e] = out.firststep;
+  }
+  __syncthreads();
+  const uint8_t* p = obs_prev + (size_t)e * CBM_FRAME;
+  uint8_t* o = obs_next + (size_t)e * CBM_FRAME;
+  const bool rs = out.was_reset;
+  // 4-byte granularity: 1764 words per plane
+  const uint32_t* p32 = reinterpret_cast<const uint32_t*>(p);
+  uint32_t* o32 = reinterpret_cast<uint32_t*>(o);
+  for (int i = threadIdx.x; i < 1764; i += 256) {
+    const int y = (4 * i) / 84, x = (4 * i) % 84;
+    const uint32_t nw = (uint32_t)env_pixel(&s, y, x) | ((uint32_t)env_pixel(&s, y, x + 1) << 8) | ((uint32_t)env_pixel(&s, y, x + 2) << 16) |
+                        ((uint32_t)env_pixel(&s, y, x + 3) << 24);
+    if (rs) { o32[i] = nw; o32[1764 + i] = nw; o32[2 * 1764 + i] = nw; }
+    else { o32[i] = p32[1764 + i]; o32[1764 + i] = p32[2 * 1764 + i]; o32[2 * 1764 + i] = p32[3 * 1764 + i]; }
+    o32[3 * 1764 + i] = nw;
+  }
+}
+void launch_env_step(uint32_t seed, int E, int max_episode_steps, const int32_t* actions, cbm_env_state* st_dev, const uint8_t* obs_prev,
+                     uint8_t* obs_next, float* reward, uint8_t* done_next, uint8_t* firststep_next, hipStream_t st) {
+  hipLaunchKernelGGL(env_step_kernel, dim3(E), dim3(256), 0, st, seed, E, max_episode_steps, actions, st_dev, obs_prev, obs_next, reward,
+                     done_next, firststep_next);
+}
+
+__global__ void env_stats_kernel(const cbm_env_state* st, int E, float* out2) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float r = 0.0f, l = 0.0f;
+  for (int e = 0; e < E; ++e) { r += st[e].ret_return; l += st[e].ret_length; }
+  out2[0] = r / (float)E; out2[1] = l / (float)E;
+}
+void launch_env_stats(const cbm_env_state* st_dev, int E, float* out2, hipStream_t st) {
+  hipLaunchKernelGGL(env_stats_kernel, dim3(1), dim3(64), 0, st, st_dev, E, out2);
+}
+
+// ------------------------------------------------------------------------------------------ host twin
+extern "C" int cbm_synth_env_reset_host(uint32_t seed, int32_t n, cbm_env_state* st, uint8_t* obs) {
+  for (int e = 0; e < n; ++e) {
+    cbm_env_state s = cbm_env_state();
+    env_new_episode(&s, seed, (uint32_t)e);
+    st[e] = s;
+    uint8_t* o = obs + (size_t)e * CBM_FRAME;
+    for (int i = 0; i < 7056; ++i) {
+      const uint8_t v = env_pixel(&s, i / 84, i % 84);
+      o[i] = v; o[7056 + i] = v; o[2 * 7056 + i] = v; o[3 * 7056 + i] = v;
+    }
+  }
+  return 0;
+}
+extern "C" int cbm_synth_env_step_host(uint32_t seed, int32_t n, int32_t max_episode_steps, const int32_t* actions, cbm_env_state* st,
+                                       uint8_t* obs, float* reward, uint8_t* done, uint8_t* terminated, int32_t* elapsed_step) {
+  for (int e = 0; e < n; ++e) {
+    cbm_env_state s = st[e];
+    const EnvOut out = env_transition(&s, seed, (uint32_t)e, actions[e], max_episode_steps);
+    st[e] = s;
+    reward[e] = out.reward; done[e] = out.done; terminated[e] = out.terminated; elapsed_step[e] = out.elapsed;
+    uint8_t* o = obs + (size_t)e * CBM_FRAME;
+    if (!out.was_reset) memmove(o, o + 7056, 3 * 7056);
+    for (int i = 0; i < 7056; ++i) {
+      const uint8_t v = env_pixel(&s, i / 84, i % 84);
+      o[3 * 7056 + i] = v;
+      if (out.was_reset) { o[i] = v; o[7056 + i] = v; o[2 * 7056 + i] = v; }
+    }
+  }
+  return 0;
+}

@@ -1,0 +1,472 @@
+// gemm_layers.hip — Nature-CNN forward / backward as implicit GEMMs on the f32 MFMA
+// (problem functors for igemm.h + the layer drivers).
+//
+// Reference: Network naturecnn:143-178, Actor/Critic ppo:192-203; backward = what
+// jax.value_and_grad emits at ppo:590,619 / impala:607.
+//
+// HBM layout: activations NHWC fp32 (= flax's layout, so conv3's output
+// is already the (h,w,c) flatten of ppo:185); frames stay uint8 NCHW exactly as the env wrote
+// them (the transpose + /255 of ppo:180-181 is folded into conv1's tile load); pre-activation
+// gradients of conv2/conv3 outputs live in zero-bordered 11x11 buffers so that both dgrads are
+// plain VALID correlations (stride-2 conv2 as 4 parity classes).
+#include "cbm_internal.h"
+#include "igemm.h"
+
+NatureLayout nature_layout(int A) {
+  NatureLayout L;
+  L.A = A;
+  const int64_t wsz[6] = {8 * 8 * 4 * 32, 4 * 4 * 32 * 64, 3 * 3 * 64 * 64, 3136 * 512, 512 * (int64_t)A, 512};
+  const int64_t bsz[6] = {32, 64, 64, 512, A, 1};
+  int64_t o = 0;
+  for (int i = 0; i < 6; ++i) { L.w[i] = o; o += wsz[i]; L.b[i] = o; o += bsz[i]; }
+  L.total = o;
+  return L;
+}
+
+static __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+static __device__ __forceinline__ float relu(float v) { return v > 0.0f ? v : 0.0f; }
+
+// ------------------------------------------------------------------------------------------
+// conv1: uint8 NCHW frames -> act1 [M=S*400][32].  k = (c, kh, kw), 8 contiguous bytes per (c,kh).
+template <class TileT>
+struct Conv1Fwd {
+  using Tile = TileT;
+  static constexpr bool A_RX = false, B_YR = false, BIAS_GRAD = false;
+  static constexpr int NCLS = 1;
+  const uint8_t* obs; const int32_t* idx; const float* W; const float* bias; float* out; int M;
+  __host__ __device__ int X() const { return M; }
+  __host__ __device__ int Y() const { return 32; }
+  __device__ void r_range(int, int& lo, int& hi) const { lo = 0; hi = 256; }
+  __device__ float4 load_a(int m, int r, int, int) const {
+    if (m >= M) return f4zero();
+    const int s = m / 400, p = m - s * 400, oh = p / 20, ow = p - oh * 20;
+    const int f = idx ? idx[s] : s;
+    const int c = r >> 6, kh = (r >> 3) & 7, kw = r & 7;
+    const uint32_t w = *reinterpret_cast<const uint32_t*>(obs + (size_t)f * CBM_FRAME + c * 7056 + (oh * 4 + kh) * 84 + ow * 4 + kw);
+    return make_float4(cbm_u8_unit(w & 255u), cbm_u8_unit((w >> 8) & 255u), cbm_u8_unit((w >> 16) & 255u), cbm_u8_unit(w >> 24));
+  }
+  __device__ float4 load_b(int r, int y, int, int) const {
+    const int c = r >> 6, kh = (r >> 3) & 7, kw = r & 7;
+    return *reinterpret_cast<const float4*>(W + ((kh * 8 + kw) * 4 + c) * 32 + y);
+  }
+  __device__ void store(int m, int n, float v, int, int) const {
+    if (m < M) out[(size_t)m * 32 + n] = relu(v + bias[n]);
+  }
+};
+
+// generic VALID NHWC conv forward, k = (kh, kw, ci)
+template <class TileT, int KH, int KW, int ST, int CI, int CO, int IH, int IW, int OH, int OW>
+struct ConvFwd {
+  using Tile = TileT;
+  static constexpr bool A_RX = false, B_YR = false, BIAS_GRAD = false;
+  static constexpr int NCLS = 1;
+  const float* in; const float* W; const float* bias; float* out; int M;
+  __host__ __device__ int X() const { return M; }
+  __host__ __device__ int Y() const { return CO; }
+  __device__ void r_range(int, int& lo, int& hi) const { lo = 0; hi = KH * KW * CI; }
+  __device__ float4 load_a(int m, int r, int, int) const {
+    if (m >= M) return f4zero();
+    const int s = m / (OH * OW), p = m - s * (OH * OW), oh = p / OW, ow = p - oh * OW;
+    const int kh = r / (KW * CI), rem = r - kh * (KW * CI);
+    return *reinterpret_cast<const float4*>(in + ((size_t)(s * IH + oh * ST + kh) * IW + ow * ST) * CI + rem);
+  }
+  __device__ float4 load_b(int r, int y, int, int) const { return *reinterpret_cast<const float4*>(W + (size_t)r * CO + y); }
+  __device__ void store(int m, int n, float v, int, int) const {
+    if (m < M) out[(size_t)m * CO + n] = relu(v + bias[n]);
+  }
+};
+
+// dense forward C[m][n] = sum_k A[m][k] W[k][n]; SPLIT: partials [z][M][N], else relu(+bias)
+template <class TileT, bool SPLIT>
+struct DenseFwd {
+  using Tile = TileT;
+  static constexpr bool A_RX = false, B_YR = false, BIAS_GRAD = false;
+  static constexpr int NCLS = 1;
+  const float* A; const float* W; const float* bias; float* out; int M, K, N, seg;
+  __host__ __device__ int X() const { return M; }
+  __host__ __device__ int Y() const { return N; }
+  __device__ void r_range(int z, int& lo, int& hi) const { lo = z * seg; hi = lo + seg; }
+  __device__ float4 load_a(int m, int r, int rhi, int) const {
+    if (m >= M || r >= rhi) return f4zero();
+    return *reinterpret_cast<const float4*>(A + (size_t)m * K + r);
+  }
+  __device__ float4 load_b(int r, int y, int rhi, int) const {
+    if (r >= rhi || y >= N) return f4zero();
+    return *reinterpret_cast<const float4*>(W + (size_t)r * N + y);
+  }
+  __device__ void store(int m, int n, float v, int z, int) const {
+    if (m >= M || n >= N) return;
+    if (SPLIT) out[((size_t)z * M + m) * N + n] = v;
+    else out[(size_t)m * N + n] = relu(v + bias[n]);
+  }
+};
+
+__global__ void dense_reduce_kernel(const float* part, const float* bias, float* out, int M, int N, int S) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M * N) return;
+  float t = part[i];
+  for (int s = 1; s < S; ++s) t = t + part[(size_t)s * M * N + i];
+  out[i] = relu(t + bias[i % N]);
+}
+
+// heads: logits[b][a] = chain_k hid[b][k] Wa[k][a] + ba[a]; value likewise (thread per output)
+__global__ __launch_bounds__(256) void heads_fwd_kernel(const float* hid, const float* Wa, const float* ba, const float* Wc,
+                                                        const float* bc, int B, int A, float* logits, float* value) {
+  __shared__ float hs[8][512];
+  const int f0 = blockIdx.x * 8;
+  for (int i = threadIdx.x; i < 8 * 512; i += 256) {
+    const int f = f0 + i / 512;
+    hs[i / 512][i % 512] = f < B ? hid[(size_t)f * 512 + i % 512] : 0.0f;
+  }
+  __syncthreads();
+  const int fl = threadIdx.x >> 5, o = threadIdx.x & 31, f = f0 + fl;
+  if (f >= B || o > A) return;
+  float acc = 0.0f;
+  if (o < A) {
+    for (int k = 0; k < 512; ++k) acc = fmaf(hs[fl][k], Wa[k * A + o], acc);
+    logits[(size_t)f * A + o] = acc + ba[o];
+  } else {
+    for (int k = 0; k < 512; ++k) acc = fmaf(hs[fl][k], Wc[k], acc);
+    value[f] = acc + bc[0];
+  }
+}
+
+// ------------------------------------------------------------------------------------------ backward
+// heads dgrad: dhid[m][k] = (sum_j dzv[m][j] * Wac[k][j]) * (hid > 0), j over A logits + value
+__global__ __launch_bounds__(256) void heads_dgrad_kernel(const float* dzv, const float* Wa, const float* Wc, const float* hid,
+                                                          int B, int A, float* dhid) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (size_t)B * 512) return;
+  const int m = (int)(i >> 9), k = (int)(i & 511);
+  const float* d = dzv + (size_t)m * 32;
+  float s = 0.0f;
+  for (int a = 0; a < A; ++a) s = fmaf(d[a], Wa[k * A + a], s);
+  s = fmaf(d[A], Wc[k], s);
+  dhid[i] = hid[i] > 0.0f ? s : 0.0f;
+}
+
+// dense dgrad: dact3[m][j] = sum_n dhid[m][n] * Wd[j][n]; stored masked into the zero-bordered
+// dact3pad [S][11][11][64] (data at rows/cols 2..8).
+template <class TileT>
+struct DenseDgrad {
+  using Tile = TileT;
+  static constexpr bool A_RX = false, B_YR = true, BIAS_GRAD = false;
+  static constexpr int NCLS = 1;
+  const float* dhid; const float* Wd; const float* act3; float* dact3pad; int M;
+  __host__ __device__ int X() const { return M; }
+  __host__ __device__ int Y() const { return 3136; }
+  __device__ void r_range(int, int& lo, int& hi) const { lo = 0; hi = 512; }
+  __device__ float4 load_a(int m, int r, int, int) const {
+    if (m >= M) return f4zero();
+    return *reinterpret_cast<const float4*>(dhid + (size_t)m * 512 + r);
+  }
+  __device__ float4 load_b(int r, int y, int, int) const {   // B[r=n..n+3][y=j] = Wd[j][n..n+3]
+    if (y >= 3136) return f4zero();
+    return *reinterpret_cast<const float4*>(Wd + (size_t)y * 512 + r);
+  }
+  __device__ void store(int m, int j, float v, int, int) const {
+    if (m >= M || j >= 3136) return;
+    const int pos = j >> 6, c = j & 63, hh = pos / 7, ww = pos - hh * 7;
+    const bool on = act3[(size_t)m * 3136 + j] > 0.0f;
+    dact3pad[((size_t)(m * 11 + hh + 2) * 11 + ww + 2) * 64 + c] = on ? v : 0.0f;
+  }
+};
+
+// conv3 dgrad (3x3 s1): X = (s, ih, iw) over 9x9, Y = ci (64), r = (jh, jw, co), reads dact3pad,
+// writes masked into dact2pad [S][11][11][64] (data at 1..9).
+template <class TileT>
+struct Conv3Dgrad {
+  using Tile = TileT;
+  static constexpr bool A_RX = false, B_YR = true, BIAS_GRAD = false;
+  static constexpr int NCLS = 1;
+  const float* dypad; const float* W; const float* act2; float* dxpad; int M;  // M = S*81
+  __host__ __device__ int X() const { return M; }
+  __host__ __device__ int Y() const { return 64; }
+  __device__ void r_range(int, int& lo, int& hi) const { lo = 0; hi = 576; }
+  __device__ float4 load_a(int m, int r, int, int) const {
+    if (m >= M) return f4zero();
+    const int s = m / 81, p = m - s * 81, ih = p / 9, iw = p - ih * 9;
+    const int jh = r / 192, rem = r - jh * 192;
+    return *reinterpret_cast<const float4*>(dypad + ((size_t)(s * 11 + ih + jh) * 11 + iw) * 64 + rem);
+  }
+  __device__ float4 load_b(int r, int ci, int, int) const {  // B[(jh,jw,co..co+3)][ci] = W[2-jh][2-jw][ci][co..]
+    const int jh = r / 192, rem = r - jh * 192, jw = rem >> 6, co = rem & 63;
+    return *reinterpret_cast<const float4*>(W + ((size_t)((2 - jh) * 3 + (2 - jw)) * 64 + ci) * 64 + co);
+  }
+  __device__ void store(int m, int ci, float v, int, int) const {
+    if (m >= M) return;
+    const int s = m / 81, p = m - s * 81, ih = p / 9, iw = p - ih * 9;
+    const bool on = act2[(size_t)m * 64 + ci] > 0.0f;
+    dxpad[((size_t)(s * 11 + ih + 1) * 11 + iw + 1) * 64 + ci] = on ? v : 0.0f;
+  }
+};
+
+// conv2 dgrad (4x4 s2) as 4 parity classes (ph,pw): X = (s, ih', iw') over 10x10, Y = ci (32),
+// r = (jh, jw, co) with kh = ph + 2(1-jh), kw = pw + 2(1-jw); reads dact2pad, writes masked dact1.
+template <class TileT>
+struct Conv2Dgrad {
+  using Tile = TileT;
+  static constexpr bool A_RX = false, B_YR = true, BIAS_GRAD = false;
+  static constexpr int NCLS = 4;
+  const float* dypad; const float* W; const float* act1; float* dact1; int M;  // M = S*100
+  __host__ __device__ int X() const { return M; }
+  __host__ __device__ int Y() const { return 32; }
+  __device__ void r_range(int, int& lo, int& hi) const { lo = 0; hi = 256; }
+  __device__ float4 load_a(int m, int r, int, int) const {
+    if (m >= M) return f4zero();
+    const int s = m / 100, p = m - s * 100, ihh = p / 10, iwh = p - ihh * 10;
+    const int jh = r >> 7, rem = r & 127;
+    return *reinterpret_cast<const float4*>(dypad + ((size_t)(s * 11 + ihh + jh) * 11 + iwh) * 64 + rem);
+  }
+  __device__ float4 load_b(int r, int ci, int, int cls) const {
+    const int jh = r >> 7, jw = (r >> 6) & 1, co = r & 63;
+    const int kh = (cls >> 1) + 2 * (1 - jh), kw = (cls & 1) + 2 * (1 - jw);
+    return *reinterpret_cast<const float4*>(W + ((size_t)(kh * 4 + kw) * 32 + ci) * 64 + co);
+  }
+  __device__ void store(int m, int ci, float v, int, int cls) const {
+    if (m >= M) return;
+    const int s = m / 100, p = m - s * 100, ihh = p / 10, iwh = p - ihh * 10;
+    const size_t pos = ((size_t)(s * 20 + 2 * ihh + (cls >> 1)) * 20 + 2 * iwh + (cls & 1)) * 32 + ci;
+    dact1[pos] = act1[pos] > 0.0f ? v : 0.0f;
+  }
+};
+
+// ---- weight gradients: C[x = k][y = co] = sum_{r = m} A[m][k] * dY[m][co], split over r into
+// partials [z][X][Y] (+ bias partial [z][Y]) reduced in ascending z (deterministic, ppo:30).
+template <class TileT>
+struct Conv1Wgrad {
+  using Tile = TileT;
+  static constexpr bool A_RX = true, B_YR = false, BIAS_GRAD = true;
+  static constexpr int NCLS = 1;
+  const uint8_t* obs; const int32_t* idx; const float* dy; float* part; float* bpart; int M, rps;
+  __host__ __device__ int X() const { return 256; }
+  __host__ __device__ int Y() const { return 32; }
+  __device__ void r_range(int z, int& lo, int& hi) const { lo = z * rps; hi = min(lo + rps, M); }
+  __device__ float4 load_a(int k, int m, int rhi, int) const {
+    if (m >= rhi) return f4zero();
+    const int s = m / 400, p = m - s * 400, oh = p / 20, ow = p - oh * 20;
+    const int f = idx ? idx[s] : s;
+    const int c = k >> 6, kh = (k >> 3) & 7, kw = k & 7;
+    const uint32_t w = *reinterpret_cast<const uint32_t*>(obs + (size_t)f * CBM_FRAME + c * 7056 + (oh * 4 + kh) * 84 + ow * 4 + kw);
+    return make_float4(cbm_u8_unit(w & 255u), cbm_u8_unit((w >> 8) & 255u), cbm_u8_unit((w >> 16) & 255u), cbm_u8_unit(w >> 24));
+  }
+  __device__ float4 load_b(int m, int y, int rhi, int) const {
+    if (m >= rhi) return f4zero();
+    return *reinterpret_cast<const float4*>(dy + (size_t)m * 32 + y);
+  }
+  __device__ void store(int k, int y, float v, int z, int) const { part[((size_t)z * 256 + k) * 32 + y] = v; }
+  __device__ void store_bias(int y, float v, int z) const { bpart[z * 32 + y] = v; }
+};
+
+template <class TileT, int KH, int KW, int ST, int CI, int CO, int IH, int IW, int OH, int OW, int PADO>
+struct ConvWgrad {  // dY lives in a zero-bordered [S][OH+2*PADO... = 11][11][CO] buffer
+  using Tile = TileT;
+  static constexpr bool A_RX = true, B_YR = false, BIAS_GRAD = true;
+  static constexpr int NCLS = 1;
+  static constexpr int KX = KH * KW * CI;
+  const float* in; const float* dypad; float* part; float* bpart; int M, rps;
+  __host__ __device__ int X() const { return KX; }
+  __host__ __device__ int Y() const { return CO; }
+  __device__ void r_range(int z, int& lo, int& hi) const { lo = z * rps; hi = min(lo + rps, M); }
+  __device__ float4 load_a(int k, int m, int rhi, int) const {
+    if (m >= rhi || k >= KX) return f4zero();
+    const int s = m / (OH * OW), p = m - s * (OH * OW), oh = p / OW, ow = p - oh * OW;
+    const int kh = k / (KW * CI), rem = k - kh * (KW * CI);
+    return *reinterpret_cast<const float4*>(in + ((size_t)(s * IH + oh * ST + kh) * IW + ow * ST) * CI + rem);
+  }
+  __device__ float4 load_b(int m, int y, int rhi, int) const {
+    if (m >= rhi) return f4zero();
+    const int s = m / (OH * OW), p = m - s * (OH * OW), oh = p / OW, ow = p - oh * OW;
+    return *reinterpret_cast<const float4*>(dypad + ((size_t)(s * 11 + oh + PADO) * 11 + ow + PADO) * CO + y);
+  }
+  __device__ void store(int k, int y, float v, int z, int) const {
+    if (k < KX) part[((size_t)z * KX + k) * CO + y] = v;
+  }
+  __device__ void store_bias(int y, float v, int z) const { bpart[z * CO + y] = v; }
+};
+
+// plain wgrad: C[x][y] = sum_m A[m][x] * G[m][y]   (dense: A = act3, G = dhid; heads: A = hid, G = dzv)
+template <class TileT>
+struct MatWgrad {
+  using Tile = TileT;
+  static constexpr bool A_RX = true, B_YR = false, BIAS_GRAD = true;
+  static constexpr int NCLS = 1;
+  const float* A; const float* G; float* part; float* bpart; int M, XK, YN, ldg, rps;
+  __host__ __device__ int X() const { return XK; }
+  __host__ __device__ int Y() const { return YN; }
+  __device__ void r_range(int z, int& lo, int& hi) const { lo = z * rps; hi = min(lo + rps, M); }
+  __device__ float4 load_a(int k, int m, int rhi, int) const {
+    if (m >= rhi || k >= XK) return f4zero();
+    return *reinterpret_cast<const float4*>(A + (size_t)m * XK + k);
+  }
+  __device__ float4 load_b(int m, int y, int rhi, int) const {
+    if (m >= rhi || y >= YN) return f4zero();
+    return *reinterpret_cast<const float4*>(G + (size_t)m * ldg + y);
+  }
+  __device__ void store(int k, int y, float v, int z, int) const {
+    if (k < XK && y < YN) part[((size_t)z * XK + k) * YN + y] = v;
+  }
+  __device__ void store_bias(int y, float v, int z) const { if (y < YN) bpart[z * YN + y] = v; }
+};
+
+// partial reduce: out = sum_z part[z] (ascending z).  mode 0: identity, 1: conv1 k=(c,kh,kw) -> HWIO,
+// 2: heads [512][32] -> actor.w [512][A] / critic.w [512]
+__global__ void wgrad_reduce_kernel(const float* part, int nz, int XY, int Ycols, int mode, int A, float* gw, float* gw2) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= XY) return;
+  float s = part[i];
+  for (int z = 1; z < nz; ++z) s += part[(size_t)z * XY + i];
+  const int x = i / Ycols, y = i - x * Ycols;
+  if (mode == 0) gw[i] = s;
+  else if (mode == 1) { const int c = x >> 6, kh = (x >> 3) & 7, kw = x & 7; gw[((kh * 8 + kw) * 4 + c) * 32 + y] = s; }
+  else { if (y < A) gw[x * A + y] = s; else if (y == A) gw2[x] = s; }
+}
+__global__ void bias_reduce_kernel(const float* part, int nz, int Y, int mode, int A, float* gb, float* gb2) {
+  const int y = blockIdx.x * blockDim.x + threadIdx.x;
+  if (y >= Y) return;
+  float s = part[y];
+  for (int z = 1; z < nz; ++z) s += part[z * Y + y];
+  if (mode == 2) { if (y < A) gb[y] = s; else if (y == A) gb2[0] = s; }
+  else gb[y] = s;
+}
+
+// ------------------------------------------------------------------------------------------ workspace
+static int dmalloc(float** p, size_t nfloats) {
+  if (hipMalloc((void**)p, nfloats * sizeof(float)) != hipSuccess) { cbm_set_error("hipMalloc of %zu floats failed", nfloats); return -1; }
+  return 0;
+}
+static int ceil_div(int a, int b) { return (a + b - 1) / b; }
+static int round_up(int a, int b) { return ceil_div(a, b) * b; }
+
+// rows of the reduction handled by one split block (multiples of BR = 32)
+static const int RPS_C1 = 1600, RPS_C2 = 1280, RPS_C3 = 1664, RPS_HEADS = 128;
+static int dense_wgrad_splits(int B) { return B >= 2048 ? 2 : 1; }
+
+int nature_ws_alloc(NatureWs& ws, int maxB, bool with_grad, int dense_ksplit_small) {
+  ws.maxB = maxB; ws.with_grad = with_grad;
+  const size_t B = (size_t)maxB;
+  if (dmalloc(&ws.act1, B * 12800) || dmalloc(&ws.act2, B * 5184) || dmalloc(&ws.act3, B * 3136) || dmalloc(&ws.hid, B * 512) ||
+      dmalloc(&ws.logits, B * 32) || dmalloc(&ws.value, B)) return -1;
+  ws.dense_part_ksplit = dense_ksplit_small;
+  if (maxB <= 512 && dense_ksplit_small > 1) { if (dmalloc(&ws.dense_part, (size_t)dense_ksplit_small * B * 512)) return -1; }
+  if (with_grad) {
+    if (dmalloc(&ws.dzv, B * 32) || dmalloc(&ws.dhid, B * 512) || dmalloc(&ws.dact3pad, B * 7744) || dmalloc(&ws.dact2pad, B * 7744) ||
+        dmalloc(&ws.dact1, B * 12800)) return -1;
+    hipMemset(ws.dact3pad, 0, B * 7744 * sizeof(float));
+    hipMemset(ws.dact2pad, 0, B * 7744 * sizeof(float));
+    hipMemset(ws.dzv, 0, B * 32 * sizeof(float));
+    size_t need = 0;
+    auto mx = [&](size_t v) { if (v > need) need = v; };
+    mx((size_t)ceil_div(maxB * 400, RPS_C1) * 256 * 32);
+    mx((size_t)ceil_div(maxB * 81, RPS_C2) * 512 * 64);
+    mx((size_t)ceil_div(maxB * 49, RPS_C3) * 576 * 64);
+    mx((size_t)dense_wgrad_splits(maxB) * 3136 * 512);
+    mx((size_t)ceil_div(maxB, RPS_HEADS) * 512 * 32);
+    ws.wg_part_floats = (int64_t)need;
+    size_t bneed = (size_t)ceil_div(maxB * 400, RPS_C1) * 512 + 4096;
+    ws.bias_part_floats = (int64_t)bneed;
+    if (dmalloc(&ws.wg_part, need) || dmalloc(&ws.bias_part, bneed)) return -1;
+  }
+  return 0;
+}
+void nature_ws_free(NatureWs& ws) {
+  float** ps[] = {&ws.act1, &ws.act2, &ws.act3, &ws.hid, &ws.logits, &ws.value, &ws.dense_part, &ws.dzv, &ws.dhid,
+                  &ws.dact3pad, &ws.dact2pad, &ws.dact1, &ws.wg_part, &ws.bias_part};
+  for (auto p : ps) { if (*p) hipFree(*p); *p = nullptr; }
+}
+
+// ------------------------------------------------------------------------------------------ drivers
+using T128x32 = IgemmTile<128, 32, 32, 4, 1>;
+using T256x32 = IgemmTile<256, 32, 32, 4, 1>;
+using T128x64 = IgemmTile<128, 64, 32, 2, 2>;
+using T64x64 = IgemmTile<64, 64, 32, 2, 2>;
+
+void nature_forward(const NatureLayout& L, const float* P, const uint8_t* obs, const int32_t* idx, int B, int dense_ksplit,
+                    NatureWs& ws, hipStream_t st) {
+  const bool small = B <= 512;
+  {
+    Conv1Fwd<T128x32> p{obs, idx, P + L.w[0], P + L.b[0], ws.act1, B * 400};
+    igemm_launch(p, 1, st);
+  }
+  if (small) {
+    ConvFwd<T64x64, 4, 4, 2, 32, 64, 20, 20, 9, 9> p2{ws.act1, P + L.w[1], P + L.b[1], ws.act2, B * 81};
+    igemm_launch(p2, 1, st);
+    ConvFwd<T64x64, 3, 3, 1, 64, 64, 9, 9, 7, 7> p3{ws.act2, P + L.w[2], P + L.b[2], ws.act3, B * 49};
+    igemm_launch(p3, 1, st);
+  } else {
+    ConvFwd<T128x64, 4, 4, 2, 32, 64, 20, 20, 9, 9> p2{ws.act1, P + L.w[1], P + L.b[1], ws.act2, B * 81};
+    igemm_launch(p2, 1, st);
+    ConvFwd<T128x64, 3, 3, 1, 64, 64, 9, 9, 7, 7> p3{ws.act2, P + L.w[2], P + L.b[2], ws.act3, B * 49};
+    igemm_launch(p3, 1, st);
+  }
+  if (dense_ksplit > 1) {
+    DenseFwd<T64x64, true> pd{ws.act3, P + L.w[3], P + L.b[3], ws.dense_part, B, 3136, 512, 3136 / dense_ksplit};
+    igemm_launch(pd, dense_ksplit, st);
+    hipLaunchKernelGGL(dense_reduce_kernel, dim3(ceil_div(B * 512, 256)), dim3(256), 0, st, ws.dense_part, P + L.b[3], ws.hid, B, 512,
+                       dense_ksplit);
+  } else {
+    DenseFwd<T64x64, false> pd{ws.act3, P + L.w[3], P + L.b[3], ws.hid, B, 3136, 512, 3136};
+    igemm_launch(pd, 1, st);
+  }
+  hipLaunchKernelGGL(heads_fwd_kernel, dim3(ceil_div(B, 8)), dim3(256), 0, st, ws.hid, P + L.w[4], P + L.b[4], P + L.w[5], P + L.b[5], B,
+                     L.A, ws.logits, ws.value);
+}
+
+void nature_backward(const NatureLayout& L, const float* P, const uint8_t* obs, const int32_t* idx, int B, NatureWs& ws, float* grads,
+                     hipStream_t st) {
+  const int A = L.A;
+  // heads: dgrad (VALU) and wgrad (MFMA, Y = A+1 padded to 32)
+  hipLaunchKernelGGL(heads_dgrad_kernel, dim3(ceil_div(B * 512, 256)), dim3(256), 0, st, ws.dzv, P + L.w[4], P + L.w[5], ws.hid, B, A,
+                     ws.dhid);
+  {
+    const int nz = ceil_div(B, RPS_HEADS);
+    MatWgrad<T128x32> p{ws.hid, ws.dzv, ws.wg_part, ws.bias_part, B, 512, 32, 32, RPS_HEADS};
+    igemm_launch(p, nz, st);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(512 * 32, 256)), dim3(256), 0, st, ws.wg_part, nz, 512 * 32, 32, 2, A,
+                       grads + L.w[4], grads + L.w[5]);
+    hipLaunchKernelGGL(bias_reduce_kernel, dim3(1), dim3(64), 0, st, ws.bias_part, nz, 32, 2, A, grads + L.b[4], grads + L.b[5]);
+  }
+  // dense: dgrad -> dact3pad, wgrad
+  {
+    DenseDgrad<T128x64> pd{ws.dhid, P + L.w[3], ws.act3, ws.dact3pad, B};
+    igemm_launch(pd, 1, st);
+    const int nz = dense_wgrad_splits(B);
+    const int rps = round_up(ceil_div(B, nz), 32);
+    MatWgrad<T64x64> pw{ws.act3, ws.dhid, ws.wg_part, ws.bias_part, B, 3136, 512, 512, rps};
+    igemm_launch(pw, nz, st);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(3136 * 512, 256)), dim3(256), 0, st, ws.wg_part, nz, 3136 * 512, 512, 0, A,
+                       grads + L.w[3], (float*)nullptr);
+    hipLaunchKernelGGL(bias_reduce_kernel, dim3(2), dim3(256), 0, st, ws.bias_part, nz, 512, 0, A, grads + L.b[3], (float*)nullptr);
+  }
+  // conv3: dgrad -> dact2pad, wgrad
+  {
+    Conv3Dgrad<T128x64> pd{ws.dact3pad, P + L.w[2], ws.act2, ws.dact2pad, B * 81};
+    igemm_launch(pd, 1, st);
+    const int M = B * 49, nz = ceil_div(M, RPS_C3);
+    ConvWgrad<T64x64, 3, 3, 1, 64, 64, 9, 9, 7, 7, 2> pw{ws.act2, ws.dact3pad, ws.wg_part, ws.bias_part, M, RPS_C3};
+    igemm_launch(pw, nz, st);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(576 * 64, 256)), dim3(256), 0, st, ws.wg_part, nz, 576 * 64, 64, 0, A,
+                       grads + L.w[2], (float*)nullptr);
+    hipLaunchKernelGGL(bias_reduce_kernel, dim3(1), dim3(64), 0, st, ws.bias_part, nz, 64, 0, A, grads + L.b[2], (float*)nullptr);
+  }
+  // conv2: dgrad -> dact1, wgrad
+  {
+    Conv2Dgrad<T128x32> pd{ws.dact2pad, P + L.w[1], ws.act1, ws.dact1, B * 100};
+    igemm_launch(pd, 1, st);
+    const int M = B * 81, nz = ceil_div(M, RPS_C2);
+    ConvWgrad<T128x64, 4, 4, 2, 32, 64, 20, 20, 9, 9, 1> pw{ws.act1, ws.dact2pad, ws.wg_part, ws.bias_part, M, RPS_C2};
+    igemm_launch(pw, nz, st);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(512 * 64, 256)), dim3(256), 0, st, ws.wg_part, nz, 512 * 64, 64, 0, A,
+                       grads + L.w[1], (float*)nullptr);
+    hipLaunchKernelGGL(bias_reduce_kernel, dim3(1), dim3(64), 0, st, ws.bias_part, nz, 64, 0, A, grads + L.b[1], (float*)nullptr);
+  }
+  // conv1: wgrad only (frames need no gradient)
+  {
+    const int M = B * 400, nz = ceil_div(M, RPS_C1);
+    Conv1Wgrad<T256x32> pw{obs, idx, ws.dact1, ws.wg_part, ws.bias_part, M, RPS_C1};
+    igemm_launch(pw, nz, st);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(256 * 32, 256)), dim3(256), 0, st, ws.wg_part, nz, 256 * 32, 32, 1, A,
+                       grads + L.w[0], (float*)nullptr);
+    hipLaunchKernelGGL(bias_reduce_kernel, dim3(1), dim3(64), 0, st, ws.bias_part, nz, 32, 0, A, grads + L.b[0], (float*)nullptr);
+  }
+}

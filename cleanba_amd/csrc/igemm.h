@@ -1,0 +1,206 @@
+// igemm.h — one LDS-tiled implicit-GEMM kernel on v_mfma_f32_32x32x2_f32 for every
+// GEMM-shaped op of the hot path (conv fwd / dgrad / wgrad, dense fwd / dgrad / wgrad).
+//
+//   C[x, y] = sum_r  Aop[x, r] * Bop[r, y]          x in [0,X), y in [0,Y), r in [r_lo, r_hi)
+//
+// The problem functor P supplies the gathers (im2col addressing, uint8->f32 conversion,
+// transposed/flipped weights) and the epilogue; the kernel supplies tiling, double-buffered
+// LDS staging with register prefetch, and the MFMA loop.
+//
+// Numerics: v_mfma_f32_32x32x2_f32 is bit-for-bit a k-ordered fmaf chain (MI355X guide §3),
+// the K loop walks r in ascending order from a zero accumulator, and out-of-range r are
+// staged as 0.0f (fma(0,b,acc) == acc), so C is exactly the chain the CPU oracle computes.
+//
+// Tiling: 256 threads = 4 waves arranged WX x WY; each wave owns TM x TN tiles of 32x32.
+//   A tile in LDS: XR layout  As[x][r] pitch BR+1 (odd -> conflict-free ds_read_b32 when lanes
+//                              walk x)            — global vectors run along r (fwd, dgrad)
+//                  RX layout  As[r][x] pitch BX   — global vectors run along x (wgrad)
+//   B tile in LDS: Bs[r][y] pitch BY; global vectors along y (RY) or along r (YR: transposed
+//                  weight gather for dgrad).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int BX_, int BY_, int BR_, int WX_, int WY_>
+struct IgemmTile {
+  static constexpr int BX = BX_, BY = BY_, BR = BR_, WX = WX_, WY = WY_;
+  static_assert(WX_ * WY_ == 4, "4 waves per block");
+  static_assert(BX_ % (32 * WX_) == 0 && BY_ % (32 * WY_) == 0 && BR_ % 4 == 0, "tile shape");
+};
+
+// P must provide:
+//   using Tile = IgemmTile<...>;  static constexpr bool A_RX, B_YR, BIAS_GRAD;  static constexpr int NCLS;
+//   int X() const, Y() const;  void r_range(int z, int& lo, int& hi) const;
+//   float4 load_a(int x, int r, int rhi, int cls) const;   XR: A[x][r..r+3]   RX: A[x..x+3][r]
+//   float4 load_b(int r, int y, int rhi, int cls) const;   RY: B[r][y..y+3]   YR: B[r..r+3][y]
+//   void store(int x, int y, float v, int z, int cls) const;
+//   void store_bias(int y, float v, int z) const;           (only if BIAS_GRAD)
+template <class P>
+__global__ __launch_bounds__(256) void igemm_kernel(const P p) {
+  using T = typename P::Tile;
+  constexpr int BX = T::BX, BY = T::BY, BR = T::BR, WX = T::WX, WY = T::WY;
+  constexpr bool A_RX = P::A_RX, B_YR = P::B_YR;
+  constexpr int TM = BX / WX / 32, TN = BY / WY / 32;
+  constexpr int PA = A_RX ? BX : (BR + 1);
+  constexpr int ASZ = A_RX ? BR * BX : BX * (BR + 1);
+  constexpr int PB = BY;
+  constexpr int BSZ = BR * BY;
+  constexpr int NVA = (BX * BR / 4 + 255) / 256;
+  constexpr int NVB = (BR * BY / 4 + 255) / 256;
+  constexpr int RED = P::BIAS_GRAD ? 256 : 0;
+  __shared__ __attribute__((aligned(16))) float smem[2 * ASZ + 2 * BSZ + RED];
+  float* As = smem;
+  float* Bs = smem + 2 * ASZ;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, h = lane >> 5;
+  const int wx = wave / WY, wy = wave % WY;
+  const int cls = P::NCLS > 1 ? (int)(blockIdx.y % P::NCLS) : 0;
+  const int x0 = blockIdx.x * BX;
+  const int y0 = (P::NCLS > 1 ? (int)(blockIdx.y / P::NCLS) : (int)blockIdx.y) * BY;
+  const int z = blockIdx.z;
+  int rlo, rhi;
+  p.r_range(z, rlo, rhi);
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+  float4 ra[NVA], rb[NVB];
+  float bsum = 0.0f;
+
+  auto gload = [&](int r0) {
+#pragma unroll
+    for (int j = 0; j < NVA; ++j) {
+      const int v = tid + 256 * j;
+      if (BX * BR / 4 % 256 == 0 || v < BX * BR / 4) {
+        if (A_RX) {
+          const int xq = v % (BX / 4), rl = v / (BX / 4);
+          ra[j] = p.load_a(x0 + 4 * xq, r0 + rl, rhi, cls);
+        } else {
+          const int rq = v % (BR / 4), xl = v / (BR / 4);
+          ra[j] = p.load_a(x0 + xl, r0 + 4 * rq, rhi, cls);
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NVB; ++j) {
+      const int v = tid + 256 * j;
+      if (BR * BY / 4 % 256 == 0 || v < BR * BY / 4) {
+        if (B_YR) {
+          const int rq = v % (BR / 4), yl = v / (BR / 4);
+          rb[j] = p.load_b(r0 + 4 * rq, y0 + yl, rhi, cls);
+        } else {
+          const int yq = v % (BY / 4), rl = v / (BY / 4);
+          rb[j] = p.load_b(r0 + rl, y0 + 4 * yq, rhi, cls);
+        }
+      }
+    }
+  };
+  auto sstore = [&](int buf) {
+    float* A_ = As + buf * ASZ;
+    float* B_ = Bs + buf * BSZ;
+#pragma unroll
+    for (int j = 0; j < NVA; ++j) {
+      const int v = tid + 256 * j;
+      if (BX * BR / 4 % 256 == 0 || v < BX * BR / 4) {
+        if (A_RX) {
+          const int xq = v % (BX / 4), rl = v / (BX / 4);
+          *reinterpret_cast<float4*>(A_ + rl * PA + 4 * xq) = ra[j];
+        } else {
+          const int rq = v % (BR / 4), xl = v / (BR / 4);
+          float* d = A_ + xl * PA + 4 * rq;
+          d[0] = ra[j].x; d[1] = ra[j].y; d[2] = ra[j].z; d[3] = ra[j].w;
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NVB; ++j) {
+      const int v = tid + 256 * j;
+      if (BR * BY / 4 % 256 == 0 || v < BR * BY / 4) {
+        if (B_YR) {
+          const int rq = v % (BR / 4), yl = v / (BR / 4);
+          float* d = B_ + (4 * rq) * PB + yl;
+          d[0] = rb[j].x; d[PB] = rb[j].y; d[2 * PB] = rb[j].z; d[3 * PB] = rb[j].w;
+        } else {
+          const int yq = v % (BY / 4), rl = v / (BY / 4);
+          *reinterpret_cast<float4*>(B_ + rl * PB + 4 * yq) = rb[j];
+        }
+      }
+    }
+  };
+
+  gload(rlo);
+  sstore(0);
+  __syncthreads();
+  int buf = 0;
+  for (int r0 = rlo; r0 < rhi; r0 += BR) {
+    const bool more = (r0 + BR) < rhi;
+    if (more) gload(r0 + BR);
+    const float* A_ = As + buf * ASZ;
+    const float* B_ = Bs + buf * BSZ;
+#pragma unroll
+    for (int rr = 0; rr < BR; rr += 2) {
+      float a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int xl = wx * (BX / WX) + i * 32 + li;
+        a[i] = A_RX ? A_[(rr + h) * PA + xl] : A_[xl * PA + rr + h];
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = B_[(rr + h) * PB + wy * (BY / WY) + j * 32 + li];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if constexpr (P::BIAS_GRAD) if (blockIdx.x == 0) {
+      // column sums of the staged dY tile -> bias gradient partial (fixed order per thread)
+      constexpr int PARTS = 256 / BY;
+      const int yy = tid % BY, part = tid / BY;
+      if (part < PARTS)
+        for (int r = part; r < BR; r += PARTS) bsum += B_[r * PB + yy];
+    }
+    if (more) sstore(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int y = y0 + wy * (BY / WY) + j * 32 + li;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
+        const int x = x0 + wx * (BX / WX) + i * 32 + row;
+        p.store(x, y, acc[i][j][e], z, cls);
+      }
+    }
+
+  if constexpr (P::BIAS_GRAD) if (blockIdx.x == 0) {
+    constexpr int PARTS = 256 / BY;
+    float* red = smem + 2 * ASZ + 2 * BSZ;
+    red[tid] = bsum;
+    __syncthreads();
+    if (tid < BY) {
+      float s = red[tid];
+      for (int q = 1; q < PARTS; ++q) s += red[q * BY + tid];
+      p.store_bias(y0 + tid, s, z);
+    }
+  }
+}
+
+template <class P>
+static inline void igemm_launch(const P& p, int nsplit, hipStream_t stream) {
+  using T = typename P::Tile;
+  dim3 grid((p.X() + T::BX - 1) / T::BX, ((p.Y() + T::BY - 1) / T::BY) * P::NCLS, nsplit);
+  hipLaunchKernelGGL(igemm_kernel<P>, grid, dim3(256), 0, stream, p);
+}

@@ -1,0 +1,376 @@
+// pointwise.hip — the HBM-stream / scan kernels of the hot path: action sampling, GAE, advantage
+// normalisation, jax-compatible permutation, PPO and IMPALA(V-trace) loss heads, Adam / RMSProp.
+// Reference lines are cited per kernel ("ppo" = cleanba_ppo.py, "impala" = cleanba_impala.py).
+#include "cbm_internal.h"
+#include <math.h>
+#include <float.h>
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// ------------------------------------------------------------------------------------------
+// ppo:256-261 / impala:296-300.  One thread per env: u = uniform(subkey,[B,A]) via threefry
+// counters, Gumbel-max argmax (first max wins), log_softmax at the chosen action.
+__global__ void sample_kernel(const float* logits, int B, int A, uint32_t sk0, uint32_t sk1, int32_t* actions, float* logprobs,
+                              const float* value_in, float* value_out, float* logits_out) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const float* z = logits + (size_t)b * A;
+  const uint32_t n = (uint32_t)(B * A);
+  int best = 0;
+  float bestv = 0.0f, mx = z[0];
+  for (int a = 0; a < A; ++a) {
+    const float u = cbm_bits_to_uniform(cbm_random_bits_at(sk0, sk1, n, (uint32_t)(b * A + a)));
+    const float g = z[a] - cbm_logf(-cbm_logf(u));
+    if (a == 0 || g > bestv) { best = a; bestv = g; }
+    mx = z[a] > mx ? z[a] : mx;
+    if (logits_out) logits_out[(size_t)b * A + a] = z[a];
+  }
+  actions[b] = best;
+  if (logprobs) {
+    float s = 0.0f;
+    for (int a = 0; a < A; ++a) s += cbm_expf(z[a] - mx);
+    logprobs[b] = (z[best] - mx) - cbm_logf(s);
+  }
+  if (value_out) value_out[b] = value_in[b];
+}
+void launch_sample(const float* logits, int B, int A, uint32_t sk0, uint32_t sk1, int32_t* actions, float* logprobs,
+                   const float* value_in, float* value_out, float* logits_out, hipStream_t st) {
+  hipLaunchKernelGGL(sample_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, st, logits, B, A, sk0, sk1, actions, logprobs, value_in,
+                     value_out, logits_out);
+}
+
+// ------------------------------------------------------------------------------------------
+// compute_gae ppo:532-560: one thread per env column, serial reverse scan over T.
+__global__ void gae_kernel(const float* rewards, const float* values, const uint8_t* dones, const float* next_value,
+                           const uint8_t* next_done, int T, int B, float gamma, float gl, float* adv, float* target) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  float a = 0.0f;
+  float nv = next_value[b];
+  float nd = (float)next_done[b];
+  for (int t = T - 1; t >= 0; --t) {
+    const float v = values[(size_t)t * B + b];
+    const float nnt = 1.0f - nd;
+    const float delta = (rewards[(size_t)t * B + b] + (gamma * nv) * nnt) - v;
+    a = delta + ((gl * nnt) * a);
+    adv[(size_t)t * B + b] = a;
+    target[(size_t)t * B + b] = a + v;
+    nv = v;
+    nd = (float)dones[(size_t)t * B + b];
+  }
+}
+void launch_gae(const float* rewards, const float* values, const uint8_t* dones, const float* next_value, const uint8_t* next_done,
+                int T, int B, float gamma, float lambda, float* adv, float* target, hipStream_t st) {
+  const float gl = (float)((double)gamma * (double)lambda);
+  hipLaunchKernelGGL(gae_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, st, rewards, values, dones, next_value, next_done, T, B, gamma, gl,
+                     adv, target);
+}
+
+// ------------------------------------------------------------------------------------------
+// ppo:592-595: per column-group mean / population std over (T, B/G); wavefront + LDS reduction.
+__device__ float block_sum_1024(float v, float* red) {
+  // fixed-order tree: wave shuffle (64 lanes) then 16 wave totals
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  __syncthreads();
+  if (l == 0) red[w] = v;
+  __syncthreads();
+  float s = 0.0f;
+  const int nw = blockDim.x >> 6;
+  for (int i = 0; i < nw; ++i) s += red[i];
+  return s;
+}
+__global__ __launch_bounds__(1024) void advnorm_kernel(float* adv, int T, int B, int groups) {
+  __shared__ float red[16];
+  const int g = blockIdx.x, w = B / groups, n = T * w;
+  float s = 0.0f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) s += adv[(size_t)(i / w) * B + g * w + (i % w)];
+  const float mean = block_sum_1024(s, red) / (float)n;
+  float v = 0.0f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) { const float d = adv[(size_t)(i / w) * B + g * w + (i % w)] - mean; v += d * d; }
+  const float sd = sqrtf(block_sum_1024(v, red) / (float)n);
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const size_t o = (size_t)(i / w) * B + g * w + (i % w);
+    adv[o] = (adv[o] - mean) / (sd + 1e-8f);
+  }
+}
+void launch_advnorm(float* adv, int T, int B, int groups, hipStream_t st) {
+  hipLaunchKernelGGL(advnorm_kernel, dim3(groups), dim3(1024), 0, st, adv, T, B, groups);
+}
+
+// ------------------------------------------------------------------------------------------
+// jax.random.permutation (ppo:606): per round, composite key (random_bits << 32 | position) makes the
+// sort stable by construction; rank by counting (n^2 compares, n = 15360: ~20 us) then scatter.
+__global__ void perm_keys_kernel(uint32_t sk0, uint32_t sk1, int n, uint64_t* ckeys) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) ckeys[i] = ((uint64_t)cbm_random_bits_at(sk0, sk1, (uint32_t)n, (uint32_t)i) << 32) | (uint32_t)i;
+}
+__global__ __launch_bounds__(256) void perm_rank_kernel(const uint64_t* ckeys, int n, const int32_t* in_vals, int32_t* out_vals) {
+  __shared__ uint64_t tile[1024];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const uint64_t mine = i < n ? ckeys[i] : 0;
+  int rank = 0;
+  for (int j0 = 0; j0 < n; j0 += 1024) {
+    __syncthreads();
+    for (int q = threadIdx.x; q < 1024; q += 256) tile[q] = (j0 + q < n) ? ckeys[j0 + q] : ~0ull;
+    __syncthreads();
+#pragma unroll 8
+    for (int q = 0; q < 1024; ++q) rank += tile[q] < mine ? 1 : 0;
+  }
+  if (i < n) out_vals[rank] = in_vals ? in_vals[i] : i;
+}
+void launch_permutation(const uint32_t key_in[2], int n, int32_t* perm, int32_t* tmp, uint64_t* ckeys, hipStream_t st) {
+  uint32_t k0 = key_in[0], k1 = key_in[1];
+  const double sz = n > 1 ? (double)n : 1.0;
+  const int rounds = (int)ceil(3.0 * log(sz) / log(4294967295.0));
+  // ping-pong so the final round lands in `perm`
+  int32_t* bufs[2] = {perm, tmp};
+  int cur = (rounds % 2 == 1) ? 0 : 1;  // round 0 writes bufs[cur]
+  const int32_t* src = nullptr;
+  for (int r = 0; r < rounds; ++r) {
+    uint32_t n0, n1, s0, s1;
+    cbm_split_at(k0, k1, 2, 0, &n0, &n1);
+    cbm_split_at(k0, k1, 2, 1, &s0, &s1);
+    k0 = n0; k1 = n1;
+    hipLaunchKernelGGL(perm_keys_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, s0, s1, n, ckeys);
+    hipLaunchKernelGGL(perm_rank_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, ckeys, n, src, bufs[cur]);
+    src = bufs[cur];
+    cur ^= 1;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// PPO loss head ppo:516-577: per-sample statistics + analytic dL/dlogits, dL/dvalue into dzv[N][32].
+__global__ __launch_bounds__(256) void ppo_loss_kernel(const float* logits, const float* value, int N, int A, const int32_t* idx,
+                                                        const int32_t* actions, const float* old_logprob, const float* adv,
+                                                        const float* target, float clip_coef, float ent_coef, float vf_coef,
+                                                        float* dzv, float* partials) {
+  __shared__ float red[4][4];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  float s_pg = 0.0f, s_v = 0.0f, s_ent = 0.0f, s_kl = 0.0f;
+  if (i < N) {
+    const int n = idx ? idx[i] : i;
+    const float* z = logits + (size_t)i * A;
+    const int a = actions[n];
+    const float invN = 1.0f / (float)N;
+    float mx = z[0];
+    for (int j = 1; j < A; ++j) mx = z[j] > mx ? z[j] : mx;
+    float se = 0.0f;
+    for (int j = 0; j < A; ++j) se += cbm_expf(z[j] - mx);
+    const float lse_shift = cbm_logf(se);
+    const float newlp = (z[a] - mx) - lse_shift;
+    const float lse = lse_shift + mx;
+    float mx2 = -INFINITY;
+    for (int j = 0; j < A; ++j) { float zn = z[j] - lse; if (zn < -FLT_MAX) zn = -FLT_MAX; mx2 = zn > mx2 ? zn : mx2; }
+    float s2 = 0.0f;
+    for (int j = 0; j < A; ++j) { float zn = z[j] - lse; if (zn < -FLT_MAX) zn = -FLT_MAX; s2 += cbm_expf(zn - mx2); }
+    float ent = 0.0f;
+    for (int j = 0; j < A; ++j) { float zn = z[j] - lse; if (zn < -FLT_MAX) zn = -FLT_MAX; ent += zn * (cbm_expf(zn - mx2) / s2); }
+    ent = -ent;
+    const float logratio = newlp - old_logprob[n];
+    const float ratio = cbm_expf(logratio);
+    const float ad = adv[n];
+    const float lo = 1.0f - clip_coef, hi = 1.0f + clip_coef;
+    const float rc = ratio < lo ? lo : (ratio > hi ? hi : ratio);
+    const float pg1 = -ad * ratio, pg2 = -ad * rc;
+    const float pg = pg1 > pg2 ? pg1 : pg2;
+    const float dv = value[i] - target[n];
+    s_pg = pg; s_v = dv * dv; s_ent = ent; s_kl = (ratio - 1.0f) - logratio;
+    const float w1 = pg1 > pg2 ? 1.0f : (pg1 == pg2 ? 0.5f : 0.0f);
+    const float dclip = (ratio > lo && ratio < hi) ? 1.0f : ((ratio == lo || ratio == hi) ? 0.5f : 0.0f);
+    const float dpg_dratio = w1 * (-ad) + (1.0f - w1) * (-ad) * dclip;
+    const float c_lp = dpg_dratio * ratio * invN;
+    float* d = dzv + (size_t)i * 32;
+    for (int j = 0; j < A; ++j) {
+      float zn = z[j] - lse; if (zn < -FLT_MAX) zn = -FLT_MAX;
+      const float pj = cbm_expf(zn - mx2) / s2;
+      d[j] = c_lp * ((j == a ? 1.0f : 0.0f) - pj) + ent_coef * invN * pj * (zn + ent);
+    }
+    d[A] = vf_coef * dv * invN;
+    for (int j = A + 1; j < 32; ++j) d[j] = 0.0f;
+  }
+  // block partial sums, fixed order
+  float vals[4] = {s_pg, s_v, s_ent, s_kl};
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  for (int q = 0; q < 4; ++q) {
+    float v = vals[q];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if (l == 0) red[w][q] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) partials[blockIdx.x * 4 + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+__global__ void ppo_stats_kernel(const float* partials, int nblk, int N, float ent_coef, float vf_coef, float* stats5) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float s[4] = {0, 0, 0, 0};
+  for (int b = 0; b < nblk; ++b) for (int q = 0; q < 4; ++q) s[q] += partials[b * 4 + q];
+  const float n = (float)N;
+  const float pg = s[0] / n, v = 0.5f * (s[1] / n), e = s[2] / n, kl = s[3] / n;
+  stats5[0] = pg - ent_coef * e + v * vf_coef;
+  stats5[1] = pg; stats5[2] = v; stats5[3] = e; stats5[4] = kl;
+}
+void launch_ppo_loss(const float* logits, const float* value, int N, int A, const int32_t* idx, const int32_t* actions,
+                     const float* old_logprob, const float* adv, const float* target, float clip_coef, float ent_coef, float vf_coef,
+                     float* dzv, float* partials, float* stats5, hipStream_t st) {
+  const int nblk = ceil_div(N, 256);
+  hipLaunchKernelGGL(ppo_loss_kernel, dim3(nblk), dim3(256), 0, st, logits, value, N, A, idx, actions, old_logprob, adv, target, clip_coef,
+                     ent_coef, vf_coef, dzv, partials);
+  hipLaunchKernelGGL(ppo_stats_kernel, dim3(1), dim3(64), 0, st, partials, nblk, N, ent_coef, vf_coef, stats5);
+}
+
+// ------------------------------------------------------------------------------------------
+// IMPALA loss head impala:569-597 + rlax 0.1.5 V-trace (lambda = 1, rho/c/pg clips = 1).
+// One thread per env column of the minibatch: network outputs are [T1][Bm] rows (t-major),
+// storage fields are [T1][ld] with this minibatch at columns col0..col0+Bm.
+__global__ void impala_loss_kernel(const float* logits, const float* value, const float* mu_logits, const int32_t* actions,
+                                   const float* rewards, const uint8_t* dones, const uint8_t* firststeps, int T1, int Bm, int A, int col0,
+                                   int ld, float gamma, float vf_coef, float ent_coef, float* dzv, float* partials) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= Bm) return;
+  const int T = T1 - 1;
+  float s_pg = 0.0f, s_bl = 0.0f, s_ent = 0.0f;
+  // pass 1 (forward in t): log pi(a), rho; stash in dzv row scratch (cols 30,31) to avoid local arrays
+  for (int t = 0; t < T; ++t) {
+    const size_t r = (size_t)t * Bm + b, sidx = (size_t)t * ld + col0 + b;
+    const int a = actions[sidx];
+    const float* z = logits + r * A;
+    const float* m = mu_logits + sidx * A;
+    float mx = z[0], mm = m[0];
+    for (int j = 1; j < A; ++j) { mx = z[j] > mx ? z[j] : mx; mm = m[j] > mm ? m[j] : mm; }
+    float sz = 0.0f, sm = 0.0f;
+    for (int j = 0; j < A; ++j) { sz += cbm_expf(z[j] - mx); sm += cbm_expf(m[j] - mm); }
+    const float lpa = (z[a] - mx) - cbm_logf(sz);
+    const float lma = (m[a] - mm) - cbm_logf(sm);
+    dzv[r * 32 + 30] = lpa;
+    dzv[r * 32 + 31] = cbm_expf(lpa - lma);
+  }
+  // pass 2 (reverse): err recursion, stash err in col 29
+  float e = 0.0f;
+  for (int t = T - 1; t >= 0; --t) {
+    const size_t r = (size_t)t * Bm + b, sidx = (size_t)t * ld + col0 + b;
+    const float disc = (1.0f - (float)dones[sidx]) * gamma;
+    const float rho = dzv[r * 32 + 31];
+    const float cr = rho < 1.0f ? rho : 1.0f;
+    const float td = cr * ((rewards[sidx] + disc * value[r + Bm]) - value[r]);
+    e = td + (disc * cr) * e;
+    dzv[r * 32 + 29] = e;
+  }
+  // pass 3: losses and gradients
+  for (int t = 0; t < T; ++t) {
+    const size_t r = (size_t)t * Bm + b, sidx = (size_t)t * ld + col0 + b;
+    const float disc = (1.0f - (float)dones[sidx]) * gamma;
+    const float mask = 1.0f - (float)firststeps[sidx];
+    const float lpa = dzv[r * 32 + 30], rho = dzv[r * 32 + 31], err = dzv[r * 32 + 29];
+    const float cr = rho < 1.0f ? rho : 1.0f;
+    const float errors = (err + value[r]) - value[r];
+    float qboot;
+    if (t == T - 1) qboot = value[r + Bm];
+    else { const float en = dzv[(r + Bm) * 32 + 29]; qboot = ((en + value[r + Bm]) - value[r + Bm]) + value[r + Bm]; }
+    const float q = rewards[sidx] + disc * qboot;
+    const float pgadv = cr * (q - value[r]);
+    s_pg += -lpa * pgadv * mask;
+    s_bl += errors * errors * mask;
+    const float* z = logits + r * A;
+    const int a = actions[sidx];
+    float mx = z[0];
+    for (int j = 1; j < A; ++j) mx = z[j] > mx ? z[j] : mx;
+    float se = 0.0f;
+    for (int j = 0; j < A; ++j) se += cbm_expf(z[j] - mx);
+    const float lse = cbm_logf(se);
+    float H = 0.0f;
+    for (int j = 0; j < A; ++j) { const float lp = (z[j] - mx) - lse; H += (cbm_expf(z[j] - mx) / se) * lp; }
+    H = -H;
+    s_ent += -H * mask;
+    float* d = dzv + r * 32;
+    for (int j = 0; j < A; ++j) {
+      const float lp = (z[j] - mx) - lse, pj = cbm_expf(z[j] - mx) / se;
+      d[j] = (-pgadv * mask) * ((j == a ? 1.0f : 0.0f) - pj) + ent_coef * mask * pj * (lp + H);
+    }
+    d[A] = vf_coef * (-errors) * mask;
+    for (int j = A + 1; j < 29; ++j) d[j] = 0.0f;
+  }
+  // bootstrap row T: no gradient; clear scratch columns everywhere
+  for (int t = 0; t < T1; ++t) {
+    float* d = dzv + ((size_t)t * Bm + b) * 32;
+    if (t == T) for (int j = 0; j < 29; ++j) d[j] = 0.0f;
+    d[29] = 0.0f; d[30] = 0.0f; d[31] = 0.0f;
+  }
+  partials[b * 3 + 0] = s_pg; partials[b * 3 + 1] = s_bl; partials[b * 3 + 2] = s_ent;
+}
+__global__ void impala_stats_kernel(const float* partials, int Bm, float vf_coef, float ent_coef, float* stats4) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float s[3] = {0, 0, 0};
+  for (int b = 0; b < Bm; ++b) for (int q = 0; q < 3; ++q) s[q] += partials[b * 3 + q];
+  stats4[1] = s[0]; stats4[2] = 0.5f * s[1]; stats4[3] = s[2];
+  stats4[0] = stats4[1] + vf_coef * stats4[2] + ent_coef * stats4[3];
+}
+void launch_impala_loss(const float* logits, const float* value, const float* mu_logits, const int32_t* actions, const float* rewards,
+                        const uint8_t* dones, const uint8_t* firststeps, int T1, int Bm, int A, int col0, int ld, float gamma,
+                        float vf_coef, float ent_coef, float* dzv, float* partials, float* stats4, hipStream_t st) {
+  hipLaunchKernelGGL(impala_loss_kernel, dim3(ceil_div(Bm, 64)), dim3(64), 0, st, logits, value, mu_logits, actions, rewards, dones,
+                     firststeps, T1, Bm, A, col0, ld, gamma, vf_coef, ent_coef, dzv, partials);
+  hipLaunchKernelGGL(impala_stats_kernel, dim3(1), dim3(64), 0, st, partials, Bm, vf_coef, ent_coef, stats4);
+}
+
+// ------------------------------------------------------------------------------------------
+// optimizer: clip_by_global_norm + adam (ppo:492-500,629) / rmsprop_pytorch_style (impala:152-188).
+// Pass 1: CBM_NORM_PARTS block partials of sum(g^2); pass 2: every block re-reduces the partials in the
+// same fixed order (bit-identical norm everywhere, no atomics) and applies the elementwise update.
+__global__ __launch_bounds__(256) void sqnorm_partials_kernel(const float* g, int64_t n, float grad_div, float* partials) {
+  __shared__ float red[4];
+  float s = 0.0f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float v = grad_div == 1.0f ? g[i] : g[i] / grad_div;
+    s += v * v;
+  }
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__device__ float norm_from_partials(const float* partials) {
+  __shared__ float red[4];
+  float s = 0.0f;
+  for (int i = threadIdx.x; i < CBM_NORM_PARTS; i += 256) s += partials[i];
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  return sqrtf((red[0] + red[1]) + (red[2] + red[3]));
+}
+__global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, float* m, float* v, int64_t n, float max_norm, float lr,
+                                                   float b1, float b2, float eps, float bc1, float bc2, float grad_div,
+                                                   const float* partials) {
+  const float gn = norm_from_partials(partials);
+  const bool clip = !(gn < max_norm);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    float gi = grad_div == 1.0f ? g[i] : g[i] / grad_div;
+    if (clip) gi = (gi / gn) * max_norm;
+    const float mi = (1.0f - b1) * gi + b1 * m[i];
+    const float vi = (1.0f - b2) * (gi * gi) + b2 * v[i];
+    m[i] = mi; v[i] = vi;
+    const float u = (mi / bc1) / (sqrtf(vi / bc2) + eps);
+    p[i] = p[i] + (-lr) * u;
+  }
+}
+__global__ __launch_bounds__(256) void rmsprop_kernel(float* p, const float* g, float* nu, int64_t n, float max_norm, float lr, float decay,
+                                                      float eps, float grad_div, const float* partials) {
+  const float gn = norm_from_partials(partials);
+  const bool clip = !(gn < max_norm);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    float gi = grad_div == 1.0f ? g[i] : g[i] / grad_div;
+    if (clip) gi = (gi / gn) * max_norm;
+    const float ni = (1.0f - decay) * (gi * gi) + decay * nu[i];
+    nu[i] = ni;
+    p[i] = p[i] + (-lr) * (gi / (sqrtf(ni) + eps));
+  }
+}
+void launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float max_norm, float lr, float b1, float b2, float eps,
+                 float bc1, float bc2, float grad_div, float* norm_partials, hipStream_t st) {
+  hipLaunchKernelGGL(sqnorm_partials_kernel, dim3(CBM_NORM_PARTS), dim3(256), 0, st, g, n, grad_div, norm_partials);
+  hipLaunchKernelGGL(adam_kernel, dim3(1024), dim3(256), 0, st, p, g, m, v, n, max_norm, lr, b1, b2, eps, bc1, bc2, grad_div, norm_partials);
+}
+void launch_rmsprop(float* p, const float* g, float* nu, int64_t n, float max_norm, float lr, float decay, float eps, float grad_div,
+                    float* norm_partials, hipStream_t st) {
+  hipLaunchKernelGGL(sqnorm_partials_kernel, dim3(CBM_NORM_PARTS), dim3(256), 0, st, g, n, grad_div, norm_partials);
+  hipLaunchKernelGGL(rmsprop_kernel, dim3(1024), dim3(256), 0, st, p, g, nu, n, max_norm, lr, decay, eps, grad_div, norm_partials);
+}

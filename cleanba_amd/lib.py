@@ -1,0 +1,284 @@
+"""ctypes binding of libcleanba_mi.so (include/cleanba_mi.h).
+
+This is the only way the Python host reaches the GPU: there is no CPU fallback.  If the
+shared library is missing, or no MI355X is visible, importing/constructing fails loudly.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libcleanba_mi.so")
+
+NET_NATURE, NET_IMPALA_RESNET = 0, 1
+ALGO_PPO, ALGO_IMPALA = 0, 1
+FRAME = 4 * 84 * 84
+
+
+class CbmError(RuntimeError):
+    pass
+
+
+class Config(C.Structure):
+    _fields_ = [("abi_version", C.c_int32), ("device", C.c_int32), ("network", C.c_int32), ("algo", C.c_int32),
+                ("num_actions", C.c_int32), ("local_num_envs", C.c_int32), ("num_actor_slots", C.c_int32),
+                ("num_steps", C.c_int32), ("num_minibatches", C.c_int32), ("update_epochs", C.c_int32),
+                ("norm_adv", C.c_int32), ("ring_depth", C.c_int32), ("gamma", C.c_float), ("gae_lambda", C.c_float),
+                ("clip_coef", C.c_float), ("ent_coef", C.c_float), ("vf_coef", C.c_float), ("max_grad_norm", C.c_float),
+                ("adam_b1", C.c_float), ("adam_b2", C.c_float), ("adam_eps", C.c_float), ("rms_decay", C.c_float),
+                ("rms_eps", C.c_float), ("actor_dense_ksplit", C.c_int32), ("reserved", C.c_int32 * 7)]
+
+
+class EnvState(C.Structure):
+    _fields_ = [("elapsed", C.c_int32), ("needs_reset", C.c_int32), ("paddle_x", C.c_int32), ("ball_x", C.c_int32),
+                ("ball_y", C.c_int32), ("ball_dx", C.c_int32), ("ball_dy", C.c_int32), ("bricks", C.c_uint32 * 3),
+                ("episode", C.c_uint32), ("ep_return", C.c_float), ("ep_length", C.c_float), ("ret_return", C.c_float),
+                ("ret_length", C.c_float)]
+
+
+# every symbol include/cleanba_mi.h declares (checked by tests/test_abi.py against the header text)
+SYMBOLS = [
+    "cbm_default_config", "cbm_ctx_create", "cbm_ctx_destroy", "cbm_last_error", "cbm_build_info", "cbm_param_count",
+    "cbm_params_set", "cbm_params_get", "cbm_actor_params_get", "cbm_buffer", "cbm_copy_to_host", "cbm_copy_to_device",
+    "cbm_dev_alloc", "cbm_dev_free", "cbm_learner_stream", "cbm_sync", "cbm_actor_set_key", "cbm_actor_get_key",
+    "cbm_actor_begin_rollout", "cbm_actor_step_host", "cbm_actor_record_host", "cbm_actor_rollout_device",
+    "cbm_actor_commit", "cbm_actor_episode_stats", "cbm_learner_wait", "cbm_learner_update", "cbm_learner_prepare",
+    "cbm_learner_epoch_begin", "cbm_learner_minibatch_grad", "cbm_learner_optimizer_step", "cbm_learner_finish",
+    "cbm_forward", "cbm_sample", "cbm_gae", "cbm_advnorm", "cbm_permutation", "cbm_ppo_loss_grad",
+    "cbm_impala_loss_grad", "cbm_adam_step", "cbm_rmsprop_step", "cbm_synth_env_reset_host", "cbm_synth_env_step_host",
+    "cbm_actor_env_reset_device",
+]
+
+_lib = None
+
+
+def build(force=False):
+    """Compile libcleanba_mi.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", os.path.join(_HERE, "csrc"), "-j4"] + (["-B"] if force else [])
+    subprocess.check_call(cmd, stdout=subprocess.DEVNULL)
+    return SO_PATH
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise CbmError(f"{SO_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(there is no CPU fallback for the hot path)")
+    lib = C.CDLL(SO_PATH)
+    lib.cbm_last_error.restype = C.c_char_p
+    lib.cbm_build_info.restype = C.c_char_p
+    lib.cbm_param_count.restype = C.c_int64
+    lib.cbm_learner_stream.restype = C.c_void_p
+    lib.cbm_learner_stream.argtypes = [C.c_void_p]
+    _lib = lib
+    return lib
+
+
+def _chk(rc):
+    if rc != 0:
+        raise CbmError(load().cbm_last_error().decode())
+
+
+def _p(a):
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data_as(C.c_void_p)
+    return C.c_void_p(a)
+
+
+def default_config(algo=ALGO_PPO):
+    cfg = Config()
+    _chk(load().cbm_default_config(int(algo), C.byref(cfg)))
+    return cfg
+
+
+def param_count(network, A):
+    return int(load().cbm_param_count(int(network), int(A)))
+
+
+class DevBuf:
+    """A raw device allocation (hipMalloc) with numpy upload/download; used by tests and the host."""
+
+    def __init__(self, ctx, arr=None, nbytes=None, dtype=np.uint8, shape=None):
+        self.ctx = ctx
+        if arr is not None:
+            arr = np.ascontiguousarray(arr)
+            nbytes, dtype, shape = arr.nbytes, arr.dtype, arr.shape
+        self.nbytes, self.dtype, self.shape = int(nbytes), np.dtype(dtype), shape
+        p = C.c_void_p()
+        _chk(load().cbm_dev_alloc(C.c_int64(max(self.nbytes, 16)), C.byref(p)))
+        self.ptr = p.value
+        if arr is not None:
+            self.upload(arr)
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        _chk(load().cbm_copy_to_device(self.ctx.h, C.c_void_p(self.ptr), _p(arr), C.c_int64(arr.nbytes)))
+
+    def download(self):
+        out = np.empty(self.nbytes // self.dtype.itemsize, self.dtype)
+        _chk(load().cbm_copy_to_host(self.ctx.h, _p(out), C.c_void_p(self.ptr), C.c_int64(self.nbytes)))
+        return out.reshape(self.shape) if self.shape is not None else out
+
+    def free(self):
+        if self.ptr:
+            load().cbm_dev_free(C.c_void_p(self.ptr))
+            self.ptr = None
+
+
+class Context:
+    """Owns one cbm_ctx (one GPU: actor slots + learner)."""
+
+    def __init__(self, cfg):
+        self.lib = load()
+        self.cfg = cfg
+        h = C.c_void_p()
+        _chk(self.lib.cbm_ctx_create(C.byref(cfg), C.byref(h)))
+        self.h = h
+        self.A = cfg.num_actions
+        self.P = param_count(cfg.network, cfg.num_actions)
+
+    def close(self):
+        if self.h:
+            self.lib.cbm_ctx_destroy(self.h)
+            self.h = None
+
+    # ---- params / buffers
+    def set_params(self, p):
+        p = np.ascontiguousarray(p, np.float32)
+        _chk(self.lib.cbm_params_set(self.h, _p(p), C.c_int64(p.size)))
+
+    def get_params(self):
+        out = np.empty(self.P, np.float32)
+        _chk(self.lib.cbm_params_get(self.h, _p(out), C.c_int64(out.size)))
+        return out
+
+    def buffer(self, name, ring=0):
+        p, n = C.c_void_p(), C.c_int64()
+        _chk(self.lib.cbm_buffer(self.h, name.encode(), int(ring), C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def read(self, name, dtype, ring=0, shape=None):
+        ptr, n = self.buffer(name, ring)
+        out = np.empty(n // np.dtype(dtype).itemsize, dtype)
+        _chk(self.lib.cbm_copy_to_host(self.h, _p(out), C.c_void_p(ptr), C.c_int64(n)))
+        return out.reshape(shape) if shape is not None else out
+
+    def write(self, name, arr, ring=0, offset_bytes=0):
+        ptr, n = self.buffer(name, ring)
+        arr = np.ascontiguousarray(arr)
+        assert offset_bytes + arr.nbytes <= n
+        _chk(self.lib.cbm_copy_to_device(self.h, C.c_void_p(ptr + offset_bytes), _p(arr), C.c_int64(arr.nbytes)))
+
+    def sync(self):
+        _chk(self.lib.cbm_sync(self.h))
+
+    def learner_stream(self):
+        return self.lib.cbm_learner_stream(self.h)
+
+    # ---- actor
+    def actor_set_key(self, slot, key):
+        k = np.ascontiguousarray(key, np.uint32)
+        _chk(self.lib.cbm_actor_set_key(self.h, int(slot), _p(k)))
+
+    def actor_get_key(self, slot):
+        k = np.zeros(2, np.uint32)
+        _chk(self.lib.cbm_actor_get_key(self.h, int(slot), _p(k)))
+        return k
+
+    def actor_env_reset_device(self, slot, seed):
+        _chk(self.lib.cbm_actor_env_reset_device(self.h, int(slot), C.c_uint32(int(seed) & 0xFFFFFFFF)))
+
+    def actor_begin_rollout(self, slot, concurrency):
+        v = C.c_int32()
+        _chk(self.lib.cbm_actor_begin_rollout(self.h, int(slot), int(bool(concurrency)), C.byref(v)))
+        return v.value
+
+    def actor_step_host(self, slot, obs, done, firststep=None, reward_with_obs=None, actions_out=None):
+        E = self.cfg.local_num_envs
+        if actions_out is None:
+            actions_out = np.empty(E, np.int32)
+        obs = np.ascontiguousarray(obs, np.uint8)
+        done = np.ascontiguousarray(done, np.uint8)
+        fs = None if firststep is None else np.ascontiguousarray(firststep, np.uint8)
+        rw = None if reward_with_obs is None else np.ascontiguousarray(reward_with_obs, np.float32)
+        _chk(self.lib.cbm_actor_step_host(self.h, int(slot), _p(obs), _p(done), _p(fs), _p(rw), _p(actions_out)))
+        return actions_out
+
+    def actor_record_host(self, slot, reward):
+        r = np.ascontiguousarray(reward, np.float32)
+        _chk(self.lib.cbm_actor_record_host(self.h, int(slot), _p(r)))
+
+    def actor_rollout_device(self, slot, nsteps):
+        _chk(self.lib.cbm_actor_rollout_device(self.h, int(slot), int(nsteps)))
+
+    def actor_commit(self, slot, next_obs=None, next_done=None):
+        no = None if next_obs is None else np.ascontiguousarray(next_obs, np.uint8)
+        nd = None if next_done is None else np.ascontiguousarray(next_done, np.uint8)
+        _chk(self.lib.cbm_actor_commit(self.h, int(slot), _p(no), _p(nd)))
+
+    def actor_episode_stats(self, slot):
+        r, l = C.c_float(), C.c_float()
+        _chk(self.lib.cbm_actor_episode_stats(self.h, int(slot), C.byref(r), C.byref(l)))
+        return r.value, l.value
+
+    # ---- learner
+    def learner_wait(self):
+        _chk(self.lib.cbm_learner_wait(self.h))
+
+    def learner_update(self, key, lrs, bc1, bc2, want_stats=True):
+        key = np.ascontiguousarray(key, np.uint32).copy()
+        lrs = np.ascontiguousarray(lrs, np.float32)
+        bc1 = np.ascontiguousarray(bc1, np.float32)
+        bc2 = np.ascontiguousarray(bc2, np.float32)
+        w = 5 if self.cfg.algo == ALGO_PPO else 4
+        stats = np.zeros((len(lrs), w), np.float32) if want_stats else None
+        _chk(self.lib.cbm_learner_update(self.h, _p(key), _p(lrs), _p(bc1), _p(bc2), int(len(lrs)), _p(stats)))
+        return key, stats
+
+    def learner_prepare(self, key):
+        key = np.ascontiguousarray(key, np.uint32).copy()
+        _chk(self.lib.cbm_learner_prepare(self.h, _p(key)))
+        return key
+
+    def learner_epoch_begin(self, key):
+        key = np.ascontiguousarray(key, np.uint32).copy()
+        _chk(self.lib.cbm_learner_epoch_begin(self.h, _p(key)))
+        return key
+
+    def learner_minibatch_grad(self, epoch, mb):
+        _chk(self.lib.cbm_learner_minibatch_grad(self.h, int(epoch), int(mb)))
+
+    def learner_optimizer_step(self, lr, bc1, bc2, grad_div=1.0):
+        _chk(self.lib.cbm_learner_optimizer_step(self.h, C.c_float(lr), C.c_float(bc1), C.c_float(bc2), C.c_float(grad_div)))
+
+    def learner_finish(self, n_rows, want_stats=True):
+        w = 5 if self.cfg.algo == ALGO_PPO else 4
+        stats = np.zeros((n_rows, w), np.float32) if want_stats else None
+        _chk(self.lib.cbm_learner_finish(self.h, _p(stats)))
+        return stats
+
+
+# ---- host twin of the synthetic env (CPU code inside the same library; no GPU needed)
+def synth_env_reset_host(seed, n):
+    st = (EnvState * n)()
+    obs = np.zeros((n, 4, 84, 84), np.uint8)
+    _chk(load().cbm_synth_env_reset_host(C.c_uint32(int(seed) & 0xFFFFFFFF), int(n), st, _p(obs)))
+    return st, obs
+
+
+def synth_env_step_host(seed, st, obs, actions, max_episode_steps=27000):
+    n = obs.shape[0]
+    actions = np.ascontiguousarray(actions, np.int32)
+    reward = np.zeros(n, np.float32)
+    done = np.zeros(n, np.uint8)
+    term = np.zeros(n, np.uint8)
+    elapsed = np.zeros(n, np.int32)
+    _chk(load().cbm_synth_env_step_host(C.c_uint32(int(seed) & 0xFFFFFFFF), int(n), int(max_episode_steps), _p(actions), st,
+                                        _p(obs), _p(reward), _p(done), _p(term), _p(elapsed)))
+    return reward, done, term, elapsed

@@ -1,0 +1,167 @@
+/* cleanba_mi.h — C ABI of libcleanba_mi.so, the MI355X (gfx950) implementation of cleanba's
+ * rollout + update hot path.  extern "C", plain pointers and sizes, no torch types.
+ *
+ * The reference (vwxyzjn/cleanba, /root/reference) has no FFI: its seam is Python-level
+ * (SURVEY.md §8b).  Each entry point below names the reference code it replaces
+ * (file:line under /root/reference/cleanba/; "ppo" = cleanba_ppo.py, "impala" =
+ * cleanba_impala.py, "naturecnn" = legacy_scripts/cleanba_ppo_envpool_impala_atari_wrapper_naturecnn.py).
+ * INTEGRATION.md shows the ctypes stubs a cleanba maintainer would add.
+ *
+ * Conventions
+ *  - every function returns 0 on success, <0 on error; cbm_last_error() gives the message
+ *    (thread-local).  Nothing throws, nothing calls back into Python.
+ *  - the library owns ctx, HBM rollout ring, workspaces, streams, events.  Host pointers passed
+ *    in are only read/written during the call.  Device pointers handed out by cbm_buffer() stay
+ *    valid until cbm_ctx_destroy().
+ *  - threading: one host thread per actor slot may call cbm_actor_* concurrently (each slot has
+ *    its own HIP stream and ring producer index); one learner thread calls cbm_learner_*.
+ *  - numerics: fp32 throughout, forward dot products are k-ascending fmaf chains
+ *    (v_mfma_f32_32x32x2_f32); scalar math from cbm_math.h.
+ */
+#ifndef CLEANBA_MI_H
+#define CLEANBA_MI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CBM_ABI_VERSION 1
+
+typedef struct cbm_ctx cbm_ctx;
+
+enum { CBM_NET_NATURE = 0, CBM_NET_IMPALA_RESNET = 1 };
+enum { CBM_ALGO_PPO = 0, CBM_ALGO_IMPALA = 1 };
+
+/* Mirrors the fields of the reference `Args` that the path reads (ppo:34-118, impala:34-110). */
+typedef struct {
+  int32_t abi_version;       /* = CBM_ABI_VERSION */
+  int32_t device;            /* HIP device ordinal (actor and learner share it: a0-l0) */
+  int32_t network;           /* CBM_NET_*            (naturecnn:143-178 / ppo:149-189) */
+  int32_t algo;              /* CBM_ALGO_*                                              */
+  int32_t num_actions;       /* envs.single_action_space.n  (ppo:253)                   */
+  int32_t local_num_envs;    /* --local-num-envs  E          (ppo:63)                   */
+  int32_t num_actor_slots;   /* len(actor_device_ids)*num_actor_threads on this GPU (ppo:668-686) */
+  int32_t num_steps;         /* --num-steps T                (ppo:67 / impala:67)       */
+  int32_t num_minibatches;   /* ppo:77                                                  */
+  int32_t update_epochs;     /* ppo:81 (IMPALA: 1)                                      */
+  int32_t norm_adv;          /* ppo:83                                                  */
+  int32_t ring_depth;        /* rollouts in flight per slot (>=2); replaces Queue(maxsize=1) ppo:672-673 */
+  float gamma, gae_lambda;   /* ppo:72-75                                               */
+  float clip_coef, ent_coef, vf_coef, max_grad_norm; /* ppo:85-92 / impala:81-86        */
+  float adam_b1, adam_b2, adam_eps;                  /* optax.adam defaults, eps=1e-5 ppo:497 */
+  float rms_decay, rms_eps;                          /* impala:534                       */
+  int32_t actor_dense_ksplit;/* K segments of the 3136->512 dense when M<=128 (numerics spec) */
+  int32_t reserved[7];
+} cbm_config;
+
+/* Fills cfg with the reference defaults for `algo` (ppo:34-118 / impala:34-110). */
+int cbm_default_config(int32_t algo, cbm_config* cfg);
+
+int cbm_ctx_create(const cbm_config* cfg, cbm_ctx** out);
+int cbm_ctx_destroy(cbm_ctx* ctx);
+const char* cbm_last_error(void);
+const char* cbm_build_info(void);
+
+/* ---- parameters: flat fp32 blob in flax layout (SURVEY §5 checkpoint names).
+ * Replaces network.init/actor.init/critic.init + device_put (ppo:481-502) and the
+ * params hand-off to the actors (ppo:721-725). */
+int64_t cbm_param_count(int32_t network, int32_t num_actions);
+int cbm_params_set(cbm_ctx* ctx, const float* host_params, int64_t n);      /* learner + actor copy, resets optimizer state */
+int cbm_params_get(cbm_ctx* ctx, float* host_params, int64_t n);            /* learner copy */
+int cbm_actor_params_get(cbm_ctx* ctx, float* host_params, int64_t n);      /* actor copy (policy version behind) */
+
+/* ---- named device buffers (for tests, all-reduce plumbing, checkpointing).
+ * names: "params", "actor_params", "grads", "opt_m", "opt_v", "adv", "target", "perm",
+ *        "obs", "actions", "logprobs", "values", "rewards", "dones", "logits", "stats" ...   */
+int cbm_buffer(cbm_ctx* ctx, const char* name, int32_t ring_index, void** dev_ptr, int64_t* nbytes);
+int cbm_copy_to_host(cbm_ctx* ctx, void* host_dst, const void* dev_src, int64_t nbytes);
+int cbm_copy_to_device(cbm_ctx* ctx, void* dev_dst, const void* host_src, int64_t nbytes);
+int cbm_dev_alloc(int64_t nbytes, void** dev_ptr);   /* plain hipMalloc/hipFree, so tests need no torch */
+int cbm_dev_free(void* dev_ptr);
+void* cbm_learner_stream(cbm_ctx* ctx);   /* hipStream_t, so torch.distributed can order its all-reduce */
+int cbm_sync(cbm_ctx* ctx);
+
+/* ---- actor side: replaces rollout()'s hot loop, ppo:308-375 / impala:351-416.
+ * PRNG key handling = jax.random.split per step (ppo:256): the slot's key lives in the ctx. */
+int cbm_actor_set_key(cbm_ctx* ctx, int32_t slot, const uint32_t key[2]);          /* ppo:677 */
+int cbm_actor_get_key(cbm_ctx* ctx, int32_t slot, uint32_t key[2]);
+/* Blocks until the slot may start rollout `update` (ring entry free + params published);
+ * implements params_queue.get() and the `update != 2` skew (ppo:287-304).  Returns the
+ * actor policy version in *policy_version. */
+int cbm_actor_begin_rollout(cbm_ctx* ctx, int32_t slot, int32_t concurrency, int32_t* policy_version);
+/* Host-env step (envpool numpy arrays): uploads obs[E,4,84,84] + done[E] into ring row t,
+ * runs get_action_and_value (ppo:246-261), returns actions[E] after the 4*E-byte D2H (ppo:317). */
+int cbm_actor_step_host(cbm_ctx* ctx, int32_t slot, const uint8_t* obs, const uint8_t* done,
+                        const uint8_t* firststep, const float* reward_with_obs, int32_t* actions_out);
+/* reward_with_obs: IMPALA stores the reward that arrived WITH obs_t (impala:372-384); NULL for PPO,
+ * which instead records what envs.step returned for the action just taken (ppo:321-342): */
+int cbm_actor_record_host(cbm_ctx* ctx, int32_t slot, const float* reward);
+/* Device-env rollout: the built-in synthetic Atari-shaped env (cbm_synth_*) steps on the GPU, so
+ * the whole T-step rollout is enqueued without host round trips.  nsteps = T (PPO) / T or T+1 (IMPALA). */
+int cbm_actor_rollout_device(cbm_ctx* ctx, int32_t slot, int32_t nsteps);
+/* Publishes the rollout (ppo:357-375): next_obs/next_done from the host env, or NULL for the
+ * device env.  Bumps the ring sequence; never blocks on the learner. */
+int cbm_actor_commit(cbm_ctx* ctx, int32_t slot, const uint8_t* next_obs, const uint8_t* next_done);
+/* Episode statistics kept on the device env (ppo:343-352): mean returned episodic return/length. */
+int cbm_actor_episode_stats(cbm_ctx* ctx, int32_t slot, float* avg_return, float* avg_length);
+
+/* ---- learner side: replaces multi_device_update (ppo:579-660 / impala:599-645).
+ * cbm_learner_wait blocks until every slot has committed rollout #update (ppo:697-711). */
+int cbm_learner_wait(cbm_ctx* ctx);
+/* Whole single-GPU update: GAE + adv-norm + epochs x minibatches x (loss, grads, optimizer).
+ * `key` is the learner PRNG key (ppo:470), updated in place exactly as jax.random.split would.
+ * lrs[i] / bc1[i] / bc2[i] are the schedule values of optimizer step i (linear_schedule
+ * ppo:475-479 evaluated by the host in float32).  stats_out: [epochs*minibatches][5]
+ * (loss, pg, v, entropy, approx_kl) for PPO, [minibatches][4] for IMPALA. */
+int cbm_learner_update(cbm_ctx* ctx, uint32_t key[2], const float* lrs, const float* bc1, const float* bc2,
+                       int32_t n_opt_steps, float* stats_out);
+/* Split form for data-parallel learners (pmean of grads, ppo:628): prepare -> per minibatch
+ * grad -> [caller all-reduces "grads"] -> optimizer step -> finish. */
+int cbm_learner_prepare(cbm_ctx* ctx, uint32_t key[2]);
+int cbm_learner_epoch_begin(cbm_ctx* ctx, uint32_t key[2]);   /* key,subkey = split(key); perm = permutation(subkey) ppo:599-606 */
+int cbm_learner_minibatch_grad(cbm_ctx* ctx, int32_t epoch, int32_t minibatch);
+int cbm_learner_optimizer_step(cbm_ctx* ctx, float lr, float bc1, float bc2, float grad_div);
+int cbm_learner_finish(cbm_ctx* ctx, float* stats_out);   /* publishes params to the actors (ppo:721-725) */
+
+/* ---- pure-function entry points (device pointers; used by the parity tests) ------------- */
+/* get_action_and_value on B frames: ppo:246-261.  outputs may be NULL. */
+int cbm_forward(cbm_ctx* ctx, const float* params, const uint8_t* obs, const int32_t* idx, int32_t B,
+                int32_t dense_ksplit, float* logits, float* value);
+int cbm_sample(cbm_ctx* ctx, const float* logits, int32_t B, const uint32_t subkey[2], int32_t* actions, float* logprobs);
+int cbm_gae(cbm_ctx* ctx, const float* rewards, const float* values, const uint8_t* dones, const float* next_value,
+            const uint8_t* next_done, int32_t T, int32_t B, float* adv, float* target);             /* ppo:532-560 */
+int cbm_advnorm(cbm_ctx* ctx, float* adv, int32_t T, int32_t B, int32_t groups);                  /* ppo:592-595 */
+int cbm_permutation(cbm_ctx* ctx, const uint32_t key[2], int32_t n, int32_t* perm);               /* ppo:606 */
+int cbm_ppo_loss_grad(cbm_ctx* ctx, const float* params, const uint8_t* obs, const int32_t* idx, int32_t N,
+                      const int32_t* actions, const float* old_logprob, const float* adv, const float* target,
+                      float* stats5, float* grads, float* logits_out, float* value_out);           /* ppo:562-577,619 */
+int cbm_impala_loss_grad(cbm_ctx* ctx, const float* params, const uint8_t* obs, const int32_t* idx, int32_t T1,
+                         int32_t Bm, const float* mu_logits, const int32_t* actions, const float* rewards,
+                         const uint8_t* dones, const uint8_t* firststeps, float* stats4, float* grads); /* impala:569-597 */
+int cbm_adam_step(cbm_ctx* ctx, float* p, const float* g, float* m, float* v, int64_t n, float max_norm, float lr,
+                  float bc1, float bc2, float grad_div);                                            /* ppo:492-500,629 */
+int cbm_rmsprop_step(cbm_ctx* ctx, float* p, const float* g, float* nu, int64_t n, float max_norm, float lr,
+                     float grad_div);                                                               /* impala:152-188 */
+
+/* ---- synthetic Atari-shaped environment (stands in for envpool.make, ppo:128-139) ------- */
+typedef struct {
+  int32_t elapsed, needs_reset;
+  int32_t paddle_x, ball_x, ball_y, ball_dx, ball_dy;
+  uint32_t bricks[3];
+  uint32_t episode;
+  float ep_return, ep_length, ret_return, ret_length;
+} cbm_env_state;
+/* Host twin of the device env (same code path compiled for the CPU): steps n envs.
+ * obs: [n,4,84,84] in/out frame stacks; outputs per env. */
+int cbm_synth_env_reset_host(uint32_t seed, int32_t n, cbm_env_state* st, uint8_t* obs);
+int cbm_synth_env_step_host(uint32_t seed, int32_t n, int32_t max_episode_steps, const int32_t* actions,
+                            cbm_env_state* st, uint8_t* obs, float* reward, uint8_t* done, uint8_t* terminated,
+                            int32_t* elapsed_step);
+int cbm_actor_env_reset_device(cbm_ctx* ctx, int32_t slot, uint32_t seed);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CLEANBA_MI_H */

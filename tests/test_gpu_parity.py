@@ -1,0 +1,172 @@
+"""GPU parity tests (run with -m gpu on an MI355X): every HIP entry point of the C ABI against the
+CPU oracle on the same seeded inputs.  Bars (BASELINE.json north_star): sampled action indices
+bit-exact, integer/index work bit-exact, logits/losses/gradients within 1e-5 (fp32).  Forward
+logits are in fact bit-exact by construction (same fmaf chain order), which is asserted too."""
+import numpy as np
+import pytest
+
+import cleanba_amd.lib as L
+from helpers import make_frames, make_params
+
+pytestmark = pytest.mark.gpu
+A = 18
+
+
+def bits(x):
+    return np.ascontiguousarray(x, np.float32).view(np.uint32)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    cfg = L.default_config(L.ALGO_PPO)
+    cfg.local_num_envs, cfg.num_actor_slots, cfg.num_steps = 16, 1, 16   # MB = 64 frames of workspace
+    c = L.Context(cfg)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def ictx():
+    cfg = L.default_config(L.ALGO_IMPALA)
+    cfg.local_num_envs, cfg.num_actor_slots, cfg.num_steps = 16, 1, 7
+    c = L.Context(cfg)
+    yield c
+    c.close()
+
+
+def test_forward_bit_exact(ctx, oracle):
+    P = make_params(A, 11)
+    obs = make_frames(40, 12)
+    dP, dO = L.DevBuf(ctx, P), L.DevBuf(ctx, obs)
+    for idx, ks in ((None, 1), (None, 14), ([7, 3, 39, 0, 3], 1), (list(range(39, 6, -1)), 14)):
+        B = len(idx) if idx is not None else 40
+        dI = L.DevBuf(ctx, np.asarray(idx, np.int32)) if idx is not None else None
+        dL = L.DevBuf(ctx, nbytes=B * A * 4, dtype=np.float32, shape=(B, A))
+        dV = L.DevBuf(ctx, nbytes=B * 4, dtype=np.float32, shape=(B,))
+        L._chk(ctx.lib.cbm_forward(ctx.h, L._p(dP.ptr), L._p(dO.ptr), L._p(dI.ptr if dI else None), B, ks, L._p(dL.ptr), L._p(dV.ptr)))
+        lo, vo = oracle.nature_forward(P, A, obs, idx=idx, ksplit=ks)
+        lg, vg = dL.download(), dV.download()
+        np.testing.assert_allclose(lg, lo, rtol=0, atol=1e-5)
+        assert (bits(lg) == bits(lo)).all() and (bits(vg) == bits(vo)).all(), "forward must be bit-exact (same chain order)"
+
+
+def test_sample_bit_exact(ctx, oracle):
+    rng = np.random.default_rng(5)
+    for B in (1, 16, 120, 121):
+        logits = rng.normal(0, 1.5, size=(B, A)).astype(np.float32)
+        key = oracle.prng_key(1234 + B)
+        sub = oracle.split(key, 2)[1]
+        dL = L.DevBuf(ctx, logits)
+        dA = L.DevBuf(ctx, nbytes=B * 4, dtype=np.int32, shape=(B,))
+        dP = L.DevBuf(ctx, nbytes=B * 4, dtype=np.float32, shape=(B,))
+        L._chk(ctx.lib.cbm_sample(ctx.h, L._p(dL.ptr), B, L._p(np.ascontiguousarray(sub)), L._p(dA.ptr), L._p(dP.ptr)))
+        a_o, lp_o, _ = oracle.sample_actions(logits, key)
+        assert (dA.download() == a_o).all()
+        assert (bits(dP.download()) == bits(lp_o)).all()
+
+
+def test_gae_advnorm_permutation(ctx, oracle):
+    rng = np.random.default_rng(6)
+    T, B = 128, 120
+    r = (rng.random((T, B)) < 0.05).astype(np.float32)
+    v = rng.normal(size=(T, B)).astype(np.float32)
+    d = (rng.random((T, B)) < 0.01).astype(np.uint8)
+    nv = rng.normal(size=B).astype(np.float32)
+    nd = (rng.random(B) < 0.05).astype(np.uint8)
+    bufs = [L.DevBuf(ctx, x) for x in (r, v, d, nv, nd)]
+    dA = L.DevBuf(ctx, nbytes=T * B * 4, dtype=np.float32, shape=(T, B))
+    dT = L.DevBuf(ctx, nbytes=T * B * 4, dtype=np.float32, shape=(T, B))
+    L._chk(ctx.lib.cbm_gae(ctx.h, *[L._p(b.ptr) for b in bufs], T, B, L._p(dA.ptr), L._p(dT.ptr)))
+    adv_o, tgt_o = oracle.gae(r, v, d, nv, nd)
+    adv = dA.download()
+    assert (bits(adv) == bits(adv_o)).all() and (bits(dT.download()) == bits(tgt_o)).all()   # same serial order
+    L._chk(ctx.lib.cbm_advnorm(ctx.h, L._p(dA.ptr), T, B, 4))
+    np.testing.assert_allclose(dA.download(), oracle.advnorm(adv_o, 4), rtol=0, atol=1e-5)
+    for n in (5, 1000, 15360, 30720):
+        key = oracle.prng_key(n)
+        dPm = L.DevBuf(ctx, nbytes=n * 4, dtype=np.int32, shape=(n,))
+        L._chk(ctx.lib.cbm_permutation(ctx.h, L._p(np.ascontiguousarray(key)), n, L._p(dPm.ptr)))
+        assert (dPm.download() == oracle.permutation(key, n)).all()
+        dPm.free()
+
+
+def test_ppo_loss_and_grads(ctx, oracle):
+    rng = np.random.default_rng(7)
+    N = 64
+    P = make_params(A, 21)
+    obs = make_frames(100, 22)
+    idx = rng.permutation(100)[:N].astype(np.int32)
+    actions = rng.integers(0, A, N).astype(np.int32)
+    old_lp = (-np.log(A) + 0.2 * rng.normal(size=N)).astype(np.float32)
+    adv = rng.normal(size=N).astype(np.float32)
+    tgt = rng.normal(size=N).astype(np.float32)
+    d = [L.DevBuf(ctx, x) for x in (P, obs, idx, actions, old_lp, adv, tgt)]
+    dS = L.DevBuf(ctx, nbytes=32, dtype=np.float32)
+    dG = L.DevBuf(ctx, nbytes=P.size * 4, dtype=np.float32)
+    dLg = L.DevBuf(ctx, nbytes=N * A * 4, dtype=np.float32, shape=(N, A))
+    dV = L.DevBuf(ctx, nbytes=N * 4, dtype=np.float32)
+    L._chk(ctx.lib.cbm_ppo_loss_grad(ctx.h, L._p(d[0].ptr), L._p(d[1].ptr), L._p(d[2].ptr), N, L._p(d[3].ptr), L._p(d[4].ptr),
+                                     L._p(d[5].ptr), L._p(d[6].ptr), L._p(dS.ptr), L._p(dG.ptr), L._p(dLg.ptr), L._p(dV.ptr)))
+    stats_o, grads_o, logits_o, value_o = oracle.ppo_loss_grad(P, A, obs, idx, actions, old_lp, adv, tgt)
+    assert (bits(dLg.download()) == bits(logits_o)).all()
+    np.testing.assert_allclose(dS.download()[:5], stats_o, rtol=1e-5, atol=1e-6)
+    g = dG.download()
+    for name, (o, shp) in oracle.nature_layout(A).items():
+        n = int(np.prod(shp))
+        ref = grads_o[o:o + n]
+        assert np.abs(g[o:o + n] - ref).max() <= 1e-5 * max(np.abs(ref).max(), 1e-7), name
+
+
+def test_impala_loss_and_grads(ictx, oracle):
+    rng = np.random.default_rng(8)
+    T1, Bm = 8, 4
+    N = T1 * Bm
+    P = make_params(A, 31)
+    obs = make_frames(N, 32)
+    mu = rng.normal(0, 0.3, size=(T1, Bm, A)).astype(np.float32)
+    actions = rng.integers(0, A, (T1, Bm)).astype(np.int32)
+    rewards = (rng.random((T1, Bm)) < 0.3).astype(np.float32)
+    dones = (rng.random((T1, Bm)) < 0.2).astype(np.uint8)
+    first = (rng.random((T1, Bm)) < 0.2).astype(np.uint8)
+    d = [L.DevBuf(ictx, x) for x in (P, obs, mu, actions, rewards, dones, first)]
+    dS = L.DevBuf(ictx, nbytes=32, dtype=np.float32)
+    dG = L.DevBuf(ictx, nbytes=P.size * 4, dtype=np.float32)
+    L._chk(ictx.lib.cbm_impala_loss_grad(ictx.h, L._p(d[0].ptr), L._p(d[1].ptr), None, T1, Bm, L._p(d[2].ptr), L._p(d[3].ptr),
+                                         L._p(d[4].ptr), L._p(d[5].ptr), L._p(d[6].ptr), L._p(dS.ptr), L._p(dG.ptr)))
+    stats_o, grads_o = oracle.impala_loss_grad(P, A, obs, None, T1, Bm, mu, actions, rewards, dones, first)
+    np.testing.assert_allclose(dS.download()[:4], stats_o, rtol=1e-5, atol=1e-5)
+    g = dG.download()
+    for name, (o, shp) in oracle.nature_layout(A).items():
+        n = int(np.prod(shp))
+        ref = grads_o[o:o + n]
+        assert np.abs(g[o:o + n] - ref).max() <= 1e-5 * max(np.abs(ref).max(), 1e-7), name
+
+
+def test_optimizers(ctx, oracle):
+    rng = np.random.default_rng(9)
+    n = 1693875
+    p0 = rng.normal(size=n).astype(np.float32)
+    for scale in (1e-5, 1.0):
+        p, m, v = p0.copy(), np.zeros(n, np.float32), np.zeros(n, np.float32)
+        dp, dm, dv = L.DevBuf(ctx, p), L.DevBuf(ctx, m), L.DevBuf(ctx, v)
+        for step in (1, 2, 3):
+            g = (scale * rng.normal(size=n)).astype(np.float32)
+            bc1 = float(np.float32(1) - np.power(np.float32(0.9), np.float32(step)))
+            bc2 = float(np.float32(1) - np.power(np.float32(0.999), np.float32(step)))
+            oracle.adam_step(p, g, m, v, 0.5, 2.5e-4, bc1=bc1, bc2=bc2)
+            dg = L.DevBuf(ctx, g)
+            L._chk(ctx.lib.cbm_adam_step(ctx.h, L._p(dp.ptr), L._p(dg.ptr), L._p(dm.ptr), L._p(dv.ptr), L.C.c_int64(n), L.C.c_float(0.5),
+                                         L.C.c_float(2.5e-4), L.C.c_float(bc1), L.C.c_float(bc2), L.C.c_float(1.0)))
+            dg.free()
+        np.testing.assert_allclose(dp.download(), p, rtol=0, atol=1e-6)
+        np.testing.assert_allclose(dm.download(), m, rtol=1e-5, atol=1e-9)
+    p, nu = p0.copy(), np.zeros(n, np.float32)
+    dp, dn = L.DevBuf(ctx, p), L.DevBuf(ctx, nu)
+    for step in range(2):
+        g = (100 * rng.normal(size=n)).astype(np.float32)     # above the clip threshold 40
+        oracle.rmsprop_step(p, g, nu, 40.0, 6e-4)
+        dg = L.DevBuf(ctx, g)
+        L._chk(ctx.lib.cbm_rmsprop_step(ctx.h, L._p(dp.ptr), L._p(dg.ptr), L._p(dn.ptr), L.C.c_int64(n), L.C.c_float(40.0),
+                                        L.C.c_float(6e-4), L.C.c_float(1.0)))
+        dg.free()
+    np.testing.assert_allclose(dp.download(), p, rtol=0, atol=1e-6)
