@@ -71,6 +71,7 @@ struct cbm_ctx {
   int committed[MAX_SLOTS];
   int updates_done = 0;
   int stat_rows = 0;
+  CbmProf prof;
 };
 
 static bool is_ppo(const cbm_ctx* c) { return c->cfg.algo == CBM_ALGO_PPO; }
@@ -126,6 +127,7 @@ extern "C" int cbm_ctx_create(const cbm_config* cfg, cbm_ctx** out) {
   c->A = cfg->num_actions; c->E = cfg->local_num_envs; c->S = cfg->num_actor_slots;
   c->Bdev = c->E * c->S; c->T = cfg->num_steps; c->T1 = c->T + 1;
   c->nmb = cfg->num_minibatches; c->epochs = is_ppo(c) ? cfg->update_epochs : 1;
+  if (c->Bdev > 1024) { cbm_set_error("local_num_envs*slots must be <= 1024 per GPU"); delete c; return -1; }
   if (c->Bdev % c->nmb) { cbm_set_error("local_num_envs*slots must be divisible by num_minibatches (ppo:416-418)"); delete c; return -1; }
   c->MB = is_ppo(c) ? (c->T * c->Bdev) / c->nmb : c->T1 * (c->Bdev / c->nmb);
   if (3136 % cfg->actor_dense_ksplit || (3136 / cfg->actor_dense_ksplit) % 4) { cbm_set_error("actor_dense_ksplit must divide 3136 into multiples of 4"); delete c; return -1; }
@@ -156,7 +158,7 @@ extern "C" int cbm_ctx_create(const cbm_config* cfg, cbm_ctx** out) {
   c->stat_rows = c->epochs * c->nmb;
   if (dalloc(&c->adv, T1 * B) || dalloc(&c->target, T1 * B) || dalloc(&c->next_value, B) || dalloc(&c->stats_dev, (size_t)c->stat_rows * 8) ||
       dalloc(&c->loss_partials, (size_t)4 * (lmax / 256 + 2) + 3 * B) || dalloc(&c->norm_partials, CBM_NORM_PARTS) ||
-      dalloc(&c->perm, T1 * B) || dalloc(&c->perm_tmp, T1 * B) || dalloc(&c->ckeys, T1 * B)) return -1;
+      dalloc(&c->perm, T1 * B) || dalloc(&c->perm_tmp, T1 * B) || dalloc(&c->ckeys, 2 * T1 * B)) return -1;
   if (!is_ppo(c)) {  // static minibatch index table: contiguous env-column chunks, all T+1 rows (impala:623-634)
     const int Bm = c->Bdev / c->nmb;
     std::vector<int32_t> h((size_t)c->nmb * c->MB);
@@ -538,6 +540,33 @@ extern "C" int cbm_learner_epoch_begin(cbm_ctx* c, uint32_t key[2]) {
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------ profiling
+extern "C" int cbm_profile_select(cbm_ctx* c, int32_t kernel_id) {
+  CBM_HIP(hipSetDevice(c->cfg.device));
+  if (!c->prof.created) {
+    for (int i = 0; i < 2 * CBM_PROF_MAX; ++i) CBM_HIP(hipEventCreate(&c->prof.ev[i]));
+    c->prof.created = true;
+  }
+  c->prof.sel = kernel_id;
+  c->prof.n = 0;
+  c->lws.prof = kernel_id >= 0 ? &c->prof : nullptr;
+  return 0;
+}
+extern "C" int cbm_profile_read(cbm_ctx* c, double* total_ms, int32_t* count) {
+  CBM_HIP(hipSetDevice(c->cfg.device));
+  CBM_HIP(hipStreamSynchronize(c->lstream));
+  double tot = 0.0;
+  for (int i = 0; i < c->prof.n; ++i) {
+    float ms = 0.0f;
+    CBM_HIP(hipEventElapsedTime(&ms, c->prof.ev[2 * i], c->prof.ev[2 * i + 1]));
+    tot += ms;
+  }
+  if (total_ms) *total_ms = tot;
+  if (count) *count = c->prof.n;
+  c->prof.n = 0;
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------------ pure functions
 static int check_B(cbm_ctx* c, int B) {
   if (B > c->lws.maxB) { cbm_set_error("B=%d exceeds the learner workspace (%d frames)", B, c->lws.maxB); return -1; }
@@ -547,7 +576,7 @@ extern "C" int cbm_forward(cbm_ctx* c, const float* params, const uint8_t* obs, 
                            float* value) {
   CBM_HIP(hipSetDevice(c->cfg.device));
   if (check_B(c, B)) return -1;
-  if (ksplit > 1 && (B > 512 || ksplit != c->lws.dense_part_ksplit || !c->lws.dense_part)) {
+  if (ksplit > 1 && (B > 1024 || ksplit != c->lws.dense_part_ksplit || !c->lws.dense_part)) {
     // a split-K plan needs its partial buffer; allocate on demand for tests
     if (c->lws.dense_part) hipFree(c->lws.dense_part);
     CBM_HIP(hipMalloc((void**)&c->lws.dense_part, (size_t)ksplit * c->lws.maxB * 512 * 4));
@@ -582,7 +611,7 @@ extern "C" int cbm_permutation(cbm_ctx* c, const uint32_t key[2], int32_t n, int
   CBM_HIP(hipSetDevice(c->cfg.device));
   int32_t* tmp = nullptr; uint64_t* ck = nullptr;
   CBM_HIP(hipMalloc((void**)&tmp, (size_t)n * 4));
-  CBM_HIP(hipMalloc((void**)&ck, (size_t)n * 8));
+  CBM_HIP(hipMalloc((void**)&ck, (size_t)n * 16));
   launch_permutation(key, n, perm, tmp, ck, c->lstream);
   CBM_HIP(hipStreamSynchronize(c->lstream));
   hipFree(tmp); hipFree(ck);

@@ -16,8 +16,21 @@ struct NatureLayout {
 };
 NatureLayout nature_layout(int A);
 
+// ---- optional per-kernel HIP-event timing (bench.py roofline): events bracket every launch of the
+// selected kernel id on the stream it is launched on.
+enum { K_CONV1_FWD = 0, K_CONV2_FWD, K_CONV3_FWD, K_DENSE_FWD, K_HEADS_WGRAD, K_DENSE_DGRAD, K_DENSE_WGRAD, K_CONV3_DGRAD,
+       K_CONV3_WGRAD, K_CONV2_DGRAD, K_CONV2_WGRAD, K_CONV1_WGRAD, K_NUM };
+#define CBM_PROF_MAX 4096
+struct CbmProf {
+  int sel = -1;
+  int n = 0;
+  hipEvent_t ev[2 * CBM_PROF_MAX];
+  bool created = false;
+};
+
 // ---- workspace for running the network on up to maxB frames ----------------------------
 struct NatureWs {
+  CbmProf* prof = nullptr;
   int maxB = 0;
   bool with_grad = false;
   float *act1 = nullptr, *act2 = nullptr, *act3 = nullptr, *hid = nullptr;

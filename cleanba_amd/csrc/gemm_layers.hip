@@ -25,6 +25,11 @@ NatureLayout nature_layout(int A) {
 
 static __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 static __device__ __forceinline__ float relu(float v) { return v > 0.0f ? v : 0.0f; }
+// Loads are always issued (clamped address) and masked afterwards: a branch around a load makes hipcc
+// wait vmcnt(0) at every merge point and serialises the gather into dependent round trips.
+static __device__ __forceinline__ float4 f4sel(bool ok, float4 v) {
+  return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+}
 
 // ------------------------------------------------------------------------------------------
 // conv1: uint8 NCHW frames -> act1 [M=S*400][32].  k = (c, kh, kw), 8 contiguous bytes per (c,kh).
@@ -38,7 +43,7 @@ struct Conv1Fwd {
   __host__ __device__ int Y() const { return 32; }
   __device__ void r_range(int, int& lo, int& hi) const { lo = 0; hi = 256; }
   __device__ float4 load_a(int m, int r, int, int) const {
-    if (m >= M) return f4zero();
+    m = min(m, M - 1);  // rows >= M are never stored
     const int s = m / 400, p = m - s * 400, oh = p / 20, ow = p - oh * 20;
     const int f = idx ? idx[s] : s;
     const int c = r >> 6, kh = (r >> 3) & 7, kw = r & 7;
@@ -65,7 +70,7 @@ struct ConvFwd {
   __host__ __device__ int Y() const { return CO; }
   __device__ void r_range(int, int& lo, int& hi) const { lo = 0; hi = KH * KW * CI; }
   __device__ float4 load_a(int m, int r, int, int) const {
-    if (m >= M) return f4zero();
+    m = min(m, M - 1);
     const int s = m / (OH * OW), p = m - s * (OH * OW), oh = p / OW, ow = p - oh * OW;
     const int kh = r / (KW * CI), rem = r - kh * (KW * CI);
     return *reinterpret_cast<const float4*>(in + ((size_t)(s * IH + oh * ST + kh) * IW + ow * ST) * CI + rem);
@@ -87,12 +92,12 @@ struct DenseFwd {
   __host__ __device__ int Y() const { return N; }
   __device__ void r_range(int z, int& lo, int& hi) const { lo = z * seg; hi = lo + seg; }
   __device__ float4 load_a(int m, int r, int rhi, int) const {
-    if (m >= M || r >= rhi) return f4zero();
-    return *reinterpret_cast<const float4*>(A + (size_t)m * K + r);
+    const bool ok = r < rhi;
+    return f4sel(ok, *reinterpret_cast<const float4*>(A + (size_t)min(m, M - 1) * K + min(r, K - 4)));
   }
   __device__ float4 load_b(int r, int y, int rhi, int) const {
-    if (r >= rhi || y >= N) return f4zero();
-    return *reinterpret_cast<const float4*>(W + (size_t)r * N + y);
+    const bool ok = r < rhi && y < N;
+    return f4sel(ok, *reinterpret_cast<const float4*>(W + (size_t)min(r, K - 1) * N + min(y, N - 4)));
   }
   __device__ void store(int m, int n, float v, int z, int) const {
     if (m >= M || n >= N) return;
@@ -109,26 +114,32 @@ __global__ void dense_reduce_kernel(const float* part, const float* bias, float*
   out[i] = relu(t + bias[i % N]);
 }
 
-// heads: logits[b][a] = chain_k hid[b][k] Wa[k][a] + ba[a]; value likewise (thread per output)
+// heads: logits[b][a] = chain_k hid[b][k] Wa[k][a] + ba[a]; value likewise.  One thread per output, the
+// 512-long fmaf chain stays serial (numerics spec); hid rows and both weight matrices are staged in LDS so the
+// chain is paced by the FMA latency, not by global loads.
 __global__ __launch_bounds__(256) void heads_fwd_kernel(const float* hid, const float* Wa, const float* ba, const float* Wc,
                                                         const float* bc, int B, int A, float* logits, float* value) {
-  __shared__ float hs[8][512];
+  extern __shared__ __attribute__((aligned(16))) float hsm[];
+  float* hs = hsm;             // [8][512]
+  float* ws = hsm + 8 * 512;   // [512][A+1]
+  const int A1 = A + 1;
   const int f0 = blockIdx.x * 8;
   for (int i = threadIdx.x; i < 8 * 512; i += 256) {
     const int f = f0 + i / 512;
-    hs[i / 512][i % 512] = f < B ? hid[(size_t)f * 512 + i % 512] : 0.0f;
+    hs[i] = f < B ? hid[(size_t)f * 512 + i % 512] : 0.0f;
   }
+  for (int i = threadIdx.x; i < 512 * A; i += 256) ws[(i / A) * A1 + i % A] = Wa[i];
+  for (int i = threadIdx.x; i < 512; i += 256) ws[i * A1 + A] = Wc[i];
   __syncthreads();
   const int fl = threadIdx.x >> 5, o = threadIdx.x & 31, f = f0 + fl;
   if (f >= B || o > A) return;
+  const float* h = hs + fl * 512;
+  const float* w = ws + o;
   float acc = 0.0f;
-  if (o < A) {
-    for (int k = 0; k < 512; ++k) acc = fmaf(hs[fl][k], Wa[k * A + o], acc);
-    logits[(size_t)f * A + o] = acc + ba[o];
-  } else {
-    for (int k = 0; k < 512; ++k) acc = fmaf(hs[fl][k], Wc[k], acc);
-    value[f] = acc + bc[0];
-  }
+#pragma unroll 8
+  for (int k = 0; k < 512; ++k) acc = fmaf(h[k], w[k * A1], acc);
+  if (o < A) logits[(size_t)f * A + o] = acc + ba[o];
+  else value[f] = acc + bc[0];
 }
 
 // ------------------------------------------------------------------------------------------ backward
@@ -157,12 +168,10 @@ struct DenseDgrad {
   __host__ __device__ int Y() const { return 3136; }
   __device__ void r_range(int, int& lo, int& hi) const { lo = 0; hi = 512; }
   __device__ float4 load_a(int m, int r, int, int) const {
-    if (m >= M) return f4zero();
-    return *reinterpret_cast<const float4*>(dhid + (size_t)m * 512 + r);
+    return *reinterpret_cast<const float4*>(dhid + (size_t)min(m, M - 1) * 512 + r);
   }
   __device__ float4 load_b(int r, int y, int, int) const {   // B[r=n..n+3][y=j] = Wd[j][n..n+3]
-    if (y >= 3136) return f4zero();
-    return *reinterpret_cast<const float4*>(Wd + (size_t)y * 512 + r);
+    return *reinterpret_cast<const float4*>(Wd + (size_t)min(y, 3135) * 512 + r);
   }
   __device__ void store(int m, int j, float v, int, int) const {
     if (m >= M || j >= 3136) return;
@@ -184,7 +193,7 @@ struct Conv3Dgrad {
   __host__ __device__ int Y() const { return 64; }
   __device__ void r_range(int, int& lo, int& hi) const { lo = 0; hi = 576; }
   __device__ float4 load_a(int m, int r, int, int) const {
-    if (m >= M) return f4zero();
+    m = min(m, M - 1);
     const int s = m / 81, p = m - s * 81, ih = p / 9, iw = p - ih * 9;
     const int jh = r / 192, rem = r - jh * 192;
     return *reinterpret_cast<const float4*>(dypad + ((size_t)(s * 11 + ih + jh) * 11 + iw) * 64 + rem);
@@ -213,7 +222,7 @@ struct Conv2Dgrad {
   __host__ __device__ int Y() const { return 32; }
   __device__ void r_range(int, int& lo, int& hi) const { lo = 0; hi = 256; }
   __device__ float4 load_a(int m, int r, int, int) const {
-    if (m >= M) return f4zero();
+    m = min(m, M - 1);
     const int s = m / 100, p = m - s * 100, ihh = p / 10, iwh = p - ihh * 10;
     const int jh = r >> 7, rem = r & 127;
     return *reinterpret_cast<const float4*>(dypad + ((size_t)(s * 11 + ihh + jh) * 11 + iwh) * 64 + rem);
@@ -243,16 +252,17 @@ struct Conv1Wgrad {
   __host__ __device__ int Y() const { return 32; }
   __device__ void r_range(int z, int& lo, int& hi) const { lo = z * rps; hi = min(lo + rps, M); }
   __device__ float4 load_a(int k, int m, int rhi, int) const {
-    if (m >= rhi) return f4zero();
+    const bool ok = m < rhi;
+    m = min(m, rhi - 1);
     const int s = m / 400, p = m - s * 400, oh = p / 20, ow = p - oh * 20;
     const int f = idx ? idx[s] : s;
     const int c = k >> 6, kh = (k >> 3) & 7, kw = k & 7;
-    const uint32_t w = *reinterpret_cast<const uint32_t*>(obs + (size_t)f * CBM_FRAME + c * 7056 + (oh * 4 + kh) * 84 + ow * 4 + kw);
+    uint32_t w = *reinterpret_cast<const uint32_t*>(obs + (size_t)f * CBM_FRAME + c * 7056 + (oh * 4 + kh) * 84 + ow * 4 + kw);
+    w = ok ? w : 0u;
     return make_float4(cbm_u8_unit(w & 255u), cbm_u8_unit((w >> 8) & 255u), cbm_u8_unit((w >> 16) & 255u), cbm_u8_unit(w >> 24));
   }
   __device__ float4 load_b(int m, int y, int rhi, int) const {
-    if (m >= rhi) return f4zero();
-    return *reinterpret_cast<const float4*>(dy + (size_t)m * 32 + y);
+    return f4sel(m < rhi, *reinterpret_cast<const float4*>(dy + (size_t)min(m, rhi - 1) * 32 + y));
   }
   __device__ void store(int k, int y, float v, int z, int) const { part[((size_t)z * 256 + k) * 32 + y] = v; }
   __device__ void store_bias(int y, float v, int z) const { bpart[z * 32 + y] = v; }
@@ -269,15 +279,17 @@ struct ConvWgrad {  // dY lives in a zero-bordered [S][OH+2*PADO... = 11][11][CO
   __host__ __device__ int Y() const { return CO; }
   __device__ void r_range(int z, int& lo, int& hi) const { lo = z * rps; hi = min(lo + rps, M); }
   __device__ float4 load_a(int k, int m, int rhi, int) const {
-    if (m >= rhi || k >= KX) return f4zero();
+    const bool ok = m < rhi && k < KX;
+    m = min(m, rhi - 1); k = min(k, KX - 4);
     const int s = m / (OH * OW), p = m - s * (OH * OW), oh = p / OW, ow = p - oh * OW;
     const int kh = k / (KW * CI), rem = k - kh * (KW * CI);
-    return *reinterpret_cast<const float4*>(in + ((size_t)(s * IH + oh * ST + kh) * IW + ow * ST) * CI + rem);
+    return f4sel(ok, *reinterpret_cast<const float4*>(in + ((size_t)(s * IH + oh * ST + kh) * IW + ow * ST) * CI + rem));
   }
   __device__ float4 load_b(int m, int y, int rhi, int) const {
-    if (m >= rhi) return f4zero();
+    const bool ok = m < rhi;
+    m = min(m, rhi - 1);
     const int s = m / (OH * OW), p = m - s * (OH * OW), oh = p / OW, ow = p - oh * OW;
-    return *reinterpret_cast<const float4*>(dypad + ((size_t)(s * 11 + oh + PADO) * 11 + ow + PADO) * CO + y);
+    return f4sel(ok, *reinterpret_cast<const float4*>(dypad + ((size_t)(s * 11 + oh + PADO) * 11 + ow + PADO) * CO + y));
   }
   __device__ void store(int k, int y, float v, int z, int) const {
     if (k < KX) part[((size_t)z * KX + k) * CO + y] = v;
@@ -296,12 +308,12 @@ struct MatWgrad {
   __host__ __device__ int Y() const { return YN; }
   __device__ void r_range(int z, int& lo, int& hi) const { lo = z * rps; hi = min(lo + rps, M); }
   __device__ float4 load_a(int k, int m, int rhi, int) const {
-    if (m >= rhi || k >= XK) return f4zero();
-    return *reinterpret_cast<const float4*>(A + (size_t)m * XK + k);
+    const bool ok = m < rhi && k < XK;
+    return f4sel(ok, *reinterpret_cast<const float4*>(A + (size_t)min(m, rhi - 1) * XK + min(k, XK - 4)));
   }
   __device__ float4 load_b(int m, int y, int rhi, int) const {
-    if (m >= rhi || y >= YN) return f4zero();
-    return *reinterpret_cast<const float4*>(G + (size_t)m * ldg + y);
+    const bool ok = m < rhi && y < YN;
+    return f4sel(ok, *reinterpret_cast<const float4*>(G + (size_t)min(m, rhi - 1) * ldg + min(y, YN - 4)));
   }
   __device__ void store(int k, int y, float v, int z, int) const {
     if (k < XK && y < YN) part[((size_t)z * XK + k) * YN + y] = v;
@@ -309,25 +321,33 @@ struct MatWgrad {
   __device__ void store_bias(int y, float v, int z) const { if (y < YN) bpart[z * YN + y] = v; }
 };
 
-// partial reduce: out = sum_z part[z] (ascending z).  mode 0: identity, 1: conv1 k=(c,kh,kw) -> HWIO,
-// 2: heads [512][32] -> actor.w [512][A] / critic.w [512]
-__global__ void wgrad_reduce_kernel(const float* part, int nz, int XY, int Ycols, int mode, int A, float* gw, float* gw2) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= XY) return;
-  float s = part[i];
-  for (int z = 1; z < nz; ++z) s += part[(size_t)z * XY + i];
+// partial reduce: out[i] = sum_z part[z][i], fixed order (deterministic, ppo:30): the block's ZG z-groups each sum
+// a strided subset of z ascending, then the ZG partials are added in ascending group order.
+// mode 0: identity, 1: conv1 k=(c,kh,kw) -> HWIO, 2: heads [512][32] -> actor.w [512][A] / critic.w [512],
+// 3: heads bias [32] -> actor.b [A] / critic.b [1]
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part, int nz, int XY, int Ycols, int mode, int A, int zg, float* gw,
+                                                            float* gw2) {
+  __shared__ float red[256];
+  const int ow = 256 / zg;
+  const int o = threadIdx.x % ow, g = threadIdx.x / ow;
+  const int i = blockIdx.x * ow + o;
+  float s = 0.0f;
+  if (i < XY)
+    for (int z = g; z < nz; z += zg) s += part[(size_t)z * XY + i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (g != 0 || i >= XY) return;
+  for (int q = 1; q < zg; ++q) s += red[q * ow + o];
   const int x = i / Ycols, y = i - x * Ycols;
   if (mode == 0) gw[i] = s;
   else if (mode == 1) { const int c = x >> 6, kh = (x >> 3) & 7, kw = x & 7; gw[((kh * 8 + kw) * 4 + c) * 32 + y] = s; }
-  else { if (y < A) gw[x * A + y] = s; else if (y == A) gw2[x] = s; }
+  else if (mode == 2) { if (y < A) gw[x * A + y] = s; else if (y == A) gw2[x] = s; }
+  else { if (y < A) gw[y] = s; else if (y == A) gw2[0] = s; }
 }
-__global__ void bias_reduce_kernel(const float* part, int nz, int Y, int mode, int A, float* gb, float* gb2) {
-  const int y = blockIdx.x * blockDim.x + threadIdx.x;
-  if (y >= Y) return;
-  float s = part[y];
-  for (int z = 1; z < nz; ++z) s += part[z * Y + y];
-  if (mode == 2) { if (y < A) gb[y] = s; else if (y == A) gb2[0] = s; }
-  else gb[y] = s;
+static void launch_reduce(const float* part, int nz, int XY, int Ycols, int mode, int A, float* gw, float* gw2, hipStream_t st) {
+  const int zg = nz >= 64 ? 16 : (nz >= 8 ? 4 : 1);
+  const int ow = 256 / zg;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((XY + ow - 1) / ow), dim3(256), 0, st, part, nz, XY, Ycols, mode, A, zg, gw, gw2);
 }
 
 // ------------------------------------------------------------------------------------------ workspace
@@ -348,7 +368,8 @@ int nature_ws_alloc(NatureWs& ws, int maxB, bool with_grad, int dense_ksplit_sma
   if (dmalloc(&ws.act1, B * 12800) || dmalloc(&ws.act2, B * 5184) || dmalloc(&ws.act3, B * 3136) || dmalloc(&ws.hid, B * 512) ||
       dmalloc(&ws.logits, B * 32) || dmalloc(&ws.value, B)) return -1;
   ws.dense_part_ksplit = dense_ksplit_small;
-  if (maxB <= 512 && dense_ksplit_small > 1) { if (dmalloc(&ws.dense_part, (size_t)dense_ksplit_small * B * 512)) return -1; }
+  // split-K partials are only used for small batches (M <= 1024 frames: actor steps, bootstrap value)
+  if (dense_ksplit_small > 1) { if (dmalloc(&ws.dense_part, (size_t)dense_ksplit_small * (B < 1024 ? B : 1024) * 512)) return -1; }
   if (with_grad) {
     if (dmalloc(&ws.dzv, B * 32) || dmalloc(&ws.dhid, B * 512) || dmalloc(&ws.dact3pad, B * 7744) || dmalloc(&ws.dact2pad, B * 7744) ||
         dmalloc(&ws.dact1, B * 12800)) return -1;
@@ -376,6 +397,14 @@ void nature_ws_free(NatureWs& ws) {
 }
 
 // ------------------------------------------------------------------------------------------ drivers
+template <class P>
+static inline void plaunch(NatureWs& ws, int kid, const P& p, int nz, hipStream_t st) {
+  CbmProf* pf = ws.prof;
+  const bool on = pf && pf->sel == kid && pf->n < CBM_PROF_MAX;
+  if (on) hipEventRecord(pf->ev[2 * pf->n], st);
+  igemm_launch(p, nz, st);
+  if (on) { hipEventRecord(pf->ev[2 * pf->n + 1], st); pf->n += 1; }
+}
 using T128x32 = IgemmTile<128, 32, 32, 4, 1>;
 using T256x32 = IgemmTile<256, 32, 32, 4, 1>;
 using T128x64 = IgemmTile<128, 64, 32, 2, 2>;
@@ -386,29 +415,29 @@ void nature_forward(const NatureLayout& L, const float* P, const uint8_t* obs, c
   const bool small = B <= 512;
   {
     Conv1Fwd<T128x32> p{obs, idx, P + L.w[0], P + L.b[0], ws.act1, B * 400};
-    igemm_launch(p, 1, st);
+    plaunch(ws, K_CONV1_FWD, p, 1, st);
   }
   if (small) {
     ConvFwd<T64x64, 4, 4, 2, 32, 64, 20, 20, 9, 9> p2{ws.act1, P + L.w[1], P + L.b[1], ws.act2, B * 81};
-    igemm_launch(p2, 1, st);
+    plaunch(ws, K_CONV2_FWD, p2, 1, st);
     ConvFwd<T64x64, 3, 3, 1, 64, 64, 9, 9, 7, 7> p3{ws.act2, P + L.w[2], P + L.b[2], ws.act3, B * 49};
-    igemm_launch(p3, 1, st);
+    plaunch(ws, K_CONV3_FWD, p3, 1, st);
   } else {
     ConvFwd<T128x64, 4, 4, 2, 32, 64, 20, 20, 9, 9> p2{ws.act1, P + L.w[1], P + L.b[1], ws.act2, B * 81};
-    igemm_launch(p2, 1, st);
+    plaunch(ws, K_CONV2_FWD, p2, 1, st);
     ConvFwd<T128x64, 3, 3, 1, 64, 64, 9, 9, 7, 7> p3{ws.act2, P + L.w[2], P + L.b[2], ws.act3, B * 49};
-    igemm_launch(p3, 1, st);
+    plaunch(ws, K_CONV3_FWD, p3, 1, st);
   }
   if (dense_ksplit > 1) {
     DenseFwd<T64x64, true> pd{ws.act3, P + L.w[3], P + L.b[3], ws.dense_part, B, 3136, 512, 3136 / dense_ksplit};
-    igemm_launch(pd, dense_ksplit, st);
+    plaunch(ws, K_DENSE_FWD, pd, dense_ksplit, st);
     hipLaunchKernelGGL(dense_reduce_kernel, dim3(ceil_div(B * 512, 256)), dim3(256), 0, st, ws.dense_part, P + L.b[3], ws.hid, B, 512,
                        dense_ksplit);
   } else {
     DenseFwd<T64x64, false> pd{ws.act3, P + L.w[3], P + L.b[3], ws.hid, B, 3136, 512, 3136};
-    igemm_launch(pd, 1, st);
+    plaunch(ws, K_DENSE_FWD, pd, 1, st);
   }
-  hipLaunchKernelGGL(heads_fwd_kernel, dim3(ceil_div(B, 8)), dim3(256), 0, st, ws.hid, P + L.w[4], P + L.b[4], P + L.w[5], P + L.b[5], B,
+  hipLaunchKernelGGL(heads_fwd_kernel, dim3(ceil_div(B, 8)), dim3(256), (8 * 512 + 512 * (L.A + 1)) * sizeof(float), st, ws.hid, P + L.w[4], P + L.b[4], P + L.w[5], P + L.b[5], B,
                      L.A, ws.logits, ws.value);
 }
 
@@ -421,52 +450,47 @@ void nature_backward(const NatureLayout& L, const float* P, const uint8_t* obs, 
   {
     const int nz = ceil_div(B, RPS_HEADS);
     MatWgrad<T128x32> p{ws.hid, ws.dzv, ws.wg_part, ws.bias_part, B, 512, 32, 32, RPS_HEADS};
-    igemm_launch(p, nz, st);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(512 * 32, 256)), dim3(256), 0, st, ws.wg_part, nz, 512 * 32, 32, 2, A,
-                       grads + L.w[4], grads + L.w[5]);
-    hipLaunchKernelGGL(bias_reduce_kernel, dim3(1), dim3(64), 0, st, ws.bias_part, nz, 32, 2, A, grads + L.b[4], grads + L.b[5]);
+    plaunch(ws, K_HEADS_WGRAD, p, nz, st);
+    launch_reduce(ws.wg_part, nz, 512 * 32, 32, 2, A, grads + L.w[4], grads + L.w[5], st);
+    launch_reduce(ws.bias_part, nz, 32, 32, 3, A, grads + L.b[4], grads + L.b[5], st);
   }
   // dense: dgrad -> dact3pad, wgrad
   {
     DenseDgrad<T128x64> pd{ws.dhid, P + L.w[3], ws.act3, ws.dact3pad, B};
-    igemm_launch(pd, 1, st);
+    plaunch(ws, K_DENSE_DGRAD, pd, 1, st);
     const int nz = dense_wgrad_splits(B);
     const int rps = round_up(ceil_div(B, nz), 32);
     MatWgrad<T64x64> pw{ws.act3, ws.dhid, ws.wg_part, ws.bias_part, B, 3136, 512, 512, rps};
-    igemm_launch(pw, nz, st);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(3136 * 512, 256)), dim3(256), 0, st, ws.wg_part, nz, 3136 * 512, 512, 0, A,
-                       grads + L.w[3], (float*)nullptr);
-    hipLaunchKernelGGL(bias_reduce_kernel, dim3(2), dim3(256), 0, st, ws.bias_part, nz, 512, 0, A, grads + L.b[3], (float*)nullptr);
+    plaunch(ws, K_DENSE_WGRAD, pw, nz, st);
+    launch_reduce(ws.wg_part, nz, 3136 * 512, 512, 0, A, grads + L.w[3], (float*)nullptr, st);
+    launch_reduce(ws.bias_part, nz, 512, 512, 0, A, grads + L.b[3], (float*)nullptr, st);
   }
   // conv3: dgrad -> dact2pad, wgrad
   {
     Conv3Dgrad<T128x64> pd{ws.dact3pad, P + L.w[2], ws.act2, ws.dact2pad, B * 81};
-    igemm_launch(pd, 1, st);
+    plaunch(ws, K_CONV3_DGRAD, pd, 1, st);
     const int M = B * 49, nz = ceil_div(M, RPS_C3);
     ConvWgrad<T64x64, 3, 3, 1, 64, 64, 9, 9, 7, 7, 2> pw{ws.act2, ws.dact3pad, ws.wg_part, ws.bias_part, M, RPS_C3};
-    igemm_launch(pw, nz, st);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(576 * 64, 256)), dim3(256), 0, st, ws.wg_part, nz, 576 * 64, 64, 0, A,
-                       grads + L.w[2], (float*)nullptr);
-    hipLaunchKernelGGL(bias_reduce_kernel, dim3(1), dim3(64), 0, st, ws.bias_part, nz, 64, 0, A, grads + L.b[2], (float*)nullptr);
+    plaunch(ws, K_CONV3_WGRAD, pw, nz, st);
+    launch_reduce(ws.wg_part, nz, 576 * 64, 64, 0, A, grads + L.w[2], (float*)nullptr, st);
+    launch_reduce(ws.bias_part, nz, 64, 64, 0, A, grads + L.b[2], (float*)nullptr, st);
   }
   // conv2: dgrad -> dact1, wgrad
   {
     Conv2Dgrad<T128x32> pd{ws.dact2pad, P + L.w[1], ws.act1, ws.dact1, B * 100};
-    igemm_launch(pd, 1, st);
+    plaunch(ws, K_CONV2_DGRAD, pd, 1, st);
     const int M = B * 81, nz = ceil_div(M, RPS_C2);
     ConvWgrad<T128x64, 4, 4, 2, 32, 64, 20, 20, 9, 9, 1> pw{ws.act1, ws.dact2pad, ws.wg_part, ws.bias_part, M, RPS_C2};
-    igemm_launch(pw, nz, st);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(512 * 64, 256)), dim3(256), 0, st, ws.wg_part, nz, 512 * 64, 64, 0, A,
-                       grads + L.w[1], (float*)nullptr);
-    hipLaunchKernelGGL(bias_reduce_kernel, dim3(1), dim3(64), 0, st, ws.bias_part, nz, 64, 0, A, grads + L.b[1], (float*)nullptr);
+    plaunch(ws, K_CONV2_WGRAD, pw, nz, st);
+    launch_reduce(ws.wg_part, nz, 512 * 64, 64, 0, A, grads + L.w[1], (float*)nullptr, st);
+    launch_reduce(ws.bias_part, nz, 64, 64, 0, A, grads + L.b[1], (float*)nullptr, st);
   }
   // conv1: wgrad only (frames need no gradient)
   {
     const int M = B * 400, nz = ceil_div(M, RPS_C1);
     Conv1Wgrad<T256x32> pw{obs, idx, ws.dact1, ws.wg_part, ws.bias_part, M, RPS_C1};
-    igemm_launch(pw, nz, st);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(256 * 32, 256)), dim3(256), 0, st, ws.wg_part, nz, 256 * 32, 32, 1, A,
-                       grads + L.w[0], (float*)nullptr);
-    hipLaunchKernelGGL(bias_reduce_kernel, dim3(1), dim3(64), 0, st, ws.bias_part, nz, 32, 0, A, grads + L.b[0], (float*)nullptr);
+    plaunch(ws, K_CONV1_WGRAD, pw, nz, st);
+    launch_reduce(ws.wg_part, nz, 256 * 32, 32, 1, A, grads + L.w[0], (float*)nullptr, st);
+    launch_reduce(ws.bias_part, nz, 32, 32, 0, A, grads + L.b[0], (float*)nullptr, st);
   }
 }

@@ -8,34 +8,44 @@
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
 // ------------------------------------------------------------------------------------------
-// ppo:256-261 / impala:296-300.  One thread per env: u = uniform(subkey,[B,A]) via threefry
-// counters, Gumbel-max argmax (first max wins), log_softmax at the chosen action.
-__global__ void sample_kernel(const float* logits, int B, int A, uint32_t sk0, uint32_t sk1, int32_t* actions, float* logprobs,
-                              const float* value_in, float* value_out, float* logits_out) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
-  const float* z = logits + (size_t)b * A;
+// ppo:256-261 / impala:296-300.  32 lanes per env (one per action): u = uniform(subkey,[B,A]) via threefry
+// counters, Gumbel-max argmax (first max wins) by a shuffle tournament, log_softmax at the chosen action with the
+// exp-sum accumulated in ascending action order (same order as the oracle -> same bits).
+__global__ __launch_bounds__(256) void sample_kernel(const float* logits, int B, int A, uint32_t sk0, uint32_t sk1, int32_t* actions,
+                                                     float* logprobs, const float* value_in, float* value_out, float* logits_out) {
+  const int b = blockIdx.x * 8 + (threadIdx.x >> 5);
+  const int a = threadIdx.x & 31;
+  const bool live = b < B && a < A;
+  const int bb = b < B ? b : B - 1, aa = a < A ? a : A - 1;
+  const float z = logits[(size_t)bb * A + aa];
   const uint32_t n = (uint32_t)(B * A);
-  int best = 0;
-  float bestv = 0.0f, mx = z[0];
-  for (int a = 0; a < A; ++a) {
-    const float u = cbm_bits_to_uniform(cbm_random_bits_at(sk0, sk1, n, (uint32_t)(b * A + a)));
-    const float g = z[a] - cbm_logf(-cbm_logf(u));
-    if (a == 0 || g > bestv) { best = a; bestv = g; }
-    mx = z[a] > mx ? z[a] : mx;
-    if (logits_out) logits_out[(size_t)b * A + a] = z[a];
+  const float u = cbm_bits_to_uniform(cbm_random_bits_at(sk0, sk1, n, (uint32_t)(bb * A + aa)));
+  float g = live ? z - cbm_logf(-cbm_logf(u)) : -INFINITY;
+  if (live && logits_out) logits_out[(size_t)b * A + a] = z;
+  // argmax with first-max-wins: a strictly greater value wins, ties go to the lower index
+  int bi = a;
+  float bv = g, mx = live ? z : -INFINITY;
+  for (int o = 16; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(bv, o, 32);
+    const int oi = __shfl_xor(bi, o, 32);
+    const float om = __shfl_xor(mx, o, 32);
+    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    mx = om > mx ? om : mx;
   }
-  actions[b] = best;
-  if (logprobs) {
-    float s = 0.0f;
-    for (int a = 0; a < A; ++a) s += cbm_expf(z[a] - mx);
-    logprobs[b] = (z[best] - mx) - cbm_logf(s);
+  // all 32 lanes of the group now agree on (bv, bi, mx)
+  const float e = live ? cbm_expf(z - mx) : 0.0f;
+  const float zb = __shfl(z, bi, 32);
+  float s = 0.0f;
+  for (int j = 0; j < A; ++j) s += __shfl(e, j, 32);
+  if (b < B && a == 0) {
+    actions[b] = bi;
+    if (logprobs) logprobs[b] = (zb - mx) - cbm_logf(s);
+    if (value_out) value_out[b] = value_in[b];
   }
-  if (value_out) value_out[b] = value_in[b];
 }
 void launch_sample(const float* logits, int B, int A, uint32_t sk0, uint32_t sk1, int32_t* actions, float* logprobs,
                    const float* value_in, float* value_out, float* logits_out, hipStream_t st) {
-  hipLaunchKernelGGL(sample_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, st, logits, B, A, sk0, sk1, actions, logprobs, value_in,
+  hipLaunchKernelGGL(sample_kernel, dim3(ceil_div(B, 8)), dim3(256), 0, st, logits, B, A, sk0, sk1, actions, logprobs, value_in,
                      value_out, logits_out);
 }
 
@@ -105,27 +115,37 @@ __global__ void perm_keys_kernel(uint32_t sk0, uint32_t sk1, int n, uint64_t* ck
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) ckeys[i] = ((uint64_t)cbm_random_bits_at(sk0, sk1, (uint32_t)n, (uint32_t)i) << 32) | (uint32_t)i;
 }
-__global__ __launch_bounds__(256) void perm_rank_kernel(const uint64_t* ckeys, int n, const int32_t* in_vals, int32_t* out_vals) {
+// rank[i] = #{j : ckey[j] < ckey[i]}; the j range is split over blockIdx.y and combined with integer atomics
+// (exact, order-independent), then a scatter pass writes out[rank[i]] = in[i].
+#define PERM_JSPLIT 8
+__global__ __launch_bounds__(256) void perm_rank_kernel(const uint64_t* ckeys, int n, int32_t* rank) {
   __shared__ uint64_t tile[1024];
   const int i = blockIdx.x * 256 + threadIdx.x;
   const uint64_t mine = i < n ? ckeys[i] : 0;
-  int rank = 0;
-  for (int j0 = 0; j0 < n; j0 += 1024) {
+  const int per = ((n + PERM_JSPLIT - 1) / PERM_JSPLIT + 1023) / 1024 * 1024;
+  const int jlo = blockIdx.y * per, jhi = min(n, jlo + per);
+  int r = 0;
+  for (int j0 = jlo; j0 < jhi; j0 += 1024) {
     __syncthreads();
-    for (int q = threadIdx.x; q < 1024; q += 256) tile[q] = (j0 + q < n) ? ckeys[j0 + q] : ~0ull;
+    for (int q = threadIdx.x; q < 1024; q += 256) tile[q] = (j0 + q < jhi) ? ckeys[j0 + q] : ~0ull;
     __syncthreads();
 #pragma unroll 8
-    for (int q = 0; q < 1024; ++q) rank += tile[q] < mine ? 1 : 0;
+    for (int q = 0; q < 1024; ++q) r += tile[q] < mine ? 1 : 0;
   }
-  if (i < n) out_vals[rank] = in_vals ? in_vals[i] : i;
+  if (i < n && r) atomicAdd(&rank[i], r);
+}
+__global__ void perm_scatter_kernel(const int32_t* rank, int n, const int32_t* in_vals, int32_t* out_vals) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out_vals[rank[i]] = in_vals ? in_vals[i] : i;
 }
 void launch_permutation(const uint32_t key_in[2], int n, int32_t* perm, int32_t* tmp, uint64_t* ckeys, hipStream_t st) {
   uint32_t k0 = key_in[0], k1 = key_in[1];
   const double sz = n > 1 ? (double)n : 1.0;
   const int rounds = (int)ceil(3.0 * log(sz) / log(4294967295.0));
-  // ping-pong so the final round lands in `perm`
+  // ckeys buffer holds n composite keys followed by n int32 ranks
+  int32_t* rank = reinterpret_cast<int32_t*>(ckeys + n);
   int32_t* bufs[2] = {perm, tmp};
-  int cur = (rounds % 2 == 1) ? 0 : 1;  // round 0 writes bufs[cur]
+  int cur = (rounds % 2 == 1) ? 0 : 1;  // ping-pong so the final round lands in `perm`
   const int32_t* src = nullptr;
   for (int r = 0; r < rounds; ++r) {
     uint32_t n0, n1, s0, s1;
@@ -133,7 +153,9 @@ void launch_permutation(const uint32_t key_in[2], int n, int32_t* perm, int32_t*
     cbm_split_at(k0, k1, 2, 1, &s0, &s1);
     k0 = n0; k1 = n1;
     hipLaunchKernelGGL(perm_keys_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, s0, s1, n, ckeys);
-    hipLaunchKernelGGL(perm_rank_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, ckeys, n, src, bufs[cur]);
+    hipMemsetAsync(rank, 0, (size_t)n * 4, st);
+    hipLaunchKernelGGL(perm_rank_kernel, dim3(ceil_div(n, 256), PERM_JSPLIT), dim3(256), 0, st, ckeys, n, rank);
+    hipLaunchKernelGGL(perm_scatter_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, rank, n, src, bufs[cur]);
     src = bufs[cur];
     cur ^= 1;
   }

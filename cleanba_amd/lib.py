@@ -48,7 +48,7 @@ SYMBOLS = [
     "cbm_learner_epoch_begin", "cbm_learner_minibatch_grad", "cbm_learner_optimizer_step", "cbm_learner_finish",
     "cbm_forward", "cbm_sample", "cbm_gae", "cbm_advnorm", "cbm_permutation", "cbm_ppo_loss_grad",
     "cbm_impala_loss_grad", "cbm_adam_step", "cbm_rmsprop_step", "cbm_synth_env_reset_host", "cbm_synth_env_step_host",
-    "cbm_actor_env_reset_device",
+    "cbm_actor_env_reset_device", "cbm_profile_select", "cbm_profile_read",
 ]
 
 _lib = None
@@ -226,6 +226,14 @@ class Context:
         r, l = C.c_float(), C.c_float()
         _chk(self.lib.cbm_actor_episode_stats(self.h, int(slot), C.byref(r), C.byref(l)))
         return r.value, l.value
+
+    def profile_select(self, kernel_id):
+        _chk(self.lib.cbm_profile_select(self.h, int(kernel_id)))
+
+    def profile_read(self):
+        ms, n = C.c_double(), C.c_int32()
+        _chk(self.lib.cbm_profile_read(self.h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
 
     # ---- learner
     def learner_wait(self):

@@ -1,0 +1,341 @@
+"""Sebulba actor-learner host loop — the Python counterpart of cleanba_ppo.py / cleanba_impala.py's
+`rollout()` (ppo:226-406, impala:268-446) and `__main__` learner loop (ppo:691-751, impala:684-760),
+driving the HIP library through its C ABI (cleanba_amd.lib.Context).
+
+What stays the same as the reference: CLI flags, thread topology (one host thread per actor slot, learner on
+the main thread), step order, storage fields, `global_step` accounting (ppo:311), the `SPS:` print (ppo:383),
+scalar names, policy-version skew with --concurrency (ppo:287-304), per-minibatch gradient
+all-reduce across learner processes (pmean, ppo:628) — here RCCL through torch.distributed.
+What is different by design: rollout data never leaves HBM (ring slots instead of Queue payloads), and with
+`--env-backend device` the env itself steps on the GPU so a whole rollout is enqueued without host syncs.
+"""
+import json
+import os
+import threading
+import time
+import uuid
+from collections import deque
+from types import SimpleNamespace
+
+import numpy as np
+
+from . import lib as L
+from . import model as M
+from . import prng
+from .args import distributed_env, finalize
+from .envs import make_env
+
+
+class JsonlWriter:
+    """Minimal stand-in for tensorboardX.SummaryWriter (not installed): same add_scalar/add_text calls,
+    one JSON line per scalar under runs/{run_name}/scalars.jsonl."""
+
+    def __init__(self, logdir):
+        os.makedirs(logdir, exist_ok=True)
+        self.f = open(os.path.join(logdir, "scalars.jsonl"), "a")
+        self.lock = threading.Lock()
+
+    def add_scalar(self, tag, value, step):
+        with self.lock:
+            self.f.write(json.dumps({"tag": tag, "value": float(value), "step": int(step), "t": time.time()}) + "\n")
+
+    def add_text(self, tag, text):
+        with self.lock:
+            self.f.write(json.dumps({"tag": tag, "text": text}) + "\n")
+
+    def close(self):
+        self.f.close()
+
+
+def make_config(args, algo):
+    cfg = L.default_config(L.ALGO_PPO if algo == "ppo" else L.ALGO_IMPALA)
+    cfg.device = args.learner_device_ids[0] if not args.distributed else int(os.environ.get("LOCAL_RANK", os.environ.get("SLURM_LOCALID", 0)))
+    cfg.network = {"nature": L.NET_NATURE, "impala_resnet": L.NET_IMPALA_RESNET}[args.network]
+    cfg.num_actions = args.num_actions
+    cfg.local_num_envs = args.local_num_envs
+    cfg.num_actor_slots = args.num_actor_threads * len(args.actor_device_ids)
+    cfg.num_steps = args.num_steps
+    cfg.num_minibatches = args.num_minibatches * args.gradient_accumulation_steps
+    cfg.update_epochs = args.update_epochs if algo == "ppo" else 1
+    cfg.norm_adv = int(args.norm_adv) if algo == "ppo" else 0
+    cfg.gamma, cfg.gae_lambda = args.gamma, args.gae_lambda
+    cfg.clip_coef, cfg.ent_coef, cfg.vf_coef, cfg.max_grad_norm = args.clip_coef, args.ent_coef, args.vf_coef, args.max_grad_norm
+    return cfg
+
+
+def rollout(key, args, algo, engine, writer, device_thread_id, world_size, process_index, stop_event, errors):
+    """One actor slot.  Mirrors rollout() ppo:226-406 / impala:268-446."""
+    try:
+        _rollout(key, args, algo, engine, writer, device_thread_id, world_size, process_index, stop_event)
+    except Exception as e:  # surface thread failures in the learner loop instead of hanging it
+        errors.append(e)
+        stop_event.set()
+        raise
+
+
+def _rollout(key, args, algo, engine, writer, slot, world_size, process_index, stop_event):
+    len_actor_device_ids = len(args.actor_device_ids)
+    E = args.local_num_envs
+    env_seed = args.seed + process_index + slot  # ppo:238
+    device_env = args.env_backend == "device"
+    engine.actor_set_key(slot, key)
+    if device_env:
+        engine.actor_env_reset_device(slot, env_seed)
+    else:
+        envs = make_env(args.env_id, env_seed, E, backend=args.env_backend, num_actions=args.num_actions)()
+    global_step = 0
+    start_time = time.time()
+    episode_returns = np.zeros((E,), dtype=np.float32)
+    returned_episode_returns = np.zeros((E,), dtype=np.float32)
+    episode_lengths = np.zeros((E,), dtype=np.float32)
+    returned_episode_lengths = np.zeros((E,), dtype=np.float32)
+    params_queue_get_time = deque(maxlen=10)
+    rollout_time = deque(maxlen=10)
+    rollout_queue_put_time = deque(maxlen=10)
+    actions = np.empty(E, np.int32)
+    first_rollout = True
+    if not device_env:
+        if algo == "ppo":
+            next_obs = envs.reset()
+            next_done = np.zeros(E, dtype=bool)
+        else:
+            envs.async_reset()
+
+    for update in range(1, args.num_updates + 2):
+        if stop_event.is_set():
+            return
+        update_time_start = time.time()
+        env_recv_time = inference_time = storage_time = d2h_time = env_send_time = 0.0
+        t0 = time.time()
+        actor_policy_version = engine.actor_begin_rollout(slot, args.concurrency)  # params_queue.get() + ring slot
+        params_queue_get_time.append(time.time() - t0)
+        rollout_time_start = time.time()
+        if algo == "ppo":
+            nsteps = args.num_steps
+        else:
+            nsteps = args.num_steps + 1 if first_rollout else args.num_steps  # impala:327-329
+        step_inc = E * args.num_actor_threads * len_actor_device_ids * world_size
+        if device_env:
+            t1 = time.time()
+            engine.actor_rollout_device(slot, nsteps)
+            inference_time += time.time() - t1
+            global_step += nsteps * step_inc
+        else:
+            for _ in range(nsteps):
+                global_step += step_inc
+                if algo == "ppo":
+                    t1 = time.time()
+                    engine.actor_step_host(slot, next_obs, next_done, None, None, actions)
+                    inference_time += time.time() - t1
+                    t1 = time.time()
+                    next_obs, next_reward, next_done, info = envs.step(actions)
+                    env_send_time += time.time() - t1
+                    t1 = time.time()
+                    engine.actor_record_host(slot, next_reward)
+                else:
+                    t1 = time.time()
+                    next_obs, next_reward, next_done, info = envs.recv()
+                    env_recv_time += time.time() - t1
+                    t1 = time.time()
+                    engine.actor_step_host(slot, next_obs, next_done, info["elapsed_step"] == 0, next_reward, actions)
+                    inference_time += time.time() - t1
+                    t1 = time.time()
+                    envs.send(actions, info["env_id"])
+                    env_send_time += time.time() - t1
+                    t1 = time.time()
+                env_id = info["env_id"]
+                truncated = info["elapsed_step"] >= envs.spec.config.max_episode_steps  # ppo:328
+                ended = (info["terminated"] + truncated) > 0
+                episode_returns[env_id] += info["reward"]
+                returned_episode_returns[env_id] = np.where(ended, episode_returns[env_id], returned_episode_returns[env_id])
+                episode_returns[env_id] *= (1 - info["terminated"]) * (1 - truncated)
+                episode_lengths[env_id] += 1
+                returned_episode_lengths[env_id] = np.where(ended, episode_lengths[env_id], returned_episode_lengths[env_id])
+                episode_lengths[env_id] *= (1 - info["terminated"]) * (1 - truncated)
+                storage_time += time.time() - t1
+        rollout_time.append(time.time() - rollout_time_start)
+        first_rollout = False
+
+        t0 = time.time()
+        if device_env or algo != "ppo":
+            engine.actor_commit(slot, None, None)
+        else:
+            engine.actor_commit(slot, next_obs, next_done)  # next_obs / next_done are still on the host (ppo:361-363)
+        rollout_queue_put_time.append(time.time() - t0)
+
+        if update % args.log_frequency == 0:
+            if device_env:
+                avg_episodic_return, avg_len = engine.actor_episode_stats(slot)
+            else:
+                avg_episodic_return, avg_len = float(np.mean(returned_episode_returns)), float(np.mean(returned_episode_lengths))
+            if slot == 0:
+                print(f"global_step={global_step}, avg_episodic_return={avg_episodic_return}, rollout_time={np.mean(rollout_time)}")
+                print("SPS:", int(global_step / (time.time() - start_time)))
+            writer.add_scalar("stats/rollout_time", np.mean(rollout_time), global_step)
+            writer.add_scalar("charts/avg_episodic_return", avg_episodic_return, global_step)
+            writer.add_scalar("charts/avg_episodic_length", avg_len, global_step)
+            writer.add_scalar("stats/params_queue_get_time", np.mean(params_queue_get_time), global_step)
+            writer.add_scalar("stats/env_recv_time", env_recv_time, global_step)
+            writer.add_scalar("stats/inference_time", inference_time, global_step)
+            writer.add_scalar("stats/storage_time", storage_time, global_step)
+            writer.add_scalar("stats/d2h_time", d2h_time, global_step)
+            writer.add_scalar("stats/env_send_time", env_send_time, global_step)
+            writer.add_scalar("stats/rollout_queue_put_time", np.mean(rollout_queue_put_time), global_step)
+            writer.add_scalar("charts/SPS", int(global_step / (time.time() - start_time)), global_step)
+            writer.add_scalar("charts/SPS_update", int(E * args.num_steps * len_actor_device_ids * args.num_actor_threads * world_size /
+                                                       (time.time() - update_time_start)), global_step)
+
+
+class GradAllReducer:
+    """pmean(grads) over all learner processes (ppo:628) = one flat all-reduce on the library's grad
+    buffer.  RCCL via torch.distributed when the engine exposes a device buffer, gloo on CPU in tests."""
+
+    def __init__(self, engine, world_size):
+        self.engine, self.world = engine, world_size
+        self.tensor = engine.grads_tensor() if world_size > 1 else None
+
+    def __call__(self):
+        if self.world > 1:
+            import torch.distributed as dist
+            with self.engine.stream_context():
+                dist.all_reduce(self.tensor, op=dist.ReduceOp.SUM)
+        return float(self.world)  # grad_div: the mean is taken inside the optimizer kernel
+
+
+def schedules(args, algo, opt_count, n_steps):
+    """lr / bias corrections for optimizer steps opt_count .. opt_count+n_steps-1 (inject_hyperparams count)."""
+    spu = args.num_minibatches * (args.update_epochs if algo == "ppo" else 1)
+    lrs, b1s, b2s = [], [], []
+    for i in range(n_steps):
+        c = opt_count + i
+        lrs.append(M.linear_schedule(c, args.learning_rate, spu, args.num_updates, args.anneal_lr))
+        bc1, bc2 = M.adam_bias_corrections(c + 1)
+        b1s.append(bc1)
+        b2s.append(bc2)
+    return np.array(lrs, np.float32), np.array(b1s, np.float32), np.array(b2s, np.float32)
+
+
+def train(args, algo="ppo", engine_factory=None, on_update=None):
+    """The `__main__` block of cleanba_ppo.py / cleanba_impala.py (ppo:409-771)."""
+    world_size, rank, local_rank, master_addr, master_port = distributed_env() if args.distributed else (1, 0, 0, None, None)
+    finalize(args, world_size, rank)
+    if args.gradient_accumulation_steps != 1:
+        raise NotImplementedError("MultiSteps(k>1) is not wired yet (reference default k=1, ppo:79)")
+    if args.distributed and world_size > 1:
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            import torch
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            if backend == "nccl":
+                torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend, init_method=f"tcp://{master_addr}:{master_port}", rank=rank, world_size=world_size)
+    run_name = f"{args.env_id}__{args.exp_name}__{args.seed}__{uuid.uuid4()}"
+    writer = JsonlWriter(f"runs/{run_name}") if rank == 0 else SimpleNamespace(add_scalar=lambda *a: None, add_text=lambda *a: None, close=lambda: None)
+    writer.add_text("hyperparameters", "|param|value|\n|-|-|\n%s" % ("\n".join([f"|{k}|{v}|" for k, v in vars(args).items()])))
+
+    # seeding (ppo:465-470): identical model / learner keys in every process, env seeds differ by process index
+    key = prng.prng_key(args.seed)
+    key, network_key, actor_key, critic_key = prng.split(key, 4)
+    learner_key = key.copy()
+
+    cfg = make_config(args, algo)
+    engine = engine_factory(cfg) if engine_factory else HipEngine(cfg)
+    params = M.init_nature_params(args.num_actions, network_key, actor_key, critic_key)
+    engine.set_params(params)
+    allreduce = GradAllReducer(engine, world_size)
+
+    dummy_writer = SimpleNamespace(add_scalar=lambda x, y, z: None)
+    stop_event, errors, threads = threading.Event(), [], []
+    n_slots = args.num_actor_threads * len(args.actor_device_ids)
+    for slot in range(n_slots):
+        th = threading.Thread(target=rollout, args=(key.copy(), args, algo, engine, writer if slot == 0 else dummy_writer, slot, world_size,
+                                                    rank, stop_event, errors), daemon=True)
+        th.start()
+        threads.append(th)
+
+    rollout_queue_get_time = deque(maxlen=10)
+    learner_policy_version = 0
+    opt_count = 0
+    n_opt = args.num_minibatches * (args.update_epochs if algo == "ppo" else 1)
+    epochs = args.update_epochs if algo == "ppo" else 1
+    start = time.time()
+    last_stats = None
+    while True:
+        learner_policy_version += 1
+        t0 = time.time()
+        engine.learner_wait()  # every actor slot's rollout (ppo:697-711)
+        if errors:
+            raise errors[0]
+        rollout_queue_get_time.append(time.time() - t0)
+        training_time_start = time.time()
+        lrs, bc1, bc2 = schedules(args, algo, opt_count, n_opt)
+        want_stats = learner_policy_version % args.log_frequency == 0 or learner_policy_version >= args.num_updates
+        if world_size == 1:
+            learner_key, stats = engine.learner_update(learner_key, lrs, bc1, bc2, want_stats)
+        else:
+            learner_key = engine.learner_prepare(learner_key)
+            i = 0
+            for e in range(epochs):
+                learner_key = engine.learner_epoch_begin(learner_key)
+                for mb in range(args.num_minibatches):
+                    engine.learner_minibatch_grad(e, mb)
+                    grad_div = allreduce()
+                    engine.learner_optimizer_step(float(lrs[i]), float(bc1[i]), float(bc2[i]), grad_div)
+                    i += 1
+            stats = engine.learner_finish(n_opt, want_stats)
+        opt_count += n_opt
+        if stats is not None:
+            last_stats = stats
+        global_step = learner_policy_version * args.local_batch_size * world_size
+        if on_update:
+            on_update(learner_policy_version, stats)
+        if learner_policy_version % args.log_frequency == 0 and stats is not None:
+            writer.add_scalar("stats/rollout_queue_get_time", np.mean(rollout_queue_get_time), global_step)
+            writer.add_scalar("stats/training_time", time.time() - training_time_start, global_step)
+            print(global_step, f"learner_policy_version={learner_policy_version}, training time: {time.time() - training_time_start}s")
+            writer.add_scalar("charts/learning_rate", float(lrs[-1]), global_step)
+            if algo == "ppo":
+                writer.add_scalar("losses/value_loss", float(stats[-1, 2]), global_step)
+                writer.add_scalar("losses/policy_loss", float(stats[-1, 1]), global_step)
+                writer.add_scalar("losses/entropy", float(stats[-1, 3]), global_step)
+                writer.add_scalar("losses/approx_kl", float(stats[-1, 4]), global_step)
+                writer.add_scalar("losses/loss", float(stats[-1, 0]), global_step)
+            else:
+                writer.add_scalar("losses/value_loss", float(stats[-1, 2]), global_step)
+                writer.add_scalar("losses/policy_loss", float(stats[-1, 1]), global_step)
+                writer.add_scalar("losses/entropy", float(stats[-1, 3]), global_step)
+                writer.add_scalar("losses/loss", float(stats[-1, 0]), global_step)
+        if learner_policy_version >= args.num_updates:
+            break
+    engine.sync()
+    elapsed = time.time() - start
+    stop_event.set()
+    for th in threads:
+        th.join(timeout=30)
+    result = {"updates": learner_policy_version, "global_step": learner_policy_version * args.local_batch_size * world_size,
+              "elapsed_s": elapsed, "stats": last_stats, "params": engine.get_params(), "run_name": run_name}
+    if args.save_model and rank == 0:
+        from .checkpoint import save_cleanrl_model
+        path = f"runs/{run_name}/{args.exp_name}.cleanrl_model"
+        save_cleanrl_model(path, args, result["params"], args.num_actions)
+        print(f"model saved to {path}")
+        result["model_path"] = path
+    writer.close()
+    engine.close()
+    return result
+
+
+class HipEngine(L.Context):
+    """The product engine: cleanba_amd.lib.Context + the torch.distributed plumbing for the grad all-reduce."""
+
+    def grads_tensor(self):
+        import torch
+        ptr, nbytes = self.buffer("grads")
+
+        class _CAI:  # __cuda_array_interface__ view of the library-owned buffer (no copy)
+            __cuda_array_interface__ = {"shape": (nbytes // 4,), "typestr": "<f4", "data": (ptr, False), "version": 2, "strides": None}
+        return torch.as_tensor(_CAI(), device=f"cuda:{self.cfg.device}")
+
+    def stream_context(self):
+        import torch
+        return torch.cuda.stream(torch.cuda.ExternalStream(self.learner_stream(), device=f"cuda:{self.cfg.device}"))

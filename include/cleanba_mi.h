@@ -145,6 +145,11 @@ int cbm_adam_step(cbm_ctx* ctx, float* p, const float* g, float* m, float* v, in
 int cbm_rmsprop_step(cbm_ctx* ctx, float* p, const float* g, float* nu, int64_t n, float max_norm, float lr,
                      float grad_div);                                                               /* impala:152-188 */
 
+/* ---- per-kernel HIP-event timing for bench.py's roofline line: brackets every learner-stream launch of
+ * the selected implicit-GEMM kernel (ids in DESIGN.md §kernels; -1 = off). */
+int cbm_profile_select(cbm_ctx* ctx, int32_t kernel_id);
+int cbm_profile_read(cbm_ctx* ctx, double* total_ms, int32_t* count);
+
 /* ---- synthetic Atari-shaped environment (stands in for envpool.make, ppo:128-139) ------- */
 typedef struct {
   int32_t elapsed, needs_reset;

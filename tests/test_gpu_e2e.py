@@ -1,0 +1,161 @@
+"""End-to-end GPU parity: a whole device-env rollout and a whole learner update through the C ABI,
+replayed step by step with the host env twin + the CPU oracle.  Frames, actions, rewards, dones are
+compared bit-for-bit; losses and post-update parameters within 1e-5."""
+import numpy as np
+import pytest
+
+import cleanba_amd.lib as L
+import cleanba_amd.model as M
+import cleanba_amd.prng as prng
+
+pytestmark = pytest.mark.gpu
+A = 18
+
+
+def bits(x):
+    return np.ascontiguousarray(x, np.float32).view(np.uint32)
+
+
+def _init(seed):
+    key = prng.prng_key(seed)
+    key, nk, ak, ck = prng.split(key, 4)
+    return key, M.init_nature_params(A, nk, ak, ck)
+
+
+def _sched(n, lr, count0=0):
+    bc = [M.adam_bias_corrections(count0 + i + 1) for i in range(n)]
+    return np.full(n, lr, np.float32), np.array([b[0] for b in bc], np.float32), np.array([b[1] for b in bc], np.float32)
+
+
+def test_ppo_rollout_and_update_match_oracle(oracle):
+    E, T, S = 8, 16, 2
+    cfg = L.default_config(L.ALGO_PPO)
+    cfg.local_num_envs, cfg.num_actor_slots, cfg.num_steps = E, S, T
+    ctx = L.Context(cfg)
+    B = E * S
+    key, params = _init(1)
+    ctx.set_params(params)
+    for s in range(S):
+        ctx.actor_set_key(s, key)
+        ctx.actor_env_reset_device(s, 5 + s)
+        ctx.actor_begin_rollout(s, False)
+        ctx.actor_rollout_device(s, T)
+        ctx.actor_commit(s)
+    ctx.learner_wait()
+    obs = ctx.read("obs", np.uint8).reshape(T + 1, B, 4, 84, 84)
+    actions = ctx.read("actions", np.int32).reshape(T + 1, B)[:T]
+    logprobs = ctx.read("logprobs", np.float32).reshape(T + 1, B)[:T]
+    values = ctx.read("values", np.float32).reshape(T + 1, B)[:T]
+    rewards = ctx.read("rewards", np.float32).reshape(T + 1, B)[:T]
+    dones = ctx.read("dones", np.uint8).reshape(T + 1, B)
+
+    # ---- replay the rollout: host env twin + oracle policy (same key chain, ppo:256)
+    for s in range(S):
+        cols = slice(s * E, (s + 1) * E)
+        st, o = L.synth_env_reset_host(5 + s, E)
+        k = key.copy()
+        assert (dones[0, cols] == 0).all()
+        for t in range(T):
+            assert (o == obs[t, cols]).all(), f"frames differ at t={t}"
+            logits, value = oracle.nature_forward(params, A, o, ksplit=cfg.actor_dense_ksplit)
+            a, lp, k = oracle.sample_actions(logits, k)
+            assert (a == actions[t, cols]).all(), f"sampled actions differ at t={t}"
+            assert (bits(lp) == bits(logprobs[t, cols])).all() and (bits(value) == bits(values[t, cols])).all()
+            r, d, _, _ = L.synth_env_step_host(5 + s, st, o, a)
+            assert (r == rewards[t, cols]).all() and (d == dones[t + 1, cols]).all()
+        assert (o == obs[T, cols]).all()
+        assert (ctx.actor_get_key(s) == k).all()
+
+    # ---- learner update vs oracle (ppo:579-654)
+    lkey = prng.prng_key(77)
+    lrs, bc1, bc2 = _sched(16, 2.5e-4)
+    key_after, stats = ctx.learner_update(lkey, lrs, bc1, bc2)
+    p_gpu = ctx.get_params()
+    adv_gpu = ctx.read("adv", np.float32).reshape(T + 1, B)[:T]
+
+    _, nv = oracle.nature_forward(params, A, obs[T], ksplit=cfg.actor_dense_ksplit)
+    adv, tgt = oracle.gae(rewards, values, dones[:T], nv, dones[T])
+    adv = oracle.advnorm(adv, 4)
+    np.testing.assert_allclose(adv_gpu, adv, rtol=0, atol=2e-5)
+    N, MB = T * B, T * B // 4
+    flat_obs = obs[:T].reshape(N, 4, 84, 84)
+    fa, fl, fadv, ftgt = actions.reshape(N), logprobs.reshape(N), adv.reshape(N), tgt.reshape(N)
+    p = params.copy(); m = np.zeros_like(p); v = np.zeros_like(p)
+    k = lkey.copy()
+    ref_stats = []
+    step = 0
+    for e in range(4):
+        ks = oracle.split(k, 2); k, sub = ks[0], ks[1]
+        perm = oracle.permutation(sub, N)
+        for mb in range(4):
+            idx = perm[mb * MB:(mb + 1) * MB]
+            st5, g, _, _ = oracle.ppo_loss_grad(p, A, flat_obs, idx, fa[idx], fl[idx], fadv[idx], ftgt[idx])
+            oracle.adam_step(p, g, m, v, 0.5, float(lrs[step]), bc1=float(bc1[step]), bc2=float(bc2[step]))
+            ref_stats.append(st5); step += 1
+    assert (key_after == k).all()
+    ref_stats = np.array(ref_stats)
+    np.testing.assert_allclose(stats, ref_stats, rtol=2e-4, atol=2e-5)
+    assert np.abs(p_gpu - p).max() <= 1e-5 * np.abs(p).max(), np.abs(p_gpu - p).max()
+    assert abs(np.abs(p_gpu).sum() - np.abs(p).sum()) <= 1e-5 * np.abs(p).sum()
+    ctx.close()
+
+
+def test_impala_rollouts_and_update_match_oracle(oracle):
+    E, T = 8, 6
+    cfg = L.default_config(L.ALGO_IMPALA)
+    cfg.local_num_envs, cfg.num_actor_slots, cfg.num_steps = E, 1, T
+    ctx = L.Context(cfg)
+    key, params = _init(2)
+    ctx.set_params(params)
+    ctx.actor_set_key(0, key)
+    ctx.actor_env_reset_device(0, 9)
+    st, o = L.synth_env_reset_host(9, E)
+    k = key.copy()
+    rew = np.zeros(E, np.float32); dn = np.zeros(E, np.uint8); fs = np.ones(E, np.uint8)
+    carried = None
+    p = params.copy(); nu = np.zeros_like(p)
+    for u in (1, 2):
+        ctx.actor_begin_rollout(0, True)
+        ctx.actor_rollout_device(0, T + 1 if u == 1 else T)
+        ctx.actor_commit(0)
+        ctx.learner_wait()
+        r = u - 1
+        obs = ctx.read("obs", np.uint8, ring=r).reshape(T + 1, E, 4, 84, 84)
+        actions = ctx.read("actions", np.int32, ring=r).reshape(T + 1, E)
+        mu = ctx.read("logits", np.float32, ring=r).reshape(T + 1, E, A)
+        rewards = ctx.read("rewards", np.float32, ring=r).reshape(T + 1, E)
+        dones = ctx.read("dones", np.uint8, ring=r).reshape(T + 1, E)
+        firsts = ctx.read("firststeps", np.uint8, ring=r).reshape(T + 1, E)
+        t0 = 0
+        if carried is not None:   # storage = storage[-1:]  (impala:416)
+            for a_, b_ in zip(carried, (obs[0], actions[0], mu[0], rewards[0], dones[0], firsts[0])):
+                assert (np.asarray(a_) == b_).all()
+            t0 = 1
+        # actor params: version 0 for both rollouts under --concurrency (ppo:287-304)
+        for t in range(t0, T + 1):
+            assert (o == obs[t]).all() and (rew == rewards[t]).all() and (dn == dones[t]).all() and (fs == firsts[t]).all()
+            logits, _ = oracle.nature_forward(params, A, o, ksplit=cfg.actor_dense_ksplit)
+            a, _, k = oracle.sample_actions(logits, k)
+            assert (a == actions[t]).all() and (bits(logits) == bits(mu[t])).all()
+            if t < T:
+                rew, d, _, el = L.synth_env_step_host(9, st, o, a)
+                dn = d; fs = (el == 0).astype(np.uint8)
+        carried = (obs[T].copy(), actions[T].copy(), mu[T].copy(), rewards[T].copy(), dones[T].copy(), firsts[T].copy())
+        # the carried action is sent to the env at the start of the next rollout
+        rew, d, _, el = L.synth_env_step_host(9, st, o, actions[T])
+        dn = d; fs = (el == 0).astype(np.uint8)
+
+        lrs = np.full(4, 6e-4, np.float32)
+        _, stats = ctx.learner_update(prng.prng_key(0), lrs, np.ones(4, np.float32), np.ones(4, np.float32))
+        Bm = E // 4
+        ref = []
+        for mb in range(4):
+            c = slice(mb * Bm, (mb + 1) * Bm)
+            st4, g = oracle.impala_loss_grad(p, A, obs[:, c].reshape(-1, 4, 84, 84), None, T + 1, Bm, mu[:, c], actions[:, c], rewards[:, c],
+                                             dones[:, c], firsts[:, c])
+            oracle.rmsprop_step(p, g, nu, 40.0, 6e-4)
+            ref.append(st4)
+        np.testing.assert_allclose(stats, np.array(ref), rtol=2e-4, atol=2e-4)
+        p_gpu = ctx.get_params()
+        assert np.abs(p_gpu - p).max() <= 2e-5 * np.abs(p).max(), np.abs(p_gpu - p).max()
+    ctx.close()
