@@ -52,6 +52,11 @@ void nature_forward(const NatureLayout& L, const float* P, const uint8_t* obs, c
 void nature_backward(const NatureLayout& L, const float* P, const uint8_t* obs, const int32_t* idx, int B,
                      NatureWs& ws, float* grads, hipStream_t st);
 
+// frame-resident conv1 kernels (conv1.hip)
+void launch_conv1_fwd_frames(const uint8_t* obs, const int32_t* idx, const float* W, const float* bias, float* out, int S, hipStream_t st);
+int conv1_wgrad_frames_splits(int S);
+void launch_conv1_wgrad_frames(const uint8_t* obs, const int32_t* idx, const float* dy, float* part, float* bpart, int S, hipStream_t st);
+
 // ---- pointwise / scan kernels -----------------------------------------------------------
 void launch_sample(const float* logits, int B, int A, uint32_t sk0, uint32_t sk1, int32_t* actions, float* logprobs,
                    const float* value_in, float* value_out, float* logits_out, hipStream_t st);

@@ -1,0 +1,232 @@
+// conv1.hip — frame-resident kernels for the first convolution (8x8 stride 4, 4 -> 32 channels on uint8 frames).
+//
+// conv1 is the one GEMM of the network whose A operand is not fp32 in HBM: it is the im2col of the raw uint8
+// NCHW frame (ppo:180-181 fold the NHWC transpose and the /255 into it).  Going through the generic gather
+// (igemm.h) costs a 4-byte scattered load + index arithmetic + 4 conversions per 4 pixels, four times per pixel
+// (each pixel sits in 2x2 patches) — measured staging-bound at 28-44 % of the f32 MFMA peak.  Here every frame is
+// copied ONCE, coalesced (16-B loads), into LDS as bytes, and the MFMA A fragments are produced straight from
+// those bytes (ds_read_u8 + exact /255) at the moment they are consumed; HBM sees each frame byte once per pass.
+//
+//   forward : block = persistent over pairs of frames (800 positions = 25 tiles of 32); each wave owns 6-7 M-tiles
+//             and walks k = (c,kh,kw) ascending with all its tiles in flight (one B fragment feeds 7 MFMAs).
+//             Same fmaf chain as the oracle -> bit-exact.
+//   wgrad   : block = persistent over a contiguous sample range; wave w owns k-tiles {2w, 2w+1} of dW[256][32];
+//             dY rows are read straight from HBM/L2 (256 B per wave-load), frames from LDS.  Pixels enter as exact
+//             integers and the 1/255 is applied once in the partial reduce (gradients carry a 1e-5 bar, not bits).
+#include "cbm_internal.h"
+#include "igemm.h"
+
+#define FR 28224
+
+static __device__ __forceinline__ float relu_(float v) { return v > 0.0f ? v : 0.0f; }
+
+// async global -> LDS copy of one 16-byte piece per lane (global_load_lds_dwordx4): the LDS destination is the
+// wave-uniform base + lane*16, which is exactly a linear frame copy; no staging registers, vmcnt-tracked.
+static __device__ __forceinline__ void glds16(const unsigned char* g_lane, unsigned char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g_lane,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+// copy one 28,224-byte frame (1764 pieces) into LDS with all 4 waves
+static __device__ __forceinline__ void frame_to_lds(const uint8_t* frame, unsigned char* dst, int wave, int lane) {
+#pragma unroll
+  for (int j = 0; j < 7; ++j) {
+    const int v0 = (wave + 4 * j) * 64;  // wave-uniform first piece of this instruction
+    if (v0 + lane < FR / 16) glds16(frame + (size_t)(v0 + lane) * 16, dst + (size_t)v0 * 16);
+  }
+}
+
+// ------------------------------------------------------------------------------------------ forward
+// LDS: W1 as [k=(c,kh,kw)][32] f32 (32 KB) + one frame of bytes (28,224 B) = 60,992 B -> two blocks per CU, i.e. two
+// waves per SIMD whose conversion chains and MFMAs interleave.  A frame is 400 positions = 12.5 tiles of 32: wave
+// (w + f) % 4 takes tiles {first, first+4, first+8, (12)}; the rotation evens out who owns the 13th half tile.
+__global__ __launch_bounds__(256, 2) void conv1_fwd_frames_kernel(const uint8_t* obs, const int32_t* idx, const float* W, const float* bias,
+                                                                  float* out, int S, int frames_per_block) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem_raw[256 * 32 * 4 + FR];
+  float* Wl = reinterpret_cast<float*>(smem_raw);            // [256][32]
+  unsigned char* F = smem_raw + 256 * 32 * 4;                // [28224]
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // weights: HWIO [kh][kw][c][n] -> k = (c,kh,kw) rows
+  for (int i = tid; i < 256 * 32 / 4; i += 256) {
+    const int k = i >> 3, n4 = (i & 7) * 4;
+    const int c = k >> 6, kh = (k >> 3) & 7, kw = k & 7;
+    *reinterpret_cast<float4*>(Wl + k * 32 + n4) = *reinterpret_cast<const float4*>(W + ((kh * 8 + kw) * 4 + c) * 32 + n4);
+  }
+  const int s_lo = blockIdx.x * frames_per_block, s_hi = min(S, s_lo + frames_per_block);
+  const float bn = bias[li];
+  constexpr int MAXT = 4;
+  if (s_lo < s_hi) {
+    const int f = idx ? idx[s_lo] : s_lo;
+    frame_to_lds(obs + (size_t)f * FR, F, wave, lane);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int s = s_lo; s < s_hi; ++s) {
+    const int first = (wave + (s - s_lo)) & 3;
+    const bool four = first == 0;  // wave-uniform: owns tile 12 (positions 384..399 valid)
+    int base[MAXT];
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) {
+      const int p = min((first + 4 * t) * 32 + li, 399);
+      const int oh = p / 20, ow = p - oh * 20;
+      base[t] = oh * 4 * 84 + ow * 4;
+    }
+    f32x16 acc[MAXT];
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[t][e] = 0.0f;
+    // One (c,kh) row of the patch = 8 contiguous pixels per position = one ds_read2_b32 per tile, feeding the four
+    // kw-pairs; the reads of row ckh+1 are issued before the MFMAs of row ckh.
+    uint2 pxa[MAXT], pxb[MAXT];
+    float wa[4], wb[4];
+    auto fetch = [&](int ckh, uint2(&px)[MAXT], float(&wv)[4]) __attribute__((always_inline)) {
+      const int koff = (ckh >> 3) * 7056 + (ckh & 7) * 84;
+#pragma unroll
+      for (int t = 0; t < MAXT; ++t) {
+        const unsigned char* q = F + base[t] + koff;  // 4-byte aligned
+        px[t] = make_uint2(*reinterpret_cast<const uint32_t*>(q), *reinterpret_cast<const uint32_t*>(q + 4));
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) wv[j] = Wl[(ckh * 8 + 2 * j + h) * 32 + li];
+    };
+    auto fma_row = [&](const uint2(&px)[MAXT], const float(&wv)[4]) __attribute__((always_inline)) {
+      // kw-pair outer / tile inner: consecutive MFMAs hit different accumulators; each accumulator still sees its
+      // k-pairs in ascending order (bit-exact with the oracle's chain).
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t) {
+          if (t < 3 || four) {
+            const uint32_t w32 = (j < 2 ? px[t].x : px[t].y) >> (8 * h + 16 * (j & 1));  // pixel kw = 2j + h
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(cbm_u8_unit(w32 & 255u), wv[j], acc[t], 0, 0, 0);
+          }
+        }
+      }
+    };
+    fetch(0, pxa, wa);
+#pragma unroll 1
+    for (int ckh = 0; ckh < 32; ckh += 2) {
+      fetch(ckh + 1, pxb, wb);
+      __builtin_amdgcn_sched_barrier(0);
+      fma_row(pxa, wa);
+      __builtin_amdgcn_sched_barrier(0);
+      if (ckh + 2 < 32) fetch(ckh + 2, pxa, wa);
+      __builtin_amdgcn_sched_barrier(0);
+      fma_row(pxb, wb);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();  // every wave is done reading this frame's bytes
+    if (s + 1 < s_hi) {
+      const int f = idx ? idx[s + 1] : s + 1;
+      frame_to_lds(obs + (size_t)f * FR, F, wave, lane);  // lands while the epilogue stores drain
+    }
+    // epilogue: out[s][pos][n] = relu(acc + bias)
+    float* o = out + (size_t)s * 400 * 32 + li;
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) {
+      if (t < 3 || four) {
+        const int m0 = (first + 4 * t) * 32 + 4 * h;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int m = m0 + (e & 3) + 8 * (e >> 2);
+#if defined(C1_ABL) && C1_ABL == 1
+          if (m < 400 && acc[t][e] == 123.456f) o[m * 32] = relu_(acc[t][e] + bn);
+#else
+          if (m < 400) o[m * 32] = relu_(acc[t][e] + bn);
+#endif
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+}
+
+void launch_conv1_fwd_frames(const uint8_t* obs, const int32_t* idx, const float* W, const float* bias, float* out, int S, hipStream_t st) {
+  int blocks = 512;
+  if (S < blocks) blocks = S;
+  const int fpb = (S + blocks - 1) / blocks;
+  blocks = (S + fpb - 1) / fpb;
+  hipLaunchKernelGGL(conv1_fwd_frames_kernel, dim3(blocks), dim3(256), 0, st, obs, idx, W, bias, out, S, fpb);
+}
+
+// ------------------------------------------------------------------------------------------ wgrad
+// part[z][k=(c,kh,kw)][n] (pixel units: the reduce multiplies by 1/255), bpart[z][n].
+// One frame of bytes in LDS (28 KB): 4-5 blocks per CU overlap each other's staging.
+__global__ __launch_bounds__(256, 2) void conv1_wgrad_frames_kernel(const uint8_t* obs, const int32_t* idx, const float* dy, float* part,
+                                                                    float* bpart, int S, int frames_per_block) {
+  __shared__ __attribute__((aligned(16))) unsigned char F[FR];
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int s_lo = blockIdx.x * frames_per_block, s_hi = min(S, s_lo + frames_per_block);
+  // this wave's two k-tiles: k = 64*wave + 32*t + li  ->  byte offset of (c,kh,kw) inside the frame
+  int kb[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int k = 64 * wave + 32 * t + li;
+    kb[t] = (k >> 6) * 7056 + ((k >> 3) & 7) * 84 + (k & 7) + 4 * h;  // + position offset of the m-pair member h
+  }
+  f32x16 acc[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[t][e] = 0.0f;
+  float bs = 0.0f;
+  for (int s = s_lo; s < s_hi; ++s) {
+    __syncthreads();  // previous frame fully consumed
+    const int f = idx ? idx[s] : s;
+    frame_to_lds(obs + (size_t)f * FR, F, wave, lane);
+    const float* g = dy + (size_t)s * 400 * 32 + h * 32 + li;  // row m0+h, column li
+    float bc[10], bn[10];
+#pragma unroll
+    for (int q = 0; q < 10; ++q) bc[q] = g[(size_t)(2 * q) * 32];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll 1
+    for (int oh = 0; oh < 20; ++oh) {
+      if (oh + 1 < 20) {
+#pragma unroll
+        for (int q = 0; q < 10; ++q) bn[q] = g[(size_t)((oh + 1) * 20 + 2 * q) * 32];
+      }
+      const int rowoff = oh * 4 * 84;
+#pragma unroll
+      for (int q = 0; q < 10; ++q) {
+        const int mo = rowoff + 8 * q;  // ow = 2q (+1 for h=1 folded into kb)
+        const float b = bc[q];
+        bs += b;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const float a = (float)F[kb[t] + mo];
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 10; ++q) bc[q] = bn[q];
+    }
+  }
+  // partial out: rows k = 64*wave + 32*t + row, column li
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
+      part[((size_t)blockIdx.x * 256 + 64 * wave + 32 * t + row) * 32 + li] = acc[t][e];
+    }
+  if (wave == 0) {
+    bs += __shfl_xor(bs, 32, 64);
+    if (h == 0) bpart[blockIdx.x * 32 + li] = bs;
+  }
+}
+
+int conv1_wgrad_frames_splits(int S) {
+  int blocks = 1024;
+  if (S < blocks) blocks = S;
+  const int fpb = (S + blocks - 1) / blocks;
+  return (S + fpb - 1) / fpb;
+}
+void launch_conv1_wgrad_frames(const uint8_t* obs, const int32_t* idx, const float* dy, float* part, float* bpart, int S, hipStream_t st) {
+  const int nz = conv1_wgrad_frames_splits(S);
+  const int fpb = (S + nz - 1) / nz;
+  hipLaunchKernelGGL(conv1_wgrad_frames_kernel, dim3(nz), dim3(256), 0, st, obs, idx, dy, part, bpart, S, fpb);
+}

@@ -325,8 +325,8 @@ struct MatWgrad {
 // a strided subset of z ascending, then the ZG partials are added in ascending group order.
 // mode 0: identity, 1: conv1 k=(c,kh,kw) -> HWIO, 2: heads [512][32] -> actor.w [512][A] / critic.w [512],
 // 3: heads bias [32] -> actor.b [A] / critic.b [1]
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part, int nz, int XY, int Ycols, int mode, int A, int zg, float* gw,
-                                                            float* gw2) {
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part, int nz, int XY, int Ycols, int mode, int A, int zg, float scale,
+                                                            float* gw, float* gw2) {
   __shared__ float red[256];
   const int ow = 256 / zg;
   const int o = threadIdx.x % ow, g = threadIdx.x / ow;
@@ -338,16 +338,17 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part, in
   __syncthreads();
   if (g != 0 || i >= XY) return;
   for (int q = 1; q < zg; ++q) s += red[q * ow + o];
+  s *= scale;
   const int x = i / Ycols, y = i - x * Ycols;
   if (mode == 0) gw[i] = s;
   else if (mode == 1) { const int c = x >> 6, kh = (x >> 3) & 7, kw = x & 7; gw[((kh * 8 + kw) * 4 + c) * 32 + y] = s; }
   else if (mode == 2) { if (y < A) gw[x * A + y] = s; else if (y == A) gw2[x] = s; }
   else { if (y < A) gw[y] = s; else if (y == A) gw2[0] = s; }
 }
-static void launch_reduce(const float* part, int nz, int XY, int Ycols, int mode, int A, float* gw, float* gw2, hipStream_t st) {
+static void launch_reduce(const float* part, int nz, int XY, int Ycols, int mode, int A, float* gw, float* gw2, hipStream_t st, float scale = 1.0f) {
   const int zg = nz >= 64 ? 16 : (nz >= 8 ? 4 : 1);
   const int ow = 256 / zg;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((XY + ow - 1) / ow), dim3(256), 0, st, part, nz, XY, Ycols, mode, A, zg, gw, gw2);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((XY + ow - 1) / ow), dim3(256), 0, st, part, nz, XY, Ycols, mode, A, zg, scale, gw, gw2);
 }
 
 // ------------------------------------------------------------------------------------------ workspace
@@ -405,7 +406,16 @@ static inline void plaunch(NatureWs& ws, int kid, const P& p, int nz, hipStream_
   igemm_launch(p, nz, st);
   if (on) { hipEventRecord(pf->ev[2 * pf->n + 1], st); pf->n += 1; }
 }
+template <class F>
+static inline void plaunch_fn(NatureWs& ws, int kid, hipStream_t st, F&& launch) {
+  CbmProf* pf = ws.prof;
+  const bool on = pf && pf->sel == kid && pf->n < CBM_PROF_MAX;
+  if (on) hipEventRecord(pf->ev[2 * pf->n], st);
+  launch();
+  if (on) { hipEventRecord(pf->ev[2 * pf->n + 1], st); pf->n += 1; }
+}
 using T128x32 = IgemmTile<128, 32, 32, 4, 1>;
+using T128x32k16 = IgemmTile<128, 32, 16, 4, 1>;
 using T256x32 = IgemmTile<256, 32, 32, 4, 1>;
 using T128x64 = IgemmTile<128, 64, 32, 2, 2>;
 using T64x64 = IgemmTile<64, 64, 32, 2, 2>;
@@ -413,9 +423,11 @@ using T64x64 = IgemmTile<64, 64, 32, 2, 2>;
 void nature_forward(const NatureLayout& L, const float* P, const uint8_t* obs, const int32_t* idx, int B, int dense_ksplit,
                     NatureWs& ws, hipStream_t st) {
   const bool small = B <= 512;
-  {
+  if (small) {
     Conv1Fwd<T128x32> p{obs, idx, P + L.w[0], P + L.b[0], ws.act1, B * 400};
     plaunch(ws, K_CONV1_FWD, p, 1, st);
+  } else {
+    plaunch_fn(ws, K_CONV1_FWD, st, [&] { launch_conv1_fwd_frames(obs, idx, P + L.w[0], P + L.b[0], ws.act1, B, st); });
   }
   if (small) {
     ConvFwd<T64x64, 4, 4, 2, 32, 64, 20, 20, 9, 9> p2{ws.act1, P + L.w[1], P + L.b[1], ws.act2, B * 81};
@@ -423,7 +435,7 @@ void nature_forward(const NatureLayout& L, const float* P, const uint8_t* obs, c
     ConvFwd<T64x64, 3, 3, 1, 64, 64, 9, 9, 7, 7> p3{ws.act2, P + L.w[2], P + L.b[2], ws.act3, B * 49};
     plaunch(ws, K_CONV3_FWD, p3, 1, st);
   } else {
-    ConvFwd<T128x64, 4, 4, 2, 32, 64, 20, 20, 9, 9> p2{ws.act1, P + L.w[1], P + L.b[1], ws.act2, B * 81};
+    ConvFwd<T64x64, 4, 4, 2, 32, 64, 20, 20, 9, 9> p2{ws.act1, P + L.w[1], P + L.b[1], ws.act2, B * 81};
     plaunch(ws, K_CONV2_FWD, p2, 1, st);
     ConvFwd<T128x64, 3, 3, 1, 64, 64, 9, 9, 7, 7> p3{ws.act2, P + L.w[2], P + L.b[2], ws.act3, B * 49};
     plaunch(ws, K_CONV3_FWD, p3, 1, st);
@@ -477,7 +489,7 @@ void nature_backward(const NatureLayout& L, const float* P, const uint8_t* obs, 
   }
   // conv2: dgrad -> dact1, wgrad
   {
-    Conv2Dgrad<T128x32> pd{ws.dact2pad, P + L.w[1], ws.act1, ws.dact1, B * 100};
+    Conv2Dgrad<T128x32k16> pd{ws.dact2pad, P + L.w[1], ws.act1, ws.dact1, B * 100};
     plaunch(ws, K_CONV2_DGRAD, pd, 1, st);
     const int M = B * 81, nz = ceil_div(M, RPS_C2);
     ConvWgrad<T128x64, 4, 4, 2, 32, 64, 20, 20, 9, 9, 1> pw{ws.act1, ws.dact2pad, ws.wg_part, ws.bias_part, M, RPS_C2};
@@ -485,12 +497,11 @@ void nature_backward(const NatureLayout& L, const float* P, const uint8_t* obs, 
     launch_reduce(ws.wg_part, nz, 512 * 64, 64, 0, A, grads + L.w[1], (float*)nullptr, st);
     launch_reduce(ws.bias_part, nz, 64, 64, 0, A, grads + L.b[1], (float*)nullptr, st);
   }
-  // conv1: wgrad only (frames need no gradient)
+  // conv1: wgrad only (frames need no gradient); frame-resident kernel, pixels as integers, 1/255 in the reduce
   {
-    const int M = B * 400, nz = ceil_div(M, RPS_C1);
-    Conv1Wgrad<T256x32> pw{obs, idx, ws.dact1, ws.wg_part, ws.bias_part, M, RPS_C1};
-    plaunch(ws, K_CONV1_WGRAD, pw, nz, st);
-    launch_reduce(ws.wg_part, nz, 256 * 32, 32, 1, A, grads + L.w[0], (float*)nullptr, st);
+    const int nz = conv1_wgrad_frames_splits(B);
+    plaunch_fn(ws, K_CONV1_WGRAD, st, [&] { launch_conv1_wgrad_frames(obs, idx, ws.dact1, ws.wg_part, ws.bias_part, B, st); });
+    launch_reduce(ws.wg_part, nz, 256 * 32, 32, 1, A, grads + L.w[0], (float*)nullptr, st, 1.0f / 255.0f);
     launch_reduce(ws.bias_part, nz, 32, 32, 0, A, grads + L.b[0], (float*)nullptr, st);
   }
 }

@@ -22,6 +22,9 @@
 #include <stdint.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+#ifndef IGEMM_MIN_WAVES
+#define IGEMM_MIN_WAVES 4
+#endif
 
 template <int BX_, int BY_, int BR_, int WX_, int WY_>
 struct IgemmTile {
@@ -38,7 +41,7 @@ struct IgemmTile {
 //   void store(int x, int y, float v, int z, int cls) const;
 //   void store_bias(int y, float v, int z) const;           (only if BIAS_GRAD)
 template <class P>
-__global__ __launch_bounds__(256) void igemm_kernel(const P p) {
+__global__ __launch_bounds__(256, IGEMM_MIN_WAVES) void igemm_kernel(const P p) {
   using T = typename P::Tile;
   constexpr int BX = T::BX, BY = T::BY, BR = T::BR, WX = T::WX, WY = T::WY;
   constexpr bool A_RX = P::A_RX, B_YR = P::B_YR;
@@ -142,24 +145,47 @@ __global__ __launch_bounds__(256) void igemm_kernel(const P p) {
   int buf = 0;
   for (int r0 = rlo; r0 < rhi; r0 += BR) {
     const bool more = (r0 + BR) < rhi;
+#if !defined(IGEMM_ABLATE) || IGEMM_ABLATE < 2
     if (more) gload(r0 + BR);
+#endif
     const float* A_ = As + buf * ASZ;
     const float* B_ = Bs + buf * BSZ;
+#if !defined(IGEMM_ABLATE) || IGEMM_ABLATE != 1
+    {
+      // Fragment reads run one group (G k-pairs) ahead of the MFMAs.  hipcc otherwise sinks every ds_read next to
+      // its MFMA (read, lgkmcnt(0), mfma, read, ...), which exposes one LDS round trip per 64-cycle MFMA; the
+      // sched_barriers pin "all reads of group g+1, then the MFMAs of group g".
+      constexpr int G = (BR / 2) % 4 == 0 ? 4 : 2, NG = BR / 2 / G;
+      float fa[2][G][TM], fb[2][G][TN];
+      auto frag = [&](int g, int set) {
 #pragma unroll
-    for (int rr = 0; rr < BR; rr += 2) {
-      float a[TM], b[TN];
+        for (int q = 0; q < G; ++q) {
+          const int rr = 2 * (g * G + q);
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int xl = wx * (BX / WX) + i * 32 + li;
-        a[i] = A_RX ? A_[(rr + h) * PA + xl] : A_[xl * PA + rr + h];
+          for (int i = 0; i < TM; ++i) {
+            const int xl = wx * (BX / WX) + i * 32 + li;
+            fa[set][q][i] = A_RX ? A_[(rr + h) * PA + xl] : A_[xl * PA + rr + h];
+          }
+#pragma unroll
+          for (int j = 0; j < TN; ++j) fb[set][q][j] = B_[(rr + h) * PB + wy * (BY / WY) + j * 32 + li];
+        }
+      };
+      frag(0, 0);
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        if (g + 1 < NG) frag(g + 1, (g + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < G; ++q)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g & 1][q][i], fb[g & 1][q][j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
-#pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = B_[(rr + h) * PB + wy * (BY / WY) + j * 32 + li];
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
+#endif
     if constexpr (P::BIAS_GRAD) if (blockIdx.x == 0) {
       // column sums of the staged dY tile -> bias gradient partial (fixed order per thread)
       constexpr int PARTS = 256 / BY;
@@ -167,9 +193,13 @@ __global__ __launch_bounds__(256) void igemm_kernel(const P p) {
       if (part < PARTS)
         for (int r = part; r < BR; r += PARTS) bsum += B_[r * PB + yy];
     }
+#if !defined(IGEMM_ABLATE) || IGEMM_ABLATE < 3
     if (more) sstore(buf ^ 1);
+#endif
+#if !defined(IGEMM_ABLATE) || IGEMM_ABLATE < 4
     __syncthreads();
     buf ^= 1;
+#endif
   }
 
 #pragma unroll

@@ -10,7 +10,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libcleanba_mi.so")
+SO_PATH = os.environ.get("CBM_SO", os.path.join(_HERE, "libcleanba_mi.so"))  # CBM_SO: ablation builds (tools/)
 
 NET_NATURE, NET_IMPALA_RESNET = 0, 1
 ALGO_PPO, ALGO_IMPALA = 0, 1
