@@ -76,7 +76,7 @@ def rollout(key, args, algo, engine, writer, device_thread_id, world_size, proce
 def _rollout(key, args, algo, engine, writer, slot, world_size, process_index, stop_event):
     len_actor_device_ids = len(args.actor_device_ids)
     E = args.local_num_envs
-    env_seed = args.seed + process_index + slot  # ppo:238
+    env_seed = args.seed + (0 if args.same_env_seed_all_ranks else process_index) + slot  # ppo:238
     device_env = args.env_backend == "device"
     engine.actor_set_key(slot, key)
     if device_env:

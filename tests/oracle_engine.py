@@ -1,0 +1,204 @@
+"""CPU stand-in for cleanba_amd.lib.Context with the SAME method surface, built on the oracle.
+
+Test infrastructure only (lives under tests/, imports oracle/): it lets the host logic of
+cleanba_amd.trainer — actor threads, ring/sequence hand-off, policy-version skew, per-minibatch gradient
+all-reduce across processes — run on a CPU box with the gloo backend, where the HIP library cannot create a
+context.  It mirrors csrc/api.hip's orchestration (row layout [T+1][B], ring depth, params versions)."""
+import contextlib
+import threading
+
+import numpy as np
+
+import oracle
+
+FRAME = 4 * 84 * 84
+
+
+class OracleEngine:
+    def __init__(self, cfg):
+        self.cfg = cfg
+        self.ppo = cfg.algo == 0
+        self.A, self.E, self.S = cfg.num_actions, cfg.local_num_envs, cfg.num_actor_slots
+        self.B, self.T = self.E * self.S, cfg.num_steps
+        self.T1 = self.T + 1
+        self.nmb = cfg.num_minibatches
+        self.epochs = cfg.update_epochs if self.ppo else 1
+        self.depth = cfg.ring_depth
+        self.P = oracle.nature_param_count(self.A)
+        z = lambda dt, *shape: np.zeros(shape, dt)
+        self.ring = [dict(obs=z(np.uint8, self.T1, self.B, 4, 84, 84), actions=z(np.int32, self.T1, self.B), logprobs=z(np.float32, self.T1, self.B),
+                          values=z(np.float32, self.T1, self.B), rewards=z(np.float32, self.T1, self.B), logits=z(np.float32, self.T1, self.B, self.A),
+                          dones=z(np.uint8, self.T1, self.B), firststeps=z(np.uint8, self.T1, self.B)) for _ in range(self.depth)]
+        self.params = np.zeros(self.P, np.float32)
+        self.grads = np.zeros(self.P, np.float32)
+        self.m = np.zeros(self.P, np.float32)
+        self.v = np.zeros(self.P, np.float32)
+        self.actor_params = {0: self.params.copy()}
+        self.keys = [np.zeros(2, np.uint32) for _ in range(self.S)]
+        self.slot = [dict(t=0, rollout=0, ring=0, pver=0) for _ in range(self.S)]
+        self.committed = [0] * self.S
+        self.updates_done = 0
+        self.cv = threading.Condition()
+        self.stats = []
+        self.h = True
+
+    # ---- params
+    def set_params(self, p):
+        self.params = np.ascontiguousarray(p, np.float32).copy()
+        self.actor_params = {0: self.params.copy()}
+        self.m[:] = 0
+        self.v[:] = 0
+
+    def get_params(self):
+        return self.params.copy()
+
+    def sync(self):
+        pass
+
+    def close(self):
+        pass
+
+    def grads_tensor(self):
+        import torch
+        return torch.from_numpy(self.grads)
+
+    def stream_context(self):
+        return contextlib.nullcontext()
+
+    # ---- actor
+    def actor_set_key(self, s, key):
+        self.keys[s] = np.ascontiguousarray(key, np.uint32).copy()
+
+    def actor_get_key(self, s):
+        return self.keys[s].copy()
+
+    def actor_begin_rollout(self, s, concurrency):
+        sl = self.slot[s]
+        sl["rollout"] += 1
+        u = sl["rollout"]
+        need = (u - 2 if u >= 2 else 0) if concurrency else u - 1
+        with self.cv:
+            self.cv.wait_for(lambda: self.updates_done >= need and self.updates_done >= u - self.depth)
+        sl["pver"], sl["ring"], sl["t"] = need, (u - 1) % self.depth, 0
+        if u >= 2 and not self.ppo:
+            prev, cur = self.ring[(u - 2) % self.depth], self.ring[sl["ring"]]
+            c = slice(s * self.E, (s + 1) * self.E)
+            for k in cur:
+                cur[k][0, c] = prev[k][self.T, c]
+            sl["t"] = 1
+        return need + 1
+
+    def actor_step_host(self, s, obs, done, firststep=None, reward_with_obs=None, actions_out=None):
+        sl = self.slot[s]
+        R, t, c = self.ring[sl["ring"]], sl["t"], slice(s * self.E, (s + 1) * self.E)
+        R["obs"][t, c] = obs
+        R["dones"][t, c] = done
+        if firststep is not None:
+            R["firststeps"][t, c] = firststep
+        if reward_with_obs is not None:
+            R["rewards"][t, c] = reward_with_obs
+        logits, value = oracle.nature_forward(self.actor_params[sl["pver"]], self.A, R["obs"][t, c], ksplit=self.cfg.actor_dense_ksplit)
+        a, lp, self.keys[s] = oracle.sample_actions(logits, self.keys[s])
+        R["actions"][t, c] = a
+        if self.ppo:
+            R["logprobs"][t, c], R["values"][t, c] = lp, value
+        else:
+            R["logits"][t, c] = logits
+        sl["t"] += 1
+        if actions_out is not None:
+            actions_out[:] = a
+            return actions_out
+        return a
+
+    def actor_record_host(self, s, reward):
+        sl = self.slot[s]
+        self.ring[sl["ring"]]["rewards"][sl["t"] - 1, s * self.E:(s + 1) * self.E] = reward
+
+    def actor_commit(self, s, next_obs=None, next_done=None):
+        sl = self.slot[s]
+        if next_obs is not None:
+            R, c = self.ring[sl["ring"]], slice(s * self.E, (s + 1) * self.E)
+            R["obs"][self.T, c] = next_obs
+            R["dones"][self.T, c] = next_done
+        with self.cv:
+            self.committed[s] = sl["rollout"]
+            self.cv.notify_all()
+
+    def actor_episode_stats(self, s):
+        return 0.0, 0.0
+
+    # ---- learner
+    def _cur(self):
+        return self.ring[self.updates_done % self.depth]
+
+    def learner_wait(self):
+        v = self.updates_done + 1
+        with self.cv:
+            self.cv.wait_for(lambda: all(c >= v for c in self.committed))
+
+    def learner_prepare(self, key):
+        if self.ppo:
+            R = self._cur()
+            _, nv = oracle.nature_forward(self.params, self.A, R["obs"][self.T], ksplit=self.cfg.actor_dense_ksplit)
+            adv, tgt = oracle.gae(R["rewards"][:self.T], R["values"][:self.T], R["dones"][:self.T], nv, R["dones"][self.T], self.cfg.gamma,
+                                  self.cfg.gae_lambda)
+            self.adv = oracle.advnorm(adv, self.nmb) if self.cfg.norm_adv else adv
+            self.tgt = tgt
+        self.stats = []
+        return np.ascontiguousarray(key, np.uint32).copy()
+
+    def learner_epoch_begin(self, key):
+        key = np.ascontiguousarray(key, np.uint32)
+        if self.ppo:
+            ks = oracle.split(key, 2)
+            key, sub = ks[0], ks[1]
+            self.perm = oracle.permutation(sub, self.T * self.B)
+        return key.copy()
+
+    def learner_minibatch_grad(self, e, mb):
+        R = self._cur()
+        c = self.cfg
+        if self.ppo:
+            N = self.T * self.B
+            MB = N // self.nmb
+            idx = self.perm[mb * MB:(mb + 1) * MB]
+            fo = R["obs"][:self.T].reshape(N, 4, 84, 84)
+            st, g, _, _ = oracle.ppo_loss_grad(self.params, self.A, fo, idx, R["actions"][:self.T].reshape(N)[idx],
+                                               R["logprobs"][:self.T].reshape(N)[idx], self.adv.reshape(N)[idx], self.tgt.reshape(N)[idx],
+                                               c.clip_coef, c.ent_coef, c.vf_coef)
+        else:
+            Bm = self.B // self.nmb
+            cs = slice(mb * Bm, (mb + 1) * Bm)
+            st, g = oracle.impala_loss_grad(self.params, self.A, R["obs"][:, cs].reshape(-1, 4, 84, 84), None, self.T1, Bm, R["logits"][:, cs],
+                                            R["actions"][:, cs], R["rewards"][:, cs], R["dones"][:, cs], R["firststeps"][:, cs], c.gamma,
+                                            c.vf_coef, c.ent_coef)
+        self.grads[:] = g
+        self.stats.append(st)
+
+    def learner_optimizer_step(self, lr, bc1, bc2, grad_div=1.0):
+        g = self.grads / np.float32(grad_div) if grad_div != 1.0 else self.grads
+        c = self.cfg
+        if self.ppo:
+            oracle.adam_step(self.params, g, self.m, self.v, c.max_grad_norm, lr, c.adam_b1, c.adam_b2, c.adam_eps, bc1=bc1, bc2=bc2)
+        else:
+            oracle.rmsprop_step(self.params, g, self.m, c.max_grad_norm, lr, c.rms_decay, c.rms_eps)
+
+    def learner_finish(self, n_rows, want_stats=True):
+        v = self.updates_done + 1
+        with self.cv:
+            self.actor_params[v] = self.params.copy()
+            self.actor_params.pop(v - 3, None)
+            self.updates_done = v
+            self.cv.notify_all()
+        return np.array(self.stats, np.float32) if want_stats else None
+
+    def learner_update(self, key, lrs, bc1, bc2, want_stats=True):
+        key = self.learner_prepare(key)
+        i = 0
+        for e in range(self.epochs):
+            key = self.learner_epoch_begin(key)
+            for mb in range(self.nmb):
+                self.learner_minibatch_grad(e, mb)
+                self.learner_optimizer_step(float(lrs[i]), float(bc1[i]), float(bc2[i]))
+                i += 1
+        return key, self.learner_finish(len(lrs), want_stats)

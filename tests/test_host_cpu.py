@@ -1,0 +1,106 @@
+"""Host logic on CPU (no GPU): the product trainer (cleanba_amd.trainer) driven through the oracle-backed engine.
+Covers BASELINE.json configs[0] (plumbing run, 1 update), CLI parsing, schedules, checkpoint format, and the N>1
+data-parallel path with world_size-2 gloo."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+
+
+def _run(world, same, tmp, tag, algo="ppo"):
+    port = 29600 + (os.getpid() + hash(tag)) % 300
+    outs, procs = [], []
+    env = dict(os.environ, CBM_TEST_TMP=str(tmp), OMP_NUM_THREADS="2")
+    for r in range(world):
+        out = os.path.join(tmp, f"{tag}_{r}.npy")
+        outs.append(out)
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "dist_worker.py"), str(r), str(world), str(port), out, str(int(same)), algo],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    logs = []
+    for p in procs:
+        o, _ = p.communicate(timeout=600)
+        logs.append(o.decode()[-2000:])
+        assert p.returncode == 0, logs[-1]
+    return [np.load(o) for o in outs]
+
+
+def test_plumbing_single_process_cpu(tmp_path):
+    # configs[0]: "--local-num-envs 8 ... 1 update (plumbing, no GPU)" at reduced T for test time
+    p1 = _run(1, False, str(tmp_path), "single")[0]
+    assert np.isfinite(p1).all()
+    from helpers import make_params  # noqa: F401
+    import cleanba_amd.model as M, cleanba_amd.prng as prng
+    key = prng.prng_key(1)
+    key, nk, ak, ck = prng.split(key, 4)
+    p0 = M.init_nature_params(18, nk, ak, ck)
+    assert np.abs(p1 - p0).max() > 1e-5      # two updates moved the parameters
+    assert np.abs(p1 - p0).max() < 5e-3      # by about lr * steps
+
+
+def test_data_parallel_gloo_world2(tmp_path):
+    # (1) identical env streams on both ranks: mean of equal grads == the grad -> dp2 must equal dp1 bit for bit
+    ref = _run(1, True, str(tmp_path), "ref")[0]
+    a, b = _run(2, True, str(tmp_path), "same")
+    assert (a == b).all() and (a == ref).all()
+    # (2) different env seeds per rank (ppo:238): replicas stay identical, and differ from the single-process run
+    c, d = _run(2, False, str(tmp_path), "diff")
+    assert (c == d).all()
+    assert np.abs(c - ref).max() > 0
+
+
+def test_impala_host_loop_cpu(tmp_path):
+    p = _run(1, False, str(tmp_path), "imp", algo="impala")[0]
+    assert np.isfinite(p).all()
+
+
+def test_cli_and_schedules():
+    from cleanba_amd.args import parse_args, finalize
+    import cleanba_amd.model as M
+    a = parse_args(["--local_num_envs", "120", "--num-actor-threads", "1", "--learner-device-ids", "1", "2", "3", "--no-anneal-lr"], "ppo")
+    assert a.local_num_envs == 120 and a.learner_device_ids == [1, 2, 3] and a.anneal_lr is False and a.concurrency is False
+    finalize(a, world_size=2)
+    assert a.local_batch_size == 120 * 128 and a.batch_size == 2 * 120 * 128 and a.num_updates == 50000000 // (2 * 120 * 128)
+    b = parse_args(["--no-concurrency"], "impala")
+    assert b.concurrency is False and b.num_steps == 20 and abs(b.learning_rate - 6e-4) < 1e-12
+    with pytest.raises(AssertionError):
+        finalize(parse_args(["--local-num-envs", "10", "--learner-device-ids", "0", "1", "2"], "ppo"))
+    # linear_schedule ppo:475-479: constant within an update, decays by 1/num_updates per update
+    lr0 = M.linear_schedule(0, 2.5e-4, 16, 100)
+    assert lr0 == np.float32(2.5e-4) and M.linear_schedule(15, 2.5e-4, 16, 100) == lr0
+    assert abs(M.linear_schedule(16, 2.5e-4, 16, 100) - 2.5e-4 * 0.99) < 1e-10
+    bc1, bc2 = M.adam_bias_corrections(1)
+    assert abs(bc1 - 0.1) < 1e-7 and abs(bc2 - 0.001) < 1e-7
+
+
+def test_prng_host_matches_oracle(oracle):
+    import cleanba_amd.prng as prng
+    for seed in (0, 1, 12345, 2 ** 40 + 7):
+        assert (prng.prng_key(seed) == oracle.prng_key(seed)).all()
+        k = prng.prng_key(seed)
+        assert (prng.split(k, 4) == oracle.split(k, 4)).all()
+        for n in (1, 7, 2160):
+            assert (prng.random_bits(k, n) == oracle.random_bits(k, n)).all()
+            assert (prng.uniform(k, n) == oracle.uniform(k, n)).all()
+
+
+def test_cleanrl_model_roundtrip(tmp_path):
+    import msgpack
+    from cleanba_amd.args import parse_args
+    from cleanba_amd.checkpoint import save_cleanrl_model, load_cleanrl_model
+    from helpers import make_params
+    p = make_params(18, 3)
+    path = str(tmp_path / "m.cleanrl_model")
+    save_cleanrl_model(path, parse_args([], "ppo"), p, 18)
+    args_d, q = load_cleanrl_model(path, 18)
+    assert (p == q).all() and args_d["env_id"] == "Breakout-v5" and args_d["learner_device_ids"] == {"0": 0}
+    raw = msgpack.unpackb(open(path, "rb").read(), raw=False, strict_map_key=False)
+    k = raw["1"]["0"]["params"]["Conv_0"]["kernel"]          # flax names, ndarray as ExtType(1)
+    assert isinstance(k, msgpack.ExtType) and k.code == 1
+    shape, dtype, buf = msgpack.unpackb(k.data, raw=False)
+    assert shape == [8, 8, 4, 32] and dtype == "float32" and len(buf) == 8 * 8 * 4 * 32 * 4
+    assert set(raw["1"]["0"]["params"]) == {"Conv_0", "Conv_1", "Conv_2", "Dense_0"} and list(raw["1"]["1"]["params"]) == ["Dense_0"]
