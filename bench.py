@@ -45,7 +45,7 @@ def cpu_baseline(params, n_frames=192):
     t_fwd (actor forward+sampling) and t_fb (learner forward+loss+backward) per frame on n_frames
     Breakout-shaped frames; env-steps/s = 1 / (t_fwd*(1+1/T) + EPOCHS*t_fb)."""
     import oracle
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 32, n_frames // 6)  # OpenMP over frames: more threads than frames/6 only adds reduction cost
     oracle.set_threads(cores)
     st, obs = L.synth_env_reset_host(1, n_frames)
     rng = np.random.default_rng(0)
@@ -72,7 +72,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--prof-kernel", type=int, default=11, help="igemm kernel id timed with HIP events for the roofline line")
+    ap.add_argument("--prof-kernel", type=int, default=9, help="igemm kernel id timed with HIP events for the roofline line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -163,8 +163,12 @@ def main():
         if prof_n > 0:
             avg_s = prof_ms / prof_n / 1e3
             ach = kflops / avg_s / 1e12
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+            if os.path.exists(tpath):
+                traffic = json.load(open(tpath)).get(str(a.prof_kernel), {}).get("traffic_bytes")
             roof = {"bound": "mfma", "kernel": kname, "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None, "launches": prof_n, "avg_us": round(avg_s * 1e6, 1),
+                    "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "launches": prof_n, "avg_us": round(avg_s * 1e6, 1),
                     "flops_per_launch": kflops}
         line = {"metric": "env-steps/sec (whole node), Breakout-v5 84x84x4, num_envs=120", "value": round(sps, 1), "unit": "env-steps/s",
                 "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,

@@ -61,7 +61,14 @@ __global__ __launch_bounds__(256, IGEMM_MIN_WAVES) void igemm_kernel(const P p) 
   const int li = lane & 31, h = lane >> 5;
   const int wx = wave / WY, wy = wave % WY;
   const int cls = P::NCLS > 1 ? (int)(blockIdx.y % P::NCLS) : 0;
-  const int x0 = blockIdx.x * BX;
+  // XCD-aware tile order: block b runs on XCD b % 8 (each XCD has its own L2), and neighbouring x-tiles of an
+  // im2col share input rows; give every XCD one contiguous run of x-tiles (bijective for any grid size).
+  int bx = blockIdx.x;
+  {
+    const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = bx & 7, k = bx >> 3;
+    bx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+  }
+  const int x0 = bx * BX;
   const int y0 = (P::NCLS > 1 ? (int)(blockIdx.y / P::NCLS) : (int)blockIdx.y) * BY;
   const int z = blockIdx.z;
   int rlo, rhi;
