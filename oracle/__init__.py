@@ -282,3 +282,51 @@ def adam_step(p, g, m, v, max_norm, lr, b1=0.9, b2=0.999, eps=1e-5, bc1=None, bc
 def rmsprop_step(p, g, nu, max_norm, lr, decay=0.99, eps=0.01):
     lib().cbo_rmsprop_step(_p(p), _p(_f32(g)), _p(nu), C.c_int64(p.size), C.c_float(max_norm), C.c_float(lr),
                            C.c_float(decay), C.c_float(eps))
+
+
+# ---------------------------------------------------------------- IMPALA-ResNet torso (ppo:149-189)
+def resnet_param_count(A):
+    lib().cbo_resnet_param_count.restype = C.c_int64
+    return int(lib().cbo_resnet_param_count(int(A)))
+
+
+def resnet_act_floats():
+    lib().cbo_resnet_act_floats.restype = C.c_int64
+    return int(lib().cbo_resnet_act_floats())
+
+
+def resnet_layout(A):
+    """name -> (offset, shape), flax tree order: ConvSequence_s/{Conv_0, ResidualBlock_{0,1}/Conv_{0,1}}, Dense_0, heads."""
+    ci, co = (4, 16, 32), (16, 32, 32)
+    out, o = {}, 0
+    for s in range(3):
+        names = ["Conv_0", "ResidualBlock_0.Conv_0", "ResidualBlock_0.Conv_1", "ResidualBlock_1.Conv_0", "ResidualBlock_1.Conv_1"]
+        for j, n in enumerate(names):
+            shp = (3, 3, ci[s] if j == 0 else co[s], co[s])
+            out[f"seq{s}.{n}.w"] = (o, shp); o += int(np.prod(shp))
+            out[f"seq{s}.{n}.b"] = (o, (co[s],)); o += co[s]
+    for n, shp in (("dense.w", (3872, 256)), ("dense.b", (256,)), ("actor.w", (256, A)), ("actor.b", (A,)), ("critic.w", (256, 1)),
+                   ("critic.b", (1,))):
+        out[n] = (o, shp); o += int(np.prod(shp))
+    assert o == resnet_param_count(A)
+    return out
+
+
+def resnet_forward(params, A, obs, idx=None, ksplit=1, save_acts=False):
+    obs = _u8(obs)
+    B = len(idx) if idx is not None else obs.shape[0]
+    idx_a = _i32(idx) if idx is not None else None
+    acts = np.zeros(B * resnet_act_floats(), np.float32) if save_acts else None
+    logits = np.zeros((B, A), np.float32)
+    value = np.zeros(B, np.float32)
+    lib().cbo_resnet_forward(_p(_f32(params)), int(A), _p(obs), _p(idx_a), int(B), int(ksplit), _p(acts), _p(logits), _p(value))
+    return (logits, value, acts) if save_acts else (logits, value)
+
+
+def resnet_backward(params, A, obs, idx, acts, dlogits, dvalue):
+    B = dlogits.shape[0]
+    idx_a = _i32(idx) if idx is not None else None
+    grads = np.zeros(resnet_param_count(A), np.float32)
+    lib().cbo_resnet_backward(_p(_f32(params)), int(A), _p(_u8(obs)), _p(idx_a), int(B), _p(_f32(acts)), _p(_f32(dlogits)), _p(_f32(dvalue)),
+                              _p(grads))
+    return grads

@@ -668,3 +668,259 @@ EXPORT void cbo_impala_loss_grad(const float* P, int A, const uint8_t* obs, cons
 EXPORT float cbo_logf(float x) { return cbm_logf(x); }
 EXPORT float cbo_expf(float x) { return cbm_expf(x); }
 EXPORT float cbo_u8_unit(uint32_t x) { return cbm_u8_unit(x); }
+
+/* ============================================================ IMPALA-ResNet torso  (ppo:149-189)
+ * Network(channels=(16,32,32), hiddens=(256,)): 3 x ConvSequence [Conv3x3 SAME -> max_pool(3,3) stride 2 SAME ->
+ * 2 x ResidualBlock(relu, conv, relu, conv, + x)], relu, flatten (h,w,c), Dense(256) + relu; heads as before.
+ * Same numerics spec: every conv/dense output is a k-ascending fmaf chain over k = (kh,kw,ci) INCLUDING the zero
+ * taps of the SAME padding (fma(0,w,acc) == acc), bias added after; dense K split as for Nature.
+ * flax SAME: out = ceil(in/stride); pad_total = max((out-1)*s + k - in, 0); lo = pad_total/2.  For the 3x3 s2 pool:
+ * 84->42 and 42->21: lo 0 / hi 1; 21->11: lo 1 / hi 1; padded cells are -inf.
+ * Parameter blob order (flax tree order): for s in 0..2: Conv_0 {w,b}, ResidualBlock_0 {Conv_0, Conv_1},
+ * ResidualBlock_1 {Conv_0, Conv_1}; Dense_0; actor; critic. */
+#define RN_NSEQ 3
+static const int RN_H[3] = {84, 42, 21}, RN_HP[3] = {42, 21, 11}, RN_CI[3] = {4, 16, 32}, RN_CO[3] = {16, 32, 32}, RN_PLO[3] = {0, 0, 1};
+#define RN_FLAT 3872
+#define RN_HID 256
+typedef struct { int A; int64_t cw[3][5], cb[3][5], dw, db, aw, ab, vw, vb, total; } rn_layout;
+static void rn_get_layout(int A, rn_layout* L) {
+  int64_t o = 0;
+  L->A = A;
+  for (int s = 0; s < 3; ++s)
+    for (int j = 0; j < 5; ++j) {
+      const int ci = j == 0 ? RN_CI[s] : RN_CO[s];
+      L->cw[s][j] = o; o += 9 * ci * RN_CO[s];
+      L->cb[s][j] = o; o += RN_CO[s];
+    }
+  L->dw = o; o += (int64_t)RN_FLAT * RN_HID; L->db = o; o += RN_HID;
+  L->aw = o; o += (int64_t)RN_HID * A; L->ab = o; o += A;
+  L->vw = o; o += RN_HID; L->vb = o; o += 1;
+  L->total = o;
+}
+EXPORT int64_t cbo_resnet_param_count(int A) { rn_layout L; rn_get_layout(A, &L); return L.total; }
+/* per-frame activation record (floats): for each seq: c0 [H*H*C], p, b0y1, b0out, b1y1, b1out [Hp*Hp*C each];
+ * then hid [256]; pool argmax kept as floats 0..8 in pidx [Hp*Hp*C] per seq (after the six tensors). */
+static int64_t rn_seq_off(int s) { int64_t o = 0; for (int i = 0; i < s; ++i) o += (int64_t)RN_H[i] * RN_H[i] * RN_CO[i] + 6 * (int64_t)RN_HP[i] * RN_HP[i] * RN_CO[i]; return o; }
+static int64_t rn_act_floats(void) { return rn_seq_off(3) + RN_HID; }
+EXPORT int64_t cbo_resnet_act_floats(void) { return rn_act_floats(); }
+
+/* 3x3 SAME stride-1 conv on NHWC fp32 (optionally relu on the input, optionally + residual) */
+static void rn_conv3(const float* in, int H, int CI, int CO, const float* W, const float* b, int pre_relu, const float* res, float* out) {
+  for (int oh = 0; oh < H; ++oh) for (int ow = 0; ow < H; ++ow) {
+    float acc[32];
+    for (int co = 0; co < CO; ++co) acc[co] = 0.0f;
+    for (int kh = 0; kh < 3; ++kh) for (int kw = 0; kw < 3; ++kw) {
+      const int ih = oh + kh - 1, iw = ow + kw - 1;
+      const int inside = ih >= 0 && ih < H && iw >= 0 && iw < H;
+      for (int ci = 0; ci < CI; ++ci) {
+        float a = inside ? in[((int64_t)ih * H + iw) * CI + ci] : 0.0f;
+        if (pre_relu && !(a > 0.0f)) a = 0.0f;
+        const float* w = W + ((kh * 3 + kw) * CI + ci) * CO;
+        for (int co = 0; co < CO; ++co) acc[co] = fmaf(a, w[co], acc[co]);
+      }
+    }
+    float* o = out + ((int64_t)oh * H + ow) * CO;
+    for (int co = 0; co < CO; ++co) { float v = acc[co] + b[co]; if (res) v = v + res[((int64_t)oh * H + ow) * CO + co]; o[co] = v; }
+  }
+}
+static void rn_conv3_u8(const uint8_t* x, int H, int CO, const float* W, const float* b, float* out) { /* NCHW u8 /255 input, CI = 4 */
+  for (int oh = 0; oh < H; ++oh) for (int ow = 0; ow < H; ++ow) {
+    float acc[32];
+    for (int co = 0; co < CO; ++co) acc[co] = 0.0f;
+    for (int kh = 0; kh < 3; ++kh) for (int kw = 0; kw < 3; ++kw) {
+      const int ih = oh + kh - 1, iw = ow + kw - 1;
+      const int inside = ih >= 0 && ih < H && iw >= 0 && iw < H;
+      for (int ci = 0; ci < 4; ++ci) {
+        const float a = inside ? cbm_u8_unit(x[((int64_t)ci * H + ih) * H + iw]) : 0.0f;
+        const float* w = W + ((kh * 3 + kw) * 4 + ci) * CO;
+        for (int co = 0; co < CO; ++co) acc[co] = fmaf(a, w[co], acc[co]);
+      }
+    }
+    float* o = out + ((int64_t)oh * H + ow) * CO;
+    for (int co = 0; co < CO; ++co) o[co] = acc[co] + b[co];
+  }
+}
+static void rn_pool(const float* in, int H, int HP, int C, int plo, float* out, float* pidx) {
+  for (int oh = 0; oh < HP; ++oh) for (int ow = 0; ow < HP; ++ow) for (int c = 0; c < C; ++c) {
+    float best = -INFINITY; int bi = 0;
+    for (int kh = 0; kh < 3; ++kh) for (int kw = 0; kw < 3; ++kw) {
+      const int ih = oh * 2 + kh - plo, iw = ow * 2 + kw - plo;
+      if (ih < 0 || ih >= H || iw < 0 || iw >= H) continue;
+      const float v = in[((int64_t)ih * H + iw) * C + c];
+      if (v > best) { best = v; bi = kh * 3 + kw; }
+    }
+    out[((int64_t)oh * HP + ow) * C + c] = best;
+    pidx[((int64_t)oh * HP + ow) * C + c] = (float)bi;
+  }
+}
+static void rn_fwd_frame(const float* P, const rn_layout* L, const uint8_t* x, int ksplit, float* act, float* logits, float* value) {
+  const float* prev = NULL;
+  for (int s = 0; s < 3; ++s) {
+    const int H = RN_H[s], HP = RN_HP[s], C = RN_CO[s];
+    float* c0 = act + rn_seq_off(s);
+    float* p = c0 + (int64_t)H * H * C;
+    const int64_t n = (int64_t)HP * HP * C;
+    float *b0y1 = p + n, *b0out = p + 2 * n, *b1y1 = p + 3 * n, *b1out = p + 4 * n, *pidx = p + 5 * n;
+    if (s == 0) rn_conv3_u8(x, H, C, P + L->cw[0][0], P + L->cb[0][0], c0);
+    else rn_conv3(prev, H, RN_CI[s], C, P + L->cw[s][0], P + L->cb[s][0], 0, NULL, c0);
+    rn_pool(c0, H, HP, C, RN_PLO[s], p, pidx);
+    rn_conv3(p, HP, C, C, P + L->cw[s][1], P + L->cb[s][1], 1, NULL, b0y1);
+    rn_conv3(b0y1, HP, C, C, P + L->cw[s][2], P + L->cb[s][2], 1, p, b0out);
+    rn_conv3(b0out, HP, C, C, P + L->cw[s][3], P + L->cb[s][3], 1, NULL, b1y1);
+    rn_conv3(b1y1, HP, C, C, P + L->cw[s][4], P + L->cb[s][4], 1, b0out, b1out);
+    prev = b1out;
+  }
+  float* hid = act + rn_seq_off(3);
+  {
+    const float* W = P + L->dw; const float* b = P + L->db;
+    float tot[RN_HID], acc[RN_HID];
+    const int seg = RN_FLAT / ksplit;
+    for (int s = 0; s < ksplit; ++s) {
+      for (int n = 0; n < RN_HID; ++n) acc[n] = 0.0f;
+      for (int k = s * seg; k < (s + 1) * seg; ++k) {
+        float a = prev[k]; if (!(a > 0.0f)) a = 0.0f;                      /* relu before flatten, ppo:184 */
+        const float* w = W + (int64_t)k * RN_HID;
+        for (int n = 0; n < RN_HID; ++n) acc[n] = fmaf(a, w[n], acc[n]);
+      }
+      if (s == 0) for (int n = 0; n < RN_HID; ++n) tot[n] = acc[n];
+      else for (int n = 0; n < RN_HID; ++n) tot[n] = tot[n] + acc[n];
+    }
+    for (int n = 0; n < RN_HID; ++n) { float v = tot[n] + b[n]; hid[n] = v > 0.0f ? v : 0.0f; }
+  }
+  const int A = L->A;
+  for (int a = 0; a < A; ++a) {
+    float acc = 0.0f;
+    for (int k = 0; k < RN_HID; ++k) acc = fmaf(hid[k], P[L->aw + k * A + a], acc);
+    logits[a] = acc + P[L->ab + a];
+  }
+  float acc = 0.0f;
+  for (int k = 0; k < RN_HID; ++k) acc = fmaf(hid[k], P[L->vw + k], acc);
+  value[0] = acc + P[L->vb];
+}
+/* acts: NULL or B*cbo_resnet_act_floats() floats (frame-major) */
+EXPORT void cbo_resnet_forward(const float* P, int A, const uint8_t* obs, const int32_t* idx, int B, int ksplit, float* acts, float* logits,
+                               float* value) {
+  rn_layout L; rn_get_layout(A, &L);
+  if (ksplit < 1) ksplit = 1;
+  const int64_t AF = rn_act_floats();
+#pragma omp parallel num_threads(g_threads)
+  {
+    float* t = (float*)malloc(sizeof(float) * (size_t)AF);
+#pragma omp for schedule(static)
+    for (int b = 0; b < B; ++b) {
+      const uint8_t* x = obs + (int64_t)(idx ? idx[b] : b) * FRAME;
+      rn_fwd_frame(P, &L, x, ksplit, acts ? acts + (int64_t)b * AF : t, logits + (int64_t)b * A, value + b);
+    }
+    free(t);
+  }
+}
+
+/* backward of one 3x3 SAME conv: dW += in_eff^T dy, db += sum dy, din (+)= W * dy; in_eff = relu(in) if pre_relu */
+static void rn_conv3_bwd(const float* in, const uint8_t* x_u8, int H, int CI, int CO, const float* W, int pre_relu, const float* dy,
+                         double* gW, double* gb, float* din) {
+  if (din) for (int64_t i = 0; i < (int64_t)H * H * CI; ++i) din[i] = 0.0f;
+  for (int oh = 0; oh < H; ++oh) for (int ow = 0; ow < H; ++ow) {
+    const float* d = dy + ((int64_t)oh * H + ow) * CO;
+    for (int co = 0; co < CO; ++co) gb[co] += d[co];
+    for (int kh = 0; kh < 3; ++kh) for (int kw = 0; kw < 3; ++kw) {
+      const int ih = oh + kh - 1, iw = ow + kw - 1;
+      if (ih < 0 || ih >= H || iw < 0 || iw >= H) continue;
+      for (int ci = 0; ci < CI; ++ci) {
+        float a = x_u8 ? cbm_u8_unit(x_u8[((int64_t)ci * H + ih) * H + iw]) : in[((int64_t)ih * H + iw) * CI + ci];
+        if (pre_relu && !(a > 0.0f)) a = 0.0f;
+        const float* w = W + ((kh * 3 + kw) * CI + ci) * CO;
+        double* g = gW + ((kh * 3 + kw) * CI + ci) * CO;
+        float s = 0.0f;
+        for (int co = 0; co < CO; ++co) { g[co] += (double)a * d[co]; s += w[co] * d[co]; }
+        if (din) din[((int64_t)ih * H + iw) * CI + ci] += s;
+      }
+    }
+  }
+}
+static void rn_bwd_frame(const float* P, const rn_layout* L, const uint8_t* x, const float* act, const float* dlog, float dval, double* G,
+                         float* s0, float* s1, float* s2) {
+  const int A = L->A;
+  const float* hid = act + rn_seq_off(3);
+  float dh[RN_HID];
+  for (int k = 0; k < RN_HID; ++k) {
+    double s = 0.0;
+    for (int a = 0; a < A; ++a) { s += (double)dlog[a] * P[L->aw + k * A + a]; G[L->aw + k * A + a] += (double)hid[k] * dlog[a]; }
+    s += (double)dval * P[L->vw + k];
+    G[L->vw + k] += (double)hid[k] * dval;
+    dh[k] = hid[k] > 0.0f ? (float)s : 0.0f;
+  }
+  for (int a = 0; a < A; ++a) G[L->ab + a] += dlog[a];
+  G[L->vb] += dval;
+  /* dense: input = relu(b1out of seq 2) */
+  const float* last = act + rn_seq_off(2) + (int64_t)RN_H[2] * RN_H[2] * RN_CO[2] + 4 * (int64_t)RN_FLAT;
+  float* dcur = s0;  /* gradient wrt the current sequence output (pre-relu tensor) */
+  for (int n = 0; n < RN_HID; ++n) G[L->db + n] += dh[n];
+  for (int k = 0; k < RN_FLAT; ++k) {
+    const float a = last[k] > 0.0f ? last[k] : 0.0f;
+    double s = 0.0;
+    if (a > 0.0f) for (int n = 0; n < RN_HID; ++n) { s += (double)P[L->dw + (int64_t)k * RN_HID + n] * dh[n]; G[L->dw + (int64_t)k * RN_HID + n] += (double)a * dh[n]; }
+    dcur[k] = a > 0.0f ? (float)s : 0.0f;
+  }
+  for (int s = 2; s >= 0; --s) {
+    const int H = RN_H[s], HP = RN_HP[s], C = RN_CO[s];
+    const float* c0 = act + rn_seq_off(s);
+    const float* p = c0 + (int64_t)H * H * C;
+    const int64_t n = (int64_t)HP * HP * C;
+    const float *b0y1 = p + n, *b0out = p + 2 * n, *b1y1 = p + 3 * n, *pidx = p + 5 * n;
+    /* two residual blocks, last first: out = x + conv2(relu(conv1(relu(x)))) */
+    const float* xs[2] = {p, b0out}; const float* y1s[2] = {b0y1, b1y1};
+    for (int blk = 1; blk >= 0; --blk) {
+      float* d_r1 = s1; float* d_r0 = s2;
+      rn_conv3_bwd(y1s[blk], NULL, HP, C, C, P + L->cw[s][2 + 2 * blk], 1, dcur, G + L->cw[s][2 + 2 * blk], G + L->cb[s][2 + 2 * blk], d_r1);
+      for (int64_t i = 0; i < n; ++i) if (!(y1s[blk][i] > 0.0f)) d_r1[i] = 0.0f;             /* d_y1 */
+      rn_conv3_bwd(xs[blk], NULL, HP, C, C, P + L->cw[s][1 + 2 * blk], 1, d_r1, G + L->cw[s][1 + 2 * blk], G + L->cb[s][1 + 2 * blk], d_r0);
+      for (int64_t i = 0; i < n; ++i) dcur[i] = dcur[i] + (xs[blk][i] > 0.0f ? d_r0[i] : 0.0f);  /* d_x = d_out + mask*d_r0 */
+    }
+    /* max-pool backward: route to the arg-max cell */
+    float* dc0 = s1;
+    for (int64_t i = 0; i < (int64_t)H * H * C; ++i) dc0[i] = 0.0f;
+    for (int oh = 0; oh < HP; ++oh) for (int ow = 0; ow < HP; ++ow) for (int c = 0; c < C; ++c) {
+      const int bi = (int)pidx[((int64_t)oh * HP + ow) * C + c];
+      const int ih = oh * 2 + bi / 3 - RN_PLO[s], iw = ow * 2 + bi % 3 - RN_PLO[s];
+      dc0[((int64_t)ih * H + iw) * C + c] += dcur[((int64_t)oh * HP + ow) * C + c];
+    }
+    /* first conv of the sequence */
+    if (s == 0) rn_conv3_bwd(NULL, x, H, 4, C, P + L->cw[0][0], 0, dc0, G + L->cw[0][0], G + L->cb[0][0], NULL);
+    else {
+      const float* prev_out = act + rn_seq_off(s - 1) + (int64_t)RN_H[s - 1] * RN_H[s - 1] * RN_CO[s - 1] + 4 * (int64_t)RN_HP[s - 1] * RN_HP[s - 1] * RN_CO[s - 1];
+      rn_conv3_bwd(prev_out, NULL, H, RN_CI[s], C, P + L->cw[s][0], 0, dc0, G + L->cw[s][0], G + L->cb[s][0], s2);
+      memcpy(dcur, s2, sizeof(float) * (size_t)H * H * RN_CI[s]);
+    }
+  }
+}
+EXPORT void cbo_resnet_backward(const float* P, int A, const uint8_t* obs, const int32_t* idx, int B, const float* acts, const float* dlogits,
+                                const float* dvalue, float* grads) {
+  rn_layout L; rn_get_layout(A, &L);
+  const int64_t AF = rn_act_floats();
+  int nt = g_threads;
+  double** Gs = (double**)calloc((size_t)nt, sizeof(double*));
+#pragma omp parallel num_threads(nt)
+  {
+    int tid = 0;
+#ifdef _OPENMP
+    tid = omp_get_thread_num();
+#endif
+    double* G = (double*)calloc((size_t)L.total, sizeof(double));
+    Gs[tid] = G;
+    const size_t big = (size_t)84 * 84 * 16;
+    float* s0 = (float*)malloc(sizeof(float) * big); float* s1 = (float*)malloc(sizeof(float) * big); float* s2 = (float*)malloc(sizeof(float) * big);
+#pragma omp for schedule(static)
+    for (int b = 0; b < B; ++b) {
+      const uint8_t* x = obs + (int64_t)(idx ? idx[b] : b) * FRAME;
+      rn_bwd_frame(P, &L, x, acts + (int64_t)b * AF, dlogits + (int64_t)b * A, dvalue[b], G, s0, s1, s2);
+    }
+    free(s0); free(s1); free(s2);
+  }
+  for (int64_t i = 0; i < L.total; ++i) {
+    double s = 0.0;
+    for (int t = 0; t < nt; ++t) if (Gs[t]) s += Gs[t][i];
+    grads[i] = (float)s;
+  }
+  for (int t = 0; t < nt; ++t) free(Gs[t]);
+  free(Gs);
+}

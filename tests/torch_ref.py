@@ -81,3 +81,37 @@ def impala_loss(logits, value, mu_logits, actions, rewards, dones, firststeps, g
     bl = 0.5 * (errors ** 2 * mask).sum()
     ent = (-(-(lp.exp() * lp).sum(-1)) * mask).sum()
     return pg + vf_coef * bl + ent_coef * ent, (pg, bl, ent)
+
+
+def unpack_resnet(params, A, dtype=torch.float64, requires_grad=False):
+    ci, co = (4, 16, 32), (16, 32, 32)
+    flat = torch.tensor(np.asarray(params), dtype=dtype, requires_grad=requires_grad)
+    P, o = {}, 0
+    def take(name, shp):
+        nonlocal o
+        k = int(np.prod(shp)); P[name] = flat[o:o + k].reshape(shp); o += k
+    for s in range(3):
+        for j in range(5):
+            take(f"s{s}c{j}w", (3, 3, ci[s] if j == 0 else co[s], co[s])); take(f"s{s}c{j}b", (co[s],))
+    take("dw", (3872, 256)); take("db", (256,)); take("aw", (256, A)); take("ab", (A,)); take("cw", (256, 1)); take("cb", (1,))
+    assert o == flat.numel()
+    return flat, P
+
+
+def resnet_forward(P, obs_u8):
+    """ppo:149-189 with flax SAME semantics: conv pad 1; max_pool(3,3) stride 2 SAME = -inf pad (lo,hi) = (0,1),(0,1),(1,1)."""
+    x = torch.tensor(np.asarray(obs_u8), dtype=P["dw"].dtype) / 255.0
+    conv = lambda x, w, b: F.conv2d(x, w.permute(3, 2, 0, 1), b, padding=1)
+    pads = [(0, 1), (0, 1), (1, 1)]
+    for s in range(3):
+        x = conv(x, P[f"s{s}c0w"], P[f"s{s}c0b"])
+        lo, hi = pads[s]
+        x = F.max_pool2d(F.pad(x, (lo, hi, lo, hi), value=float("-inf")), 3, 2)
+        for blk in range(2):
+            inp = x
+            x = conv(F.relu(x), P[f"s{s}c{1 + 2 * blk}w"], P[f"s{s}c{1 + 2 * blk}b"])
+            x = conv(F.relu(x), P[f"s{s}c{2 + 2 * blk}w"], P[f"s{s}c{2 + 2 * blk}b"])
+            x = x + inp
+    x = F.relu(x).permute(0, 2, 3, 1).reshape(x.shape[0], -1)
+    h = F.relu(x @ P["dw"] + P["db"])
+    return h @ P["aw"] + P["ab"], (h @ P["cw"] + P["cb"]).squeeze(-1)
