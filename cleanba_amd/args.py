@@ -50,7 +50,7 @@ class Args:
     concurrency: bool = False
 
     # [mi] build-only
-    network: str = "nature"          # "nature" (naturecnn:143-178) | "impala_resnet" (ppo:149-189)
+    network: str = "impala_resnet"   # "impala_resnet" (ppo:149-189, the reference default) | "nature" (naturecnn:143-178)
     env_backend: str = "device"      # "device": synthetic env stepping on the GPU; "host": same env on the CPU
                                      # through the envpool API; "envpool": real envpool if installed
     num_actions: int = 18            # full_action_space=True (ppo:135)

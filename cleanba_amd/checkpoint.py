@@ -36,15 +36,17 @@ def _unpack_ext(code, data):
     return msgpack.ExtType(code, data)
 
 
-def save_cleanrl_model(path, args, flat_params, num_actions):
-    tree = [dict(vars(args)), M.params_to_flax_tree(np.asarray(flat_params, np.float32), num_actions)]
+def save_cleanrl_model(path, args, flat_params, num_actions, network="nature"):
+    to_tree = M.params_to_flax_tree if network == "nature" else M.resnet_params_to_flax_tree
+    tree = [dict(vars(args)), to_tree(np.asarray(flat_params, np.float32), num_actions)]
     with open(path, "wb") as f:
         f.write(msgpack.packb(_to_state(tree), default=_pack_ext, strict_types=True))
 
 
-def load_cleanrl_model(path, num_actions):
+def load_cleanrl_model(path, num_actions, network="nature"):
     with open(path, "rb") as f:
         state = msgpack.unpackb(f.read(), ext_hook=_unpack_ext, raw=False)
     args_dict, params = state["0"], state["1"]
     tree = [params["0"], params["1"], params["2"]]
-    return args_dict, M.flax_tree_to_params(tree, num_actions)
+    from_tree = M.flax_tree_to_params if network == "nature" else M.resnet_flax_tree_to_params
+    return args_dict, from_tree(tree, num_actions)

@@ -102,8 +102,8 @@ extern "C" int cbm_default_config(int32_t algo, cbm_config* cfg) {
 }
 
 extern "C" int64_t cbm_param_count(int32_t network, int32_t num_actions) {
-  if (network != CBM_NET_NATURE) return -1;
-  return nature_layout(num_actions).total;
+  if (network != CBM_NET_NATURE && network != CBM_NET_IMPALA_RESNET) return -1;
+  return net_layout(network, num_actions).total;
 }
 
 template <class Tp>
@@ -114,7 +114,7 @@ static int dalloc(Tp** p, size_t n) {
 
 extern "C" int cbm_ctx_create(const cbm_config* cfg, cbm_ctx** out) {
   if (!cfg || cfg->abi_version != CBM_ABI_VERSION) { cbm_set_error("bad config / abi version"); return -1; }
-  if (cfg->network != CBM_NET_NATURE) { cbm_set_error("network kind %d not built into this library yet", cfg->network); return -2; }
+  if (cfg->network != CBM_NET_NATURE && cfg->network != CBM_NET_IMPALA_RESNET) { cbm_set_error("unknown network kind %d", cfg->network); return -2; }
   if (cfg->num_actor_slots < 1 || cfg->num_actor_slots > MAX_SLOTS || cfg->ring_depth < 2 || cfg->ring_depth > MAX_RING) {
     cbm_set_error("num_actor_slots in [1,%d], ring_depth in [2,%d]", MAX_SLOTS, MAX_RING); return -1;
   }
@@ -130,8 +130,10 @@ extern "C" int cbm_ctx_create(const cbm_config* cfg, cbm_ctx** out) {
   if (c->Bdev > 1024) { cbm_set_error("local_num_envs*slots must be <= 1024 per GPU"); delete c; return -1; }
   if (c->Bdev % c->nmb) { cbm_set_error("local_num_envs*slots must be divisible by num_minibatches (ppo:416-418)"); delete c; return -1; }
   c->MB = is_ppo(c) ? (c->T * c->Bdev) / c->nmb : c->T1 * (c->Bdev / c->nmb);
-  if (3136 % cfg->actor_dense_ksplit || (3136 / cfg->actor_dense_ksplit) % 4) { cbm_set_error("actor_dense_ksplit must divide 3136 into multiples of 4"); delete c; return -1; }
-  c->L = nature_layout(c->A);
+  c->L = net_layout(cfg->network, c->A);
+  if (c->L.flat % cfg->actor_dense_ksplit || (c->L.flat / cfg->actor_dense_ksplit) % 32) {
+    cbm_set_error("actor_dense_ksplit must cut the %d-wide flatten into multiples of 32 (Nature: 14, ResNet: 11)", c->L.flat); delete c; return -1;
+  }
   c->P = c->L.total;
   const size_t P = (size_t)c->P, B = (size_t)c->Bdev, T1 = (size_t)c->T1;
   if (dalloc(&c->params, P) || dalloc(&c->grads, P) || dalloc(&c->opt_m, P) || dalloc(&c->opt_v, P)) return -1;
@@ -148,13 +150,13 @@ extern "C" int cbm_ctx_create(const cbm_config* cfg, cbm_ctx** out) {
   for (int s = 0; s < c->S; ++s) {
     Slot& sl = c->slots[s];
     CBM_HIP(hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
-    if (nature_ws_alloc(sl.ws, c->E, false, cfg->actor_dense_ksplit)) return -1;
+    if (nature_ws_alloc(sl.ws, c->E, false, cfg->actor_dense_ksplit, cfg->network)) return -1;
     if (dalloc(&sl.env_state, (size_t)c->E) || dalloc(&sl.stats_dev, 2)) return -1;
     c->committed[s] = 0;
   }
   CBM_HIP(hipStreamCreateWithFlags(&c->lstream, hipStreamNonBlocking));
   const int lmax = c->MB > c->Bdev ? c->MB : c->Bdev;
-  if (nature_ws_alloc(c->lws, lmax, true, cfg->actor_dense_ksplit)) return -1;
+  if (nature_ws_alloc(c->lws, lmax, true, cfg->actor_dense_ksplit, cfg->network)) return -1;
   c->stat_rows = c->epochs * c->nmb;
   if (dalloc(&c->adv, T1 * B) || dalloc(&c->target, T1 * B) || dalloc(&c->next_value, B) || dalloc(&c->stats_dev, (size_t)c->stat_rows * 8) ||
       dalloc(&c->loss_partials, (size_t)4 * (lmax / 256 + 2) + 3 * B) || dalloc(&c->norm_partials, CBM_NORM_PARTS) ||
@@ -579,7 +581,7 @@ extern "C" int cbm_forward(cbm_ctx* c, const float* params, const uint8_t* obs, 
   if (ksplit > 1 && (B > 1024 || ksplit != c->lws.dense_part_ksplit || !c->lws.dense_part)) {
     // a split-K plan needs its partial buffer; allocate on demand for tests
     if (c->lws.dense_part) hipFree(c->lws.dense_part);
-    CBM_HIP(hipMalloc((void**)&c->lws.dense_part, (size_t)ksplit * c->lws.maxB * 512 * 4));
+    CBM_HIP(hipMalloc((void**)&c->lws.dense_part, (size_t)ksplit * c->lws.maxB * c->L.hid * 4));
     c->lws.dense_part_ksplit = ksplit;
   }
   nature_forward(c->L, params, obs, idx, B, ksplit, c->lws, c->lstream);

@@ -11,10 +11,13 @@
 // ---- parameter layout (flax shapes): Nature-CNN ------------------------------
 struct NatureLayout {
   int A;
-  int64_t w[6], b[6];  // 0 conv1, 1 conv2, 2 conv3, 3 dense, 4 actor, 5 critic
+  int kind = 0, hid = 512, flat = 3136;  // CBM_NET_NATURE: 3136 -> 512;  CBM_NET_IMPALA_RESNET: 3872 -> 256
+  int64_t w[6], b[6];  // 0 conv1, 1 conv2, 2 conv3, 3 dense, 4 actor, 5 critic  (ResNet: only 3..5)
+  int64_t rcw[3][5], rcb[3][5];  // ResNet: per ConvSequence {Conv_0, RB0.Conv_0, RB0.Conv_1, RB1.Conv_0, RB1.Conv_1}
   int64_t total;
 };
 NatureLayout nature_layout(int A);
+NatureLayout net_layout(int kind, int A);
 
 // ---- optional per-kernel HIP-event timing (bench.py roofline): events bracket every launch of the
 // selected kernel id on the stream it is launched on.
@@ -41,8 +44,13 @@ struct NatureWs {
   float *dzv = nullptr, *dhid = nullptr, *dact3pad = nullptr, *dact2pad = nullptr, *dact1 = nullptr;
   float *wg_part = nullptr, *bias_part = nullptr;
   int64_t wg_part_floats = 0, bias_part_floats = 0;
+  // IMPALA-ResNet activations (resnet_layers.inc): per sequence {c0, p, b0y1, b0out, b1y1, b1out}, pool arg-max, grad ping-pong
+  int kind = 0;
+  float* rn_t[3][6] = {};
+  uint8_t* rn_pidx[3] = {};
+  float* rn_g[2] = {};
 };
-int nature_ws_alloc(NatureWs& ws, int maxB, bool with_grad, int dense_ksplit_small);
+int nature_ws_alloc(NatureWs& ws, int maxB, bool with_grad, int dense_ksplit_small, int kind = 0);
 void nature_ws_free(NatureWs& ws);
 
 // forward: obs[idx[b]] (idx may be null) -> ws.logits [B,A], ws.value [B]; activations kept in ws.

@@ -11,6 +11,8 @@
 // plain VALID correlations (stride-2 conv2 as 4 parity classes).
 #include "cbm_internal.h"
 #include "igemm.h"
+#include <algorithm>
+#include <type_traits>
 
 NatureLayout nature_layout(int A) {
   NatureLayout L;
@@ -82,7 +84,8 @@ struct ConvFwd {
 };
 
 // dense forward C[m][n] = sum_k A[m][k] W[k][n]; SPLIT: partials [z][M][N], else relu(+bias)
-template <class TileT, bool SPLIT>
+static __device__ __forceinline__ float4 f4relu(float4 v) { return make_float4(relu(v.x), relu(v.y), relu(v.z), relu(v.w)); }
+template <class TileT, bool SPLIT, bool PRE_RELU = false>
 struct DenseFwd {
   using Tile = TileT;
   static constexpr bool A_RX = false, B_YR = false, BIAS_GRAD = false;
@@ -93,7 +96,8 @@ struct DenseFwd {
   __device__ void r_range(int z, int& lo, int& hi) const { lo = z * seg; hi = lo + seg; }
   __device__ float4 load_a(int m, int r, int rhi, int) const {
     const bool ok = r < rhi;
-    return f4sel(ok, *reinterpret_cast<const float4*>(A + (size_t)min(m, M - 1) * K + min(r, K - 4)));
+    const float4 v = f4sel(ok, *reinterpret_cast<const float4*>(A + (size_t)min(m, M - 1) * K + min(r, K - 4)));
+    return PRE_RELU ? f4relu(v) : v;
   }
   __device__ float4 load_b(int r, int y, int rhi, int) const {
     const bool ok = r < rhi && y < N;
@@ -118,37 +122,43 @@ __global__ void dense_reduce_kernel(const float* part, const float* bias, float*
 // 512-long fmaf chain stays serial (numerics spec); hid rows and both weight matrices are staged in LDS so the
 // chain is paced by the FMA latency, not by global loads.
 __global__ __launch_bounds__(256) void heads_fwd_kernel(const float* hid, const float* Wa, const float* ba, const float* Wc,
-                                                        const float* bc, int B, int A, float* logits, float* value) {
+                                                        const float* bc, int B, int A, int HD, float* logits, float* value) {
   extern __shared__ __attribute__((aligned(16))) float hsm[];
-  float* hs = hsm;             // [8][512]
-  float* ws = hsm + 8 * 512;   // [512][A+1]
+  float* hs = hsm;             // [8][HD]
+  float* ws = hsm + 8 * HD;    // [HD][A+1]
   const int A1 = A + 1;
   const int f0 = blockIdx.x * 8;
-  for (int i = threadIdx.x; i < 8 * 512; i += 256) {
-    const int f = f0 + i / 512;
-    hs[i] = f < B ? hid[(size_t)f * 512 + i % 512] : 0.0f;
+  for (int i = threadIdx.x; i < 8 * HD; i += 256) {
+    const int f = f0 + i / HD;
+    hs[i] = f < B ? hid[(size_t)f * HD + i % HD] : 0.0f;
   }
-  for (int i = threadIdx.x; i < 512 * A; i += 256) ws[(i / A) * A1 + i % A] = Wa[i];
-  for (int i = threadIdx.x; i < 512; i += 256) ws[i * A1 + A] = Wc[i];
+  for (int i = threadIdx.x; i < HD * A; i += 256) ws[(i / A) * A1 + i % A] = Wa[i];
+  for (int i = threadIdx.x; i < HD; i += 256) ws[i * A1 + A] = Wc[i];
   __syncthreads();
   const int fl = threadIdx.x >> 5, o = threadIdx.x & 31, f = f0 + fl;
   if (f >= B || o > A) return;
-  const float* h = hs + fl * 512;
+  const float* h = hs + fl * HD;
   const float* w = ws + o;
   float acc = 0.0f;
 #pragma unroll 8
-  for (int k = 0; k < 512; ++k) acc = fmaf(h[k], w[k * A1], acc);
+  for (int k = 0; k < HD; ++k) acc = fmaf(h[k], w[k * A1], acc);
   if (o < A) logits[(size_t)f * A + o] = acc + ba[o];
   else value[f] = acc + bc[0];
+}
+
+static void launch_heads_fwd(const float* hid, const float* Wa, const float* ba, const float* Wc, const float* bc, int B, int A, int HD,
+                             float* logits, float* value, hipStream_t st) {
+  hipLaunchKernelGGL(heads_fwd_kernel, dim3((B + 7) / 8), dim3(256), (8 * HD + HD * (A + 1)) * sizeof(float), st, hid, Wa, ba, Wc, bc, B, A, HD,
+                     logits, value);
 }
 
 // ------------------------------------------------------------------------------------------ backward
 // heads dgrad: dhid[m][k] = (sum_j dzv[m][j] * Wac[k][j]) * (hid > 0), j over A logits + value
 __global__ __launch_bounds__(256) void heads_dgrad_kernel(const float* dzv, const float* Wa, const float* Wc, const float* hid,
-                                                          int B, int A, float* dhid) {
+                                                          int B, int A, int HD, float* dhid) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= (size_t)B * 512) return;
-  const int m = (int)(i >> 9), k = (int)(i & 511);
+  if (i >= (size_t)B * HD) return;
+  const int m = (int)(i / HD), k = (int)(i % HD);
   const float* d = dzv + (size_t)m * 32;
   float s = 0.0f;
   for (int a = 0; a < A; ++a) s = fmaf(d[a], Wa[k * A + a], s);
@@ -298,7 +308,7 @@ struct ConvWgrad {  // dY lives in a zero-bordered [S][OH+2*PADO... = 11][11][CO
 };
 
 // plain wgrad: C[x][y] = sum_m A[m][x] * G[m][y]   (dense: A = act3, G = dhid; heads: A = hid, G = dzv)
-template <class TileT>
+template <class TileT, bool PRE_RELU = false>
 struct MatWgrad {
   using Tile = TileT;
   static constexpr bool A_RX = true, B_YR = false, BIAS_GRAD = true;
@@ -309,7 +319,8 @@ struct MatWgrad {
   __device__ void r_range(int z, int& lo, int& hi) const { lo = z * rps; hi = min(lo + rps, M); }
   __device__ float4 load_a(int k, int m, int rhi, int) const {
     const bool ok = m < rhi && k < XK;
-    return f4sel(ok, *reinterpret_cast<const float4*>(A + (size_t)min(m, rhi - 1) * XK + min(k, XK - 4)));
+    const float4 v = f4sel(ok, *reinterpret_cast<const float4*>(A + (size_t)min(m, rhi - 1) * XK + min(k, XK - 4)));
+    return PRE_RELU ? f4relu(v) : v;
   }
   __device__ float4 load_b(int m, int y, int rhi, int) const {
     const bool ok = m < rhi && y < YN;
@@ -363,8 +374,10 @@ static int round_up(int a, int b) { return ceil_div(a, b) * b; }
 static const int RPS_C1 = 1600, RPS_C2 = 1280, RPS_C3 = 1664, RPS_HEADS = 128;
 static int dense_wgrad_splits(int B) { return B >= 2048 ? 2 : 1; }
 
-int nature_ws_alloc(NatureWs& ws, int maxB, bool with_grad, int dense_ksplit_small) {
-  ws.maxB = maxB; ws.with_grad = with_grad;
+static int rn_ws_alloc(NatureWs& ws, int maxB, bool with_grad, int dense_ksplit_small);
+int nature_ws_alloc(NatureWs& ws, int maxB, bool with_grad, int dense_ksplit_small, int kind) {
+  ws.maxB = maxB; ws.with_grad = with_grad; ws.kind = kind;
+  if (kind == CBM_NET_IMPALA_RESNET) return rn_ws_alloc(ws, maxB, with_grad, dense_ksplit_small);
   const size_t B = (size_t)maxB;
   if (dmalloc(&ws.act1, B * 12800) || dmalloc(&ws.act2, B * 5184) || dmalloc(&ws.act3, B * 3136) || dmalloc(&ws.hid, B * 512) ||
       dmalloc(&ws.logits, B * 32) || dmalloc(&ws.value, B)) return -1;
@@ -379,13 +392,13 @@ int nature_ws_alloc(NatureWs& ws, int maxB, bool with_grad, int dense_ksplit_sma
     hipMemset(ws.dzv, 0, B * 32 * sizeof(float));
     size_t need = 0;
     auto mx = [&](size_t v) { if (v > need) need = v; };
-    mx((size_t)ceil_div(maxB * 400, RPS_C1) * 256 * 32);
+    mx((size_t)std::max(ceil_div(maxB * 400, RPS_C1), conv1_wgrad_frames_splits(maxB)) * 256 * 32);  // generic or frame-resident conv1 wgrad
     mx((size_t)ceil_div(maxB * 81, RPS_C2) * 512 * 64);
     mx((size_t)ceil_div(maxB * 49, RPS_C3) * 576 * 64);
     mx((size_t)dense_wgrad_splits(maxB) * 3136 * 512);
     mx((size_t)ceil_div(maxB, RPS_HEADS) * 512 * 32);
     ws.wg_part_floats = (int64_t)need;
-    size_t bneed = (size_t)ceil_div(maxB * 400, RPS_C1) * 512 + 4096;
+    size_t bneed = (size_t)std::max(ceil_div(maxB * 400, RPS_C1), conv1_wgrad_frames_splits(maxB)) * 512 + 4096;
     ws.bias_part_floats = (int64_t)bneed;
     if (dmalloc(&ws.wg_part, need) || dmalloc(&ws.bias_part, bneed)) return -1;
   }
@@ -395,6 +408,12 @@ void nature_ws_free(NatureWs& ws) {
   float** ps[] = {&ws.act1, &ws.act2, &ws.act3, &ws.hid, &ws.logits, &ws.value, &ws.dense_part, &ws.dzv, &ws.dhid,
                   &ws.dact3pad, &ws.dact2pad, &ws.dact1, &ws.wg_part, &ws.bias_part};
   for (auto p : ps) { if (*p) hipFree(*p); *p = nullptr; }
+  for (int s = 0; s < 3; ++s) {
+    for (int j = 0; j < 6; ++j) { if (ws.rn_t[s][j]) hipFree(ws.rn_t[s][j]); ws.rn_t[s][j] = nullptr; }
+    if (ws.rn_pidx[s]) hipFree(ws.rn_pidx[s]);
+    ws.rn_pidx[s] = nullptr;
+  }
+  for (int j = 0; j < 2; ++j) { if (ws.rn_g[j]) hipFree(ws.rn_g[j]); ws.rn_g[j] = nullptr; }
 }
 
 // ------------------------------------------------------------------------------------------ drivers
@@ -420,8 +439,11 @@ using T256x32 = IgemmTile<256, 32, 32, 4, 1>;
 using T128x64 = IgemmTile<128, 64, 32, 2, 2>;
 using T64x64 = IgemmTile<64, 64, 32, 2, 2>;
 
+#include "resnet_layers.inc"
+
 void nature_forward(const NatureLayout& L, const float* P, const uint8_t* obs, const int32_t* idx, int B, int dense_ksplit,
                     NatureWs& ws, hipStream_t st) {
+  if (L.kind == CBM_NET_IMPALA_RESNET) { resnet_forward(L, P, obs, idx, B, dense_ksplit, ws, st); return; }
   const bool small = B <= 512;
   if (small) {
     Conv1Fwd<T128x32> p{obs, idx, P + L.w[0], P + L.b[0], ws.act1, B * 400};
@@ -449,15 +471,15 @@ void nature_forward(const NatureLayout& L, const float* P, const uint8_t* obs, c
     DenseFwd<T64x64, false> pd{ws.act3, P + L.w[3], P + L.b[3], ws.hid, B, 3136, 512, 3136};
     plaunch(ws, K_DENSE_FWD, pd, 1, st);
   }
-  hipLaunchKernelGGL(heads_fwd_kernel, dim3(ceil_div(B, 8)), dim3(256), (8 * 512 + 512 * (L.A + 1)) * sizeof(float), st, ws.hid, P + L.w[4], P + L.b[4], P + L.w[5], P + L.b[5], B,
-                     L.A, ws.logits, ws.value);
+  launch_heads_fwd(ws.hid, P + L.w[4], P + L.b[4], P + L.w[5], P + L.b[5], B, L.A, 512, ws.logits, ws.value, st);
 }
 
 void nature_backward(const NatureLayout& L, const float* P, const uint8_t* obs, const int32_t* idx, int B, NatureWs& ws, float* grads,
                      hipStream_t st) {
+  if (L.kind == CBM_NET_IMPALA_RESNET) { resnet_backward(L, P, obs, idx, B, ws, grads, st); return; }
   const int A = L.A;
   // heads: dgrad (VALU) and wgrad (MFMA, Y = A+1 padded to 32)
-  hipLaunchKernelGGL(heads_dgrad_kernel, dim3(ceil_div(B * 512, 256)), dim3(256), 0, st, ws.dzv, P + L.w[4], P + L.w[5], ws.hid, B, A,
+  hipLaunchKernelGGL(heads_dgrad_kernel, dim3(ceil_div(B * 512, 256)), dim3(256), 0, st, ws.dzv, P + L.w[4], P + L.w[5], ws.hid, B, A, 512,
                      ws.dhid);
   {
     const int nz = ceil_div(B, RPS_HEADS);

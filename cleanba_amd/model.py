@@ -101,3 +101,96 @@ def flax_tree_to_params(tree, A):
     put("critic.w", critic["params"]["Dense_0"]["kernel"])
     put("critic.b", critic["params"]["Dense_0"]["bias"])
     return p
+
+
+# ------------------------------------------------------------------ IMPALA-ResNet torso (ppo:149-189), the reference default
+_RN_CI, _RN_CO = (4, 16, 32), (16, 32, 32)
+_RN_CONVS = ("Conv_0", "ResidualBlock_0/Conv_0", "ResidualBlock_0/Conv_1", "ResidualBlock_1/Conv_0", "ResidualBlock_1/Conv_1")
+
+
+def resnet_layout(A):
+    """name -> (offset, shape), flax tree order (ConvSequence_s/{Conv_0, ResidualBlock_{0,1}/Conv_{0,1}}, Dense_0, heads)."""
+    out, o = {}, 0
+    for s in range(3):
+        for j, n in enumerate(_RN_CONVS):
+            shp = (3, 3, _RN_CI[s] if j == 0 else _RN_CO[s], _RN_CO[s])
+            out[f"ConvSequence_{s}/{n}/kernel"] = (o, shp); o += int(np.prod(shp))
+            out[f"ConvSequence_{s}/{n}/bias"] = (o, (_RN_CO[s],)); o += _RN_CO[s]
+    for n, shp in (("Dense_0/kernel", (3872, 256)), ("Dense_0/bias", (256,)), ("actor/kernel", (256, A)), ("actor/bias", (A,)),
+                   ("critic/kernel", (256, 1)), ("critic/bias", (1,))):
+        out[n] = (o, shp); o += int(np.prod(shp))
+    return out, o
+
+
+def _lecun_normal(rng, shape):
+    """flax default kernel_init (nn.Conv, ppo:156): truncated normal (+-2 sigma) with variance 1/fan_in."""
+    fan_in = int(np.prod(shape[:-1]))
+    std = np.sqrt(1.0 / fan_in) / 0.87962566103423978
+    x = rng.standard_normal(shape)
+    bad = np.abs(x) > 2.0
+    while bad.any():
+        x[bad] = rng.standard_normal(int(bad.sum()))
+        bad = np.abs(x) > 2.0
+    return (std * x).astype(np.float32)
+
+
+def init_resnet_params(A, network_key, actor_key, critic_key):
+    layout, total = resnet_layout(A)
+    p = np.zeros(total, np.float32)
+
+    def rng_for(key, i):
+        return np.random.Generator(np.random.Philox(key=[int(key[0]) << 32 | int(key[1]), i]))
+    i = 0
+    for name, (o, shp) in layout.items():
+        if name.endswith("/kernel") and name.startswith("ConvSequence"):
+            p[o:o + int(np.prod(shp))] = _lecun_normal(rng_for(network_key, i), shp).ravel()
+            i += 1
+    o, shp = layout["Dense_0/kernel"]
+    p[o:o + int(np.prod(shp))] = _orthogonal(rng_for(network_key, 100), shp, np.sqrt(2.0)).ravel()
+    o, shp = layout["actor/kernel"]
+    p[o:o + int(np.prod(shp))] = _orthogonal(rng_for(actor_key, 0), shp, 0.01).ravel()
+    o, shp = layout["critic/kernel"]
+    p[o:o + int(np.prod(shp))] = _orthogonal(rng_for(critic_key, 0), shp, 1.0).ravel()
+    return p
+
+
+def init_params(network, A, network_key, actor_key, critic_key):
+    if network == "nature":
+        return init_nature_params(A, network_key, actor_key, critic_key)
+    return init_resnet_params(A, network_key, actor_key, critic_key)
+
+
+def resnet_params_to_flax_tree(p, A):
+    layout, _ = resnet_layout(A)
+    net = {"params": {}}
+    for name, (o, shp) in layout.items():
+        parts = name.split("/")
+        if parts[0] in ("actor", "critic"):
+            continue
+        d = net["params"]
+        for k in parts[:-1]:
+            d = d.setdefault(k, {})
+        d[parts[-1]] = p[o:o + int(np.prod(shp))].reshape(shp).copy()
+
+    def head(n):
+        ow, sw = layout[f"{n}/kernel"]; ob, sb = layout[f"{n}/bias"]
+        return {"params": {"Dense_0": {"kernel": p[ow:ow + int(np.prod(sw))].reshape(sw).copy(), "bias": p[ob:ob + sb[0]].copy()}}}
+    return [net, head("actor"), head("critic")]
+
+
+def resnet_flax_tree_to_params(tree, A):
+    layout, total = resnet_layout(A)
+    net, actor, critic = tree
+    p = np.zeros(total, np.float32)
+    for name, (o, shp) in layout.items():
+        parts = name.split("/")
+        if parts[0] == "actor":
+            a = actor["params"]["Dense_0"][parts[1]]
+        elif parts[0] == "critic":
+            a = critic["params"]["Dense_0"][parts[1]]
+        else:
+            a = net["params"]
+            for k in parts:
+                a = a[k]
+        p[o:o + int(np.prod(shp))] = np.asarray(a, np.float32).reshape(shp).ravel()
+    return p

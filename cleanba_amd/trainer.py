@@ -52,6 +52,7 @@ def make_config(args, algo):
     cfg.device = args.learner_device_ids[0] if not args.distributed else int(os.environ.get("LOCAL_RANK", os.environ.get("SLURM_LOCALID", 0)))
     cfg.network = {"nature": L.NET_NATURE, "impala_resnet": L.NET_IMPALA_RESNET}[args.network]
     cfg.num_actions = args.num_actions
+    cfg.actor_dense_ksplit = 14 if args.network == "nature" else 11  # K segments of the flatten->dense when M <= 1024 rows
     cfg.local_num_envs = args.local_num_envs
     cfg.num_actor_slots = args.num_actor_threads * len(args.actor_device_ids)
     cfg.num_steps = args.num_steps
@@ -240,7 +241,7 @@ def train(args, algo="ppo", engine_factory=None, on_update=None):
 
     cfg = make_config(args, algo)
     engine = engine_factory(cfg) if engine_factory else HipEngine(cfg)
-    params = M.init_nature_params(args.num_actions, network_key, actor_key, critic_key)
+    params = M.init_params(args.network, args.num_actions, network_key, actor_key, critic_key)
     engine.set_params(params)
     allreduce = GradAllReducer(engine, world_size)
 
@@ -317,7 +318,7 @@ def train(args, algo="ppo", engine_factory=None, on_update=None):
     if args.save_model and rank == 0:
         from .checkpoint import save_cleanrl_model
         path = f"runs/{run_name}/{args.exp_name}.cleanrl_model"
-        save_cleanrl_model(path, args, result["params"], args.num_actions)
+        save_cleanrl_model(path, args, result["params"], args.num_actions, args.network)
         print(f"model saved to {path}")
         result["model_path"] = path
     writer.close()

