@@ -26,9 +26,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define IGEMM_MIN_WAVES 4
 #endif
 
-template <int BX_, int BY_, int BR_, int WX_, int WY_>
+template <int BX_, int BY_, int BR_, int WX_, int WY_, int MINW_ = IGEMM_MIN_WAVES>
 struct IgemmTile {
-  static constexpr int BX = BX_, BY = BY_, BR = BR_, WX = WX_, WY = WY_;
+  static constexpr int BX = BX_, BY = BY_, BR = BR_, WX = WX_, WY = WY_, MINW = MINW_;  // MINW: min waves per SIMD (register budget)
   static_assert(WX_ * WY_ == 4, "4 waves per block");
   static_assert(BX_ % (32 * WX_) == 0 && BY_ % (32 * WY_) == 0 && BR_ % 4 == 0, "tile shape");
 };
@@ -41,7 +41,7 @@ struct IgemmTile {
 //   void store(int x, int y, float v, int z, int cls) const;
 //   void store_bias(int y, float v, int z) const;           (only if BIAS_GRAD)
 template <class P>
-__global__ __launch_bounds__(256, IGEMM_MIN_WAVES) void igemm_kernel(const P p) {
+__global__ __launch_bounds__(256, P::Tile::MINW) void igemm_kernel(const P p) {
   using T = typename P::Tile;
   constexpr int BX = T::BX, BY = T::BY, BR = T::BR, WX = T::WX, WY = T::WY;
   constexpr bool A_RX = P::A_RX, B_YR = P::B_YR;
