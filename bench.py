@@ -80,7 +80,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
     dist = None
-    if world > 1:
+    force_dist = os.environ.get("CBM_FORCE_DIST") == "1"  # exercise the N>1 code path (split form + all-reduce) on one GPU
+    if world > 1 or force_dist:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world,
@@ -97,7 +98,7 @@ def main():
     ctx.actor_set_key(0, key)
     ctx.actor_env_reset_device(0, 1 + rank)  # env seed = seed + process_index + thread id (ppo:238)
     lkey = key.copy()
-    grads_t = ctx.grads_tensor() if world > 1 else None
+    grads_t = ctx.grads_tensor() if dist is not None else None
     n_opt = EPOCHS * NMB
     total_updates = a.warmup + a.steps
     opt_count = 0
@@ -112,7 +113,7 @@ def main():
         ctx.learner_wait()
         lrs = [M.linear_schedule(opt_count + i, 2.5e-4, n_opt, max(total_updates, 1)) for i in range(n_opt)]
         bcs = [M.adam_bias_corrections(opt_count + i + 1) for i in range(n_opt)]
-        if world == 1:
+        if dist is None:
             lkey, _ = ctx.learner_update(lkey, lrs, [b[0] for b in bcs], [b[1] for b in bcs], want_stats=False)
         else:
             lkey = ctx.learner_prepare(lkey)
