@@ -425,6 +425,55 @@ extern "C" int cbm_actor_episode_stats(cbm_ctx* c, int32_t s, float* avg_return,
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------ split topologies
+// a0-l1,2,3 style runs (ppo:97-100, README.md:62): actor and learners are different processes / GPUs.  A learner-only
+// ctx treats its "slots" as ingest ports: the host copies (or RCCL-receives) a rollout shard straight into the ring
+// entry returned by cbm_ingest_begin and publishes it with cbm_ingest_commit; an actor-only ctx receives parameter
+// versions through cbm_params_publish_external (the params_queue.put of ppo:721-725 coming from another process).
+extern "C" int cbm_ingest_begin(cbm_ctx* c, int32_t s, int32_t* ring_index) {
+  Slot& sl = c->slots[s];
+  CBM_HIP(hipSetDevice(c->cfg.device));
+  const int u = ++sl.rollout;
+  const int depth = c->cfg.ring_depth;
+  {
+    std::unique_lock<std::mutex> lk(c->mu);
+    c->cv.wait(lk, [&] { return c->updates_done >= u - depth; });
+  }
+  sl.ring = (u - 1) % depth;
+  if (u > depth) CBM_HIP(hipStreamWaitEvent(sl.stream, c->ring[sl.ring].consumed, 0));
+  CBM_HIP(hipStreamSynchronize(sl.stream));  // the entry is free on the device too: the caller may overwrite it from any stream
+  if (ring_index) *ring_index = sl.ring;
+  return 0;
+}
+extern "C" int cbm_ingest_commit(cbm_ctx* c, int32_t s) {
+  Slot& sl = c->slots[s];
+  CBM_HIP(hipSetDevice(c->cfg.device));
+  // contract: the caller's shard copies into the entry have COMPLETED (it synchronised the stream it issued them on)
+  CBM_HIP(hipEventRecord(c->ring[sl.ring].ready[s], sl.stream));
+  {
+    std::lock_guard<std::mutex> lk(c->mu);
+    c->committed[s] = sl.rollout;
+  }
+  c->cv.notify_all();
+  return 0;
+}
+extern "C" int cbm_params_publish_external(cbm_ctx* c, const float* dev_params, int64_t n) {
+  if (n != c->P) { cbm_set_error("param count mismatch"); return -1; }
+  CBM_HIP(hipSetDevice(c->cfg.device));
+  const int v = c->updates_done + 1;
+  CBM_HIP(hipMemcpyAsync(c->actor_params[v % NPV], dev_params, (size_t)n * 4, hipMemcpyDeviceToDevice, c->lstream));
+  CBM_HIP(hipEventRecord(c->params_ready[v % NPV], c->lstream));
+  CBM_HIP(hipStreamSynchronize(c->lstream));  // the source buffer may be reused by the caller
+  {
+    std::lock_guard<std::mutex> lk(c->mu);
+    c->updates_done = v;
+  }
+  c->cv.notify_all();
+  return 0;
+}
+extern "C" void* cbm_actor_stream(cbm_ctx* c, int32_t s) { return (void*)c->slots[s].stream; }
+extern "C" int cbm_actor_ring_index(cbm_ctx* c, int32_t s) { return c->slots[s].ring; }
+
 // ------------------------------------------------------------------------------------------ learner
 extern "C" int cbm_learner_wait(cbm_ctx* c) {
   CBM_HIP(hipSetDevice(c->cfg.device));

@@ -48,7 +48,8 @@ SYMBOLS = [
     "cbm_learner_epoch_begin", "cbm_learner_minibatch_grad", "cbm_learner_optimizer_step", "cbm_learner_finish",
     "cbm_forward", "cbm_sample", "cbm_gae", "cbm_advnorm", "cbm_permutation", "cbm_ppo_loss_grad",
     "cbm_impala_loss_grad", "cbm_adam_step", "cbm_rmsprop_step", "cbm_synth_env_reset_host", "cbm_synth_env_step_host",
-    "cbm_actor_env_reset_device", "cbm_profile_select", "cbm_profile_read",
+    "cbm_actor_env_reset_device", "cbm_profile_select", "cbm_profile_read", "cbm_ingest_begin", "cbm_ingest_commit",
+    "cbm_params_publish_external", "cbm_actor_stream", "cbm_actor_ring_index",
 ]
 
 _lib = None
@@ -74,6 +75,8 @@ def load():
     lib.cbm_param_count.restype = C.c_int64
     lib.cbm_learner_stream.restype = C.c_void_p
     lib.cbm_learner_stream.argtypes = [C.c_void_p]
+    lib.cbm_actor_stream.restype = C.c_void_p
+    lib.cbm_actor_stream.argtypes = [C.c_void_p, C.c_int32]
     _lib = lib
     return lib
 
@@ -234,6 +237,24 @@ class Context:
         ms, n = C.c_double(), C.c_int32()
         _chk(self.lib.cbm_profile_read(self.h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    # ---- split topologies
+    def ingest_begin(self, slot):
+        r = C.c_int32()
+        _chk(self.lib.cbm_ingest_begin(self.h, int(slot), C.byref(r)))
+        return r.value
+
+    def ingest_commit(self, slot):
+        _chk(self.lib.cbm_ingest_commit(self.h, int(slot)))
+
+    def params_publish_external(self, dev_ptr):
+        _chk(self.lib.cbm_params_publish_external(self.h, C.c_void_p(dev_ptr), C.c_int64(self.P)))
+
+    def actor_stream(self, slot):
+        return self.lib.cbm_actor_stream(self.h, int(slot))
+
+    def actor_ring_index(self, slot):
+        return int(self.lib.cbm_actor_ring_index(self.h, int(slot)))
 
     # ---- learner
     def learner_wait(self):

@@ -64,17 +64,17 @@ def make_config(args, algo):
     return cfg
 
 
-def rollout(key, args, algo, engine, writer, device_thread_id, world_size, process_index, stop_event, errors):
+def rollout(key, args, algo, engine, writer, device_thread_id, world_size, process_index, stop_event, errors, on_commit=None):
     """One actor slot.  Mirrors rollout() ppo:226-406 / impala:268-446."""
     try:
-        _rollout(key, args, algo, engine, writer, device_thread_id, world_size, process_index, stop_event)
+        _rollout(key, args, algo, engine, writer, device_thread_id, world_size, process_index, stop_event, on_commit)
     except Exception as e:  # surface thread failures in the learner loop instead of hanging it
         errors.append(e)
         stop_event.set()
         raise
 
 
-def _rollout(key, args, algo, engine, writer, slot, world_size, process_index, stop_event):
+def _rollout(key, args, algo, engine, writer, slot, world_size, process_index, stop_event, on_commit=None):
     len_actor_device_ids = len(args.actor_device_ids)
     E = args.local_num_envs
     env_seed = args.seed + (0 if args.same_env_seed_all_ranks else process_index) + slot  # ppo:238
@@ -163,6 +163,8 @@ def _rollout(key, args, algo, engine, writer, slot, world_size, process_index, s
         else:
             engine.actor_commit(slot, next_obs, next_done)  # next_obs / next_done are still on the host (ppo:361-363)
         rollout_queue_put_time.append(time.time() - t0)
+        if on_commit is not None:  # split topology: ship this slot's shards to the learner processes
+            on_commit(slot, update, engine.actor_ring_index(slot))
 
         if update % args.log_frequency == 0:
             if device_env:
@@ -191,15 +193,15 @@ class GradAllReducer:
     """pmean(grads) over all learner processes (ppo:628) = one flat all-reduce on the library's grad
     buffer.  RCCL via torch.distributed when the engine exposes a device buffer, gloo on CPU in tests."""
 
-    def __init__(self, engine, world_size):
-        self.engine, self.world = engine, world_size
+    def __init__(self, engine, world_size, group=None):
+        self.engine, self.world, self.group = engine, world_size, group
         self.tensor = engine.grads_tensor() if world_size > 1 else None
 
     def __call__(self):
         if self.world > 1:
             import torch.distributed as dist
             with self.engine.stream_context():
-                dist.all_reduce(self.tensor, op=dist.ReduceOp.SUM)
+                dist.all_reduce(self.tensor, op=dist.ReduceOp.SUM, group=self.group)
         return float(self.world)  # grad_div: the mean is taken inside the optimizer kernel
 
 
@@ -219,7 +221,17 @@ def schedules(args, algo, opt_count, n_steps):
 def train(args, algo="ppo", engine_factory=None, on_update=None):
     """The `__main__` block of cleanba_ppo.py / cleanba_impala.py (ppo:409-771)."""
     world_size, rank, local_rank, master_addr, master_port = distributed_env() if args.distributed else (1, 0, 0, None, None)
-    finalize(args, world_size, rank)
+    from . import topology
+    lay = None
+    if topology.is_split(args):  # actor GPU(s) and learner GPUs are different processes (README.md:62, benchmark.sh:80)
+        if not args.distributed or world_size < 2:
+            raise SystemExit("split topologies (--actor-device-ids != --learner-device-ids) run one process per GPU: launch with "
+                             "torchrun / the SLURM variables and pass --distributed")
+        lay = topology.Layout(args, world_size, rank)
+        n_proc, proc_index = lay.groups, lay.group   # the reference's world_size counts actor+learner groups (ppo:425-430)
+    else:
+        n_proc, proc_index = world_size, rank
+    finalize(args, n_proc, proc_index)
     if args.gradient_accumulation_steps != 1:
         raise NotImplementedError("MultiSteps(k>1) is not wired yet (reference default k=1, ppo:79)")
     if args.distributed and world_size > 1:
@@ -240,9 +252,13 @@ def train(args, algo="ppo", engine_factory=None, on_update=None):
     learner_key = key.copy()
 
     cfg = make_config(args, algo)
+    if lay is not None and not lay.is_actor:   # learner-only context: its slots are ingest ports for E/L env columns each
+        cfg.local_num_envs = args.local_num_envs // lay.nl
     engine = engine_factory(cfg) if engine_factory else HipEngine(cfg)
     params = M.init_params(args.network, args.num_actions, network_key, actor_key, critic_key)
     engine.set_params(params)
+    if lay is not None:
+        return _train_split(args, algo, engine, lay, writer, key, rank, run_name)
     allreduce = GradAllReducer(engine, world_size)
 
     dummy_writer = SimpleNamespace(add_scalar=lambda x, y, z: None)
@@ -326,8 +342,74 @@ def train(args, algo="ppo", engine_factory=None, on_update=None):
     return result
 
 
+def _train_split(args, algo, engine, lay, writer, key, rank, run_name):
+    """One process of an actor/learner-split run (cleanba_amd.topology).  Actor ranks run the rollout threads and ship shards;
+    learner ranks ingest shards, all-reduce gradients over every learner rank of every group, and learner 0 returns params."""
+    import torch.distributed as dist
+    from . import topology
+    groups = topology.Groups(dist, lay)
+    n_opt = args.num_minibatches * (args.update_epochs if algo == "ppo" else 1)
+    epochs = args.update_epochs if algo == "ppo" else 1
+    start = time.time()
+    if lay.is_actor:
+        shipper = topology.ActorShipper(engine, lay, groups, args, algo, dist, args.num_updates)
+        receiver = topology.ParamReceiver(engine, lay, groups, dist, args.num_updates)
+        stop_event, errors, threads = threading.Event(), [], []
+        dummy_writer = SimpleNamespace(add_scalar=lambda x, y, z: None)
+        for slot in range(args.num_actor_threads * len(args.actor_device_ids)):
+            th = threading.Thread(target=rollout, args=(key.copy(), args, algo, engine, writer if slot == 0 else dummy_writer, slot, lay.groups,
+                                                        lay.group, stop_event, errors, shipper.on_commit), daemon=True)
+            th.start()
+            threads.append(th)
+        shipper.thread.start()
+        receiver.thread.start()
+        shipper.thread.join()
+        receiver.thread.join()
+        stop_event.set()
+        if errors or shipper.error or receiver.error:
+            raise (errors + [shipper.error, receiver.error])[0] or RuntimeError("actor failed")
+        engine.sync()
+        result = {"updates": args.num_updates, "elapsed_s": time.time() - start, "stats": None, "params": engine.get_actor_params(),
+                  "run_name": run_name, "role": "actor"}
+        writer.close()
+        return result
+    allreduce = GradAllReducer(engine, len(lay.all_learner_ranks), groups.learners)
+    ingest = topology.LearnerReceiver(engine, lay, groups, args, algo, dist, args.num_updates)
+    ingest.thread.start()
+    learner_key = key.copy()
+    opt_count, stats = 0, None
+    for version in range(1, args.num_updates + 1):
+        engine.learner_wait()
+        lrs, bc1, bc2 = schedules(args, algo, opt_count, n_opt)
+        learner_key = engine.learner_prepare(learner_key)
+        i = 0
+        for e in range(epochs):
+            learner_key = engine.learner_epoch_begin(learner_key)
+            for mb in range(args.num_minibatches):
+                engine.learner_minibatch_grad(e, mb)
+                grad_div = allreduce()
+                engine.learner_optimizer_step(float(lrs[i]), float(bc1[i]), float(bc2[i]), grad_div)
+                i += 1
+        stats = engine.learner_finish(n_opt, True)
+        opt_count += n_opt
+        if lay.learner_index == 0:
+            with engine.stream_context():
+                dist.send(engine.params_tensor(), dst=lay.actor_rank, group=groups.params[lay.group])
+        if version % args.log_frequency == 0 and lay.learner_index == 0:
+            print(version * args.local_batch_size * lay.groups, f"learner_policy_version={version}")
+    engine.sync()
+    result = {"updates": args.num_updates, "elapsed_s": time.time() - start, "stats": stats, "params": engine.get_params(), "run_name": run_name,
+              "role": f"learner{lay.learner_index}"}
+    writer.close()
+    return result
+
+
 class HipEngine(L.Context):
     """The product engine: cleanba_amd.lib.Context + the torch.distributed plumbing for the grad all-reduce."""
+
+    def __init__(self, cfg):
+        super().__init__(cfg)
+        self._tls = threading.local()
 
     def grads_tensor(self):
         import torch
@@ -340,3 +422,55 @@ class HipEngine(L.Context):
     def stream_context(self):
         import torch
         return torch.cuda.stream(torch.cuda.ExternalStream(self.learner_stream(), device=f"cuda:{self.cfg.device}"))
+
+    # ---- split topologies (cleanba_amd.topology): zero-copy torch views of the library-owned ring / parameter buffers
+    def _view(self, name, ring, dtype, shape):
+        import torch
+        ptr, _ = self.buffer(name, ring)
+        typestr = {"u8": "|u1", "i32": "<i4", "f32": "<f4"}[dtype]
+
+        class _CAI:
+            __cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (ptr, False), "version": 2, "strides": None}
+        return torch.as_tensor(_CAI(), device=f"cuda:{self.cfg.device}")
+
+    def ring_tensors(self, ring):
+        c = self.cfg
+        T1, B, A = c.num_steps + 1, c.local_num_envs * c.num_actor_slots, c.num_actions
+        return {"obs": self._view("obs", ring, "u8", (T1, B, L.FRAME)), "actions": self._view("actions", ring, "i32", (T1, B)),
+                "logprobs": self._view("logprobs", ring, "f32", (T1, B)), "values": self._view("values", ring, "f32", (T1, B)),
+                "rewards": self._view("rewards", ring, "f32", (T1, B)), "dones": self._view("dones", ring, "u8", (T1, B)),
+                "firststeps": self._view("firststeps", ring, "u8", (T1, B)), "logits": self._view("logits", ring, "f32", (T1, B, A))}
+
+    def actor_fence(self, slot):
+        import torch
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.ExternalStream(self.actor_stream(slot), device=f"cuda:{self.cfg.device}"))
+        return ev
+
+    def io_context(self):
+        """A per-thread side stream for shard / parameter transfers (never the actor or learner compute streams)."""
+        import torch
+        if not hasattr(self._tls, "stream"):
+            self._tls.stream = torch.cuda.Stream(device=f"cuda:{self.cfg.device}")
+        return torch.cuda.stream(self._tls.stream)
+
+    def io_wait(self, fence):
+        self._tls.stream.wait_event(fence)
+
+    def io_sync(self):
+        self._tls.stream.synchronize()
+
+    def params_tensor(self):
+        return self._view("params", 0, "f32", (self.P,))
+
+    def params_staging_tensor(self):
+        import torch
+        return torch.empty(self.P, dtype=torch.float32, device=f"cuda:{self.cfg.device}")
+
+    def params_publish_external_tensor(self, t):
+        self.params_publish_external(t.data_ptr())
+
+    def get_actor_params(self):
+        out = np.empty(self.P, np.float32)
+        L._chk(self.lib.cbm_actor_params_get(self.h, L._p(out), L.C.c_int64(out.size)))
+        return out

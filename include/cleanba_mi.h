@@ -107,6 +107,15 @@ int cbm_actor_commit(cbm_ctx* ctx, int32_t slot, const uint8_t* next_obs, const 
 /* Episode statistics kept on the device env (ppo:343-352): mean returned episodic return/length. */
 int cbm_actor_episode_stats(cbm_ctx* ctx, int32_t slot, float* avg_return, float* avg_length);
 
+/* ---- split topologies (actor GPU != learner GPUs, ppo:97-100 / README.md:62 `--actor-device-ids 0 --learner-device-ids 1 2 3`):
+ * replaces jax.device_put_sharded of the rollout shards (ppo:358-363) and the cross-device params put (ppo:721-725)
+ * when actor and learners live in different processes.  Learner side: slots act as ingest ports. */
+int cbm_ingest_begin(cbm_ctx* ctx, int32_t slot, int32_t* ring_index);   /* blocks until a ring entry is free; caller then fills cbm_buffer(name, ring_index) */
+int cbm_ingest_commit(cbm_ctx* ctx, int32_t slot);                        /* publishes the entry to cbm_learner_wait; the caller's copies into it must have completed */
+int cbm_params_publish_external(cbm_ctx* ctx, const float* dev_params, int64_t n);  /* actor side: a new parameter version arrived */
+void* cbm_actor_stream(cbm_ctx* ctx, int32_t slot);                       /* hipStream_t of an actor slot (ordering of shard sends) */
+int cbm_actor_ring_index(cbm_ctx* ctx, int32_t slot);                     /* ring entry of the slot's current / last rollout */
+
 /* ---- learner side: replaces multi_device_update (ppo:579-660 / impala:599-645).
  * cbm_learner_wait blocks until every slot has committed rollout #update (ppo:697-711). */
 int cbm_learner_wait(cbm_ctx* ctx);

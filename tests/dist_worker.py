@@ -18,7 +18,7 @@ from cleanba_amd.trainer import train  # noqa: E402
 from oracle_engine import OracleEngine  # noqa: E402
 
 argv = ["--local-num-envs", "4", "--num-actor-threads", "1", "--num-steps", "4", "--env-backend", "host", "--total-timesteps",
-        str(2 * 4 * 4 * world), "--log-frequency", "1", "--update-epochs", "1", "--network", "nature"]
+        str(int(os.environ.get("CBM_TEST_UPDATES", "2")) * 4 * 4 * world), "--log-frequency", "1", "--update-epochs", "1", "--network", "nature"]
 if world > 1:
     argv.append("--distributed")
 if same:

@@ -127,6 +127,62 @@ class OracleEngine:
     def actor_episode_stats(self, s):
         return 0.0, 0.0
 
+    # ---- split topologies (same surface as HipEngine)
+    def actor_ring_index(self, s):
+        return self.slot[s]["ring"]
+
+    def ring_tensors(self, ring):
+        import torch
+        R = self.ring[ring]
+        out = {k: torch.from_numpy(v) for k, v in R.items() if k != "obs"}
+        out["obs"] = torch.from_numpy(R["obs"].reshape(self.T1, self.B, FRAME))
+        return out
+
+    def actor_fence(self, slot):
+        return None
+
+    def io_context(self):
+        return contextlib.nullcontext()
+
+    def io_wait(self, fence):
+        pass
+
+    def io_sync(self):
+        pass
+
+    def ingest_begin(self, s):
+        sl = self.slot[s]
+        sl["rollout"] += 1
+        u = sl["rollout"]
+        with self.cv:
+            self.cv.wait_for(lambda: self.updates_done >= u - self.depth)
+        sl["ring"] = (u - 1) % self.depth
+        return sl["ring"]
+
+    def ingest_commit(self, s):
+        with self.cv:
+            self.committed[s] = self.slot[s]["rollout"]
+            self.cv.notify_all()
+
+    def params_tensor(self):
+        import torch
+        return torch.from_numpy(self.params)
+
+    def params_staging_tensor(self):
+        import torch
+        return torch.empty(self.P, dtype=torch.float32)
+
+    def params_publish_external_tensor(self, t):
+        v = self.updates_done + 1
+        with self.cv:
+            self.actor_params[v] = t.numpy().copy()
+            self.actor_params.pop(v - 3, None)
+            self.updates_done = v
+            self.cv.notify_all()
+
+    def get_actor_params(self):
+        return self.actor_params[max(self.actor_params)].copy()
+
     # ---- learner
     def _cur(self):
         return self.ring[self.updates_done % self.depth]

@@ -12,6 +12,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def _run(world, same, tmp, tag, algo="ppo"):
     port = 29600 + (os.getpid() + hash(tag)) % 300
     outs, procs = [], []
@@ -104,3 +111,53 @@ def test_cleanrl_model_roundtrip(tmp_path):
     shape, dtype, buf = msgpack.unpackb(k.data, raw=False)
     assert shape == [8, 8, 4, 32] and dtype == "float32" and len(buf) == 8 * 8 * 4 * 32 * 4
     assert set(raw["1"]["0"]["params"]) == {"Conv_0", "Conv_1", "Conv_2", "Dense_0"} and list(raw["1"]["1"]["params"]) == ["Dense_0"]
+
+
+def _run_split(world, nl, tmp, tag, algo="ppo"):
+    port = _free_port()
+    env = dict(os.environ, CBM_TEST_TMP=str(tmp), OMP_NUM_THREADS="2")
+    outs, procs = [], []
+    for r in range(world):
+        out = os.path.join(tmp, f"{tag}_{r}.npz")
+        outs.append(out)
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "split_worker.py"), str(r), str(world), str(port), out, algo, str(nl)],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    for p in procs:
+        o, _ = p.communicate(timeout=600)
+        assert p.returncode == 0, o.decode()[-3000:]
+    return [np.load(o) for o in outs]
+
+
+def test_split_topology_one_learner_equals_single_process(tmp_path):
+    # a0-l1 (README.md:62 family): the actor process ships whole rollouts to one learner process and gets params back.  With one
+    # learner nothing is re-sharded, so the run must reproduce the single-process a0-l0 run bit for bit (3 updates).
+    port = _free_port()
+    out = os.path.join(str(tmp_path), "single3.npy")
+    env = dict(os.environ, CBM_TEST_TMP=str(tmp_path), OMP_NUM_THREADS="2", CBM_TEST_UPDATES="3")
+    p = subprocess.run([sys.executable, os.path.join(HERE, "dist_worker.py"), "0", "1", str(port), out, "0", "ppo"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert p.returncode == 0, p.stdout.decode()[-3000:]
+    ref = np.load(out)
+    a, l0 = _run_split(2, 1, str(tmp_path), "a0l1")
+    assert str(a["role"]) == "actor" and str(l0["role"]) == "learner0"
+    assert np.array_equal(l0["params"], ref)
+    assert np.array_equal(a["params"], l0["params"])   # the actor holds the version learner 0 sent last
+
+
+@pytest.mark.parametrize("algo", ["ppo", "impala"])
+def test_split_topology_two_learners(tmp_path, algo):
+    # a0-l1,2: env columns split in two shards; both learners all-reduce every minibatch -> identical params, returned to the actor
+    a, l0, l1 = _run_split(3, 2, str(tmp_path), "a0l12" + algo, algo)
+    assert np.isfinite(l0["params"]).all()
+    assert np.array_equal(l0["params"], l1["params"])
+    assert np.array_equal(a["params"], l0["params"])
+    assert int(l0["updates"]) == 3
+
+
+def test_split_topology_two_groups(tmp_path):
+    # benchmark.sh:80 family (`--distributed` with a split layout): two (actor, learner) groups; gradients are averaged over the
+    # learners of BOTH groups, each actor gets its own group's learner-0 params (identical everywhere)
+    a0, l0, a1, l1 = _run_split(4, 1, str(tmp_path), "2xa0l1")
+    assert str(a1["role"]) == "actor" and str(l1["role"]) == "learner0"
+    assert np.array_equal(l0["params"], l1["params"])
+    assert np.array_equal(a0["params"], l0["params"]) and np.array_equal(a1["params"], l1["params"])
