@@ -234,6 +234,7 @@ extern "C" int cbm_buffer(cbm_ctx* c, const char* name, int32_t ri, void** p, in
   struct { const char* k; void* ptr; size_t sz; } tab[] = {
       {"params", c->params, (size_t)c->P * 4}, {"grads", c->grads, (size_t)c->P * 4}, {"opt_m", c->opt_m, (size_t)c->P * 4},
       {"opt_v", c->opt_v, (size_t)c->P * 4}, {"actor_params", c->actor_params[c->slots[0].pver % NPV], (size_t)c->P * 4},
+      {"actor_params_latest", c->actor_params[c->updates_done % NPV], (size_t)c->P * 4},
       {"adv", c->adv, TB * 4}, {"target", c->target, TB * 4}, {"perm", c->perm, TB * 4}, {"next_value", c->next_value, (size_t)c->Bdev * 4},
       {"stats", c->stats_dev, (size_t)c->stat_rows * 8 * 4}, {"obs", R.obs, TB * CBM_FRAME}, {"actions", R.actions, TB * 4},
       {"logprobs", R.logprobs, TB * 4}, {"values", R.values, TB * 4}, {"rewards", R.rewards, TB * 4}, {"logits", R.logits, TB * c->A * 4},

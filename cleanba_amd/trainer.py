@@ -218,9 +218,10 @@ def schedules(args, algo, opt_count, n_steps):
     return np.array(lrs, np.float32), np.array(b1s, np.float32), np.array(b2s, np.float32)
 
 
-def train(args, algo="ppo", engine_factory=None, on_update=None):
-    """The `__main__` block of cleanba_ppo.py / cleanba_impala.py (ppo:409-771)."""
-    world_size, rank, local_rank, master_addr, master_port = distributed_env() if args.distributed else (1, 0, 0, None, None)
+def train(args, algo="ppo", engine_factory=None, on_update=None, rendezvous=None, dist_module=None):
+    """The `__main__` block of cleanba_ppo.py / cleanba_impala.py (ppo:409-771).  `rendezvous` = (world, rank, local_rank, addr, port)
+    and `dist_module` override the process environment / torch.distributed (used by the single-GPU loopback test of the split path)."""
+    world_size, rank, local_rank, master_addr, master_port = rendezvous or (distributed_env() if args.distributed else (1, 0, 0, None, None))
     from . import topology
     lay = None
     if topology.is_split(args):  # actor GPU(s) and learner GPUs are different processes (README.md:62, benchmark.sh:80)
@@ -234,7 +235,7 @@ def train(args, algo="ppo", engine_factory=None, on_update=None):
     finalize(args, n_proc, proc_index)
     if args.gradient_accumulation_steps != 1:
         raise NotImplementedError("MultiSteps(k>1) is not wired yet (reference default k=1, ppo:79)")
-    if args.distributed and world_size > 1:
+    if args.distributed and world_size > 1 and dist_module is None:
         import torch.distributed as dist
         if not dist.is_initialized():
             import torch
@@ -258,7 +259,7 @@ def train(args, algo="ppo", engine_factory=None, on_update=None):
     params = M.init_params(args.network, args.num_actions, network_key, actor_key, critic_key)
     engine.set_params(params)
     if lay is not None:
-        return _train_split(args, algo, engine, lay, writer, key, rank, run_name)
+        return _train_split(args, algo, engine, lay, writer, key, rank, run_name, dist_module)
     allreduce = GradAllReducer(engine, world_size)
 
     dummy_writer = SimpleNamespace(add_scalar=lambda x, y, z: None)
@@ -342,10 +343,13 @@ def train(args, algo="ppo", engine_factory=None, on_update=None):
     return result
 
 
-def _train_split(args, algo, engine, lay, writer, key, rank, run_name):
+def _train_split(args, algo, engine, lay, writer, key, rank, run_name, dist_module=None):
     """One process of an actor/learner-split run (cleanba_amd.topology).  Actor ranks run the rollout threads and ship shards;
     learner ranks ingest shards, all-reduce gradients over every learner rank of every group, and learner 0 returns params."""
-    import torch.distributed as dist
+    if dist_module is None:
+        import torch.distributed as dist
+    else:
+        dist = dist_module
     from . import topology
     groups = topology.Groups(dist, lay)
     n_opt = args.num_minibatches * (args.update_epochs if algo == "ppo" else 1)
@@ -471,6 +475,4 @@ class HipEngine(L.Context):
         self.params_publish_external(t.data_ptr())
 
     def get_actor_params(self):
-        out = np.empty(self.P, np.float32)
-        L._chk(self.lib.cbm_actor_params_get(self.h, L._p(out), L.C.c_int64(out.size)))
-        return out
+        return self.read("actor_params_latest", np.float32)

@@ -73,7 +73,7 @@ int cbm_params_get(cbm_ctx* ctx, float* host_params, int64_t n);            /* l
 int cbm_actor_params_get(cbm_ctx* ctx, float* host_params, int64_t n);      /* actor copy (policy version behind) */
 
 /* ---- named device buffers (for tests, all-reduce plumbing, checkpointing).
- * names: "params", "actor_params", "grads", "opt_m", "opt_v", "adv", "target", "perm",
+ * names: "params", "actor_params", "actor_params_latest", "grads", "opt_m", "opt_v", "adv", "target", "perm",
  *        "obs", "actions", "logprobs", "values", "rewards", "dones", "logits", "stats" ...   */
 int cbm_buffer(cbm_ctx* ctx, const char* name, int32_t ring_index, void** dev_ptr, int64_t* nbytes);
 int cbm_copy_to_host(cbm_ctx* ctx, void* host_dst, const void* dev_src, int64_t nbytes);
