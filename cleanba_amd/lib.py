@@ -62,10 +62,27 @@ def build(force=False):
     return SO_PATH
 
 
+def _share_hip_runtime_with_torch():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so / libhsa-runtime64.so (torch/lib, DT_NEEDED without the .7 suffix), which the
+    loader does not unify with /opt/rocm's copy when OUR library is loaded first: the process then holds two HIP runtimes and torch finds
+    "No HIP GPUs".  The distributed paths share streams and buffers with torch (RCCL all-reduce, shard sends), so bind to torch's runtime
+    up front — by path, without importing torch.  CBM_SYSTEM_HIP=1 keeps /opt/rocm's runtime (torch-free deployments)."""
+    if os.environ.get("CBM_SYSTEM_HIP") == "1":
+        return
+    import importlib.util
+    spec = importlib.util.find_spec("torch")
+    for loc in (spec.submodule_search_locations or []) if spec else []:
+        p = os.path.join(loc, "lib", "libamdhip64.so")
+        if os.path.exists(p):
+            C.CDLL(p, mode=C.RTLD_GLOBAL)
+            return
+
+
 def load():
     global _lib
     if _lib is not None:
         return _lib
+    _share_hip_runtime_with_torch()
     if not os.path.exists(SO_PATH):
         raise CbmError(f"{SO_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                        "(there is no CPU fallback for the hot path)")

@@ -372,10 +372,14 @@ def _train_split(args, algo, engine, lay, writer, key, rank, run_name, dist_modu
         stop_event.set()
         if errors or shipper.error or receiver.error:
             raise (errors + [shipper.error, receiver.error])[0] or RuntimeError("actor failed")
+        elapsed = time.time() - start
+        for th in threads:   # like the reference's actors, each slot runs one rollout past the last update before it sees the stop
+            th.join(timeout=60)
         engine.sync()
-        result = {"updates": args.num_updates, "elapsed_s": time.time() - start, "stats": None, "params": engine.get_actor_params(),
+        result = {"updates": args.num_updates, "elapsed_s": elapsed, "stats": None, "params": engine.get_actor_params(),
                   "run_name": run_name, "role": "actor"}
         writer.close()
+        engine.close()
         return result
     allreduce = GradAllReducer(engine, len(lay.all_learner_ranks), groups.learners)
     ingest = topology.LearnerReceiver(engine, lay, groups, args, algo, dist, args.num_updates)
@@ -402,9 +406,13 @@ def _train_split(args, algo, engine, lay, writer, key, rank, run_name, dist_modu
         if version % args.log_frequency == 0 and lay.learner_index == 0:
             print(version * args.local_batch_size * lay.groups, f"learner_policy_version={version}")
     engine.sync()
+    ingest.thread.join(timeout=60)
+    if ingest.error:
+        raise ingest.error
     result = {"updates": args.num_updates, "elapsed_s": time.time() - start, "stats": stats, "params": engine.get_params(), "run_name": run_name,
               "role": f"learner{lay.learner_index}"}
     writer.close()
+    engine.close()
     return result
 
 

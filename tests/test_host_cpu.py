@@ -128,17 +128,18 @@ def _run_split(world, nl, tmp, tag, algo="ppo"):
     return [np.load(o) for o in outs]
 
 
-def test_split_topology_one_learner_equals_single_process(tmp_path):
+@pytest.mark.parametrize("algo", ["ppo", "impala"])
+def test_split_topology_one_learner_equals_single_process(tmp_path, algo):
     # a0-l1 (README.md:62 family): the actor process ships whole rollouts to one learner process and gets params back.  With one
     # learner nothing is re-sharded, so the run must reproduce the single-process a0-l0 run bit for bit (3 updates).
     port = _free_port()
     out = os.path.join(str(tmp_path), "single3.npy")
     env = dict(os.environ, CBM_TEST_TMP=str(tmp_path), OMP_NUM_THREADS="2", CBM_TEST_UPDATES="3")
-    p = subprocess.run([sys.executable, os.path.join(HERE, "dist_worker.py"), "0", "1", str(port), out, "0", "ppo"], env=env,
+    p = subprocess.run([sys.executable, os.path.join(HERE, "dist_worker.py"), "0", "1", str(port), out, "0", algo], env=env,
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     assert p.returncode == 0, p.stdout.decode()[-3000:]
     ref = np.load(out)
-    a, l0 = _run_split(2, 1, str(tmp_path), "a0l1")
+    a, l0 = _run_split(2, 1, str(tmp_path), "a0l1", algo)
     assert str(a["role"]) == "actor" and str(l0["role"]) == "learner0"
     assert np.array_equal(l0["params"], ref)
     assert np.array_equal(a["params"], l0["params"])   # the actor holds the version learner 0 sent last
