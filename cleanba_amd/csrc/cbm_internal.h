@@ -49,6 +49,7 @@ struct NatureWs {
   float* rn_t[3][6] = {};
   uint8_t* rn_pidx[3] = {};
   float* rn_g[2] = {};
+  float* rn_wT = nullptr;  // flipped/transposed conv weights for the dgrad convs (rebuilt per backward)
 };
 int nature_ws_alloc(NatureWs& ws, int maxB, bool with_grad, int dense_ksplit_small, int kind = 0);
 void nature_ws_free(NatureWs& ws);

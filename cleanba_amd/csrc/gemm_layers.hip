@@ -414,6 +414,7 @@ void nature_ws_free(NatureWs& ws) {
     ws.rn_pidx[s] = nullptr;
   }
   for (int j = 0; j < 2; ++j) { if (ws.rn_g[j]) hipFree(ws.rn_g[j]); ws.rn_g[j] = nullptr; }
+  if (ws.rn_wT) { hipFree(ws.rn_wT); ws.rn_wT = nullptr; }
 }
 
 // ------------------------------------------------------------------------------------------ drivers

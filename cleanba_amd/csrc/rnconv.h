@@ -1,0 +1,411 @@
+// rnconv.h — direct 3x3 SAME convolutions of the IMPALA-ResNet torso (ppo:149-189) for gfx950.
+//
+// Why not the implicit-GEMM template: these convs have tiny N (16/32 output channels) and K = 9*Cin, so the im2col
+// gather (9 scattered re-reads per input, per-chunk LDS stores and barriers) costs more than the math.  Here a block
+// owns a strip of R image rows (or NF whole small frames), copies the (R+2)-row input slab ONCE into LDS as channel
+// planes with a zero pad column per row, and then every tap of the 3x3 window is the SAME slab read at a constant
+// offset:  with row pitch WP = W+1 (the pad column of row r is also the left pad of row r+1) the input of flat
+// output position q for tap (kh,kw) sits at slab index q + kh*WP + kw.  The K loop is therefore barrier-free, all
+// LDS addresses are one base register + immediates, and the weights stay in LDS for the whole block.
+//
+// Numerics (forward): per output, k = (kh,kw,ci) ascending fp32 fmaf chain from 0, bias added afterwards — identical
+// to the oracle and to the implicit-GEMM kernels this replaces; pad taps contribute fma(0,w,acc).
+//   CO == 32: v_mfma_f32_32x32x2_f32  (A: lane -> position l%32, k = 2j + l/32)
+//   CO == 16: v_mfma_f32_16x16x4_f32  (A: lane -> position l%16, k = 4j + l/16)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <type_traits>
+
+typedef float rn_f32x4 __attribute__((ext_vector_type(4)));
+typedef float rn_f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int rn_round_up_mod(int v, int m, int r) {  // smallest x >= v with x % m == r
+  int x = v - (v % m) + r;
+  return x < v ? x + m : x;
+}
+
+template <int CI_, int CO_, int H_, int R_, int NF_>
+struct RnGeom {
+  static constexpr int CI = CI_, CO = CO_, H = H_, R = R_, NF = NF_;
+  static constexpr int WP = H + 1;
+  static constexpr bool M16 = CO == 16;
+  static constexpr int TP = M16 ? 16 : 32;                        // positions per MFMA tile
+  static constexpr int KK = M16 ? 4 : 2;                          // k per MFMA
+  static constexpr int OROWS = NF == 1 ? R : NF * (H + 1);        // output rows per block (incl. inter-frame gap rows)
+  static constexpr int SROWS = NF == 1 ? R + 2 : NF * (H + 1) + 1;  // slab rows
+  static constexpr int NQ = OROWS * WP;
+  static constexpr int NT = (NQ + TP - 1) / TP;
+  static constexpr int NTW = (NT + 3) / 4;                        // tiles per wave
+  static constexpr int S = NT * TP + 2 * WP + 3;                  // slab positions that may be read
+  // channel-plane placement: M16 reads planes (4j..4j+3) with 16 lanes each -> planes of a pair must sit 16 banks apart
+  static constexpr int PLH = M16 ? rn_round_up_mod(S, 32, 16) : 0;
+  static constexpr int PL = M16 ? rn_round_up_mod(PLH + S, 16, 4) : rn_round_up_mod(S, 8, 2);  // M16: pitch of a plane PAIR
+  static constexpr int NPL = CI < 4 ? 4 : CI;
+  static constexpr int SLAB = M16 ? (NPL / 2) * PL : NPL * PL;    // floats
+  static constexpr int WSZ = 9 * CI * CO;
+  static constexpr int STRIPS = NF == 1 ? (H + R - 1) / R : 1;    // strips per frame
+  __host__ __device__ static constexpr int poff(int p) { return M16 ? (p >> 1) * PL + (p & 1) * PLH : p * PL; }
+  static int blocks(int B) { return NF == 1 ? B * STRIPS : (B + NF - 1) / NF; }
+};
+
+// ---- slab staging: fp32 NHWC activations -> channel planes (optionally relu), zero rows/columns outside the image
+template <class G, bool PRE_RELU>
+__device__ __forceinline__ void rn_stage_f32(float* slab, const float* in, int b0, int y0, int B) {
+  constexpr int H = G::H, CI = G::CI, WP = G::WP, NV = G::SROWS * H * (CI / 4);
+  const int tid = threadIdx.x;
+  for (int v = tid; v < NV; v += 256) {
+    const int g = v % (CI / 4), pix = v / (CI / 4), c = pix % H, sr = pix / H;
+    int f, y;
+    if (G::NF == 1) { f = b0; y = y0 + sr - 1; }
+    else { f = b0 + sr / (H + 1); y = sr % (H + 1) - 1; }
+    const bool ok = y >= 0 && y < H && f < B;
+    const float4 x = *reinterpret_cast<const float4*>(in + ((size_t)(min(f, B - 1) * H + min(max(y, 0), H - 1)) * H + c) * CI + 4 * g);
+    const int s = 1 + sr * WP + c;
+    float e[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float val = ok ? e[q] : 0.0f;
+      if (PRE_RELU) val = fmaxf(val, 0.0f);
+      const int p = 4 * g + q;
+      slab[(G::M16 ? (p >> 1) * G::PL + (p & 1) * G::PLH : p * G::PL) + s] = val;
+    }
+  }
+  // pad column of every slab row (index sr*WP + WP) and the leading pad (index 0)
+  for (int v = tid; v < (G::SROWS + 1) * G::NPL; v += 256) {
+    const int p = v % G::NPL, sr = v / G::NPL;
+    slab[G::poff(p) + sr * WP] = 0.0f;
+  }
+}
+
+// uint8 NCHW frames (4 planes of 84x84) / 255 -> 4 channel planes
+template <class G>
+__device__ __forceinline__ void rn_stage_u8(float* slab, const uint8_t* obs, const int32_t* idx, int b0, int y0) {
+  constexpr int H = G::H, WP = G::WP, NV = G::SROWS * (H / 4) * 4;
+  const int tid = threadIdx.x;
+  const int f = idx ? idx[b0] : b0;
+  const uint8_t* fr = obs + (size_t)f * CBM_FRAME;
+  for (int v = tid; v < NV; v += 256) {
+    const int cq = v % (H / 4), t = v / (H / 4), sr = t % G::SROWS, p = t / G::SROWS;
+    const int y = y0 + sr - 1;
+    const bool ok = y >= 0 && y < H;
+    const uint32_t w = *reinterpret_cast<const uint32_t*>(fr + (size_t)p * H * H + min(max(y, 0), H - 1) * H + 4 * cq);
+    float* d = slab + G::poff(p) + 1 + sr * WP + 4 * cq;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) d[q] = ok ? cbm_u8_unit((uint8_t)((w >> (8 * q)) & 0xffu)) : 0.0f;
+  }
+  for (int v = tid; v < (G::SROWS + 1) * 4; v += 256) {
+    const int p = v % 4, sr = v / 4;
+    slab[G::poff(p) + sr * WP] = 0.0f;
+  }
+}
+
+// EPI: 0 out = v + bias            (forward)
+//      1 out = v + bias + aux      (forward, residual add)
+//      2 out = v                   (dgrad)
+//      3 out = aux > 0 ? v : 0     (dgrad through the relu in front of the conv)
+//      4 out += aux > 0 ? v : 0    (dgrad joined with the residual path, in place)
+template <class G, bool U8, bool PRE_RELU, int EPI>
+__global__ __launch_bounds__(256, 2) void rn_conv_kernel(const void* in_, const int32_t* idx, const float* W, const float* bias, const float* aux,
+                                                      float* out, int B) {
+  constexpr int H = G::H, CI = G::CI, CO = G::CO, WP = G::WP, TP = G::TP, NTW = G::NTW, NT = G::NT;
+  extern __shared__ __attribute__((aligned(16))) float rn_smem[];
+  float* slab = rn_smem;
+  float* Wl = rn_smem + G::SLAB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int b0, y0;
+  if (G::NF == 1) { b0 = blockIdx.x / G::STRIPS; y0 = (blockIdx.x % G::STRIPS) * G::R; }
+  else { b0 = blockIdx.x * G::NF; y0 = 0; }
+
+  for (int v = tid; v < G::WSZ / 4; v += 256) reinterpret_cast<float4*>(Wl)[v] = reinterpret_cast<const float4*>(W)[v];
+  if constexpr (U8) rn_stage_u8<G>(slab, (const uint8_t*)in_, idx, b0, y0);
+  else rn_stage_f32<G, PRE_RELU>(slab, (const float*)in_, b0, y0, B);
+  __syncthreads();
+
+  if constexpr (G::M16) {
+    const int li = lane & 15, kq = lane >> 4;
+    rn_f32x4 acc[NTW];
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) acc[i] = rn_f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* abase = slab + (kq >> 1) * G::PL + (kq & 1) * G::PLH + wave * TP + li;   // plane of k = 4j + kq
+    const float* bbase = Wl + kq * CO + li;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int off = (t / 3) * WP + (t % 3);
+#pragma unroll
+      for (int j = 0; j < (CI < 4 ? 1 : CI / 4); ++j) {
+        const float bv = bbase[(t * CI + 4 * j) * CO];
+        const float* ap = abase + 2 * j * G::PL + off;
+#pragma unroll
+        for (int i = 0; i < NTW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[i * 4 * TP], bv, acc[i], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
+      const int tile = wave + 4 * i;
+      if (tile >= NT) continue;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int q = tile * TP + 4 * kq + e;
+        const int orow = q / WP, c = q - orow * WP;
+        int f, y;
+        if (G::NF == 1) { f = b0; y = y0 + orow; }
+        else { f = b0 + orow / (H + 1); y = orow % (H + 1); }
+        if (c >= H || y >= H || f >= B || (G::NF == 1 && orow >= G::R)) continue;
+        const size_t o = ((size_t)(f * H + y) * H + c) * CO + li;
+        float v = acc[i][e];
+        if (EPI == 0) v = v + bias[li];
+        else if (EPI == 1) v = (v + bias[li]) + aux[o];
+        else if (EPI == 3) v = aux[o] > 0.0f ? v : 0.0f;
+        else if (EPI == 4) v = out[o] + (aux[o] > 0.0f ? v : 0.0f);
+        out[o] = v;
+      }
+    }
+  } else {
+    const int li = lane & 31, h = lane >> 5;
+    rn_f32x16 acc[NTW];
+#pragma unroll
+    for (int i = 0; i < NTW; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][e] = 0.0f;
+    const float* abase = slab + h * G::PL + wave * TP + li;
+    const float* bbase = Wl + h * CO + li;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int off = (t / 3) * WP + (t % 3);
+#pragma unroll
+      for (int j = 0; j < CI / 2; ++j) {
+        const float bv = bbase[(t * CI + 2 * j) * CO];
+        const float* ap = abase + 2 * j * G::PL + off;
+#pragma unroll
+        for (int i = 0; i < NTW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[i * 4 * TP], bv, acc[i], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
+      const int tile = wave + 4 * i;
+      if (tile >= NT) continue;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int q = tile * TP + (e & 3) + 8 * (e >> 2) + 4 * h;
+        const int orow = q / WP, c = q - orow * WP;
+        int f, y;
+        if (G::NF == 1) { f = b0; y = y0 + orow; }
+        else { f = b0 + orow / (H + 1); y = orow % (H + 1); }
+        if (c >= H || y >= H || f >= B || (G::NF == 1 && orow >= G::R)) continue;
+        const size_t o = ((size_t)(f * H + y) * H + c) * CO + li;
+        float v = acc[i][e];
+        if (EPI == 0) v = v + bias[li];
+        else if (EPI == 1) v = (v + bias[li]) + aux[o];
+        else if (EPI == 3) v = aux[o] > 0.0f ? v : 0.0f;
+        else if (EPI == 4) v = out[o] + (aux[o] > 0.0f ? v : 0.0f);
+        out[o] = v;
+      }
+    }
+  }
+}
+
+template <class G, bool U8, bool PRE_RELU, int EPI>
+static void rn_conv_launch(const void* in, const int32_t* idx, const float* W, const float* bias, const float* aux, float* out, int B, hipStream_t st) {
+  constexpr size_t lds = (size_t)(G::SLAB + G::WSZ) * sizeof(float);
+  static_assert(lds <= 160 * 1024, "slab + weights exceed the 160 KB LDS of a gfx950 CU");
+  static bool attr = false;
+  if (!attr) {
+    hipFuncSetAttribute((const void*)rn_conv_kernel<G, U8, PRE_RELU, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr = true;
+  }
+  hipLaunchKernelGGL((rn_conv_kernel<G, U8, PRE_RELU, EPI>), dim3(G::blocks(B)), dim3(256), lds, st, in, idx, W, bias, aux, out, B);
+}
+
+// dgrad as a forward conv: Wt[(jh,jw)][co][ci] = W[(2-jh,2-jw)][ci][co]   (all 14 convs that need a dgrad, one launch)
+struct RnFlipJob { int src, dst, ci, co; };
+struct RnFlipJobs { RnFlipJob j[14]; int n; };
+__global__ void rn_wflip_kernel(const float* P, float* Wt, RnFlipJobs jobs) {
+  const RnFlipJob jb = jobs.j[blockIdx.y];
+  const int n = 9 * jb.ci * jb.co;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int co = i % jb.co, t = i / jb.co, ci = t % jb.ci, tap = t / jb.ci;
+    Wt[jb.dst + ((8 - tap) * jb.co + co) * jb.ci + ci] = P[jb.src + i];
+  }
+}
+
+// ================================================================================================ weight gradient
+// dW[(kh,kw,ci)][co] = sum over positions q of X[ci][q + kh*WP + kw] * dY[q][co]  — the same slab trick with the
+// roles swapped: D rows = (tap, ci), D cols = co, MFMA reduction = positions.  Every wave keeps ALL tap tiles in
+// registers and the 4 waves take interleaved position steps, so one dY fragment feeds 9 (5, 3) MFMAs.  Blocks are
+// persistent over strips and emit one partial per block (fixed-order cross-wave sum), reduced by wgrad_reduce_kernel.
+template <int CI_, int CO_, int H_, int R_, int NF_>
+struct RnWGeom {
+  using G = RnGeom<CI_, CO_, H_, R_, NF_>;
+  static constexpr int CI = CI_, CO = CO_, H = H_, WP = G::WP, KK = G::KK;
+  static constexpr bool M16 = G::M16;
+  static constexpr int TPI = M16 ? 16 : 32;                       // D rows per tile
+  static constexpr int NTI = (9 * CI + TPI - 1) / TPI;            // tap tiles per wave
+  static constexpr int NKS = (G::NQ + KK - 1) / KK, KSW = (NKS + 3) / 4;  // position steps per strip / per wave
+  static constexpr int NQP = KSW * 4 * KK;                        // padded positions
+  static constexpr int S = NQP + 2 * WP + 3;
+  static constexpr int PL = M16 ? rn_round_up_mod(S, 32, 2) : rn_round_up_mod(S, 32, 1);
+  static constexpr int NPL = CI < 4 ? 4 : CI;
+  static constexpr int SLAB = NPL * PL;
+  static constexpr int DYS = NQP * CO;
+  static constexpr int RED = 4 * TPI * CO;                        // cross-wave reduction scratch (one tile)
+  static constexpr int LDS_FLOATS = SLAB + (DYS > RED ? DYS : RED);
+  static constexpr int KX = 9 * CI;
+  static int strips(int B) { return G::blocks(B); }
+};
+
+template <class WG, bool U8, bool PRE_RELU>
+__global__ __launch_bounds__(256, 2) void rn_wgrad_kernel(const void* in_, const int32_t* idx, const float* dy, float* part, float* bpart, int B,
+                                                       int nstrips) {
+  using G = typename WG::G;
+  constexpr int H = WG::H, CI = WG::CI, CO = WG::CO, WP = WG::WP, KK = WG::KK, NTI = WG::NTI, TPI = WG::TPI, PL = WG::PL;
+  extern __shared__ __attribute__((aligned(16))) float rn_smem[];
+  float* slab = rn_smem;
+  float* dys = rn_smem + WG::SLAB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int v = tid; v < WG::LDS_FLOATS; v += 256) rn_smem[v] = 0.0f;   // pads / slack must be finite zeros for the whole kernel
+  __syncthreads();
+
+  // per-lane A bases: row i of tile T -> (tap, ci); invalid taps (k >= 9*CI) read tap 0 and are dropped at the end
+  int abase[NTI];
+  const int irow = WG::M16 ? (lane & 15) : (lane & 31), kpos = WG::M16 ? (lane >> 4) : (lane >> 5);
+#pragma unroll
+  for (int T = 0; T < NTI; ++T) {
+    const int k = T * TPI + irow;
+    int tap = k / (CI < 4 ? 4 : CI);
+    const int ci = k - tap * (CI < 4 ? 4 : CI);
+    if (tap > 8) tap = 0;
+    abase[T] = ci * PL + (tap / 3) * WP + (tap % 3) + kpos;
+  }
+  const int ncol = WG::M16 ? (lane & 15) : (lane & 31);
+
+  using AccT = typename std::conditional<WG::M16, rn_f32x4, rn_f32x16>::type;
+  AccT acc[NTI];
+#pragma unroll
+  for (int T = 0; T < NTI; ++T)
+#pragma unroll
+    for (int e = 0; e < (WG::M16 ? 4 : 16); ++e) acc[T][e] = 0.0f;
+  float bsum = 0.0f;
+
+  for (int s = blockIdx.x; s < nstrips; s += gridDim.x) {
+    int b0, y0;
+    if (G::NF == 1) { b0 = s / G::STRIPS; y0 = (s % G::STRIPS) * G::R; }
+    else { b0 = s * G::NF; y0 = 0; }
+    __syncthreads();  // previous strip fully consumed
+    // ---- X slab (planes at pitch PL)
+    if constexpr (U8) {
+      constexpr int NV = G::SROWS * (H / 4) * 4;
+      const int f = idx ? idx[b0] : b0;
+      const uint8_t* fr = (const uint8_t*)in_ + (size_t)f * CBM_FRAME;
+      for (int v = tid; v < NV; v += 256) {
+        const int cq = v % (H / 4), t = v / (H / 4), sr = t % G::SROWS, p = t / G::SROWS;
+        const int y = y0 + sr - 1;
+        const bool ok = y >= 0 && y < H;
+        const uint32_t w = *reinterpret_cast<const uint32_t*>(fr + (size_t)p * H * H + min(max(y, 0), H - 1) * H + 4 * cq);
+        float* d = slab + p * PL + 1 + sr * WP + 4 * cq;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) d[q] = ok ? cbm_u8_unit((uint8_t)((w >> (8 * q)) & 0xffu)) : 0.0f;
+      }
+    } else {
+      constexpr int NV = G::SROWS * H * (CI / 4);
+      const float* in = (const float*)in_;
+      for (int v = tid; v < NV; v += 256) {
+        const int g = v % (CI / 4), pix = v / (CI / 4), c = pix % H, sr = pix / H;
+        int f, y;
+        if (G::NF == 1) { f = b0; y = y0 + sr - 1; }
+        else { f = b0 + sr / (H + 1); y = sr % (H + 1) - 1; }
+        const bool ok = y >= 0 && y < H && f < B;
+        const float4 x = *reinterpret_cast<const float4*>(in + ((size_t)(min(f, B - 1) * H + min(max(y, 0), H - 1)) * H + c) * CI + 4 * g);
+        float* d = slab + (4 * g) * PL + 1 + sr * WP + c;
+        float e[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float val = ok ? e[q] : 0.0f;
+          if (PRE_RELU) val = fmaxf(val, 0.0f);
+          d[q * PL] = val;
+        }
+      }
+    }
+    // ---- dY strip [position][co], zero at pad columns / rows outside the image
+    {
+      constexpr int NV = G::OROWS * WP * (CO / 4);
+      for (int v = tid; v < NV; v += 256) {
+        const int g = v % (CO / 4), q = v / (CO / 4), orow = q / WP, c = q - orow * WP;
+        int f, y;
+        if (G::NF == 1) { f = b0; y = y0 + orow; }
+        else { f = b0 + orow / (H + 1); y = orow % (H + 1); }
+        const bool ok = c < H && y < H && f < B && (G::NF != 1 || orow < G::R);
+        float4 x = *reinterpret_cast<const float4*>(dy + ((size_t)(min(f, B - 1) * H + min(y, H - 1)) * H + min(c, H - 1)) * CO + 4 * g);
+        if (!ok) x = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(dys + q * CO + 4 * g) = x;
+      }
+    }
+    __syncthreads();
+    // ---- bias partial: column sums of the strip (fixed order per thread)
+    {
+      constexpr int PARTS = 256 / CO;
+      const int n = tid % CO, part_ = tid / CO;
+      for (int q = part_; q < G::NQ; q += PARTS) bsum += dys[q * CO + n];
+    }
+    // ---- MFMA sweep: wave w takes position steps w, w+4, ...
+    const float* bptr = dys + (wave * KK + kpos) * CO + ncol;
+    const float* aptr = slab + wave * KK;
+#pragma unroll 2
+    for (int it = 0; it < WG::KSW; ++it) {
+      const float bv = bptr[it * 4 * KK * CO];
+      const float* ap = aptr + it * 4 * KK;
+#pragma unroll
+      for (int T = 0; T < NTI; ++T) {
+        if constexpr (WG::M16) acc[T] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[abase[T]], bv, acc[T], 0, 0, 0);
+        else acc[T] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[abase[T]], bv, acc[T], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- one partial per block: sum the 4 waves' tiles in wave order through LDS
+  float* red = dys;
+  const int z = blockIdx.x;
+#pragma unroll
+  for (int T = 0; T < NTI; ++T) {
+    __syncthreads();
+    if constexpr (WG::M16) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) red[(wave * TPI + 4 * kpos + e) * CO + ncol] = acc[T][e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) red[(wave * TPI + (e & 3) + 8 * (e >> 2) + 4 * kpos) * CO + ncol] = acc[T][e];
+    }
+    __syncthreads();
+    for (int v = tid; v < TPI * CO; v += 256) {
+      const int i = v / CO, n = v - i * CO, k = T * TPI + i;
+      if (k < WG::KX) {
+        float sum = red[v];
+        for (int w = 1; w < 4; ++w) sum += red[w * TPI * CO + v];
+        part[((size_t)z * WG::KX + k) * CO + n] = sum;
+      }
+    }
+  }
+  __syncthreads();
+  red[tid] = bsum;
+  __syncthreads();
+  if (tid < CO) {
+    float sum = red[tid];
+    for (int q = 1; q < 256 / CO; ++q) sum += red[q * CO + tid];
+    bpart[z * CO + tid] = sum;
+  }
+}
+
+template <class WG, bool U8, bool PRE_RELU>
+static int rn_wgrad_launch(const void* in, const int32_t* idx, const float* dy, float* part, float* bpart, int B, int max_blocks, hipStream_t st) {
+  constexpr size_t lds = (size_t)WG::LDS_FLOATS * sizeof(float);
+  static_assert(lds <= 160 * 1024, "wgrad slab exceeds LDS");
+  static bool attr = false;
+  if (!attr) {
+    hipFuncSetAttribute((const void*)rn_wgrad_kernel<WG, U8, PRE_RELU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr = true;
+  }
+  const int nstrips = WG::strips(B);
+  const int nb = nstrips < max_blocks ? nstrips : max_blocks;
+  hipLaunchKernelGGL((rn_wgrad_kernel<WG, U8, PRE_RELU>), dim3(nb), dim3(256), lds, st, in, idx, dy, part, bpart, B, nstrips);
+  return nb;
+}
