@@ -15,6 +15,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <type_traits>
 
 typedef float rn_f32x4 __attribute__((ext_vector_type(4)));
@@ -25,9 +26,9 @@ constexpr int rn_round_up_mod(int v, int m, int r) {  // smallest x >= v with x 
   return x < v ? x + m : x;
 }
 
-template <int CI_, int CO_, int H_, int R_, int NF_>
+template <int CI_, int CO_, int H_, int R_, int NF_, int NW_ = 4>
 struct RnGeom {
-  static constexpr int CI = CI_, CO = CO_, H = H_, R = R_, NF = NF_;
+  static constexpr int CI = CI_, CO = CO_, H = H_, R = R_, NF = NF_, NW = NW_, NTHR = 64 * NW_;   // NW waves share one slab + weight copy
   static constexpr int WP = H + 1;
   static constexpr bool M16 = CO == 16;
   static constexpr int TP = M16 ? 16 : 32;                        // positions per MFMA tile
@@ -36,7 +37,7 @@ struct RnGeom {
   static constexpr int SROWS = NF == 1 ? R + 2 : NF * (H + 1) + 1;  // slab rows
   static constexpr int NQ = OROWS * WP;
   static constexpr int NT = (NQ + TP - 1) / TP;
-  static constexpr int NTW = (NT + 3) / 4;                        // tiles per wave
+  static constexpr int NTW = (NT + NW - 1) / NW;                  // tiles per wave
   static constexpr int S = NT * TP + 2 * WP + 3;                  // slab positions that may be read
   // channel-plane placement: M16 reads planes (4j..4j+3) with 16 lanes each -> planes of a pair must sit 16 banks apart
   static constexpr int PLH = M16 ? rn_round_up_mod(S, 32, 16) : 0;
@@ -45,6 +46,9 @@ struct RnGeom {
   static constexpr int SLAB = M16 ? (NPL / 2) * PL : NPL * PL;    // floats
   static constexpr int WSZ = 9 * CI * CO;
   static constexpr int STRIPS = NF == 1 ? (H + R - 1) / R : 1;    // strips per frame
+  static constexpr int LDS_BYTES = (SLAB + WSZ) * 4;
+  static constexpr int OCC = 160 * 1024 / LDS_BYTES >= 4 ? 4 : (160 * 1024 / LDS_BYTES < 1 ? 1 : 160 * 1024 / LDS_BYTES);  // blocks per CU by LDS
+  static constexpr int MINW = OCC * NW / 4 >= 4 ? 4 : (OCC * NW / 4 >= 2 ? 2 : 1);   // waves per SIMD the LDS footprint allows -> VGPR budget
   __host__ __device__ static constexpr int poff(int p) { return M16 ? (p >> 1) * PL + (p & 1) * PLH : p * PL; }
   static int blocks(int B) { return NF == 1 ? B * STRIPS : (B + NF - 1) / NF; }
 };
@@ -54,7 +58,7 @@ template <class G, bool PRE_RELU>
 __device__ __forceinline__ void rn_stage_f32(float* slab, const float* in, int b0, int y0, int B) {
   constexpr int H = G::H, CI = G::CI, WP = G::WP, NV = G::SROWS * H * (CI / 4);
   const int tid = threadIdx.x;
-  for (int v = tid; v < NV; v += 256) {
+  for (int v = tid; v < NV; v += G::NTHR) {
     const int g = v % (CI / 4), pix = v / (CI / 4), c = pix % H, sr = pix / H;
     int f, y;
     if (G::NF == 1) { f = b0; y = y0 + sr - 1; }
@@ -72,7 +76,7 @@ __device__ __forceinline__ void rn_stage_f32(float* slab, const float* in, int b
     }
   }
   // pad column of every slab row (index sr*WP + WP) and the leading pad (index 0)
-  for (int v = tid; v < (G::SROWS + 1) * G::NPL; v += 256) {
+  for (int v = tid; v < (G::SROWS + 1) * G::NPL; v += G::NTHR) {
     const int p = v % G::NPL, sr = v / G::NPL;
     slab[G::poff(p) + sr * WP] = 0.0f;
   }
@@ -85,7 +89,7 @@ __device__ __forceinline__ void rn_stage_u8(float* slab, const uint8_t* obs, con
   const int tid = threadIdx.x;
   const int f = idx ? idx[b0] : b0;
   const uint8_t* fr = obs + (size_t)f * CBM_FRAME;
-  for (int v = tid; v < NV; v += 256) {
+  for (int v = tid; v < NV; v += G::NTHR) {
     const int cq = v % (H / 4), t = v / (H / 4), sr = t % G::SROWS, p = t / G::SROWS;
     const int y = y0 + sr - 1;
     const bool ok = y >= 0 && y < H;
@@ -94,7 +98,7 @@ __device__ __forceinline__ void rn_stage_u8(float* slab, const uint8_t* obs, con
 #pragma unroll
     for (int q = 0; q < 4; ++q) d[q] = ok ? cbm_u8_unit((uint8_t)((w >> (8 * q)) & 0xffu)) : 0.0f;
   }
-  for (int v = tid; v < (G::SROWS + 1) * 4; v += 256) {
+  for (int v = tid; v < (G::SROWS + 1) * 4; v += G::NTHR) {
     const int p = v % 4, sr = v / 4;
     slab[G::poff(p) + sr * WP] = 0.0f;
   }
@@ -106,7 +110,7 @@ __device__ __forceinline__ void rn_stage_u8(float* slab, const uint8_t* obs, con
 //      3 out = aux > 0 ? v : 0     (dgrad through the relu in front of the conv)
 //      4 out += aux > 0 ? v : 0    (dgrad joined with the residual path, in place)
 template <class G, bool U8, bool PRE_RELU, int EPI>
-__global__ __launch_bounds__(256, 2) void rn_conv_kernel(const void* in_, const int32_t* idx, const float* W, const float* bias, const float* aux,
+__global__ __launch_bounds__(G::NTHR, G::MINW) void rn_conv_kernel(const void* in_, const int32_t* idx, const float* W, const float* bias, const float* aux,
                                                       float* out, int B) {
   constexpr int H = G::H, CI = G::CI, CO = G::CO, WP = G::WP, TP = G::TP, NTW = G::NTW, NT = G::NT;
   extern __shared__ __attribute__((aligned(16))) float rn_smem[];
@@ -117,7 +121,7 @@ __global__ __launch_bounds__(256, 2) void rn_conv_kernel(const void* in_, const 
   if (G::NF == 1) { b0 = blockIdx.x / G::STRIPS; y0 = (blockIdx.x % G::STRIPS) * G::R; }
   else { b0 = blockIdx.x * G::NF; y0 = 0; }
 
-  for (int v = tid; v < G::WSZ / 4; v += 256) reinterpret_cast<float4*>(Wl)[v] = reinterpret_cast<const float4*>(W)[v];
+  for (int v = tid; v < G::WSZ / 4; v += G::NTHR) reinterpret_cast<float4*>(Wl)[v] = reinterpret_cast<const float4*>(W)[v];
   if constexpr (U8) rn_stage_u8<G>(slab, (const uint8_t*)in_, idx, b0, y0);
   else rn_stage_f32<G, PRE_RELU>(slab, (const float*)in_, b0, y0, B);
   __syncthreads();
@@ -129,20 +133,22 @@ __global__ __launch_bounds__(256, 2) void rn_conv_kernel(const void* in_, const 
     for (int i = 0; i < NTW; ++i) acc[i] = rn_f32x4{0.f, 0.f, 0.f, 0.f};
     const float* abase = slab + (kq >> 1) * G::PL + (kq & 1) * G::PLH + wave * TP + li;   // plane of k = 4j + kq
     const float* bbase = Wl + kq * CO + li;
-#pragma unroll
+    // one tap per (rolled) iteration: bounds the scheduling region and with it the number of hoisted LDS reads (VGPRs)
+#pragma unroll 1
     for (int t = 0; t < 9; ++t) {
-      const int off = (t / 3) * WP + (t % 3);
+      const int kh = (t * 11) >> 5, off = kh * WP + (t - 3 * kh);
+      const float* bt = bbase + t * CI * CO;
 #pragma unroll
       for (int j = 0; j < (CI < 4 ? 1 : CI / 4); ++j) {
-        const float bv = bbase[(t * CI + 4 * j) * CO];
+        const float bv = bt[4 * j * CO];
         const float* ap = abase + 2 * j * G::PL + off;
 #pragma unroll
-        for (int i = 0; i < NTW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[i * 4 * TP], bv, acc[i], 0, 0, 0);
+        for (int i = 0; i < NTW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[i * G::NW * TP], bv, acc[i], 0, 0, 0);
       }
     }
 #pragma unroll
     for (int i = 0; i < NTW; ++i) {
-      const int tile = wave + 4 * i;
+      const int tile = wave + G::NW * i;
       if (tile >= NT) continue;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -170,20 +176,21 @@ __global__ __launch_bounds__(256, 2) void rn_conv_kernel(const void* in_, const 
       for (int e = 0; e < 16; ++e) acc[i][e] = 0.0f;
     const float* abase = slab + h * G::PL + wave * TP + li;
     const float* bbase = Wl + h * CO + li;
-#pragma unroll
+#pragma unroll 1
     for (int t = 0; t < 9; ++t) {
-      const int off = (t / 3) * WP + (t % 3);
+      const int kh = (t * 11) >> 5, off = kh * WP + (t - 3 * kh);
+      const float* bt = bbase + t * CI * CO;
 #pragma unroll
       for (int j = 0; j < CI / 2; ++j) {
-        const float bv = bbase[(t * CI + 2 * j) * CO];
+        const float bv = bt[2 * j * CO];
         const float* ap = abase + 2 * j * G::PL + off;
 #pragma unroll
-        for (int i = 0; i < NTW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[i * 4 * TP], bv, acc[i], 0, 0, 0);
+        for (int i = 0; i < NTW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[i * G::NW * TP], bv, acc[i], 0, 0, 0);
       }
     }
 #pragma unroll
     for (int i = 0; i < NTW; ++i) {
-      const int tile = wave + 4 * i;
+      const int tile = wave + G::NW * i;
       if (tile >= NT) continue;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
@@ -214,7 +221,8 @@ static void rn_conv_launch(const void* in, const int32_t* idx, const float* W, c
     hipFuncSetAttribute((const void*)rn_conv_kernel<G, U8, PRE_RELU, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr = true;
   }
-  hipLaunchKernelGGL((rn_conv_kernel<G, U8, PRE_RELU, EPI>), dim3(G::blocks(B)), dim3(256), lds, st, in, idx, W, bias, aux, out, B);
+  hipLaunchKernelGGL((rn_conv_kernel<G, U8, PRE_RELU, EPI>), dim3(G::blocks(B)), dim3(G::NTHR), lds, st, in, idx, W, bias, aux, out, B);
+  if (hipError_t e = hipGetLastError(); e != hipSuccess) fprintf(stderr, "rn_conv launch failed: %s (threads %d, lds %zu)\n", hipGetErrorString(e), G::NTHR, lds);
 }
 
 // dgrad as a forward conv: Wt[(jh,jw)][co][ci] = W[(2-jh,2-jw)][ci][co]   (all 14 convs that need a dgrad, one launch)
