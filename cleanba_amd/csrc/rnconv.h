@@ -259,6 +259,7 @@ struct RnWGeom {
   static constexpr int RED = 4 * TPI * CO;                        // cross-wave reduction scratch (one tile)
   static constexpr int LDS_FLOATS = SLAB + (DYS > RED ? DYS : RED);
   static constexpr int KX = 9 * CI;
+  static constexpr bool PREFETCH = NF_ == 1 && NTI * (M16 ? 4 : 16) <= 96;   // next strip's loads in flight during the MFMA sweep (register budget)
   static int strips(int B) { return G::blocks(B); }
 };
 
@@ -267,6 +268,7 @@ __global__ __launch_bounds__(256, 2) void rn_wgrad_kernel(const void* in_, const
                                                        int nstrips) {
   using G = typename WG::G;
   constexpr int H = WG::H, CI = WG::CI, CO = WG::CO, WP = WG::WP, KK = WG::KK, NTI = WG::NTI, TPI = WG::TPI, PL = WG::PL;
+  constexpr bool PF = WG::PREFETCH;
   extern __shared__ __attribute__((aligned(16))) float rn_smem[];
   float* slab = rn_smem;
   float* dys = rn_smem + WG::SLAB;
@@ -295,11 +297,107 @@ __global__ __launch_bounds__(256, 2) void rn_wgrad_kernel(const void* in_, const
     for (int e = 0; e < (WG::M16 ? 4 : 16); ++e) acc[T][e] = 0.0f;
   float bsum = 0.0f;
 
-  for (int s = blockIdx.x; s < nstrips; s += gridDim.x) {
-    int b0, y0;
-    if (G::NF == 1) { b0 = s / G::STRIPS; y0 = (s % G::STRIPS) * G::R; }
-    else { b0 = s * G::NF; y0 = 0; }
+  // staged vectors per thread (strips of one frame are contiguous in memory: one base + per-item constant strides)
+  constexpr int NVX = U8 ? G::SROWS * (H / 4) * 4 : G::SROWS * H * (CI < 4 ? 1 : CI / 4);
+  constexpr int NVY = G::OROWS * H * (CO / 4);
+  constexpr int NIX = (NVX + 255) / 256, NIY = (NVY + 255) / 256;
+  float4 rx[PF && !U8 ? NIX : 1];
+  uint32_t ru[PF && U8 ? NIX : 1];
+  float4 ry[PF ? NIY : 1];
+
+  auto where = [&](int st, int& b0, int& y0) {
+    if (G::NF == 1) { b0 = st / G::STRIPS; y0 = (st - b0 * G::STRIPS) * G::R; }
+    else { b0 = st * G::NF; y0 = 0; }
+  };
+  auto fetch = [&](int b0, int y0) {
+    if constexpr (U8) {
+      const uint8_t* fr = (const uint8_t*)in_ + (size_t)(idx ? idx[b0] : b0) * CBM_FRAME;
+#pragma unroll
+      for (int it = 0; it < NIX; ++it) {
+        const int v = min(tid + 256 * it, NVX - 1);
+        const int cq = v % (H / 4), t = v / (H / 4), sr = t % G::SROWS, p = t / G::SROWS;
+        const int y = y0 + sr - 1;
+        ru[it] = *reinterpret_cast<const uint32_t*>(fr + (size_t)p * H * H + min(max(y, 0), H - 1) * H + 4 * cq);
+      }
+    } else {
+      const float* in = (const float*)in_;
+#pragma unroll
+      for (int it = 0; it < NIX; ++it) {
+        const int v = min(tid + 256 * it, NVX - 1);
+        const int g = v % (CI / 4), pix = v / (CI / 4), c = pix % H, sr = pix / H;
+        int f, y;
+        if (G::NF == 1) { f = b0; y = y0 + sr - 1; }
+        else { f = b0 + sr / (H + 1); y = sr % (H + 1) - 1; }
+        rx[it] = *reinterpret_cast<const float4*>(in + ((size_t)(min(f, B - 1) * H + min(max(y, 0), H - 1)) * H + c) * CI + 4 * g);
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < NIY; ++it) {
+      const int v = min(tid + 256 * it, NVY - 1);
+      const int g = v % (CO / 4), pix = v / (CO / 4), c = pix % H, orow = pix / H;
+      int f, y;
+      if (G::NF == 1) { f = b0; y = y0 + orow; }
+      else { f = b0 + orow / (H + 1); y = orow % (H + 1); }
+      ry[it] = *reinterpret_cast<const float4*>(dy + ((size_t)(min(f, B - 1) * H + min(y, H - 1)) * H + c) * CO + 4 * g);
+    }
+  };
+  auto commit = [&](int b0, int y0) {
+    if constexpr (U8) {
+#pragma unroll
+      for (int it = 0; it < NIX; ++it) {
+        const int v = tid + 256 * it;
+        if (NVX % 256 != 0 && v >= NVX) break;
+        const int cq = v % (H / 4), t = v / (H / 4), sr = t % G::SROWS, p = t / G::SROWS;
+        const int y = y0 + sr - 1;
+        const bool ok = y >= 0 && y < H;
+        float* d = slab + p * PL + 1 + sr * WP + 4 * cq;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) d[q] = ok ? cbm_u8_unit((uint8_t)((ru[it] >> (8 * q)) & 0xffu)) : 0.0f;
+      }
+    } else {
+#pragma unroll
+      for (int it = 0; it < NIX; ++it) {
+        const int v = tid + 256 * it;
+        if (NVX % 256 != 0 && v >= NVX) break;
+        const int g = v % (CI / 4), pix = v / (CI / 4), c = pix % H, sr = pix / H;
+        int f, y;
+        if (G::NF == 1) { f = b0; y = y0 + sr - 1; }
+        else { f = b0 + sr / (H + 1); y = sr % (H + 1) - 1; }
+        const bool ok = y >= 0 && y < H && f < B;
+        float* d = slab + (4 * g) * PL + 1 + sr * WP + c;
+        const float e[4] = {rx[it].x, rx[it].y, rx[it].z, rx[it].w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float val = ok ? e[q] : 0.0f;
+          if (PRE_RELU) val = fmaxf(val, 0.0f);
+          d[q * PL] = val;
+        }
+      }
+    }
+    // dY strip [position][co]; pad columns stay zero from the initial clear, rows outside the image are written as zeros
+#pragma unroll
+    for (int it = 0; it < NIY; ++it) {
+      const int v = tid + 256 * it;
+      if (NVY % 256 != 0 && v >= NVY) break;
+      const int g = v % (CO / 4), pix = v / (CO / 4), c = pix % H, orow = pix / H;
+      int f, y;
+      if (G::NF == 1) { f = b0; y = y0 + orow; }
+      else { f = b0 + orow / (H + 1); y = orow % (H + 1); }
+      const bool ok = y < H && f < B;
+      float4 x = ry[it];
+      if (!ok) x = make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4*>(dys + (orow * WP + c) * CO + 4 * g) = x;
+    }
+  };
+
+  int s = blockIdx.x, b0 = 0, y0 = 0;
+  if constexpr (PF) { if (s < nstrips) { where(s, b0, y0); fetch(b0, y0); } }
+  for (; s < nstrips; s += gridDim.x) {
     __syncthreads();  // previous strip fully consumed
+    if constexpr (PF) {
+      commit(b0, y0);
+    } else {   // streaming copy (no registers held across the MFMA sweep: these geometries need them for accumulators)
+      where(s, b0, y0);
     // ---- X slab (planes at pitch PL)
     if constexpr (U8) {
       constexpr int NV = G::SROWS * (H / 4) * 4;
@@ -348,7 +446,12 @@ __global__ __launch_bounds__(256, 2) void rn_wgrad_kernel(const void* in_, const
         *reinterpret_cast<float4*>(dys + q * CO + 4 * g) = x;
       }
     }
+    }
     __syncthreads();
+    if constexpr (PF) {
+      const int sn = s + gridDim.x;
+      if (sn < nstrips) { where(sn, b0, y0); fetch(b0, y0); }
+    }
     // ---- bias partial: column sums of the strip (fixed order per thread)
     {
       constexpr int PARTS = 256 / CO;
