@@ -41,8 +41,10 @@ class LoopbackDist:
         self.sh.q[(self.rank, dst, group)].put(t)
 
     def recv(self, tensor, src, group=None):
+        import torch
         t = self.sh.q[(src, self.rank, group)].get(timeout=300)
         tensor.copy_(t)
+        torch.cuda.current_stream().synchronize()   # `t` belongs to the sender's stream in torch's caching allocator: finish before dropping it
 
 
 @pytest.mark.parametrize("algo", ["ppo", "impala"])

@@ -6,7 +6,7 @@ from cleanba_amd.args import parse_args
 from cleanba_amd.trainer import train
 os.chdir("/tmp")
 algo = sys.argv[1]
-for updates in (1, 2, 3):
+for updates in (3,) * int(os.environ.get('REPS', '6')):
     E, T = 8, 8
     base = ["--local-num-envs", str(E), "--num-actor-threads", "2", "--num-steps", str(T), "--env-backend", "device", "--network", "nature",
             "--total-timesteps", str(updates * E * 2 * T), "--log-frequency", "1000", "--update-epochs", "1"]
