@@ -264,12 +264,13 @@ extern "C" int cbm_sync(cbm_ctx* c) { CBM_HIP(hipSetDevice(c->cfg.device)); CBM_
 extern "C" int cbm_actor_set_key(cbm_ctx* c, int32_t s, const uint32_t key[2]) { c->slots[s].key[0] = key[0]; c->slots[s].key[1] = key[1]; return 0; }
 extern "C" int cbm_actor_get_key(cbm_ctx* c, int32_t s, uint32_t key[2]) { key[0] = c->slots[s].key[0]; key[1] = c->slots[s].key[1]; return 0; }
 
-extern "C" int cbm_actor_env_reset_device(cbm_ctx* c, int32_t s, uint32_t seed) {
+extern "C" int cbm_actor_env_reset_device(cbm_ctx* c, int32_t s, uint32_t seed) { return cbm_actor_env_reset_device_games(c, s, seed, 0); }
+extern "C" int cbm_actor_env_reset_device_games(cbm_ctx* c, int32_t s, uint32_t seed, int32_t atari57_mix) {
   Slot& sl = c->slots[s];
   CBM_HIP(hipSetDevice(c->cfg.device));
   RingEntry& R = c->ring[0];
   sl.env_seed = seed;
-  launch_env_reset(seed, c->E, sl.env_state, R.obs + (size_t)s * c->E * CBM_FRAME, CBM_FRAME, R.dones + s * c->E, R.firststeps + s * c->E, sl.stream);
+  launch_env_reset(seed, c->E, atari57_mix, sl.env_state, R.obs + (size_t)s * c->E * CBM_FRAME, CBM_FRAME, R.dones + s * c->E, R.firststeps + s * c->E, sl.stream);
   sl.env_inited = true;
   return 0;
 }

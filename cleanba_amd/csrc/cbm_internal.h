@@ -89,7 +89,7 @@ void launch_rmsprop(float* p, const float* g, float* nu, int64_t n, float max_no
 #define CBM_NORM_PARTS 512
 
 // ---- synthetic env ------------------------------------------------------------------------
-void launch_env_reset(uint32_t seed, int E, cbm_env_state* st_dev, uint8_t* obs, int64_t obs_stride, uint8_t* done,
+void launch_env_reset(uint32_t seed, int E, int atari57_mix, cbm_env_state* st_dev, uint8_t* obs, int64_t obs_stride, uint8_t* done,
                       uint8_t* firststep, hipStream_t st);
 void launch_env_step(uint32_t seed, int E, int max_episode_steps, const int32_t* actions, cbm_env_state* st_dev,
                      const uint8_t* obs_prev, uint8_t* obs_next, float* reward, uint8_t* done_next,

@@ -20,7 +20,31 @@ CBM_HD uint32_t env_hash(uint32_t seed, uint32_t env_id, uint32_t a, uint32_t b)
   return o0 ^ (o1 >> 3);
 }
 
+// "Atari-57 synthetic frame mix" (BASELINE configs[4]): env e plays game e % 57.  A game is a preset of the same
+// pure-integer dynamics: action-set size (policy head stays 18 wide: action % n_actions, as envpool games with smaller action
+// sets would ignore the rest), paddle width, ball speed, which brick rows exist, reward / termination rates (episode length) and
+// a few static rectangles (frame sparsity).  Game 0 is the Breakout preset = the constants this env always had.
+struct EnvGame { int32_t n_actions, paddle_w, speed_x, speed_y, rows_mask, reward_thr, term_thr, n_rects; uint32_t rect_key; };
+CBM_HD EnvGame env_game(int32_t g) {
+  EnvGame m;
+  if (g == 0) { m.n_actions = 18; m.paddle_w = PADDLE_W; m.speed_x = 2; m.speed_y = 2; m.rows_mask = 0x3F; m.reward_thr = 1311; m.term_thr = 82;
+                m.n_rects = 0; m.rect_key = 0; return m; }
+  uint32_t a, b;
+  cbm_threefry2x32(0xA7A5157u, (uint32_t)g, 57u, 0x51ED270Bu, &a, &b);
+  m.n_actions = 4 + (int32_t)(a % 15u);                    // 4..18
+  m.paddle_w = 8 + 2 * (int32_t)((a >> 4) & 7u);           // 8..22
+  m.speed_x = 1 + (int32_t)((a >> 8) % 3u);
+  m.speed_y = 1 + (int32_t)((a >> 12) % 3u);
+  m.rows_mask = (int32_t)((a >> 16) & 0x3Fu);              // any subset of the six brick rows
+  m.reward_thr = 328 + (int32_t)((a >> 22) % 2949u);       // p(reward) in [0.005, 0.05)
+  m.term_thr = 22 + (int32_t)(b % 197u);                   // p(termination) in [1/3000, 1/300)
+  m.n_rects = (int32_t)((b >> 8) % 6u);
+  m.rect_key = b >> 11;
+  return m;
+}
+
 CBM_HD void env_new_episode(cbm_env_state* s, uint32_t seed, uint32_t env_id) {
+  const EnvGame gm = env_game(s->game);
   s->episode += 1u;
   const uint32_t h = env_hash(seed, env_id, s->episode, 0x9E3779B9u);
   s->elapsed = 0;
@@ -28,18 +52,19 @@ CBM_HD void env_new_episode(cbm_env_state* s, uint32_t seed, uint32_t env_id) {
   s->paddle_x = 36;
   s->ball_x = 4 + (int32_t)(h % 72u);
   s->ball_y = 40;
-  s->ball_dx = (h >> 8) & 1u ? 2 : -2;
-  s->ball_dy = 2;
+  s->ball_dx = (h >> 8) & 1u ? gm.speed_x : -gm.speed_x;
+  s->ball_dy = gm.speed_y;
   s->bricks[0] = s->bricks[1] = s->bricks[2] = 0x0FFFFFFFu;
 }
 
 // one env.step(action); returns clipped reward, sets *terminated / *truncated
 CBM_HD float env_advance(cbm_env_state* s, uint32_t seed, uint32_t env_id, int32_t action, int32_t max_steps, int* terminated,
                          int* truncated) {
+  const EnvGame gm = env_game(s->game);
   s->elapsed += 1;
-  const int dir = action % 3;
+  const int dir = (action % gm.n_actions) % 3;
   int px = s->paddle_x + (dir == 1 ? 4 : (dir == 2 ? -4 : 0));
-  s->paddle_x = px < 1 ? 1 : (px > 83 - PADDLE_W ? 83 - PADDLE_W : px);
+  s->paddle_x = px < 1 ? 1 : (px > 83 - gm.paddle_w ? 83 - gm.paddle_w : px);
   int bx = s->ball_x + s->ball_dx, by = s->ball_y + s->ball_dy;
   if (bx < 1) { bx = 1; s->ball_dx = -s->ball_dx; }
   if (bx > 81) { bx = 81; s->ball_dx = -s->ball_dx; }
@@ -49,7 +74,7 @@ CBM_HD float env_advance(cbm_env_state* s, uint32_t seed, uint32_t env_id, int32
   // events depend on the action through the paddle position: nothing can be precomputed
   const uint32_t h = env_hash(seed ^ (s->episode * 0x85EBCA6Bu), env_id, (uint32_t)s->elapsed, (uint32_t)s->paddle_x);
   float reward = 0.0f;
-  if ((h & 0xFFFFu) < 1311u) {  // ~0.02
+  if ((h & 0xFFFFu) < (uint32_t)gm.reward_thr) {  // Breakout preset: ~0.02
     reward = 1.0f;
     uint32_t k = (h >> 7) % NBRICK;
     for (int tries = 0; tries < NBRICK; ++tries) {  // clear the next standing brick
@@ -59,24 +84,29 @@ CBM_HD float env_advance(cbm_env_state* s, uint32_t seed, uint32_t env_id, int32
     }
     if ((s->bricks[0] | s->bricks[1] | s->bricks[2]) == 0u) s->bricks[0] = s->bricks[1] = s->bricks[2] = 0x0FFFFFFFu;
   }
-  *terminated = ((h >> 16) & 0xFFFFu) < 82u ? 1 : 0;  // ~1/800
+  *terminated = ((h >> 16) & 0xFFFFu) < (uint32_t)gm.term_thr ? 1 : 0;  // Breakout preset: ~1/800
   *truncated = s->elapsed >= max_steps ? 1 : 0;
   return reward;
 }
 
-CBM_HD uint8_t env_pixel(const cbm_env_state* s, int y, int x) {
+CBM_HD uint8_t env_pixel(const cbm_env_state* s, const EnvGame& gm, int y, int x) {
   if (y >= 17 && y < 35) {  // six brick rows, 2 px tall + 1 px gap; 14 bricks of 5 px + 1 px gap
     const int row = (y - 17) / 3, ry = (y - 17) % 3, col = x / 6, rx = x % 6;
-    if (ry < 2 && rx < 5) {
+    if (ry < 2 && rx < 5 && ((gm.rows_mask >> row) & 1)) {
       const int k = row * 14 + col;
       if (s->bricks[k / 28] & (1u << (k % 28))) return (uint8_t)(200 - 24 * row);
     }
     return 0;
   }
-  if (y >= 78 && y < 80 && x >= s->paddle_x && x < s->paddle_x + PADDLE_W) return 200;
+  if (y >= 78 && y < 80 && x >= s->paddle_x && x < s->paddle_x + gm.paddle_w) return 200;
   if (y >= s->ball_y && y < s->ball_y + 2 && x >= s->ball_x && x < s->ball_x + 2) return 255;
   if (y >= 10 && y < 12) return 142;
   if (y >= 12 && (x == 0 || x == 83)) return 142;
+  for (int r = 0; r < gm.n_rects; ++r) {   // static scenery of the game preset (rows 36..75: below the bricks, above the paddle)
+    const uint32_t k = gm.rect_key * 2654435761u + (uint32_t)r * 0x9E3779B9u;
+    const int ry0 = 36 + (int)(k % 32u), rx0 = 2 + (int)((k >> 5) % 64u), rh = 2 + (int)((k >> 11) % 6u), rw = 4 + (int)((k >> 14) % 14u);
+    if (y >= ry0 && y < ry0 + rh && x >= rx0 && x < rx0 + rw && x < 83) return (uint8_t)(90 + 20 * r);
+  }
   return 0;
 }
 
@@ -106,13 +136,16 @@ CBM_HD EnvOut env_transition(cbm_env_state* s, uint32_t seed, uint32_t env_id, i
 }
 
 // ------------------------------------------------------------------------------------------ device
-__global__ __launch_bounds__(256) void env_reset_kernel(uint32_t seed, int E, cbm_env_state* st, uint8_t* obs, int64_t stride,
+__global__ __launch_bounds__(256) void env_reset_kernel(uint32_t seed, int E, int mix, cbm_env_state* st, uint8_t* obs, int64_t stride,
                                                          uint8_t* done, uint8_t* firststep) {
   __shared__ cbm_env_state s;
+  __shared__ EnvGame gm;
   const int e = blockIdx.x;
   if (threadIdx.x == 0) {
     s = cbm_env_state();
     s.episode = 0;
+    s.game = mix ? e % 57 : 0;
+    gm = env_game(s.game);
     env_new_episode(&s, seed, (uint32_t)e);
     st[e] = s;
     if (done) done[e] = 0;
@@ -121,13 +154,13 @@ __global__ __launch_bounds__(256) void env_reset_kernel(uint32_t seed, int E, cb
   __syncthreads();
   uint8_t* o = obs + (size_t)e * stride;
   for (int i = threadIdx.x; i < 7056; i += 256) {
-    const uint8_t v = env_pixel(&s, i / 84, i % 84);
+    const uint8_t v = env_pixel(&s, gm, i / 84, i % 84);
     o[i] = v; o[7056 + i] = v; o[2 * 7056 + i] = v; o[3 * 7056 + i] = v;
   }
 }
-void launch_env_reset(uint32_t seed, int E, cbm_env_state* st_dev, uint8_t* obs, int64_t obs_stride, uint8_t* done, uint8_t* firststep,
+void launch_env_reset(uint32_t seed, int E, int mix, cbm_env_state* st_dev, uint8_t* obs, int64_t obs_stride, uint8_t* done, uint8_t* firststep,
                       hipStream_t st) {
-  hipLaunchKernelGGL(env_reset_kernel, dim3(E), dim3(256), 0, st, seed, E, st_dev, obs, obs_stride, done, firststep);
+  hipLaunchKernelGGL(env_reset_kernel, dim3(E), dim3(256), 0, st, seed, E, mix, st_dev, obs, obs_stride, done, firststep);
 }
 
 __global__ __launch_bounds__(256) void env_step_kernel(uint32_t seed, int E, int max_steps, const int32_t* actions, cbm_env_state* st,
@@ -135,9 +168,11 @@ __global__ __launch_bounds__(256) void env_step_kernel(uint32_t seed, int E, int
                                                         uint8_t* firststep_next) {
   __shared__ cbm_env_state s;
   __shared__ EnvOut out;
+  __shared__ EnvGame gm;
   const int e = blockIdx.x;
   if (threadIdx.x == 0) {
     s = st[e];
+    gm = env_game(s.game);
     out = env_transition(&s, seed, (uint32_t)e, actions[e], max_steps);
     st[e] = s;
     reward[e] = out.reward;
@@ -153,8 +188,8 @@ __global__ __launch_bounds__(256) void env_step_kernel(uint32_t seed, int E, int
   uint32_t* o32 = reinterpret_cast<uint32_t*>(o);
   for (int i = threadIdx.x; i < 1764; i += 256) {
     const int y = (4 * i) / 84, x = (4 * i) % 84;
-    const uint32_t nw = (uint32_t)env_pixel(&s, y, x) | ((uint32_t)env_pixel(&s, y, x + 1) << 8) | ((uint32_t)env_pixel(&s, y, x + 2) << 16) |
-                        ((uint32_t)env_pixel(&s, y, x + 3) << 24);
+    const uint32_t nw = (uint32_t)env_pixel(&s, gm, y, x) | ((uint32_t)env_pixel(&s, gm, y, x + 1) << 8) |
+                        ((uint32_t)env_pixel(&s, gm, y, x + 2) << 16) | ((uint32_t)env_pixel(&s, gm, y, x + 3) << 24);
     if (rs) { o32[i] = nw; o32[1764 + i] = nw; o32[2 * 1764 + i] = nw; }
     else { o32[i] = p32[1764 + i]; o32[1764 + i] = p32[2 * 1764 + i]; o32[2 * 1764 + i] = p32[3 * 1764 + i]; }
     o32[3 * 1764 + i] = nw;
@@ -178,13 +213,18 @@ void launch_env_stats(const cbm_env_state* st_dev, int E, float* out2, hipStream
 
 // ------------------------------------------------------------------------------------------ host twin
 extern "C" int cbm_synth_env_reset_host(uint32_t seed, int32_t n, cbm_env_state* st, uint8_t* obs) {
+  return cbm_synth_env_reset_host_games(seed, n, 0, st, obs);
+}
+extern "C" int cbm_synth_env_reset_host_games(uint32_t seed, int32_t n, int32_t atari57_mix, cbm_env_state* st, uint8_t* obs) {
   for (int e = 0; e < n; ++e) {
     cbm_env_state s = cbm_env_state();
+    s.game = atari57_mix ? e % 57 : 0;
+    const EnvGame gm = env_game(s.game);
     env_new_episode(&s, seed, (uint32_t)e);
     st[e] = s;
     uint8_t* o = obs + (size_t)e * CBM_FRAME;
     for (int i = 0; i < 7056; ++i) {
-      const uint8_t v = env_pixel(&s, i / 84, i % 84);
+      const uint8_t v = env_pixel(&s, gm, i / 84, i % 84);
       o[i] = v; o[7056 + i] = v; o[2 * 7056 + i] = v; o[3 * 7056 + i] = v;
     }
   }
@@ -194,13 +234,14 @@ extern "C" int cbm_synth_env_step_host(uint32_t seed, int32_t n, int32_t max_epi
                                        uint8_t* obs, float* reward, uint8_t* done, uint8_t* terminated, int32_t* elapsed_step) {
   for (int e = 0; e < n; ++e) {
     cbm_env_state s = st[e];
+    const EnvGame gm = env_game(s.game);
     const EnvOut out = env_transition(&s, seed, (uint32_t)e, actions[e], max_episode_steps);
     st[e] = s;
     reward[e] = out.reward; done[e] = out.done; terminated[e] = out.terminated; elapsed_step[e] = out.elapsed;
     uint8_t* o = obs + (size_t)e * CBM_FRAME;
     if (!out.was_reset) memmove(o, o + 7056, 3 * 7056);
     for (int i = 0; i < 7056; ++i) {
-      const uint8_t v = env_pixel(&s, i / 84, i % 84);
+      const uint8_t v = env_pixel(&s, gm, i / 84, i % 84);
       o[3 * 7056 + i] = v;
       if (out.was_reset) { o[i] = v; o[7056 + i] = v; o[2 * 7056 + i] = v; }
     }

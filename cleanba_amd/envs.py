@@ -26,6 +26,11 @@ class _Space:
         return np.random.randint(0, 256, size=self.shape, dtype=np.uint8)
 
 
+def is_atari57_mix(env_id):
+    """`--env-id Atari57Mix-v5`: env e plays preset e % 57 of the synthetic family (BASELINE configs[4]; benchmark.sh:5 lists the 57 games)."""
+    return str(env_id).lower().startswith("atari57")
+
+
 class SyntheticAtariEnv:
     def __init__(self, env_id="Breakout-v5", num_envs=8, seed=1, max_episode_steps=ATARI_MAX_FRAMES, num_actions=18, **_):
         self.env_id, self.num_envs, self.seed = env_id, int(num_envs), int(seed)
@@ -44,7 +49,7 @@ class SyntheticAtariEnv:
                 "elapsed_step": elapsed, "TimeLimit.truncated": elapsed >= self.spec.config.max_episode_steps}
 
     def reset(self):
-        self._st, self._obs = L.synth_env_reset_host(self.seed, self.num_envs)
+        self._st, self._obs = L.synth_env_reset_host(self.seed, self.num_envs, atari57_mix=is_atari57_mix(self.env_id))
         return self._obs.copy()
 
     def step(self, actions):

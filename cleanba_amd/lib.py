@@ -35,7 +35,7 @@ class EnvState(C.Structure):
     _fields_ = [("elapsed", C.c_int32), ("needs_reset", C.c_int32), ("paddle_x", C.c_int32), ("ball_x", C.c_int32),
                 ("ball_y", C.c_int32), ("ball_dx", C.c_int32), ("ball_dy", C.c_int32), ("bricks", C.c_uint32 * 3),
                 ("episode", C.c_uint32), ("ep_return", C.c_float), ("ep_length", C.c_float), ("ret_return", C.c_float),
-                ("ret_length", C.c_float)]
+                ("ret_length", C.c_float), ("game", C.c_int32)]
 
 
 # every symbol include/cleanba_mi.h declares (checked by tests/test_abi.py against the header text)
@@ -47,7 +47,7 @@ SYMBOLS = [
     "cbm_actor_commit", "cbm_actor_episode_stats", "cbm_learner_wait", "cbm_learner_update", "cbm_learner_prepare",
     "cbm_learner_epoch_begin", "cbm_learner_minibatch_grad", "cbm_learner_optimizer_step", "cbm_learner_finish",
     "cbm_forward", "cbm_sample", "cbm_gae", "cbm_advnorm", "cbm_permutation", "cbm_ppo_loss_grad",
-    "cbm_impala_loss_grad", "cbm_adam_step", "cbm_rmsprop_step", "cbm_synth_env_reset_host", "cbm_synth_env_step_host",
+    "cbm_impala_loss_grad", "cbm_adam_step", "cbm_rmsprop_step", "cbm_synth_env_reset_host", "cbm_synth_env_reset_host_games", "cbm_synth_env_step_host", "cbm_actor_env_reset_device_games",
     "cbm_actor_env_reset_device", "cbm_profile_select", "cbm_profile_read", "cbm_ingest_begin", "cbm_ingest_commit",
     "cbm_params_publish_external", "cbm_actor_stream", "cbm_actor_ring_index",
 ]
@@ -211,8 +211,8 @@ class Context:
         _chk(self.lib.cbm_actor_get_key(self.h, int(slot), _p(k)))
         return k
 
-    def actor_env_reset_device(self, slot, seed):
-        _chk(self.lib.cbm_actor_env_reset_device(self.h, int(slot), C.c_uint32(int(seed) & 0xFFFFFFFF)))
+    def actor_env_reset_device(self, slot, seed, atari57_mix=False):
+        _chk(self.lib.cbm_actor_env_reset_device_games(self.h, int(slot), C.c_uint32(int(seed) & 0xFFFFFFFF), int(bool(atari57_mix))))
 
     def actor_begin_rollout(self, slot, concurrency):
         v = C.c_int32()
@@ -311,10 +311,10 @@ class Context:
 
 
 # ---- host twin of the synthetic env (CPU code inside the same library; no GPU needed)
-def synth_env_reset_host(seed, n):
+def synth_env_reset_host(seed, n, atari57_mix=False):
     st = (EnvState * n)()
     obs = np.zeros((n, 4, 84, 84), np.uint8)
-    _chk(load().cbm_synth_env_reset_host(C.c_uint32(int(seed) & 0xFFFFFFFF), int(n), st, _p(obs)))
+    _chk(load().cbm_synth_env_reset_host_games(C.c_uint32(int(seed) & 0xFFFFFFFF), int(n), int(bool(atari57_mix)), st, _p(obs)))
     return st, obs
 
 

@@ -81,7 +81,8 @@ def _rollout(key, args, algo, engine, writer, slot, world_size, process_index, s
     device_env = args.env_backend == "device"
     engine.actor_set_key(slot, key)
     if device_env:
-        engine.actor_env_reset_device(slot, env_seed)
+        from .envs import is_atari57_mix
+        engine.actor_env_reset_device(slot, env_seed, is_atari57_mix(args.env_id))
     else:
         envs = make_env(args.env_id, env_seed, E, backend=args.env_backend, num_actions=args.num_actions)()
     global_step = 0

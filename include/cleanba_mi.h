@@ -166,14 +166,17 @@ typedef struct {
   uint32_t bricks[3];
   uint32_t episode;
   float ep_return, ep_length, ret_return, ret_length;
+  int32_t game;   /* 0 = Breakout preset; env e of an "Atari-57 mix" plays game e % 57 (BASELINE configs[4]) */
 } cbm_env_state;
 /* Host twin of the device env (same code path compiled for the CPU): steps n envs.
  * obs: [n,4,84,84] in/out frame stacks; outputs per env. */
 int cbm_synth_env_reset_host(uint32_t seed, int32_t n, cbm_env_state* st, uint8_t* obs);
+int cbm_synth_env_reset_host_games(uint32_t seed, int32_t n, int32_t atari57_mix, cbm_env_state* st, uint8_t* obs);
 int cbm_synth_env_step_host(uint32_t seed, int32_t n, int32_t max_episode_steps, const int32_t* actions,
                             cbm_env_state* st, uint8_t* obs, float* reward, uint8_t* done, uint8_t* terminated,
                             int32_t* elapsed_step);
 int cbm_actor_env_reset_device(cbm_ctx* ctx, int32_t slot, uint32_t seed);
+int cbm_actor_env_reset_device_games(cbm_ctx* ctx, int32_t slot, uint32_t seed, int32_t atari57_mix);
 
 #ifdef __cplusplus
 }

@@ -42,3 +42,28 @@ def test_env_is_deterministic_and_action_dependent():
     a = run(5, [1] * 20); b = run(5, [1] * 20); c = run(5, [2] * 20)
     assert all((x[0] == y[0]).all() for x, y in zip(a, b))
     assert any((x[0] != y[0]).any() for x, y in zip(a, c))
+
+
+def test_atari57_mix_presets():
+    # BASELINE configs[4] "synthetic Atari-57 frame mix": env e plays preset e % 57; preset 0 is Breakout (the plain env)
+    n = 114
+    st0, obs0 = L.synth_env_reset_host(5, n)
+    st, obs = L.synth_env_reset_host(5, n, atari57_mix=True)
+    assert [s.game for s in st] == [e % 57 for e in range(n)] and all(s.game == 0 for s in st0)
+    assert (obs[0] == obs0[0]).all() and (obs[57] == obs0[57]).all()          # game 0 == Breakout preset, bit for bit
+    first = obs[:57, 3].reshape(57, -1)
+    assert len({f.tobytes() for f in first}) > 50                             # the presets really look different
+    sparsity = (first == 0).mean(1)
+    assert sparsity.min() > 0.7 and sparsity.max() - sparsity.min() > 0.05
+    rng = np.random.default_rng(1)
+    steps, rew, done = 1500, np.zeros(n), np.zeros(n)
+    for t in range(steps):
+        a = rng.integers(0, 18, n).astype(np.int32)
+        r, d, _, _ = L.synth_env_step_host(5, st, obs, a)
+        r0, d0, _, _ = L.synth_env_step_host(5, st0, obs0, a)
+        rew += r; done += d
+        assert (obs[0] == obs0[0]).all() and r[0] == r0[0] and d[0] == d0[0]
+    # same game, different env id -> different event stream; reward / episode-length rates spread over the presets
+    rate = (rew[:57] + rew[57:]) / (2 * steps)
+    assert 0.002 < rate.min() and rate.max() < 0.07 and rate.max() > 2 * rate.min()
+    assert done.sum() > 0

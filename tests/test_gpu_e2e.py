@@ -159,3 +159,31 @@ def test_impala_rollouts_and_update_match_oracle(oracle):
         p_gpu = ctx.get_params()
         assert np.abs(p_gpu - p).max() <= 2e-5 * np.abs(p).max(), np.abs(p_gpu - p).max()
     ctx.close()
+
+
+def test_atari57_mix_device_env_matches_host_twin():
+    # configs[4]: the device env renders the 57-preset mix straight into the ring; the host twin must produce the same bytes
+    E, T = 64, 12
+    cfg = L.default_config(L.ALGO_PPO)
+    cfg.local_num_envs, cfg.num_actor_slots, cfg.num_steps = E, 1, T
+    ctx = L.Context(cfg)
+    key, params = _init(3)
+    ctx.set_params(params)
+    ctx.actor_set_key(0, key)
+    ctx.actor_env_reset_device(0, 11, atari57_mix=True)
+    ctx.actor_begin_rollout(0, False)
+    ctx.actor_rollout_device(0, T)
+    ctx.actor_commit(0)
+    ctx.learner_wait()
+    obs = ctx.read("obs", np.uint8).reshape(T + 1, E, 4, 84, 84)
+    actions = ctx.read("actions", np.int32).reshape(T + 1, E)[:T]
+    rewards = ctx.read("rewards", np.float32).reshape(T + 1, E)[:T]
+    dones = ctx.read("dones", np.uint8).reshape(T + 1, E)
+    st, o = L.synth_env_reset_host(11, E, atari57_mix=True)
+    for t in range(T):
+        assert (o == obs[t]).all(), f"frames differ at t={t}"
+        r, d, _, _ = L.synth_env_step_host(11, st, o, actions[t])
+        assert (r == rewards[t]).all() and (d == dones[t + 1]).all()
+    assert (o == obs[T]).all()
+    assert len({obs[0, e, 3].tobytes() for e in range(57)}) > 50
+    ctx.close()
