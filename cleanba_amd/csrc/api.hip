@@ -151,12 +151,14 @@ extern "C" int cbm_ctx_create(const cbm_config* cfg, cbm_ctx** out) {
     Slot& sl = c->slots[s];
     CBM_HIP(hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
     if (nature_ws_alloc(sl.ws, c->E, false, cfg->actor_dense_ksplit, cfg->network)) return -1;
+    sl.ws.bf16_fwd = cfg->forward_bf16 != 0 && cfg->network == CBM_NET_NATURE;
     if (dalloc(&sl.env_state, (size_t)c->E) || dalloc(&sl.stats_dev, 2)) return -1;
     c->committed[s] = 0;
   }
   CBM_HIP(hipStreamCreateWithFlags(&c->lstream, hipStreamNonBlocking));
   const int lmax = c->MB > c->Bdev ? c->MB : c->Bdev;
   if (nature_ws_alloc(c->lws, lmax, true, cfg->actor_dense_ksplit, cfg->network)) return -1;
+  c->lws.bf16_fwd = cfg->forward_bf16 != 0 && cfg->network == CBM_NET_NATURE;
   c->stat_rows = c->epochs * c->nmb;
   if (dalloc(&c->adv, T1 * B) || dalloc(&c->target, T1 * B) || dalloc(&c->next_value, B) || dalloc(&c->stats_dev, (size_t)c->stat_rows * 8) ||
       dalloc(&c->loss_partials, (size_t)4 * (lmax / 256 + 2) + 3 * B) || dalloc(&c->norm_partials, CBM_NORM_PARTS) ||

@@ -426,6 +426,16 @@ static inline void plaunch(NatureWs& ws, int kid, const P& p, int nz, hipStream_
   igemm_launch(p, nz, st);
   if (on) { hipEventRecord(pf->ev[2 * pf->n + 1], st); pf->n += 1; }
 }
+// forward GEMMs: fp32 chain (default) or the bf16-MFMA variant when the context was created with forward_bf16
+template <class P>
+static inline void plaunch_fwd(NatureWs& ws, int kid, const P& p, int nz, hipStream_t st) {
+  if (!ws.bf16_fwd) { plaunch(ws, kid, p, nz, st); return; }
+  CbmProf* pf = ws.prof;
+  const bool on = pf && pf->sel == kid && pf->n < CBM_PROF_MAX;
+  if (on) hipEventRecord(pf->ev[2 * pf->n], st);
+  igemm_bf16_launch(p, nz, st);
+  if (on) { hipEventRecord(pf->ev[2 * pf->n + 1], st); pf->n += 1; }
+}
 template <class F>
 static inline void plaunch_fn(NatureWs& ws, int kid, hipStream_t st, F&& launch) {
   CbmProf* pf = ws.prof;
@@ -454,23 +464,23 @@ void nature_forward(const NatureLayout& L, const float* P, const uint8_t* obs, c
   }
   if (small) {
     ConvFwd<T64x64, 4, 4, 2, 32, 64, 20, 20, 9, 9> p2{ws.act1, P + L.w[1], P + L.b[1], ws.act2, B * 81};
-    plaunch(ws, K_CONV2_FWD, p2, 1, st);
+    plaunch_fwd(ws, K_CONV2_FWD, p2, 1, st);
     ConvFwd<T64x64, 3, 3, 1, 64, 64, 9, 9, 7, 7> p3{ws.act2, P + L.w[2], P + L.b[2], ws.act3, B * 49};
-    plaunch(ws, K_CONV3_FWD, p3, 1, st);
+    plaunch_fwd(ws, K_CONV3_FWD, p3, 1, st);
   } else {
     ConvFwd<T64x64, 4, 4, 2, 32, 64, 20, 20, 9, 9> p2{ws.act1, P + L.w[1], P + L.b[1], ws.act2, B * 81};
-    plaunch(ws, K_CONV2_FWD, p2, 1, st);
+    plaunch_fwd(ws, K_CONV2_FWD, p2, 1, st);
     ConvFwd<T128x64, 3, 3, 1, 64, 64, 9, 9, 7, 7> p3{ws.act2, P + L.w[2], P + L.b[2], ws.act3, B * 49};
-    plaunch(ws, K_CONV3_FWD, p3, 1, st);
+    plaunch_fwd(ws, K_CONV3_FWD, p3, 1, st);
   }
   if (dense_ksplit > 1) {
     DenseFwd<T64x64, true> pd{ws.act3, P + L.w[3], P + L.b[3], ws.dense_part, B, 3136, 512, 3136 / dense_ksplit};
-    plaunch(ws, K_DENSE_FWD, pd, dense_ksplit, st);
+    plaunch_fwd(ws, K_DENSE_FWD, pd, dense_ksplit, st);
     hipLaunchKernelGGL(dense_reduce_kernel, dim3(ceil_div(B * 512, 256)), dim3(256), 0, st, ws.dense_part, P + L.b[3], ws.hid, B, 512,
                        dense_ksplit);
   } else {
     DenseFwd<T64x64, false> pd{ws.act3, P + L.w[3], P + L.b[3], ws.hid, B, 3136, 512, 3136};
-    plaunch(ws, K_DENSE_FWD, pd, 1, st);
+    plaunch_fwd(ws, K_DENSE_FWD, pd, 1, st);
   }
   launch_heads_fwd(ws.hid, P + L.w[4], P + L.b[4], P + L.w[5], P + L.b[5], B, L.A, 512, ws.logits, ws.value, st);
 }

@@ -241,3 +241,146 @@ static inline void igemm_launch(const P& p, int nsplit, hipStream_t stream) {
   dim3 grid((p.X() + T::BX - 1) / T::BX, ((p.Y() + T::BY - 1) / T::BY) * P::NCLS, nsplit);
   hipLaunchKernelGGL(igemm_kernel<P>, grid, dim3(256), 0, stream, p);
 }
+
+// ------------------------------------------------------------------------------------------------ bf16 forward variant
+// Build-only extension (the reference is fp32 everywhere): `cbm_config.forward_bf16` runs the forward GEMMs of conv2 /
+// conv3 / dense on v_mfma_f32_32x32x16_bf16 — operands rounded to bf16 (RNE, v_cvt_pk_bf16_f32) when the tile is staged,
+// fp32 accumulation, fp32 outputs.  Same functors, same global gathers; the LDS tiles hold bf16 with both operands
+// k-contiguous (A[x][r], B[y][r], row pitch BR+8 halves = 80 B: 16-byte aligned and conflict-free for ds_read_b128), one
+// 16-byte fragment per operand per MFMA.  Not bit-comparable with the fp32 chain: tolerance 2e-2 on logits.
+typedef __bf16 ig_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 ig_bf16x4 __attribute__((ext_vector_type(4)));
+
+template <class P>
+__global__ __launch_bounds__(256, P::Tile::MINW) void igemm_bf16_kernel(const P p) {
+  using T = typename P::Tile;
+  constexpr int BX = T::BX, BY = T::BY, BR = T::BR, WX = T::WX, WY = T::WY;
+  static_assert(!P::A_RX && !P::BIAS_GRAD && P::NCLS == 1 && BR % 16 == 0, "bf16 variant covers the forward / dgrad style problems");
+  constexpr bool B_YR = P::B_YR;
+  constexpr int TM = BX / WX / 32, TN = BY / WY / 32;
+  constexpr int PH = BR + 8;                       // halves per LDS row
+  constexpr int ASZ = BX * PH, BSZ = BY * PH;      // halves per buffer
+  constexpr int NVA = (BX * BR / 4 + 255) / 256;
+  constexpr int NVB = (BR * BY / 4 + 255) / 256;
+  __shared__ __attribute__((aligned(16))) __bf16 hmem[2 * ASZ + 2 * BSZ];
+  __bf16* As = hmem;
+  __bf16* Bs = hmem + 2 * ASZ;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, h = lane >> 5;
+  const int wx = wave / WY, wy = wave % WY;
+  int bx = blockIdx.x;
+  {
+    const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = bx & 7, k = bx >> 3;
+    bx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+  }
+  const int x0 = bx * BX, y0 = (int)blockIdx.y * BY, z = blockIdx.z;
+  int rlo, rhi;
+  p.r_range(z, rlo, rhi);
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+  float4 ra[NVA], rb[NVB];
+  auto gload = [&](int r0) {
+#pragma unroll
+    for (int j = 0; j < NVA; ++j) {
+      const int v = tid + 256 * j;
+      if (BX * BR / 4 % 256 == 0 || v < BX * BR / 4) {
+        const int rq = v % (BR / 4), xl = v / (BR / 4);
+        ra[j] = p.load_a(x0 + xl, r0 + 4 * rq, rhi, 0);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NVB; ++j) {
+      const int v = tid + 256 * j;
+      if (BR * BY / 4 % 256 == 0 || v < BR * BY / 4) {
+        if (B_YR) {
+          const int rq = v % (BR / 4), yl = v / (BR / 4);
+          rb[j] = p.load_b(r0 + 4 * rq, y0 + yl, rhi, 0);
+        } else {
+          const int yq = v % (BY / 4), rl = v / (BY / 4);
+          rb[j] = p.load_b(r0 + rl, y0 + 4 * yq, rhi, 0);
+        }
+      }
+    }
+  };
+  auto cvt4 = [](float4 v) { ig_bf16x4 o; o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w; return o; };
+  auto sstore = [&](int buf) {
+    __bf16* A_ = As + buf * ASZ;
+    __bf16* B_ = Bs + buf * BSZ;
+#pragma unroll
+    for (int j = 0; j < NVA; ++j) {
+      const int v = tid + 256 * j;
+      if (BX * BR / 4 % 256 == 0 || v < BX * BR / 4) {
+        const int rq = v % (BR / 4), xl = v / (BR / 4);
+        *reinterpret_cast<ig_bf16x4*>(A_ + xl * PH + 4 * rq) = cvt4(ra[j]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NVB; ++j) {
+      const int v = tid + 256 * j;
+      if (BR * BY / 4 % 256 == 0 || v < BR * BY / 4) {
+        const ig_bf16x4 c = cvt4(rb[j]);
+        if (B_YR) {
+          const int rq = v % (BR / 4), yl = v / (BR / 4);
+          *reinterpret_cast<ig_bf16x4*>(B_ + yl * PH + 4 * rq) = c;
+        } else {  // global vector ran along y: transpose into B[y][r]
+          const int yq = v % (BY / 4), rl = v / (BY / 4);
+          __bf16* d = B_ + (4 * yq) * PH + rl;
+          d[0] = c[0]; d[PH] = c[1]; d[2 * PH] = c[2]; d[3 * PH] = c[3];
+        }
+      }
+    }
+  };
+
+  gload(rlo);
+  sstore(0);
+  __syncthreads();
+  int buf = 0;
+  for (int r0 = rlo; r0 < rhi; r0 += BR) {
+    const bool more = (r0 + BR) < rhi;
+    if (more) gload(r0 + BR);
+    const __bf16* A_ = As + buf * ASZ;
+    const __bf16* B_ = Bs + buf * BSZ;
+#pragma unroll
+    for (int g = 0; g < BR / 16; ++g) {
+      ig_bf16x8 fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const ig_bf16x8*>(A_ + (wx * (BX / WX) + i * 32 + li) * PH + 16 * g + 8 * h);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const ig_bf16x8*>(B_ + (wy * (BY / WY) + j * 32 + li) * PH + 16 * g + 8 * h);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) sstore(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int y = y0 + wy * (BY / WY) + j * 32 + li;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
+        p.store(x0 + wx * (BX / WX) + i * 32 + row, y, acc[i][j][e], z, 0);
+      }
+    }
+}
+
+template <class P>
+static inline void igemm_bf16_launch(const P& p, int nsplit, hipStream_t stream) {
+  using T = typename P::Tile;
+  dim3 grid((p.X() + T::BX - 1) / T::BX, (p.Y() + T::BY - 1) / T::BY, nsplit);
+  hipLaunchKernelGGL(igemm_bf16_kernel<P>, grid, dim3(256), 0, stream, p);
+}

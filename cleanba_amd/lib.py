@@ -28,7 +28,7 @@ class Config(C.Structure):
                 ("norm_adv", C.c_int32), ("ring_depth", C.c_int32), ("gamma", C.c_float), ("gae_lambda", C.c_float),
                 ("clip_coef", C.c_float), ("ent_coef", C.c_float), ("vf_coef", C.c_float), ("max_grad_norm", C.c_float),
                 ("adam_b1", C.c_float), ("adam_b2", C.c_float), ("adam_eps", C.c_float), ("rms_decay", C.c_float),
-                ("rms_eps", C.c_float), ("actor_dense_ksplit", C.c_int32), ("reserved", C.c_int32 * 7)]
+                ("rms_eps", C.c_float), ("actor_dense_ksplit", C.c_int32), ("forward_bf16", C.c_int32), ("reserved", C.c_int32 * 6)]
 
 
 class EnvState(C.Structure):

@@ -52,6 +52,7 @@ def make_config(args, algo):
     cfg.device = args.learner_device_ids[0] if not args.distributed else int(os.environ.get("LOCAL_RANK", os.environ.get("SLURM_LOCALID", 0)))
     cfg.network = {"nature": L.NET_NATURE, "impala_resnet": L.NET_IMPALA_RESNET}[args.network]
     cfg.num_actions = args.num_actions
+    cfg.forward_bf16 = int(bool(getattr(args, "bf16_forward", False)))
     cfg.actor_dense_ksplit = 14 if args.network == "nature" else 11  # K segments of the flatten->dense when M <= 1024 rows
     cfg.local_num_envs = args.local_num_envs
     cfg.num_actor_slots = args.num_actor_threads * len(args.actor_device_ids)

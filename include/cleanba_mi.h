@@ -53,7 +53,9 @@ typedef struct {
   float adam_b1, adam_b2, adam_eps;                  /* optax.adam defaults, eps=1e-5 ppo:497 */
   float rms_decay, rms_eps;                          /* impala:534                       */
   int32_t actor_dense_ksplit;/* K segments of the 3136->512 dense when M<=128 (numerics spec) */
-  int32_t reserved[7];
+  int32_t forward_bf16;       /* build-only extension (BASELINE configs[2]): forward GEMMs of conv2/conv3/dense on bf16 MFMA, fp32 accumulate;
+                                 0 = the reference's fp32 everywhere.  Nature-CNN only. */
+  int32_t reserved[6];
 } cbm_config;
 
 /* Fills cfg with the reference defaults for `algo` (ppo:34-118 / impala:34-110). */

@@ -170,3 +170,28 @@ def test_optimizers(ctx, oracle):
                                         L.C.c_float(6e-4), L.C.c_float(1.0)))
         dg.free()
     np.testing.assert_allclose(dp.download(), p, rtol=0, atol=1e-6)
+
+
+def test_bf16_forward_extension_close_to_fp32_oracle(oracle):
+    # BASELINE configs[2] / SURVEY §8d: bf16 forward is a build-only extension; tolerance vs the fp32 oracle 2e-2 on logits
+    cfg = L.default_config(L.ALGO_PPO)
+    cfg.forward_bf16 = 1
+    cfg.local_num_envs, cfg.num_actor_slots, cfg.num_steps = 64, 1, 48   # learner workspace for 768-frame minibatches
+    ctx = L.Context(cfg)
+    try:
+        A = 18
+        P = make_params(A, 5)
+        obs = make_frames(700, 9)           # > 512 frames: the learner-size code path; 12 frames: the actor-size path (split-K dense)
+        for B, ks in ((700, 1), (12, 14)):
+            dP, dO = L.DevBuf(ctx, P), L.DevBuf(ctx, obs[:B])
+            dL = L.DevBuf(ctx, nbytes=B * A * 4, dtype=np.float32, shape=(B, A))
+            dV = L.DevBuf(ctx, nbytes=B * 4, dtype=np.float32, shape=(B,))
+            L._chk(ctx.lib.cbm_forward(ctx.h, L._p(dP.ptr), L._p(dO.ptr), None, B, ks, L._p(dL.ptr), L._p(dV.ptr)))
+            lo, vo = oracle.nature_forward(P, A, obs[:B], ksplit=ks)
+            lg, vg = dL.download(), dV.download()
+            assert np.isfinite(lg).all()
+            assert np.abs(lg - lo).max() <= 2e-2 * max(1.0, np.abs(lo).max()), np.abs(lg - lo).max()
+            assert np.abs(vg - vo).max() <= 2e-2 * max(1.0, np.abs(vo).max())
+            assert np.abs(lg - lo).max() > 0      # it really is a different arithmetic (not silently the fp32 path)
+    finally:
+        ctx.close()
