@@ -65,6 +65,8 @@ struct cbm_ctx {
   NatureWs lws;
   float *adv = nullptr, *target = nullptr, *next_value = nullptr, *stats_dev = nullptr, *loss_partials = nullptr, *norm_partials = nullptr;
   int32_t *perm = nullptr, *perm_tmp = nullptr, *impala_idx = nullptr;
+  float* gacc = nullptr;   // MultiSteps running mean (grad_accum_steps > 1)
+  int accum = 1, nmicro = 0;
   uint64_t* ckeys = nullptr;
   std::mutex mu;
   std::condition_variable cv;
@@ -127,9 +129,14 @@ extern "C" int cbm_ctx_create(const cbm_config* cfg, cbm_ctx** out) {
   c->A = cfg->num_actions; c->E = cfg->local_num_envs; c->S = cfg->num_actor_slots;
   c->Bdev = c->E * c->S; c->T = cfg->num_steps; c->T1 = c->T + 1;
   c->nmb = cfg->num_minibatches; c->epochs = is_ppo(c) ? cfg->update_epochs : 1;
+  c->accum = cfg->grad_accum_steps > 1 ? cfg->grad_accum_steps : 1;
+  c->nmicro = c->nmb * c->accum;   // micro-batches per epoch (ppo:607, impala:627)
   if (c->Bdev > 1024) { cbm_set_error("local_num_envs*slots must be <= 1024 per GPU"); delete c; return -1; }
   if (c->Bdev % c->nmb) { cbm_set_error("local_num_envs*slots must be divisible by num_minibatches (ppo:416-418)"); delete c; return -1; }
-  c->MB = is_ppo(c) ? (c->T * c->Bdev) / c->nmb : c->T1 * (c->Bdev / c->nmb);
+  if (is_ppo(c) ? (c->T * c->Bdev) % c->nmicro : c->Bdev % c->nmicro) {
+    cbm_set_error("the batch does not split into num_minibatches*gradient_accumulation_steps = %d micro-batches", c->nmicro); delete c; return -1;
+  }
+  c->MB = is_ppo(c) ? (c->T * c->Bdev) / c->nmicro : c->T1 * (c->Bdev / c->nmicro);
   c->L = net_layout(cfg->network, c->A);
   if (c->L.flat % cfg->actor_dense_ksplit || (c->L.flat / cfg->actor_dense_ksplit) % 32) {
     cbm_set_error("actor_dense_ksplit must cut the %d-wide flatten into multiples of 32 (Nature: 14, ResNet: 11)", c->L.flat); delete c; return -1;
@@ -147,26 +154,33 @@ extern "C" int cbm_ctx_create(const cbm_config* cfg, cbm_ctx** out) {
     for (int s = 0; s < c->S; ++s) CBM_HIP(hipEventCreateWithFlags(&R.ready[s], hipEventDisableTiming));
     CBM_HIP(hipEventCreateWithFlags(&R.consumed, hipEventDisableTiming));
   }
+  // stream priorities (experiment knob): CBM_STREAM_PRIO=learner|actor gives that side the high-priority queue
+  int prio_lo = 0, prio_hi = 0;
+  hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+  const char* pe = getenv("CBM_STREAM_PRIO");
+  const int prio_actor = pe && !strcmp(pe, "actor") ? prio_hi : (pe && !strcmp(pe, "learner") ? prio_lo : 0);
+  const int prio_learner = pe && !strcmp(pe, "learner") ? prio_hi : (pe && !strcmp(pe, "actor") ? prio_lo : 0);
   for (int s = 0; s < c->S; ++s) {
     Slot& sl = c->slots[s];
-    CBM_HIP(hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
+    CBM_HIP(hipStreamCreateWithPriority(&sl.stream, hipStreamNonBlocking, prio_actor));
     if (nature_ws_alloc(sl.ws, c->E, false, cfg->actor_dense_ksplit, cfg->network)) return -1;
     sl.ws.bf16_fwd = cfg->forward_bf16 != 0 && cfg->network == CBM_NET_NATURE;
     if (dalloc(&sl.env_state, (size_t)c->E) || dalloc(&sl.stats_dev, 2)) return -1;
     c->committed[s] = 0;
   }
-  CBM_HIP(hipStreamCreateWithFlags(&c->lstream, hipStreamNonBlocking));
+  CBM_HIP(hipStreamCreateWithPriority(&c->lstream, hipStreamNonBlocking, prio_learner));
   const int lmax = c->MB > c->Bdev ? c->MB : c->Bdev;
   if (nature_ws_alloc(c->lws, lmax, true, cfg->actor_dense_ksplit, cfg->network)) return -1;
   c->lws.bf16_fwd = cfg->forward_bf16 != 0 && cfg->network == CBM_NET_NATURE;
-  c->stat_rows = c->epochs * c->nmb;
+  c->stat_rows = c->epochs * c->nmicro;
+  if (c->accum > 1) { if (dalloc(&c->gacc, P)) return -1; hipMemset(c->gacc, 0, P * 4); }
   if (dalloc(&c->adv, T1 * B) || dalloc(&c->target, T1 * B) || dalloc(&c->next_value, B) || dalloc(&c->stats_dev, (size_t)c->stat_rows * 8) ||
       dalloc(&c->loss_partials, (size_t)4 * (lmax / 256 + 2) + 3 * B) || dalloc(&c->norm_partials, CBM_NORM_PARTS) ||
       dalloc(&c->perm, T1 * B) || dalloc(&c->perm_tmp, T1 * B) || dalloc(&c->ckeys, 2 * T1 * B)) return -1;
   if (!is_ppo(c)) {  // static minibatch index table: contiguous env-column chunks, all T+1 rows (impala:623-634)
-    const int Bm = c->Bdev / c->nmb;
-    std::vector<int32_t> h((size_t)c->nmb * c->MB);
-    for (int mb = 0; mb < c->nmb; ++mb)
+    const int Bm = c->Bdev / c->nmicro;
+    std::vector<int32_t> h((size_t)c->nmicro * c->MB);
+    for (int mb = 0; mb < c->nmicro; ++mb)
       for (int t = 0; t < c->T1; ++t)
         for (int j = 0; j < Bm; ++j) h[(size_t)mb * c->MB + t * Bm + j] = t * c->Bdev + mb * Bm + j;
     if (dalloc(&c->impala_idx, h.size())) return -1;
@@ -182,7 +196,7 @@ extern "C" int cbm_ctx_destroy(cbm_ctx* c) {
   hipSetDevice(c->cfg.device);
   hipDeviceSynchronize();
   void* ps[] = {c->params, c->grads, c->opt_m, c->opt_v, c->adv, c->target, c->next_value, c->stats_dev, c->loss_partials, c->norm_partials,
-                c->perm, c->perm_tmp, c->ckeys, c->impala_idx};
+                c->perm, c->perm_tmp, c->ckeys, c->impala_idx, c->gacc};
   for (void* p : ps) if (p) hipFree(p);
   for (int i = 0; i < NPV; ++i) { if (c->actor_params[i]) hipFree(c->actor_params[i]); hipEventDestroy(c->params_ready[i]); }
   for (int r = 0; r < c->cfg.ring_depth; ++r) {
@@ -521,7 +535,7 @@ static int learner_epoch_perm(cbm_ctx* c, uint32_t key[2]) {
 extern "C" int cbm_learner_minibatch_grad(cbm_ctx* c, int32_t epoch, int32_t mb) {
   CBM_HIP(hipSetDevice(c->cfg.device));
   RingEntry& R = cur_ring(c);
-  float* stats = c->stats_dev + (size_t)(epoch * c->nmb + mb) * 8;
+  float* stats = c->stats_dev + (size_t)(epoch * c->nmicro + mb) * 8;
   if (is_ppo(c)) {
     const int32_t* idx = c->perm + (size_t)mb * c->MB;
     nature_forward(c->L, c->params, R.obs, idx, c->MB, 1, c->lws, c->lstream);
@@ -529,7 +543,7 @@ extern "C" int cbm_learner_minibatch_grad(cbm_ctx* c, int32_t epoch, int32_t mb)
                     c->cfg.vf_coef, c->lws.dzv, c->loss_partials, stats, c->lstream);
     nature_backward(c->L, c->params, R.obs, idx, c->MB, c->lws, c->grads, c->lstream);
   } else {
-    const int Bm = c->Bdev / c->nmb;
+    const int Bm = c->Bdev / c->nmicro;
     const int32_t* idx = c->impala_idx + (size_t)mb * c->MB;
     nature_forward(c->L, c->params, R.obs, idx, c->MB, 1, c->lws, c->lstream);
     launch_impala_loss(c->lws.logits, c->lws.value, R.logits, R.actions, R.rewards, R.dones, R.firststeps, c->T1, Bm, c->A, mb * Bm, c->Bdev,
@@ -539,6 +553,13 @@ extern "C" int cbm_learner_minibatch_grad(cbm_ctx* c, int32_t epoch, int32_t mb)
   return 0;
 }
 
+// optax.MultiSteps (0.1.4): acc <- (g - acc)/(mini_step+1) + acc; the k-th micro-batch hands the mean to the inner optimizer and clears acc
+extern "C" int cbm_learner_accumulate(cbm_ctx* c, int32_t mini_step, float grad_div) {
+  CBM_HIP(hipSetDevice(c->cfg.device));
+  if (c->accum <= 1) { cbm_set_error("context was created without gradient accumulation"); return -1; }
+  launch_grad_accumulate(c->grads, c->gacc, c->P, mini_step, mini_step == c->accum - 1, grad_div, c->lstream);
+  return 0;
+}
 extern "C" int cbm_learner_optimizer_step(cbm_ctx* c, float lr, float bc1, float bc2, float grad_div) {
   CBM_HIP(hipSetDevice(c->cfg.device));
   if (is_ppo(c))
@@ -580,9 +601,14 @@ extern "C" int cbm_learner_update(cbm_ctx* c, uint32_t key[2], const float* lrs,
   int step = 0;
   for (int e = 0; e < c->epochs; ++e) {
     if (is_ppo(c)) learner_epoch_perm(c, key);
-    for (int mb = 0; mb < c->nmb; ++mb, ++step) {
+    for (int mb = 0; mb < c->nmicro; ++mb) {
       if (cbm_learner_minibatch_grad(c, e, mb)) return -1;
+      if (c->accum > 1) {
+        if (cbm_learner_accumulate(c, mb % c->accum, 1.0f)) return -1;
+        if (mb % c->accum != c->accum - 1) continue;
+      }
       if (cbm_learner_optimizer_step(c, lrs[step], bc1 ? bc1[step] : 1.0f, bc2 ? bc2[step] : 1.0f, 1.0f)) return -1;
+      ++step;
     }
   }
   return cbm_learner_finish(c, stats_out);

@@ -83,6 +83,7 @@ void launch_impala_loss(const float* logits, const float* value, const float* mu
                         const float* rewards, const uint8_t* dones, const uint8_t* firststeps, int T1, int Bm, int A,
                         int col0, int ld, float gamma, float vf_coef, float ent_coef, float* dzv, float* partials,
                         float* stats4, hipStream_t st);
+void launch_grad_accumulate(float* g, float* acc, int64_t n, int mini_step, bool last, float grad_div, hipStream_t st);
 void launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float max_norm, float lr, float b1, float b2,
                  float eps, float bc1, float bc2, float grad_div, float* norm_partials, hipStream_t st);
 void launch_rmsprop(float* p, const float* g, float* nu, int64_t n, float max_norm, float lr, float decay, float eps,

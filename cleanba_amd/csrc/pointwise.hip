@@ -395,6 +395,16 @@ __global__ __launch_bounds__(256) void rmsprop_kernel(float* p, const float* g, 
     p[i] = p[i] + (-lr) * (gi / (sqrtf(ni) + eps));
   }
 }
+__global__ __launch_bounds__(256) void grad_accumulate_kernel(float* g, float* acc, int64_t n, float inv_steps_arg, float steps, int last, float grad_div) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float gi = grad_div == 1.0f ? g[i] : g[i] / grad_div;
+    const float a = (gi - acc[i]) / steps + acc[i];
+    if (last) { g[i] = a; acc[i] = 0.0f; } else acc[i] = a;
+  }
+}
+void launch_grad_accumulate(float* g, float* acc, int64_t n, int mini_step, bool last, float grad_div, hipStream_t st) {
+  hipLaunchKernelGGL(grad_accumulate_kernel, dim3(1024), dim3(256), 0, st, g, acc, n, 0.0f, (float)(mini_step + 1), last ? 1 : 0, grad_div);
+}
 void launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float max_norm, float lr, float b1, float b2, float eps,
                  float bc1, float bc2, float grad_div, float* norm_partials, hipStream_t st) {
   hipLaunchKernelGGL(sqnorm_partials_kernel, dim3(CBM_NORM_PARTS), dim3(256), 0, st, g, n, grad_div, norm_partials);

@@ -28,7 +28,7 @@ class Config(C.Structure):
                 ("norm_adv", C.c_int32), ("ring_depth", C.c_int32), ("gamma", C.c_float), ("gae_lambda", C.c_float),
                 ("clip_coef", C.c_float), ("ent_coef", C.c_float), ("vf_coef", C.c_float), ("max_grad_norm", C.c_float),
                 ("adam_b1", C.c_float), ("adam_b2", C.c_float), ("adam_eps", C.c_float), ("rms_decay", C.c_float),
-                ("rms_eps", C.c_float), ("actor_dense_ksplit", C.c_int32), ("forward_bf16", C.c_int32), ("reserved", C.c_int32 * 6)]
+                ("rms_eps", C.c_float), ("actor_dense_ksplit", C.c_int32), ("forward_bf16", C.c_int32), ("grad_accum_steps", C.c_int32), ("reserved", C.c_int32 * 5)]
 
 
 class EnvState(C.Structure):
@@ -45,7 +45,7 @@ SYMBOLS = [
     "cbm_dev_alloc", "cbm_dev_free", "cbm_learner_stream", "cbm_sync", "cbm_actor_set_key", "cbm_actor_get_key",
     "cbm_actor_begin_rollout", "cbm_actor_step_host", "cbm_actor_record_host", "cbm_actor_rollout_device",
     "cbm_actor_commit", "cbm_actor_episode_stats", "cbm_learner_wait", "cbm_learner_update", "cbm_learner_prepare",
-    "cbm_learner_epoch_begin", "cbm_learner_minibatch_grad", "cbm_learner_optimizer_step", "cbm_learner_finish",
+    "cbm_learner_epoch_begin", "cbm_learner_minibatch_grad", "cbm_learner_accumulate", "cbm_learner_optimizer_step", "cbm_learner_finish",
     "cbm_forward", "cbm_sample", "cbm_gae", "cbm_advnorm", "cbm_permutation", "cbm_ppo_loss_grad",
     "cbm_impala_loss_grad", "cbm_adam_step", "cbm_rmsprop_step", "cbm_synth_env_reset_host", "cbm_synth_env_reset_host_games", "cbm_synth_env_step_host", "cbm_actor_env_reset_device_games",
     "cbm_actor_env_reset_device", "cbm_profile_select", "cbm_profile_read", "cbm_ingest_begin", "cbm_ingest_commit",
@@ -283,7 +283,7 @@ class Context:
         bc1 = np.ascontiguousarray(bc1, np.float32)
         bc2 = np.ascontiguousarray(bc2, np.float32)
         w = 5 if self.cfg.algo == ALGO_PPO else 4
-        stats = np.zeros((len(lrs), w), np.float32) if want_stats else None
+        stats = np.zeros((len(lrs) * max(1, self.cfg.grad_accum_steps), w), np.float32) if want_stats else None   # one row per micro-batch
         _chk(self.lib.cbm_learner_update(self.h, _p(key), _p(lrs), _p(bc1), _p(bc2), int(len(lrs)), _p(stats)))
         return key, stats
 
@@ -300,12 +300,15 @@ class Context:
     def learner_minibatch_grad(self, epoch, mb):
         _chk(self.lib.cbm_learner_minibatch_grad(self.h, int(epoch), int(mb)))
 
+    def learner_accumulate(self, mini_step, grad_div=1.0):
+        _chk(self.lib.cbm_learner_accumulate(self.h, int(mini_step), C.c_float(grad_div)))
+
     def learner_optimizer_step(self, lr, bc1, bc2, grad_div=1.0):
         _chk(self.lib.cbm_learner_optimizer_step(self.h, C.c_float(lr), C.c_float(bc1), C.c_float(bc2), C.c_float(grad_div)))
 
     def learner_finish(self, n_rows, want_stats=True):
         w = 5 if self.cfg.algo == ALGO_PPO else 4
-        stats = np.zeros((n_rows, w), np.float32) if want_stats else None
+        stats = np.zeros((n_rows * max(1, self.cfg.grad_accum_steps), w), np.float32) if want_stats else None
         _chk(self.lib.cbm_learner_finish(self.h, _p(stats)))
         return stats
 

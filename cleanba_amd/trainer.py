@@ -57,7 +57,8 @@ def make_config(args, algo):
     cfg.local_num_envs = args.local_num_envs
     cfg.num_actor_slots = args.num_actor_threads * len(args.actor_device_ids)
     cfg.num_steps = args.num_steps
-    cfg.num_minibatches = args.num_minibatches * args.gradient_accumulation_steps
+    cfg.num_minibatches = args.num_minibatches
+    cfg.grad_accum_steps = args.gradient_accumulation_steps   # optax.MultiSteps(every_k_schedule) ppo:492-500
     cfg.update_epochs = args.update_epochs if algo == "ppo" else 1
     cfg.norm_adv = int(args.norm_adv) if algo == "ppo" else 0
     cfg.gamma, cfg.gae_lambda = args.gamma, args.gae_lambda
@@ -235,8 +236,6 @@ def train(args, algo="ppo", engine_factory=None, on_update=None, rendezvous=None
     else:
         n_proc, proc_index = world_size, rank
     finalize(args, n_proc, proc_index)
-    if args.gradient_accumulation_steps != 1:
-        raise NotImplementedError("MultiSteps(k>1) is not wired yet (reference default k=1, ppo:79)")
     if args.distributed and world_size > 1 and dist_module is None:
         import torch.distributed as dist
         if not dist.is_initialized():
@@ -297,9 +296,15 @@ def train(args, algo="ppo", engine_factory=None, on_update=None, rendezvous=None
             i = 0
             for e in range(epochs):
                 learner_key = engine.learner_epoch_begin(learner_key)
-                for mb in range(args.num_minibatches):
+                k = args.gradient_accumulation_steps
+                for mb in range(args.num_minibatches * k):
                     engine.learner_minibatch_grad(e, mb)
                     grad_div = allreduce()
+                    if k > 1:   # optax.MultiSteps: running mean of the (already pmean-ed) micro-batch gradients, step on every k-th
+                        engine.learner_accumulate(mb % k, grad_div)
+                        if mb % k != k - 1:
+                            continue
+                        grad_div = 1.0
                     engine.learner_optimizer_step(float(lrs[i]), float(bc1[i]), float(bc2[i]), grad_div)
                     i += 1
             stats = engine.learner_finish(n_opt, want_stats)
@@ -395,9 +400,15 @@ def _train_split(args, algo, engine, lay, writer, key, rank, run_name, dist_modu
         i = 0
         for e in range(epochs):
             learner_key = engine.learner_epoch_begin(learner_key)
-            for mb in range(args.num_minibatches):
+            k = args.gradient_accumulation_steps
+            for mb in range(args.num_minibatches * k):
                 engine.learner_minibatch_grad(e, mb)
                 grad_div = allreduce()
+                if k > 1:
+                    engine.learner_accumulate(mb % k, grad_div)
+                    if mb % k != k - 1:
+                        continue
+                    grad_div = 1.0
                 engine.learner_optimizer_step(float(lrs[i]), float(bc1[i]), float(bc2[i]), grad_div)
                 i += 1
         stats = engine.learner_finish(n_opt, True)

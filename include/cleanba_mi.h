@@ -55,7 +55,9 @@ typedef struct {
   int32_t actor_dense_ksplit;/* K segments of the 3136->512 dense when M<=128 (numerics spec) */
   int32_t forward_bf16;       /* build-only extension (BASELINE configs[2]): forward GEMMs of conv2/conv3/dense on bf16 MFMA, fp32 accumulate;
                                  0 = the reference's fp32 everywhere.  Nature-CNN only. */
-  int32_t reserved[6];
+  int32_t grad_accum_steps;   /* optax.MultiSteps every_k (ppo:79,492-500): each of the num_minibatches*k micro-batches feeds a running
+                                 mean; the optimizer steps on every k-th.  0/1 = off. */
+  int32_t reserved[5];
 } cbm_config;
 
 /* Fills cfg with the reference defaults for `algo` (ppo:34-118 / impala:34-110). */
@@ -133,6 +135,10 @@ int cbm_learner_update(cbm_ctx* ctx, uint32_t key[2], const float* lrs, const fl
 int cbm_learner_prepare(cbm_ctx* ctx, uint32_t key[2]);
 int cbm_learner_epoch_begin(cbm_ctx* ctx, uint32_t key[2]);   /* key,subkey = split(key); perm = permutation(subkey) ppo:599-606 */
 int cbm_learner_minibatch_grad(cbm_ctx* ctx, int32_t epoch, int32_t minibatch);
+/* gradient accumulation (grad_accum_steps = k > 1), split form: after each micro-batch's all-reduce call cbm_learner_accumulate with
+ * mini_step = micro_batch % k; it folds "grads"/grad_div into the running mean and, on mini_step == k-1, leaves that mean in "grads" for
+ * cbm_learner_optimizer_step(..., grad_div = 1). */
+int cbm_learner_accumulate(cbm_ctx* ctx, int32_t mini_step, float grad_div);
 int cbm_learner_optimizer_step(cbm_ctx* ctx, float lr, float bc1, float bc2, float grad_div);
 int cbm_learner_finish(cbm_ctx* ctx, float* stats_out);   /* publishes params to the actors (ppo:721-725) */
 

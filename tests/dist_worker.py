@@ -23,6 +23,8 @@ if world > 1:
     argv.append("--distributed")
 if same:
     argv.append("--same-env-seed-all-ranks")
+if os.environ.get("CBM_TEST_ACCUM"):
+    argv += ["--gradient-accumulation-steps", os.environ["CBM_TEST_ACCUM"], "--num-minibatches", "2"]
 args = parse_args(argv, algo)
 os.chdir(os.environ.get("CBM_TEST_TMP", "/tmp"))
 res = train(args, algo, engine_factory=OracleEngine)

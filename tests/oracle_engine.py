@@ -22,6 +22,8 @@ class OracleEngine:
         self.B, self.T = self.E * self.S, cfg.num_steps
         self.T1 = self.T + 1
         self.nmb = cfg.num_minibatches
+        self.accum = max(1, cfg.grad_accum_steps)
+        self.nmicro = self.nmb * self.accum
         self.epochs = cfg.update_epochs if self.ppo else 1
         self.depth = cfg.ring_depth
         self.P = oracle.nature_param_count(self.A)
@@ -33,6 +35,7 @@ class OracleEngine:
         self.grads = np.zeros(self.P, np.float32)
         self.m = np.zeros(self.P, np.float32)
         self.v = np.zeros(self.P, np.float32)
+        self.gacc = np.zeros(self.P, np.float32)
         self.actor_params = {0: self.params.copy()}
         self.keys = [np.zeros(2, np.uint32) for _ in range(self.S)]
         self.slot = [dict(t=0, rollout=0, ring=0, pver=0) for _ in range(self.S)]
@@ -216,20 +219,29 @@ class OracleEngine:
         c = self.cfg
         if self.ppo:
             N = self.T * self.B
-            MB = N // self.nmb
+            MB = N // self.nmicro
             idx = self.perm[mb * MB:(mb + 1) * MB]
             fo = R["obs"][:self.T].reshape(N, 4, 84, 84)
             st, g, _, _ = oracle.ppo_loss_grad(self.params, self.A, fo, idx, R["actions"][:self.T].reshape(N)[idx],
                                                R["logprobs"][:self.T].reshape(N)[idx], self.adv.reshape(N)[idx], self.tgt.reshape(N)[idx],
                                                c.clip_coef, c.ent_coef, c.vf_coef)
         else:
-            Bm = self.B // self.nmb
+            Bm = self.B // self.nmicro
             cs = slice(mb * Bm, (mb + 1) * Bm)
             st, g = oracle.impala_loss_grad(self.params, self.A, R["obs"][:, cs].reshape(-1, 4, 84, 84), None, self.T1, Bm, R["logits"][:, cs],
                                             R["actions"][:, cs], R["rewards"][:, cs], R["dones"][:, cs], R["firststeps"][:, cs], c.gamma,
                                             c.vf_coef, c.ent_coef)
         self.grads[:] = g
         self.stats.append(st)
+
+    def learner_accumulate(self, mini_step, grad_div=1.0):
+        g = self.grads / np.float32(grad_div) if grad_div != 1.0 else self.grads
+        a = (g - self.gacc) / np.float32(mini_step + 1) + self.gacc   # optax.MultiSteps running mean
+        if mini_step == self.accum - 1:
+            self.grads[:] = a
+            self.gacc[:] = 0
+        else:
+            self.gacc[:] = a
 
     def learner_optimizer_step(self, lr, bc1, bc2, grad_div=1.0):
         g = self.grads / np.float32(grad_div) if grad_div != 1.0 else self.grads
@@ -253,8 +265,12 @@ class OracleEngine:
         i = 0
         for e in range(self.epochs):
             key = self.learner_epoch_begin(key)
-            for mb in range(self.nmb):
+            for mb in range(self.nmicro):
                 self.learner_minibatch_grad(e, mb)
+                if self.accum > 1:
+                    self.learner_accumulate(mb % self.accum)
+                    if mb % self.accum != self.accum - 1:
+                        continue
                 self.learner_optimizer_step(float(lrs[i]), float(bc1[i]), float(bc2[i]))
                 i += 1
         return key, self.learner_finish(len(lrs), want_stats)

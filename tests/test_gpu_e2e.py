@@ -187,3 +187,45 @@ def test_atari57_mix_device_env_matches_host_twin():
     assert (o == obs[T]).all()
     assert len({obs[0, e, 3].tobytes() for e in range(57)}) > 50
     ctx.close()
+
+
+@pytest.mark.parametrize("algo", ["ppo", "impala"])
+def test_gradient_accumulation_update_matches_oracle(oracle, algo):
+    # optax.MultiSteps(every_k_schedule=2): the library's fused update vs the oracle-backed engine replaying the same ring
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from oracle_engine import OracleEngine
+    E, T, S = 8, 8, 2
+    cfg = L.default_config(L.ALGO_PPO if algo == "ppo" else L.ALGO_IMPALA)
+    cfg.local_num_envs, cfg.num_actor_slots, cfg.num_steps = E, S, T
+    cfg.num_minibatches, cfg.grad_accum_steps, cfg.update_epochs = 2, 2, 2
+    ctx = L.Context(cfg)
+    key, params = _init(4)
+    ctx.set_params(params)
+    for s in range(S):
+        ctx.actor_set_key(s, key)
+        ctx.actor_env_reset_device(s, 21 + s)
+        ctx.actor_begin_rollout(s, False)
+        ctx.actor_rollout_device(s, T + (0 if algo == "ppo" else 1))
+        ctx.actor_commit(s)
+    ctx.learner_wait()
+    ora = OracleEngine(cfg)
+    ora.set_params(params)
+    B = E * S
+    R = ora.ring[0]
+    R["obs"][:] = ctx.read("obs", np.uint8).reshape(T + 1, B, 4, 84, 84)
+    for name, dt in (("actions", np.int32), ("logprobs", np.float32), ("values", np.float32), ("rewards", np.float32), ("dones", np.uint8),
+                     ("firststeps", np.uint8)):
+        R[name][:] = ctx.read(name, dt).reshape(T + 1, B)
+    R["logits"][:] = ctx.read("logits", np.float32).reshape(T + 1, B, A)
+    ora.committed = [1] * S
+    n_opt = 2 * (2 if algo == "ppo" else 1)
+    lrs, bc1, bc2 = _sched(n_opt, 1e-3)
+    k1, stats = ctx.learner_update(key, lrs, bc1, bc2)
+    k2, stats_o = ora.learner_update(key, lrs, bc1, bc2)
+    assert stats.shape == stats_o.shape == (n_opt * 2, 5 if algo == "ppo" else 4)
+    np.testing.assert_allclose(stats, stats_o, rtol=2e-4, atol=2e-5)
+    p_gpu, p_ora = ctx.get_params(), ora.get_params()
+    assert np.abs(p_gpu - p_ora).max() <= 1e-5 * max(1.0, np.abs(p_ora).max())
+    assert (k1 == k2).all()
+    ctx.close()

@@ -162,3 +162,16 @@ def test_split_topology_two_groups(tmp_path):
     assert str(a1["role"]) == "actor" and str(l1["role"]) == "learner0"
     assert np.array_equal(l0["params"], l1["params"])
     assert np.array_equal(a0["params"], l0["params"]) and np.array_equal(a1["params"], l1["params"])
+
+
+@pytest.mark.parametrize("algo", ["ppo", "impala"])
+def test_gradient_accumulation_data_parallel(tmp_path, algo, monkeypatch):
+    # optax.MultiSteps(every_k=2) (ppo:492-500): 2 minibatches x 2 micro-batches; the running mean is taken after the all-reduce,
+    # so with identical env streams dp2 must equal dp1 bit for bit, and it must differ from the k=1 run on the same data
+    monkeypatch.setenv("CBM_TEST_ACCUM", "2")
+    a1 = _run(1, True, str(tmp_path), "acc1", algo)[0]
+    a2 = _run(2, True, str(tmp_path), "acc2", algo)
+    assert np.array_equal(a2[0], a1) and np.array_equal(a2[1], a1)
+    monkeypatch.setenv("CBM_TEST_ACCUM", "1")
+    b1 = _run(1, True, str(tmp_path), "acc0", algo)[0]
+    assert np.isfinite(a1).all() and not np.array_equal(a1, b1)
