@@ -114,6 +114,9 @@ def parse_args(argv=None, algo="ppo"):
 def finalize(args, world_size=1, rank=0):
     """Derived fields and the reference's assertions (ppo:411-430)."""
     n_actor_dev, n_learner = len(args.actor_device_ids), len(args.learner_device_ids)
+    if getattr(args, "network", "impala_resnet") == "impala_resnet" and (list(args.channels) != [16, 32, 32] or list(args.hiddens) != [256]):
+        # the HIP torso is specialised for the reference defaults (ppo:59-61); other widths would silently train a different net
+        raise SystemExit("--channels/--hiddens: only the reference defaults [16, 32, 32] / [256] are built into the HIP ResNet torso")
     args.local_batch_size = int(args.local_num_envs * args.num_steps * args.num_actor_threads * n_actor_dev)
     args.local_minibatch_size = int(args.local_batch_size // args.num_minibatches)
     assert args.local_num_envs % n_learner == 0, "local_num_envs must be divisible by len(learner_device_ids)"
