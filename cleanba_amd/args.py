@@ -55,6 +55,8 @@ class Args:
                                      # through the envpool API; "envpool": real envpool if installed
     num_actions: int = 18            # full_action_space=True (ppo:135)
     max_updates: int = 0             # stop early after this many updates (0 = total_timesteps)
+    eval_episodes: int = 10  # episodes of the post-training evaluation that follows --save-model (ppo:773-782)
+    eval_max_episode_steps: int = 0  # 0 = the env's own limit (27000 for Atari); smaller values bound smoke runs
     bf16_forward: bool = False  # build-only extension (reference is fp32): conv2/conv3/dense forward on bf16 MFMA, fp32 accumulate + fp32 returns (Nature-CNN)
     same_env_seed_all_ranks: bool = False  # testing aid: every process steps identical envs (then dp-N == dp-1 bitwise)
 

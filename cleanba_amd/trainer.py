@@ -345,6 +345,17 @@ def train(args, algo="ppo", engine_factory=None, on_update=None, rendezvous=None
         save_cleanrl_model(path, args, result["params"], args.num_actions, args.network)
         print(f"model saved to {path}")
         result["model_path"] = path
+        if engine_factory is None and args.eval_episodes > 0:   # ppo:773-785: 10 evaluation episodes logged as eval/episodic_return
+            from .envs import make_env as _mk
+            from .evals import evaluate
+            engine.close()
+            thunk = lambda env_id, seed, num_envs: _mk(env_id, seed, num_envs, backend="envpool" if args.env_backend == "envpool" else "host",
+                                                       num_actions=args.num_actions)
+            rets = evaluate(path, thunk, args.env_id, eval_episodes=args.eval_episodes, run_name=f"{run_name}-eval", network=args.network,
+                            max_episode_steps=args.eval_max_episode_steps or None)
+            for idx, r in enumerate(rets):
+                writer.add_scalar("eval/episodic_return", r, idx)
+            result["eval_returns"] = rets
     writer.close()
     engine.close()
     return result

@@ -229,3 +229,33 @@ def test_gradient_accumulation_update_matches_oracle(oracle, algo):
     assert np.abs(p_gpu - p_ora).max() <= 1e-5 * max(1.0, np.abs(p_ora).max())
     assert (k1 == k2).all()
     ctx.close()
+
+
+def test_save_model_then_evaluate_matches_oracle_replay(tmp_path, oracle):
+    # ppo:753-785: --save-model writes the .cleanrl_model and runs the evaluation loop (eval.py:13-82); replay it with the oracle
+    import os
+    from cleanba_amd.args import parse_args
+    from cleanba_amd.checkpoint import load_cleanrl_model
+    from cleanba_amd.envs import make_env
+    from cleanba_amd.trainer import train
+    os.chdir(str(tmp_path))
+    args = parse_args(["--local-num-envs", "8", "--num-actor-threads", "1", "--num-steps", "8", "--env-backend", "device", "--network", "nature",
+                       "--total-timesteps", "128", "--save-model", "--eval-episodes", "2", "--eval-max-episode-steps", "48"], "ppo")
+    res = train(args, "ppo")
+    assert os.path.exists(res["model_path"]) and len(res["eval_returns"]) == 2
+    _, params = load_cleanrl_model(res["model_path"], 18, "nature")
+    assert np.array_equal(params, res["params"])
+    envs = make_env(args.env_id, 1, 1, backend="host")()
+    key = prng.split(prng.prng_key(1), 4)[0]
+    want = []
+    for ep in range(2):
+        obs, ret = envs.reset(), 0.0
+        for _ in range(48):
+            logits, _ = oracle.nature_forward(params, 18, obs, ksplit=14)
+            a, _, key = oracle.sample_actions(logits, key)
+            obs, _, _, info = envs.step(a)
+            ret += float(info["reward"][0])
+            if int(info["terminated"].sum()) + int(info["TimeLimit.truncated"].sum()) >= 1:
+                break
+        want.append(ret)
+    assert res["eval_returns"] == want
