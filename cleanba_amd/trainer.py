@@ -27,24 +27,29 @@ from .envs import make_env
 
 
 class JsonlWriter:
-    """Minimal stand-in for tensorboardX.SummaryWriter (not installed): same add_scalar/add_text calls,
-    one JSON line per scalar under runs/{run_name}/scalars.jsonl."""
+    """Stand-in for tensorboardX.SummaryWriter (not installed): same add_scalar/add_text calls.  Every scalar goes to a TensorBoard
+    event file (cleanba_amd.tb) AND to runs/{run_name}/scalars.jsonl (one JSON line each, greppable)."""
 
     def __init__(self, logdir):
+        from .tb import SummaryWriter
         os.makedirs(logdir, exist_ok=True)
         self.f = open(os.path.join(logdir, "scalars.jsonl"), "a")
+        self.tb = SummaryWriter(logdir)
         self.lock = threading.Lock()
 
     def add_scalar(self, tag, value, step):
         with self.lock:
             self.f.write(json.dumps({"tag": tag, "value": float(value), "step": int(step), "t": time.time()}) + "\n")
+        self.tb.add_scalar(tag, value, step)
 
     def add_text(self, tag, text):
         with self.lock:
             self.f.write(json.dumps({"tag": tag, "text": text}) + "\n")
+        self.tb.add_text(tag, text)
 
     def close(self):
         self.f.close()
+        self.tb.close()
 
 
 def make_config(args, algo):
