@@ -114,7 +114,7 @@ static int dalloc(Tp** p, size_t n) {
   return 0;
 }
 
-extern "C" int cbm_ctx_create(const cbm_config* cfg, cbm_ctx** out) {
+static int ctx_create_impl(const cbm_config* cfg, cbm_ctx** out, cbm_ctx** partial) {
   if (!cfg || cfg->abi_version != CBM_ABI_VERSION) { cbm_set_error("bad config / abi version"); return -1; }
   if (cfg->network != CBM_NET_NATURE && cfg->network != CBM_NET_IMPALA_RESNET) { cbm_set_error("unknown network kind %d", cfg->network); return -2; }
   if (cfg->num_actor_slots < 1 || cfg->num_actor_slots > MAX_SLOTS || cfg->ring_depth < 2 || cfg->ring_depth > MAX_RING) {
@@ -125,21 +125,22 @@ extern "C" int cbm_ctx_create(const cbm_config* cfg, cbm_ctx** out) {
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { cbm_set_error("no HIP device visible: libcleanba_mi needs an MI355X"); return -3; }
   CBM_HIP(hipSetDevice(cfg->device));
   cbm_ctx* c = new cbm_ctx();
+  *partial = c;   // the wrapper releases whatever was allocated if anything below fails
   c->cfg = *cfg;
   c->A = cfg->num_actions; c->E = cfg->local_num_envs; c->S = cfg->num_actor_slots;
   c->Bdev = c->E * c->S; c->T = cfg->num_steps; c->T1 = c->T + 1;
   c->nmb = cfg->num_minibatches; c->epochs = is_ppo(c) ? cfg->update_epochs : 1;
   c->accum = cfg->grad_accum_steps > 1 ? cfg->grad_accum_steps : 1;
   c->nmicro = c->nmb * c->accum;   // micro-batches per epoch (ppo:607, impala:627)
-  if (c->Bdev > 1024) { cbm_set_error("local_num_envs*slots must be <= 1024 per GPU"); delete c; return -1; }
-  if (c->Bdev % c->nmb) { cbm_set_error("local_num_envs*slots must be divisible by num_minibatches (ppo:416-418)"); delete c; return -1; }
+  if (c->Bdev > 1024) { cbm_set_error("local_num_envs*slots must be <= 1024 per GPU"); return -1; }
+  if (c->Bdev % c->nmb) { cbm_set_error("local_num_envs*slots must be divisible by num_minibatches (ppo:416-418)"); return -1; }
   if (is_ppo(c) ? (c->T * c->Bdev) % c->nmicro : c->Bdev % c->nmicro) {
-    cbm_set_error("the batch does not split into num_minibatches*gradient_accumulation_steps = %d micro-batches", c->nmicro); delete c; return -1;
+    cbm_set_error("the batch does not split into num_minibatches*gradient_accumulation_steps = %d micro-batches", c->nmicro); return -1;
   }
   c->MB = is_ppo(c) ? (c->T * c->Bdev) / c->nmicro : c->T1 * (c->Bdev / c->nmicro);
   c->L = net_layout(cfg->network, c->A);
   if (c->L.flat % cfg->actor_dense_ksplit || (c->L.flat / cfg->actor_dense_ksplit) % 32) {
-    cbm_set_error("actor_dense_ksplit must cut the %d-wide flatten into multiples of 32 (Nature: 14, ResNet: 11)", c->L.flat); delete c; return -1;
+    cbm_set_error("actor_dense_ksplit must cut the %d-wide flatten into multiples of 32 (Nature: 14, ResNet: 11)", c->L.flat); return -1;
   }
   c->P = c->L.total;
   const size_t P = (size_t)c->P, B = (size_t)c->Bdev, T1 = (size_t)c->T1;
@@ -191,6 +192,17 @@ extern "C" int cbm_ctx_create(const cbm_config* cfg, cbm_ctx** out) {
   return 0;
 }
 
+extern "C" int cbm_ctx_destroy(cbm_ctx* c);
+extern "C" int cbm_ctx_create(const cbm_config* cfg, cbm_ctx** out) {
+  cbm_ctx* partial = nullptr;
+  const int rc = ctx_create_impl(cfg, out, &partial);
+  if (rc != 0 && partial) {   // no leaks on a failed create (device memory of a half-built 9 GB ResNet workspace matters)
+    const std::string msg = cbm_last_error();
+    cbm_ctx_destroy(partial);
+    cbm_set_error("%s", msg.c_str());
+  }
+  return rc;
+}
 extern "C" int cbm_ctx_destroy(cbm_ctx* c) {
   if (!c) return 0;
   hipSetDevice(c->cfg.device);
