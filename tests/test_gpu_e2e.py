@@ -259,3 +259,20 @@ def test_save_model_then_evaluate_matches_oracle_replay(tmp_path, oracle):
                 break
         want.append(ret)
     assert res["eval_returns"] == want
+
+
+@pytest.mark.parametrize("algo", ["ppo", "impala"])
+def test_host_env_loop_equals_device_env_loop(tmp_path, algo):
+    # the envpool-style loop (cbm_actor_step_host / record_host / commit(next_obs), ppo:308-375, impala:351-416) against the device
+    # env: the two envs are byte-identical twins, so the whole run must agree bit for bit
+    import os
+    from cleanba_amd.args import parse_args
+    from cleanba_amd.trainer import train
+    os.chdir(str(tmp_path))
+    out = {}
+    for backend in ("device", "host"):
+        args = parse_args(["--local-num-envs", "8", "--num-actor-threads", "2", "--num-steps", "8", "--env-backend", backend, "--network", "nature",
+                           "--total-timesteps", str(3 * 8 * 2 * 8), "--log-frequency", "1000", "--update-epochs", "2"], algo)
+        out[backend] = train(args, algo)
+    assert out["host"]["updates"] == out["device"]["updates"] == 3
+    assert np.array_equal(out["host"]["params"], out["device"]["params"])
