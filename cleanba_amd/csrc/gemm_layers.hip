@@ -78,6 +78,16 @@ struct ConvFwd {
     return *reinterpret_cast<const float4*>(in + ((size_t)(s * IH + oh * ST + kh) * IW + ow * ST) * CI + rem);
   }
   __device__ float4 load_b(int r, int y, int, int) const { return *reinterpret_cast<const float4*>(W + (size_t)r * CO + y); }
+  // DMA-staged variant (igemm_dma_kernel): plain addresses, nothing to zero-fill in a VALID conv.  Measured slower for the convs
+  // (conv3 148 -> 194 us: the 16-byte-stride A fragments cost more than the saved staging), faster for the dense layer (155 -> 136 us).
+  static constexpr bool DMA_OK = false;
+  __device__ const float* a_ptr(int m, int r, int) const {
+    m = min(m, M - 1);
+    const int s = m / (OH * OW), p = m - s * (OH * OW), oh = p / OW, ow = p - oh * OW;
+    const int kh = r / (KW * CI), rem = r - kh * (KW * CI);
+    return in + ((size_t)(s * IH + oh * ST + kh) * IW + ow * ST) * CI + rem;
+  }
+  __device__ const float* b_ptr(int r, int y, int) const { return W + (size_t)r * CO + y; }
   __device__ void store(int m, int n, float v, int, int) const {
     if (m < M) out[(size_t)m * CO + n] = relu(v + bias[n]);
   }
@@ -103,6 +113,9 @@ struct DenseFwd {
     const bool ok = r < rhi && y < N;
     return f4sel(ok, *reinterpret_cast<const float4*>(W + (size_t)min(r, K - 1) * N + min(y, N - 4)));
   }
+  static constexpr bool DMA_OK = !PRE_RELU;   // needs seg % BR == 0 and N % BY == 0 (checked at the call site)
+  __device__ const float* a_ptr(int m, int r, int) const { return A + (size_t)min(m, M - 1) * K + r; }
+  __device__ const float* b_ptr(int r, int y, int) const { return W + (size_t)r * N + y; }
   __device__ void store(int m, int n, float v, int z, int) const {
     if (m >= M || n >= N) return;
     if (SPLIT) out[((size_t)z * M + m) * N + n] = v;
@@ -427,9 +440,25 @@ static inline void plaunch(NatureWs& ws, int kid, const P& p, int nz, hipStream_
   if (on) { hipEventRecord(pf->ev[2 * pf->n + 1], st); pf->n += 1; }
 }
 // forward GEMMs: fp32 chain (default) or the bf16-MFMA variant when the context was created with forward_bf16
+#ifndef IGEMM_USE_DMA
+#define IGEMM_USE_DMA 1
+#endif
 template <class P>
 static inline void plaunch_fwd(NatureWs& ws, int kid, const P& p, int nz, hipStream_t st) {
-  if (!ws.bf16_fwd) { plaunch(ws, kid, p, nz, st); return; }
+  if (!ws.bf16_fwd) {
+    if constexpr (P::DMA_OK) {
+      if (IGEMM_USE_DMA && p.X() >= 1024) {   // learner-size grids: tiles staged by the load unit (igemm_dma_kernel), same bits
+        CbmProf* pf = ws.prof;
+        const bool on = pf && pf->sel == kid && pf->n < CBM_PROF_MAX;
+        if (on) hipEventRecord(pf->ev[2 * pf->n], st);
+        igemm_dma_launch(p, nz, st);
+        if (on) { hipEventRecord(pf->ev[2 * pf->n + 1], st); pf->n += 1; }
+        return;
+      }
+    }
+    plaunch(ws, kid, p, nz, st);
+    return;
+  }
   CbmProf* pf = ws.prof;
   const bool on = pf && pf->sel == kid && pf->n < CBM_PROF_MAX;
   if (on) hipEventRecord(pf->ev[2 * pf->n], st);

@@ -242,6 +242,128 @@ static inline void igemm_launch(const P& p, int nsplit, hipStream_t stream) {
   hipLaunchKernelGGL(igemm_kernel<P>, grid, dim3(256), 0, stream, p);
 }
 
+// ------------------------------------------------------------------------------------------------ DMA-staged variant
+// Same math and the same k-ascending accumulation order as igemm_kernel (bit-identical results), but the LDS tiles are filled by
+// global_load_lds_dwordx4: the load unit writes 16 bytes per lane straight into LDS (wave-uniform base + lane*16) — no staging
+// VGPRs, no ds_write instructions, no select/convert VALU work between the global load and the tile.  That fixes the tile layouts:
+//   A[r/4][x][4]   one instruction = 64 rows x of one k-quad (the functor returns the address of A[x][r..r+3])
+//   B[r][y]        one instruction = 64 consecutive 16-byte pieces of the row-major [BR][BY] tile
+// A fragments are ds_read_b32 at a 16-byte lane stride (4-way bank conflict; a ds_read_b128 + v_permlane32_swap variant was not
+// faster — tools/ubench/gemm_dma.hip).  Usable when the gather needs no zero fill or conversion: P::DMA_OK, a_ptr(), b_ptr().
+static __device__ __forceinline__ void ig_glds16(const float* g_lane, float* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g_lane, (__attribute__((address_space(3))) void*)lds_wave_base, 16,
+                                   0, 0);
+}
+
+template <class P>
+__global__ __launch_bounds__(256, P::Tile::MINW) void igemm_dma_kernel(const P p) {
+  using T = typename P::Tile;
+  constexpr int BX = T::BX, BY = T::BY, BR = T::BR, WX = T::WX, WY = T::WY;
+  static_assert(P::DMA_OK && !P::A_RX && !P::B_YR && !P::BIAS_GRAD && P::NCLS == 1 && BX % 64 == 0 && BY % 4 == 0 && BR % 4 == 0, "DMA tile shape");
+  constexpr int TM = BX / WX / 32, TN = BY / WY / 32;
+  constexpr int ASZ = BR * BX, BSZ = BR * BY, PB = BY;
+  constexpr int NIA = (BR / 4) * (BX / 64), NIB = BR * BY / 4 / 64;     // wave-instructions per tile
+  static_assert(NIA % 4 == 0 && NIB % 4 == 0, "every wave issues the same number of DMA instructions");
+  __shared__ __attribute__((aligned(16))) float smem[2 * ASZ + 2 * BSZ];
+  float* As = smem;
+  float* Bs = smem + 2 * ASZ;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, h = lane >> 5;
+  const int wx = wave / WY, wy = wave % WY;
+  int bx = blockIdx.x;
+  {
+    const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = bx & 7, k = bx >> 3;
+    bx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+  }
+  const int x0 = bx * BX, y0 = (int)blockIdx.y * BY, z = blockIdx.z;
+  int rlo, rhi;
+  p.r_range(z, rlo, rhi);
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+  auto dma = [&](int r0, int buf) {
+    float* A_ = As + buf * ASZ;
+    float* B_ = Bs + buf * BSZ;
+#pragma unroll
+    for (int i = 0; i < NIA / 4; ++i) {
+      const int t = wave + 4 * i, rq = t / (BX / 64), xb = t % (BX / 64);
+      ig_glds16(p.a_ptr(x0 + xb * 64 + lane, r0 + 4 * rq, 0), A_ + (rq * BX + xb * 64) * 4);
+    }
+#pragma unroll
+    for (int i = 0; i < NIB / 4; ++i) {
+      const int t = wave + 4 * i, u = t * 64 + lane, k = u / (BY / 4), n4 = u % (BY / 4);
+      ig_glds16(p.b_ptr(r0 + k, y0 + 4 * n4, 0), B_ + t * 64 * 4);
+    }
+  };
+
+  dma(rlo, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int buf = 0;
+  for (int r0 = rlo; r0 < rhi; r0 += BR) {
+    if (r0 + BR < rhi) dma(r0 + BR, buf ^ 1);
+    const float* A_ = As + buf * ASZ;
+    const float* B_ = Bs + buf * BSZ;
+    {
+      constexpr int G = (BR / 2) % 4 == 0 ? 4 : 2, NG = BR / 2 / G;
+      float fa[2][G][TM], fb[2][G][TN];
+      auto frag = [&](int g, int set) {
+#pragma unroll
+        for (int q = 0; q < G; ++q) {
+          const int rr = 2 * (g * G + q);
+#pragma unroll
+          for (int i = 0; i < TM; ++i) fa[set][q][i] = A_[((rr >> 2) * BX + wx * (BX / WX) + i * 32 + li) * 4 + (rr & 3) + h];
+#pragma unroll
+          for (int j = 0; j < TN; ++j) fb[set][q][j] = B_[(rr + h) * PB + wy * (BY / WY) + j * 32 + li];
+        }
+      };
+      frag(0, 0);
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        if (g + 1 < NG) frag(g + 1, (g + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < G; ++q)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g & 1][q][i], fb[g & 1][q][j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    buf ^= 1;
+  }
+
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int y = y0 + wy * (BY / WY) + j * 32 + li;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
+        p.store(x0 + wx * (BX / WX) + i * 32 + row, y, acc[i][j][e], z, 0);
+      }
+    }
+}
+
+template <class P>
+static inline void igemm_dma_launch(const P& p, int nsplit, hipStream_t stream) {
+  using T = typename P::Tile;
+  dim3 grid((p.X() + T::BX - 1) / T::BX, (p.Y() + T::BY - 1) / T::BY, nsplit);
+  hipLaunchKernelGGL(igemm_dma_kernel<P>, grid, dim3(256), 0, stream, p);
+}
+
 // ------------------------------------------------------------------------------------------------ bf16 forward variant
 // Build-only extension (the reference is fp32 everywhere): `cbm_config.forward_bf16` runs the forward GEMMs of conv2 /
 // conv3 / dense on v_mfma_f32_32x32x16_bf16 — operands rounded to bf16 (RNE, v_cvt_pk_bf16_f32) when the tile is staged,
