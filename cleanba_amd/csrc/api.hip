@@ -544,20 +544,24 @@ static int learner_epoch_perm(cbm_ctx* c, uint32_t key[2]) {
   return 0;
 }
 
+// Small minibatches (<= 1024 frames, e.g. IMPALA's default 21 x 30) leave the 3136 -> 512 dense with ~80 blocks and a 98-chunk
+// serial K loop (119 us at 630 frames, 17 TF); they use the actor's K split instead, which also makes the learner's logits the
+// actor's bit for bit.  Large minibatches keep the single chain.
+static int learner_ksplit(const cbm_ctx* c) { return c->MB <= 1024 ? c->cfg.actor_dense_ksplit : 1; }
 extern "C" int cbm_learner_minibatch_grad(cbm_ctx* c, int32_t epoch, int32_t mb) {
   CBM_HIP(hipSetDevice(c->cfg.device));
   RingEntry& R = cur_ring(c);
   float* stats = c->stats_dev + (size_t)(epoch * c->nmicro + mb) * 8;
   if (is_ppo(c)) {
     const int32_t* idx = c->perm + (size_t)mb * c->MB;
-    nature_forward(c->L, c->params, R.obs, idx, c->MB, 1, c->lws, c->lstream);
+    nature_forward(c->L, c->params, R.obs, idx, c->MB, learner_ksplit(c), c->lws, c->lstream);
     launch_ppo_loss(c->lws.logits, c->lws.value, c->MB, c->A, idx, R.actions, R.logprobs, c->adv, c->target, c->cfg.clip_coef, c->cfg.ent_coef,
                     c->cfg.vf_coef, c->lws.dzv, c->loss_partials, stats, c->lstream);
     nature_backward(c->L, c->params, R.obs, idx, c->MB, c->lws, c->grads, c->lstream);
   } else {
     const int Bm = c->Bdev / c->nmicro;
     const int32_t* idx = c->impala_idx + (size_t)mb * c->MB;
-    nature_forward(c->L, c->params, R.obs, idx, c->MB, 1, c->lws, c->lstream);
+    nature_forward(c->L, c->params, R.obs, idx, c->MB, learner_ksplit(c), c->lws, c->lstream);
     launch_impala_loss(c->lws.logits, c->lws.value, R.logits, R.actions, R.rewards, R.dones, R.firststeps, c->T1, Bm, c->A, mb * Bm, c->Bdev,
                        c->cfg.gamma, c->cfg.vf_coef, c->cfg.ent_coef, c->lws.dzv, c->loss_partials, stats, c->lstream);
     nature_backward(c->L, c->params, R.obs, idx, c->MB, c->lws, c->grads, c->lstream);
