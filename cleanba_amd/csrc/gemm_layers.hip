@@ -10,6 +10,16 @@
 // gradients of conv2/conv3 outputs live in zero-bordered 11x11 buffers so that both dgrads are
 // plain VALID correlations (stride-2 conv2 as 4 parity classes).
 #include "cbm_internal.h"
+// Sibling-aware tile orders (igemm.h ORDER 1/2) were measured on MI355X and are OFF: the weight-gradient GEMMs got slower with them
+// (conv3 wgrad 161 -> 201 us, conv2 wgrad 251 -> 293 us), conv2 dgrad did not move.  The redundant operand fetches of sibling tiles
+// that FETCH_SIZE reports are Infinity-Cache hits when all XCDs walk the same rows at the same time; giving each XCD its own rows
+// removes that sharing and buys nothing in HBM traffic.  Build with -DIGEMM_ORDER_1=1 -DIGEMM_ORDER_2=2 to reproduce.
+#ifndef IGEMM_ORDER_1
+#define IGEMM_ORDER_1 0
+#endif
+#ifndef IGEMM_ORDER_2
+#define IGEMM_ORDER_2 0
+#endif
 #include "igemm.h"
 #include <algorithm>
 #include <type_traits>
@@ -238,6 +248,7 @@ struct Conv3Dgrad {
 template <class TileT>
 struct Conv2Dgrad {
   using Tile = TileT;
+  static constexpr int ORDER = IGEMM_ORDER_2;   // sibling tiles share an XCD's L2 (igemm.h)
   static constexpr bool A_RX = false, B_YR = true, BIAS_GRAD = false;
   static constexpr int NCLS = 4;
   const float* dypad; const float* W; const float* act1; float* dact1; int M;  // M = S*100
@@ -294,6 +305,7 @@ struct Conv1Wgrad {
 template <class TileT, int KH, int KW, int ST, int CI, int CO, int IH, int IW, int OH, int OW, int PADO>
 struct ConvWgrad {  // dY lives in a zero-bordered [S][OH+2*PADO... = 11][11][CO] buffer
   using Tile = TileT;
+  static constexpr int ORDER = IGEMM_ORDER_1;   // sibling tiles share an XCD's L2 (igemm.h)
   static constexpr bool A_RX = true, B_YR = false, BIAS_GRAD = true;
   static constexpr int NCLS = 1;
   static constexpr int KX = KH * KW * CI;
@@ -324,6 +336,7 @@ struct ConvWgrad {  // dY lives in a zero-bordered [S][OH+2*PADO... = 11][11][CO
 template <class TileT, bool PRE_RELU = false>
 struct MatWgrad {
   using Tile = TileT;
+  static constexpr int ORDER = IGEMM_ORDER_1;   // sibling tiles share an XCD's L2 (igemm.h)
   static constexpr bool A_RX = true, B_YR = false, BIAS_GRAD = true;
   static constexpr int NCLS = 1;
   const float* A; const float* G; float* part; float* bpart; int M, XK, YN, ldg, rps;

@@ -33,6 +33,15 @@ struct IgemmTile {
   static_assert(BX_ % (32 * WX_) == 0 && BY_ % (32 * WY_) == 0 && BR_ % 4 == 0, "tile shape");
 };
 
+// Optional P::ORDER (block -> tile order; blocks are dealt to the 8 XCDs round-robin by linear id, each XCD has its own L2):
+//   0 (default)  every XCD gets one contiguous run of x-tiles (neighbouring im2col tiles share input rows)
+//   1            every XCD gets a contiguous run of (z, y, x) tiles with x fastest: the x/y tiles of one reduction slice z are
+//                siblings that re-read the same operand rows (weight-gradient GEMMs: each of the 9 tap tiles of a 3x3 wgrad reads
+//                the whole dY slice) and now share an L2 instead of fetching it 8 times
+//   2            like 1 with the NCLS parity classes fastest (conv2 dgrad: the 4 classes of a pixel tile read the same dY rows)
+template <class P, class = void> struct igemm_order { static constexpr int value = 0; };
+template <class P> struct igemm_order<P, decltype((void)P::ORDER)> { static constexpr int value = P::ORDER; };
+
 // P must provide:
 //   using Tile = IgemmTile<...>;  static constexpr bool A_RX, B_YR, BIAS_GRAD;  static constexpr int NCLS;
 //   int X() const, Y() const;  void r_range(int z, int& lo, int& hi) const;
@@ -60,17 +69,32 @@ __global__ __launch_bounds__(256, P::Tile::MINW) void igemm_kernel(const P p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, h = lane >> 5;
   const int wx = wave / WY, wy = wave % WY;
-  const int cls = P::NCLS > 1 ? (int)(blockIdx.y % P::NCLS) : 0;
-  // XCD-aware tile order: block b runs on XCD b % 8 (each XCD has its own L2), and neighbouring x-tiles of an
-  // im2col share input rows; give every XCD one contiguous run of x-tiles (bijective for any grid size).
-  int bx = blockIdx.x;
-  {
-    const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = bx & 7, k = bx >> 3;
-    bx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+  constexpr int ORDER = igemm_order<P>::value;
+  int cls, x0, y0, z;
+  if constexpr (ORDER == 0) {
+    cls = P::NCLS > 1 ? (int)(blockIdx.y % P::NCLS) : 0;
+    // XCD-aware tile order: block b runs on XCD b % 8 (each XCD has its own L2), and neighbouring x-tiles of an
+    // im2col share input rows; give every XCD one contiguous run of x-tiles (bijective for any grid size).
+    int bx = blockIdx.x;
+    {
+      const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = bx & 7, k = bx >> 3;
+      bx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    }
+    x0 = bx * BX;
+    y0 = (P::NCLS > 1 ? (int)(blockIdx.y / P::NCLS) : (int)blockIdx.y) * BY;
+    z = blockIdx.z;
+  } else {
+    // linear id -> position in XCD-major order (same bijection as above, over the whole grid), then decode with siblings adjacent
+    const int gx = gridDim.x, gy = gridDim.y, nb = gx * gy * (int)gridDim.z;
+    const int lin = (int)blockIdx.x + gx * ((int)blockIdx.y + gy * (int)blockIdx.z);
+    const int q = nb >> 3, r = nb & 7, xcd = lin & 7, k = lin >> 3;
+    int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    if constexpr (ORDER == 2) { cls = t % P::NCLS; t /= P::NCLS; } else { cls = 0; }
+    const int gyt = ORDER == 2 ? gy / P::NCLS : gy;
+    x0 = (t % gx) * BX; t /= gx;
+    y0 = (t % gyt) * BY;
+    z = t / gyt;
   }
-  const int x0 = bx * BX;
-  const int y0 = (P::NCLS > 1 ? (int)(blockIdx.y / P::NCLS) : (int)blockIdx.y) * BY;
-  const int z = blockIdx.z;
   int rlo, rhi;
   p.r_range(z, rlo, rhi);
 
@@ -193,7 +217,7 @@ __global__ __launch_bounds__(256, P::Tile::MINW) void igemm_kernel(const P p) {
       }
     }
 #endif
-    if constexpr (P::BIAS_GRAD) if (blockIdx.x == 0) {
+    if constexpr (P::BIAS_GRAD) if (x0 == 0) {
       // column sums of the staged dY tile -> bias gradient partial (fixed order per thread)
       constexpr int PARTS = 256 / BY;
       const int yy = tid % BY, part = tid / BY;
@@ -222,7 +246,7 @@ __global__ __launch_bounds__(256, P::Tile::MINW) void igemm_kernel(const P p) {
       }
     }
 
-  if constexpr (P::BIAS_GRAD) if (blockIdx.x == 0) {
+  if constexpr (P::BIAS_GRAD) if (x0 == 0) {
     constexpr int PARTS = 256 / BY;
     float* red = smem + 2 * ASZ + 2 * BSZ;
     red[tid] = bsum;
