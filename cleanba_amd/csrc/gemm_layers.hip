@@ -489,8 +489,14 @@ static inline void plaunch_fn(NatureWs& ws, int kid, hipStream_t st, F&& launch)
 using T128x32 = IgemmTile<128, 32, 32, 4, 1>;
 using T128x32k16 = IgemmTile<128, 32, 16, 4, 1>;
 using T256x32 = IgemmTile<256, 32, 32, 4, 1>;
-using T128x64 = IgemmTile<128, 64, 32, 2, 2>;
-using T64x64 = IgemmTile<64, 64, 32, 2, 2>;
+#ifndef BR_128x64
+#define BR_128x64 16
+#endif
+#ifndef BR_64x64
+#define BR_64x64 32
+#endif
+using T128x64 = IgemmTile<128, 64, BR_128x64, 2, 2>;
+using T64x64 = IgemmTile<64, 64, BR_64x64, 2, 2>;
 
 #include "resnet_layers.inc"
 
