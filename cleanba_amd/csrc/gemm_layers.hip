@@ -398,7 +398,10 @@ static int round_up(int a, int b) { return ceil_div(a, b) * b; }
 
 // rows of the reduction handled by one split block (multiples of BR = 32)
 static const int RPS_C1 = 1600, RPS_C2 = 1280, RPS_C3 = 1664, RPS_HEADS = 128;
-static int dense_wgrad_splits(int B) { return B >= 2048 ? 2 : 1; }
+#ifndef DENSE_WGRAD_NZ
+#define DENSE_WGRAD_NZ 2
+#endif
+static int dense_wgrad_splits(int B) { return B >= 2048 ? DENSE_WGRAD_NZ : 1; }
 
 static int rn_ws_alloc(NatureWs& ws, int maxB, bool with_grad, int dense_ksplit_small);
 int nature_ws_alloc(NatureWs& ws, int maxB, bool with_grad, int dense_ksplit_small, int kind) {
@@ -497,6 +500,15 @@ using T256x32 = IgemmTile<256, 32, 32, 4, 1>;
 #endif
 using T128x64 = IgemmTile<128, 64, BR_128x64, 2, 2>;
 using T64x64 = IgemmTile<64, 64, BR_64x64, 2, 2>;
+#ifndef TILE_C2F
+#define TILE_C2F T64x64
+#endif
+#ifndef TILE_C3W
+#define TILE_C3W T64x64
+#endif
+#ifndef TILE_DW
+#define TILE_DW T64x64
+#endif
 
 #include "resnet_layers.inc"
 
@@ -516,7 +528,7 @@ void nature_forward(const NatureLayout& L, const float* P, const uint8_t* obs, c
     ConvFwd<T64x64, 3, 3, 1, 64, 64, 9, 9, 7, 7> p3{ws.act2, P + L.w[2], P + L.b[2], ws.act3, B * 49};
     plaunch_fwd(ws, K_CONV3_FWD, p3, 1, st);
   } else {
-    ConvFwd<T64x64, 4, 4, 2, 32, 64, 20, 20, 9, 9> p2{ws.act1, P + L.w[1], P + L.b[1], ws.act2, B * 81};
+    ConvFwd<TILE_C2F, 4, 4, 2, 32, 64, 20, 20, 9, 9> p2{ws.act1, P + L.w[1], P + L.b[1], ws.act2, B * 81};
     plaunch_fwd(ws, K_CONV2_FWD, p2, 1, st);
     ConvFwd<T128x64, 3, 3, 1, 64, 64, 9, 9, 7, 7> p3{ws.act2, P + L.w[2], P + L.b[2], ws.act3, B * 49};
     plaunch_fwd(ws, K_CONV3_FWD, p3, 1, st);
@@ -553,7 +565,7 @@ void nature_backward(const NatureLayout& L, const float* P, const uint8_t* obs, 
     plaunch(ws, K_DENSE_DGRAD, pd, 1, st);
     const int nz = dense_wgrad_splits(B);
     const int rps = round_up(ceil_div(B, nz), 32);
-    MatWgrad<T64x64> pw{ws.act3, ws.dhid, ws.wg_part, ws.bias_part, B, 3136, 512, 512, rps};
+    MatWgrad<TILE_DW> pw{ws.act3, ws.dhid, ws.wg_part, ws.bias_part, B, 3136, 512, 512, rps};
     plaunch(ws, K_DENSE_WGRAD, pw, nz, st);
     launch_reduce(ws.wg_part, nz, 3136 * 512, 512, 0, A, grads + L.w[3], (float*)nullptr, st);
     launch_reduce(ws.bias_part, nz, 512, 512, 0, A, grads + L.b[3], (float*)nullptr, st);
@@ -563,7 +575,7 @@ void nature_backward(const NatureLayout& L, const float* P, const uint8_t* obs, 
     Conv3Dgrad<T128x64> pd{ws.dact3pad, P + L.w[2], ws.act2, ws.dact2pad, B * 81};
     plaunch(ws, K_CONV3_DGRAD, pd, 1, st);
     const int M = B * 49, nz = ceil_div(M, RPS_C3);
-    ConvWgrad<T64x64, 3, 3, 1, 64, 64, 9, 9, 7, 7, 2> pw{ws.act2, ws.dact3pad, ws.wg_part, ws.bias_part, M, RPS_C3};
+    ConvWgrad<TILE_C3W, 3, 3, 1, 64, 64, 9, 9, 7, 7, 2> pw{ws.act2, ws.dact3pad, ws.wg_part, ws.bias_part, M, RPS_C3};
     plaunch(ws, K_CONV3_WGRAD, pw, nz, st);
     launch_reduce(ws.wg_part, nz, 576 * 64, 64, 0, A, grads + L.w[2], (float*)nullptr, st);
     launch_reduce(ws.bias_part, nz, 64, 64, 0, A, grads + L.b[2], (float*)nullptr, st);
