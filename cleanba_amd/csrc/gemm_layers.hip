@@ -500,6 +500,11 @@ using T256x32 = IgemmTile<256, 32, 32, 4, 1>;
 #endif
 using T128x64 = IgemmTile<128, 64, BR_128x64, 2, 2>;
 using T64x64 = IgemmTile<64, 64, BR_64x64, 2, 2>;
+// actor-step (small batch) tiles: half the K chunk = half the LDS, so a block still finds room on CUs mostly held by learner blocks
+using T64x64k16 = IgemmTile<64, 64, 16, 2, 2>;
+#ifndef ACTOR_K16
+#define ACTOR_K16 1
+#endif
 #ifndef TILE_C2F
 #define TILE_C2F T64x64
 #endif
@@ -517,15 +522,24 @@ void nature_forward(const NatureLayout& L, const float* P, const uint8_t* obs, c
   if (L.kind == CBM_NET_IMPALA_RESNET) { resnet_forward(L, P, obs, idx, B, dense_ksplit, ws, st); return; }
   const bool small = B <= 512;
   if (small) {
+#if ACTOR_K16
+    Conv1Fwd<T128x32k16> p{obs, idx, P + L.w[0], P + L.b[0], ws.act1, B * 400};
+#else
     Conv1Fwd<T128x32> p{obs, idx, P + L.w[0], P + L.b[0], ws.act1, B * 400};
+#endif
     plaunch(ws, K_CONV1_FWD, p, 1, st);
   } else {
     plaunch_fn(ws, K_CONV1_FWD, st, [&] { launch_conv1_fwd_frames(obs, idx, P + L.w[0], P + L.b[0], ws.act1, B, st); });
   }
   if (small) {
-    ConvFwd<T64x64, 4, 4, 2, 32, 64, 20, 20, 9, 9> p2{ws.act1, P + L.w[1], P + L.b[1], ws.act2, B * 81};
+#if ACTOR_K16
+    using TS = T64x64k16;
+#else
+    using TS = T64x64;
+#endif
+    ConvFwd<TS, 4, 4, 2, 32, 64, 20, 20, 9, 9> p2{ws.act1, P + L.w[1], P + L.b[1], ws.act2, B * 81};
     plaunch_fwd(ws, K_CONV2_FWD, p2, 1, st);
-    ConvFwd<T64x64, 3, 3, 1, 64, 64, 9, 9, 7, 7> p3{ws.act2, P + L.w[2], P + L.b[2], ws.act3, B * 49};
+    ConvFwd<TS, 3, 3, 1, 64, 64, 9, 9, 7, 7> p3{ws.act2, P + L.w[2], P + L.b[2], ws.act3, B * 49};
     plaunch_fwd(ws, K_CONV3_FWD, p3, 1, st);
   } else {
     ConvFwd<TILE_C2F, 4, 4, 2, 32, 64, 20, 20, 9, 9> p2{ws.act1, P + L.w[1], P + L.b[1], ws.act2, B * 81};
@@ -534,7 +548,11 @@ void nature_forward(const NatureLayout& L, const float* P, const uint8_t* obs, c
     plaunch_fwd(ws, K_CONV3_FWD, p3, 1, st);
   }
   if (dense_ksplit > 1) {
+#if ACTOR_K16
+    DenseFwd<T64x64k16, true> pd{ws.act3, P + L.w[3], P + L.b[3], ws.dense_part, B, 3136, 512, 3136 / dense_ksplit};
+#else
     DenseFwd<T64x64, true> pd{ws.act3, P + L.w[3], P + L.b[3], ws.dense_part, B, 3136, 512, 3136 / dense_ksplit};
+#endif
     plaunch_fwd(ws, K_DENSE_FWD, pd, dense_ksplit, st);
     hipLaunchKernelGGL(dense_reduce_kernel, dim3(ceil_div(B * 512, 256)), dim3(256), 0, st, ws.dense_part, P + L.b[3], ws.hid, B, 512,
                        dense_ksplit);
