@@ -225,6 +225,93 @@ static void rn_conv_launch(const void* in, const int32_t* idx, const float* W, c
   if (hipError_t e = hipGetLastError(); e != hipSuccess) fprintf(stderr, "rn_conv launch failed: %s (threads %d, lds %zu)\n", hipGetErrorString(e), G::NTHR, lds);
 }
 
+// ---- first conv of the torso fused with its max_pool(3,3) stride 2 SAME (ppo:158-166): the 84x84x16 conv output (1.7 GB per
+// 3840-frame minibatch) never reaches HBM.  A block produces PR pooled rows: it convolves the 2*PR+1 rows they cover into LDS
+// (+bias), then pools them (same (kh,kw) scan, first max wins -> same arg-max bytes as rn_pool_fwd_kernel).  One conv row per
+// strip is computed twice (7 rows for 6 unique); nothing downstream reads the un-pooled tensor (pool backward uses the arg-max).
+template <int PR>
+struct RnPool0Geom {
+  static constexpr int H = 84, HP = 42, CO = 16, R = 2 * PR + 1;
+  using G = RnGeom<4, 16, 84, R, 1, 4>;
+  static constexpr int STRIPS = (HP + PR - 1) / PR;
+  static constexpr int CV = R * H * CO;                           // conv rows held in LDS
+  static constexpr int LDS_FLOATS = G::SLAB + G::WSZ + CV;
+};
+template <int PR>
+__global__ __launch_bounds__(256, 2) void rn_conv0_pool_kernel(const uint8_t* obs, const int32_t* idx, const float* W, const float* bias, float* pooled,
+                                                               uint8_t* pidx, int B) {
+  using PG = RnPool0Geom<PR>;
+  using G = typename PG::G;
+  constexpr int H = 84, HP = 42, CO = 16, WP = G::WP, TP = G::TP, NTW = G::NTW, NT = G::NT, R = PG::R;
+  extern __shared__ __attribute__((aligned(16))) float rn_smem[];
+  float* slab = rn_smem;
+  float* Wl = rn_smem + G::SLAB;
+  float* cv = Wl + G::WSZ;                                        // [R][H][CO]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b0 = blockIdx.x / PG::STRIPS, p0 = (blockIdx.x % PG::STRIPS) * PR, y0 = 2 * p0;   // pad_lo = 0 for 84 -> 42
+  for (int v = tid; v < G::WSZ / 4; v += 256) reinterpret_cast<float4*>(Wl)[v] = reinterpret_cast<const float4*>(W)[v];
+  rn_stage_u8<G>(slab, obs, idx, b0, y0);
+  __syncthreads();
+  {
+    const int li = lane & 15, kq = lane >> 4;
+    rn_f32x4 acc[NTW];
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) acc[i] = rn_f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* abase = slab + (kq >> 1) * G::PL + (kq & 1) * G::PLH + wave * TP + li;
+    const float* bbase = Wl + kq * CO + li;
+#pragma unroll 1
+    for (int t = 0; t < 9; ++t) {
+      const int kh = (t * 11) >> 5, off = kh * WP + (t - 3 * kh);
+      const float bv = bbase[t * 4 * CO];
+      const float* ap = abase + off;
+#pragma unroll
+      for (int i = 0; i < NTW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[i * 4 * TP], bv, acc[i], 0, 0, 0);
+    }
+    const float bz = bias[li];
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
+      const int tile = wave + 4 * i;
+      if (tile >= NT) continue;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int q = tile * TP + 4 * kq + e;
+        const int orow = q / WP, c = q - orow * WP;
+        if (c < H && orow < R) cv[(orow * H + c) * CO + li] = acc[i][e] + bz;
+      }
+    }
+  }
+  __syncthreads();
+  // max_pool over the rows held in LDS
+  for (int i = tid; i < PR * HP * (CO / 4); i += 256) {
+    const int c4 = i % (CO / 4), ow = (i / (CO / 4)) % HP, ohl = i / ((CO / 4) * HP), oh = p0 + ohl;
+    if (oh >= HP) continue;
+    float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    uint32_t bi = 0;
+    for (int kh = 0; kh < 3; ++kh) for (int kw = 0; kw < 3; ++kw) {
+      const int ih = oh * 2 + kh, iw = ow * 2 + kw;
+      if (ih >= H || iw >= H) continue;
+      const float4 v = *reinterpret_cast<const float4*>(cv + ((ih - y0) * H + iw) * CO + 4 * c4);
+      const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (e[q] > best[q]) { best[q] = e[q]; bi = (bi & ~(0xffu << (8 * q))) | ((uint32_t)(kh * 3 + kw) << (8 * q)); }
+    }
+    const size_t o = (((size_t)(b0 * HP + oh) * HP + ow) * (CO / 4) + c4) * 4;
+    *reinterpret_cast<float4*>(pooled + o) = make_float4(best[0], best[1], best[2], best[3]);
+    *reinterpret_cast<uint32_t*>(pidx + o) = bi;
+  }
+}
+template <int PR>
+static void rn_conv0_pool_launch(const uint8_t* obs, const int32_t* idx, const float* W, const float* bias, float* pooled, uint8_t* pidx, int B,
+                                 hipStream_t st) {
+  using PG = RnPool0Geom<PR>;
+  constexpr size_t lds = (size_t)PG::LDS_FLOATS * sizeof(float);
+  static_assert(lds <= 160 * 1024, "conv0+pool strip exceeds LDS");
+  static bool attr = false;
+  if (!attr) { hipFuncSetAttribute((const void*)rn_conv0_pool_kernel<PR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+  hipLaunchKernelGGL((rn_conv0_pool_kernel<PR>), dim3(B * PG::STRIPS), dim3(256), lds, st, obs, idx, W, bias, pooled, pidx, B);
+}
+
 // dgrad as a forward conv: Wt[(jh,jw)][co][ci] = W[(2-jh,2-jw)][ci][co]   (all 14 convs that need a dgrad, one launch)
 struct RnFlipJob { int src, dst, ci, co; };
 struct RnFlipJobs { RnFlipJob j[14]; int n; };
@@ -263,12 +350,16 @@ struct RnWGeom {
   static int strips(int B) { return G::blocks(B); }
 };
 
-template <class WG, bool U8, bool PRE_RELU>
+// POOLB: dY is not read but rebuilt from the gradient of the pooled map (dy = dout [B][H/2][H/2][CO]) and the pool's arg-max bytes —
+// the max_pool backward of rn_pool_bwd_kernel (same (oh, ow) visiting order -> same bits) done while staging, so the un-pooled
+// gradient (1.7 GB per 3840-frame minibatch for the first conv) is never written or read.  Used for the 84 -> 42 pool (pad_lo = 0).
+template <class WG, bool U8, bool PRE_RELU, bool POOLB = false>
 __global__ __launch_bounds__(256, 2) void rn_wgrad_kernel(const void* in_, const int32_t* idx, const float* dy, float* part, float* bpart, int B,
-                                                       int nstrips) {
+                                                       int nstrips, const uint8_t* pidx = nullptr) {
   using G = typename WG::G;
   constexpr int H = WG::H, CI = WG::CI, CO = WG::CO, WP = WG::WP, KK = WG::KK, NTI = WG::NTI, TPI = WG::TPI, PL = WG::PL;
   constexpr bool PF = WG::PREFETCH;
+  static_assert(!POOLB || PF, "the pool-backward staging is wired into the prefetch path");
   extern __shared__ __attribute__((aligned(16))) float rn_smem[];
   float* slab = rn_smem;
   float* dys = rn_smem + WG::SLAB;
@@ -309,6 +400,31 @@ __global__ __launch_bounds__(256, 2) void rn_wgrad_kernel(const void* in_, const
     if (G::NF == 1) { b0 = st / G::STRIPS; y0 = (st - b0 * G::STRIPS) * G::R; }
     else { b0 = st * G::NF; y0 = 0; }
   };
+  // gradient of max_pool(3,3) stride 2 SAME (pad_lo 0) at input pixel (y, x), channels 4g..4g+3 of frame f
+  // gradient of max_pool(3,3) stride 2 SAME (pad_lo 0) at input pixel (y, x), channels 4g..4g+3 of frame f.  (A branch-free form with
+  // four unconditional clamped loads measured slower: 1254 vs 1137 us for the fused kernel — most pixels have one or two windows.)
+  auto pool_bwd_at = [&](int f, int y, int x, int g, bool ok) -> float4 {
+    constexpr int HP = H / 2;
+    float sx[4] = {0.f, 0.f, 0.f, 0.f};
+    if (ok) {
+      for (int oh = (y - 1) / 2; 2 * oh <= y; ++oh) {   // windows covering row y, ascending (as rn_pool_bwd_kernel)
+        if (oh < 0 || oh >= HP) continue;
+        const int kh = y - 2 * oh;
+        for (int ow = (x - 1) / 2; 2 * ow <= x; ++ow) {
+          if (ow < 0 || ow >= HP) continue;
+          const int kw = x - 2 * ow;
+          const size_t o = (((size_t)(f * HP + oh) * HP + ow) * (CO / 4) + g) * 4;
+          const uint32_t pi = *reinterpret_cast<const uint32_t*>(pidx + o);
+          const float4 d = *reinterpret_cast<const float4*>(dy + o);
+          const float e[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (((pi >> (8 * q)) & 0xffu) == (uint32_t)(kh * 3 + kw)) sx[q] += e[q];
+        }
+      }
+    }
+    return make_float4(sx[0], sx[1], sx[2], sx[3]);
+  };
   auto fetch = [&](int b0, int y0) {
     if constexpr (U8) {
       const uint8_t* fr = (const uint8_t*)in_ + (size_t)(idx ? idx[b0] : b0) * CBM_FRAME;
@@ -338,7 +454,7 @@ __global__ __launch_bounds__(256, 2) void rn_wgrad_kernel(const void* in_, const
       int f, y;
       if (G::NF == 1) { f = b0; y = y0 + orow; }
       else { f = b0 + orow / (H + 1); y = orow % (H + 1); }
-      ry[it] = *reinterpret_cast<const float4*>(dy + ((size_t)(min(f, B - 1) * H + min(y, H - 1)) * H + c) * CO + 4 * g);
+      if constexpr (!POOLB) ry[it] = *reinterpret_cast<const float4*>(dy + ((size_t)(min(f, B - 1) * H + min(y, H - 1)) * H + c) * CO + 4 * g);
     }
   };
   auto commit = [&](int b0, int y0) {
@@ -384,7 +500,9 @@ __global__ __launch_bounds__(256, 2) void rn_wgrad_kernel(const void* in_, const
       if (G::NF == 1) { f = b0; y = y0 + orow; }
       else { f = b0 + orow / (H + 1); y = orow % (H + 1); }
       const bool ok = y < H && f < B;
-      float4 x = ry[it];
+      float4 x;
+      if constexpr (POOLB) x = pool_bwd_at(f, y, c, g, ok);
+      else x = ry[it];
       if (!ok) x = make_float4(0.f, 0.f, 0.f, 0.f);
       *reinterpret_cast<float4*>(dys + (orow * WP + c) * CO + 4 * g) = x;
     }
@@ -506,17 +624,18 @@ __global__ __launch_bounds__(256, 2) void rn_wgrad_kernel(const void* in_, const
   }
 }
 
-template <class WG, bool U8, bool PRE_RELU>
-static int rn_wgrad_launch(const void* in, const int32_t* idx, const float* dy, float* part, float* bpart, int B, int max_blocks, hipStream_t st) {
+template <class WG, bool U8, bool PRE_RELU, bool POOLB = false>
+static int rn_wgrad_launch(const void* in, const int32_t* idx, const float* dy, float* part, float* bpart, int B, int max_blocks, hipStream_t st,
+                           const uint8_t* pidx = nullptr) {
   constexpr size_t lds = (size_t)WG::LDS_FLOATS * sizeof(float);
   static_assert(lds <= 160 * 1024, "wgrad slab exceeds LDS");
   static bool attr = false;
   if (!attr) {
-    hipFuncSetAttribute((const void*)rn_wgrad_kernel<WG, U8, PRE_RELU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute((const void*)rn_wgrad_kernel<WG, U8, PRE_RELU, POOLB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr = true;
   }
   const int nstrips = WG::strips(B);
   const int nb = nstrips < max_blocks ? nstrips : max_blocks;
-  hipLaunchKernelGGL((rn_wgrad_kernel<WG, U8, PRE_RELU>), dim3(nb), dim3(256), lds, st, in, idx, dy, part, bpart, B, nstrips);
+  hipLaunchKernelGGL((rn_wgrad_kernel<WG, U8, PRE_RELU, POOLB>), dim3(nb), dim3(256), lds, st, in, idx, dy, part, bpart, B, nstrips, pidx);
   return nb;
 }
