@@ -22,6 +22,9 @@
 #include <stdint.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+#ifndef IGEMM_BYR_YFAST
+#define IGEMM_BYR_YFAST 1
+#endif
 #ifndef IGEMM_MIN_WAVES
 #define IGEMM_MIN_WAVES 4
 #endif
@@ -128,7 +131,11 @@ __global__ __launch_bounds__(256, P::Tile::MINW) void igemm_kernel(const P p) {
       const int v = tid + 256 * j;
       if (BR * BY / 4 % 256 == 0 || v < BR * BY / 4) {
         if (B_YR) {
+#if IGEMM_BYR_YFAST
+          const int yl = v % BY, rq = v / BY;   // consecutive lanes -> consecutive y: the transposing LDS stores below are conflict-free
+#else
           const int rq = v % (BR / 4), yl = v / (BR / 4);
+#endif
           rb[j] = p.load_b(r0 + 4 * rq, y0 + yl, rhi, cls);
         } else {
           const int yq = v % (BY / 4), rl = v / (BY / 4);
@@ -159,7 +166,11 @@ __global__ __launch_bounds__(256, P::Tile::MINW) void igemm_kernel(const P p) {
       const int v = tid + 256 * j;
       if (BR * BY / 4 % 256 == 0 || v < BR * BY / 4) {
         if (B_YR) {
+#if IGEMM_BYR_YFAST
+          const int yl = v % BY, rq = v / BY;
+#else
           const int rq = v % (BR / 4), yl = v / (BR / 4);
+#endif
           float* d = B_ + (4 * rq) * PB + yl;
           d[0] = rb[j].x; d[PB] = rb[j].y; d[2 * PB] = rb[j].z; d[3 * PB] = rb[j].w;
         } else {
