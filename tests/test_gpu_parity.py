@@ -195,3 +195,54 @@ def test_bf16_forward_extension_close_to_fp32_oracle(oracle):
             assert np.abs(lg - lo).max() > 0      # it really is a different arithmetic (not silently the fp32 path)
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("na", [4, 6, 9, 28])
+def test_other_action_set_sizes(oracle, na):
+    # envpool games with reduced action sets (Breakout minimal = 4, Pong = 6, ...; SURVEY 8a: "A=18 ... or 4") and the ABI maximum 28:
+    # forward / sampling bit-exact, one PPO update within 1e-5 of the oracle-backed engine
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from oracle_engine import OracleEngine
+    import cleanba_amd.model as M
+    import cleanba_amd.prng as prng
+    E, T = 8, 8
+    cfg = L.default_config(L.ALGO_PPO)
+    cfg.num_actions, cfg.local_num_envs, cfg.num_actor_slots, cfg.num_steps, cfg.update_epochs = na, E, 1, T, 2
+    ctx = L.Context(cfg)
+    try:
+        key = prng.prng_key(3)
+        key, nk, ak, ck = prng.split(key, 4)
+        params = M.init_nature_params(na, nk, ak, ck)
+        ctx.set_params(params)
+        ctx.actor_set_key(0, key)
+        ctx.actor_env_reset_device(0, 9)
+        ctx.actor_begin_rollout(0, False)
+        ctx.actor_rollout_device(0, T)
+        ctx.actor_commit(0)
+        ctx.learner_wait()
+        obs = ctx.read("obs", np.uint8).reshape(T + 1, E, 4, 84, 84)
+        actions = ctx.read("actions", np.int32).reshape(T + 1, E)
+        logprobs = ctx.read("logprobs", np.float32).reshape(T + 1, E)
+        k = key.copy()
+        for t in range(T):   # replay the policy part of the rollout
+            logits, value = oracle.nature_forward(params, na, obs[t], ksplit=cfg.actor_dense_ksplit)
+            a, lp, k = oracle.sample_actions(logits, k)
+            assert (a == actions[t]).all() and (bits(lp) == bits(logprobs[t])).all() and a.max() < na
+        ora = OracleEngine(cfg)
+        ora.set_params(params)
+        R = ora.ring[0]
+        R["obs"][:] = obs
+        for name, dt in (("actions", np.int32), ("logprobs", np.float32), ("values", np.float32), ("rewards", np.float32), ("dones", np.uint8)):
+            R[name][:] = ctx.read(name, dt).reshape(T + 1, E)
+        ora.committed = [1]
+        n_opt = 8
+        bc = [M.adam_bias_corrections(i + 1) for i in range(n_opt)]
+        lrs, b1, b2 = np.full(n_opt, 1e-3, np.float32), np.array([b[0] for b in bc], np.float32), np.array([b[1] for b in bc], np.float32)
+        _, s_g = ctx.learner_update(key, lrs, b1, b2)
+        _, s_o = ora.learner_update(key, lrs, b1, b2)
+        np.testing.assert_allclose(s_g, s_o, rtol=2e-4, atol=2e-5)
+        p_g, p_o = ctx.get_params(), ora.get_params()
+        assert np.abs(p_g - p_o).max() <= 1e-5 * max(1.0, np.abs(p_o).max())
+    finally:
+        ctx.close()
