@@ -276,3 +276,28 @@ def test_host_env_loop_equals_device_env_loop(tmp_path, algo):
         out[backend] = train(args, algo)
     assert out["host"]["updates"] == out["device"]["updates"] == 3
     assert np.array_equal(out["host"]["params"], out["device"]["params"])
+
+
+@pytest.mark.parametrize("algo,E,thr,T,nmb,epochs,accum,conc", [
+    ("ppo", 2, 1, 4, 1, 1, 1, False), ("ppo", 3, 2, 5, 2, 3, 1, True), ("ppo", 4, 3, 4, 4, 2, 2, True),
+    ("impala", 2, 2, 4, 2, 1, 1, False), ("impala", 6, 1, 5, 3, 1, 2, True), ("impala", 4, 3, 3, 4, 1, 1, True)])
+def test_whole_training_runs_match_the_oracle_engine(tmp_path, algo, E, thr, T, nmb, epochs, accum, conc):
+    # the same host program (cleanba_amd.trainer.train) once on the HIP library and once on the oracle-backed CPU engine, odd shapes:
+    # actor threads, ring hand-off, policy-version skew, minibatching, accumulation, schedules.  Actions are bit-exact, so the runs see
+    # the same data; parameters may differ by the backward tolerance.
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from oracle_engine import OracleEngine
+    from cleanba_amd.args import parse_args
+    from cleanba_amd.trainer import train
+    os.chdir(str(tmp_path))
+    updates = 4
+    argv = ["--local-num-envs", str(E), "--num-actor-threads", str(thr), "--num-steps", str(T), "--num-minibatches", str(nmb),
+            "--update-epochs", str(epochs), "--gradient-accumulation-steps", str(accum), "--network", "nature", "--env-backend", "host",
+            "--total-timesteps", str(updates * E * thr * T), "--log-frequency", "1000"] + (["--concurrency"] if conc else [])
+    gpu = train(parse_args(argv, algo), algo)
+    cpu = train(parse_args(argv, algo), algo, engine_factory=OracleEngine)
+    assert gpu["updates"] == cpu["updates"] == updates
+    d = np.abs(gpu["params"] - cpu["params"]).max()
+    assert d <= 2e-5 * max(1.0, np.abs(cpu["params"]).max()), d
+    np.testing.assert_allclose(gpu["stats"], cpu["stats"], rtol=5e-4, atol=5e-5)
