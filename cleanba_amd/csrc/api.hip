@@ -121,6 +121,7 @@ static int ctx_create_impl(const cbm_config* cfg, cbm_ctx** out, cbm_ctx** parti
     cbm_set_error("num_actor_slots in [1,%d], ring_depth in [2,%d]", MAX_SLOTS, MAX_RING); return -1;
   }
   if (cfg->num_actions < 2 || cfg->num_actions > 28) { cbm_set_error("num_actions must be in [2,28]"); return -1; }
+  if (cfg->algo == CBM_ALGO_IMPALA && cfg->num_steps + 1 > 2000) { cbm_set_error("IMPALA num_steps must be <= 1999 (the V-trace kernel keeps 8 floats per step in LDS)"); return -1; }
   if (cfg->forward_bf16 && cfg->network != CBM_NET_NATURE) { cbm_set_error("forward_bf16 is built for the Nature-CNN torso only"); return -1; }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { cbm_set_error("no HIP device visible: libcleanba_mi needs an MI355X"); return -3; }
