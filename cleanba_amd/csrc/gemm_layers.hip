@@ -505,6 +505,9 @@ using T64x64k16 = IgemmTile<64, 64, 16, 2, 2>;
 #ifndef ACTOR_K16
 #define ACTOR_K16 1
 #endif
+#ifndef TILE_C2D
+#define TILE_C2D T128x32k16
+#endif
 #ifndef TILE_C2F
 #define TILE_C2F T64x64
 #endif
@@ -600,7 +603,7 @@ void nature_backward(const NatureLayout& L, const float* P, const uint8_t* obs, 
   }
   // conv2: dgrad -> dact1, wgrad
   {
-    Conv2Dgrad<T128x32k16> pd{ws.dact2pad, P + L.w[1], ws.act1, ws.dact1, B * 100};
+    Conv2Dgrad<TILE_C2D> pd{ws.dact2pad, P + L.w[1], ws.act1, ws.dact1, B * 100};
     plaunch(ws, K_CONV2_DGRAD, pd, 1, st);
     const int M = B * 81, nz = ceil_div(M, RPS_C2);
     ConvWgrad<T128x64, 4, 4, 2, 32, 64, 20, 20, 9, 9, 1> pw{ws.act1, ws.dact2pad, ws.wg_part, ws.bias_part, M, RPS_C2};
