@@ -5,6 +5,10 @@ from .trainer import train
 
 def main(argv=None):
     args = parse_args(argv, "impala")
+    from .launch import maybe_fan_out
+    rc = maybe_fan_out(args, "cleanba_amd.cleanba_impala", argv)   # split topologies: one worker process per GPU (cleanba_amd/launch.py)
+    if rc is not None:
+        raise SystemExit(rc)
     return train(args, "impala")
 
 

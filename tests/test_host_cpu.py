@@ -175,3 +175,21 @@ def test_gradient_accumulation_data_parallel(tmp_path, algo, monkeypatch):
     monkeypatch.setenv("CBM_TEST_ACCUM", "1")
     b1 = _run(1, True, str(tmp_path), "acc0", algo)[0]
     assert np.isfinite(a1).all() and not np.array_equal(a1, b1)
+
+
+def test_split_fan_out_plan_follows_the_reference_recipes():
+    # README.md:62 (`--actor-device-ids 0 --learner-device-ids 1 2 3`, one command) and README.md:71-72 (two SLURM tasks of 4 GPUs)
+    from cleanba_amd.args import parse_args
+    from cleanba_amd.launch import plan
+    a = parse_args(["--actor-device-ids", "0", "--learner-device-ids", "1", "2", "3"], "ppo")
+    envs = plan(a, {"PATH": "x"})
+    assert [(e["RANK"], e["WORLD_SIZE"], e["LOCAL_RANK"]) for e in envs] == [("0", "4", "0"), ("1", "4", "1"), ("2", "4", "2"), ("3", "4", "3")]
+    assert len({e["MASTER_PORT"] for e in envs}) == 1 and envs[0]["MASTER_ADDR"] == "127.0.0.1"
+    a = parse_args(["--distributed", "--actor-device-ids", "0", "--learner-device-ids", "1", "2", "3", "--local-num-envs", "60"], "ppo")
+    slurm = {"SLURM_JOB_ID": "26017", "SLURM_STEP_NODELIST": "localhost", "SLURM_NTASKS": "2", "SLURM_PROCID": "1", "SLURM_LOCALID": "0"}
+    envs = plan(a, slurm)
+    assert [(e["RANK"], e["WORLD_SIZE"], e["LOCAL_RANK"]) for e in envs] == [("4", "8", "0"), ("5", "8", "1"), ("6", "8", "2"), ("7", "8", "3")]
+    assert envs[0]["MASTER_PORT"] == str(29500 + 26017 % 1000)
+    # workers (RANK set) and non-split runs are left alone
+    assert plan(a, dict(slurm, RANK="4", WORLD_SIZE="8")) is None
+    assert plan(parse_args([], "ppo"), {}) is None
