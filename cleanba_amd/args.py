@@ -57,6 +57,8 @@ class Args:
     max_updates: int = 0             # stop early after this many updates (0 = total_timesteps)
     eval_episodes: int = 10  # episodes of the post-training evaluation that follows --save-model (ppo:773-782)
     eval_max_episode_steps: int = 0  # 0 = the env's own limit (27000 for Atari); smaller values bound smoke runs
+    async_batch_size: int = 0  # legacy `--async-batch-size` (legacy_scripts/..._naturecnn.py:65-66): envpool async mode, recv() returns this many
+                               # of the local_num_envs envs; env-id-indexed GAE, per-minibatch advantage normalisation.  0 = off (cleanba_ppo.py)
     bf16_forward: bool = False  # build-only extension (reference is fp32): conv2/conv3/dense forward on bf16 MFMA, fp32 accumulate + fp32 returns (Nature-CNN)
     same_env_seed_all_ranks: bool = False  # testing aid: every process steps identical envs (then dp-N == dp-1 bitwise)
 
@@ -119,6 +121,27 @@ def finalize(args, world_size=1, rank=0):
     if getattr(args, "network", "impala_resnet") == "impala_resnet" and (list(args.channels) != [16, 32, 32] or list(args.hiddens) != [256]):
         # the HIP torso is specialised for the reference defaults (ppo:59-61); other widths would silently train a different net
         raise SystemExit("--channels/--hiddens: only the reference defaults [16, 32, 32] / [256] are built into the HIP ResNet torso")
+    if getattr(args, "async_batch_size", 0):
+        # the legacy async script (naturecnn:102-105): one actor thread on one actor device, host envs, PPO, learner on the same GPU
+        if args.local_num_envs % args.async_batch_size:
+            raise SystemExit("--local-num-envs must be a multiple of --async-batch-size (naturecnn:104)")
+        if args.env_backend == "device":
+            raise SystemExit("--async-batch-size models envpool's async recv/send: use --env-backend host (or envpool)")
+        if n_actor_dev != 1 or n_learner != 1 or args.actor_device_ids != args.learner_device_ids or args.gradient_accumulation_steps != 1:
+            raise SystemExit("--async-batch-size runs a0-l0 without gradient accumulation (naturecnn:105)")
+        args.num_actor_threads = 1
+        if (args.local_num_envs * args.num_steps) % args.num_minibatches:
+            raise SystemExit("local_num_envs*num_steps must be divisible by num_minibatches")
+        args.local_batch_size = int(args.local_num_envs * args.num_steps)
+        args.local_minibatch_size = int(args.local_batch_size // args.num_minibatches)
+        args.world_size, args.local_rank = world_size, rank
+        args.num_envs = args.local_num_envs * world_size
+        args.batch_size = args.local_batch_size * world_size
+        args.minibatch_size = args.local_minibatch_size * world_size
+        args.num_updates = args.total_timesteps // (args.local_batch_size * world_size)
+        if args.max_updates:
+            args.num_updates = min(args.num_updates, args.max_updates)
+        return args
     args.local_batch_size = int(args.local_num_envs * args.num_steps * args.num_actor_threads * n_actor_dev)
     args.local_minibatch_size = int(args.local_batch_size // args.num_minibatches)
     assert args.local_num_envs % n_learner == 0, "local_num_envs must be divisible by len(learner_device_ids)"

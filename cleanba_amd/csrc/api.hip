@@ -38,6 +38,7 @@ struct RingEntry {
   int32_t* actions = nullptr;
   float *logprobs = nullptr, *values = nullptr, *rewards = nullptr, *logits = nullptr;
   uint8_t *dones = nullptr, *firststeps = nullptr;
+  int32_t* env_ids = nullptr;   // async rollouts: which env each sample of a row belongs to (naturecnn:355,367)
   hipEvent_t ready[MAX_SLOTS];
   hipEvent_t consumed;
 };
@@ -55,6 +56,7 @@ struct cbm_ctx {
   cbm_config cfg;
   NatureLayout L;
   int E, S, Bdev, T, T1, A, MB, nmb, epochs;
+  int asyncB = 0, NE = 0;   // legacy --async-batch-size: rows of asyncB samples drawn from NE envs (0 = synchronous)
   int64_t P;
   float *params = nullptr, *grads = nullptr, *opt_m = nullptr, *opt_v = nullptr;
   float* actor_params[NPV] = {nullptr, nullptr, nullptr};
@@ -63,6 +65,7 @@ struct cbm_ctx {
   Slot slots[MAX_SLOTS];
   hipStream_t lstream = nullptr;
   NatureWs lws;
+  float* advn = nullptr;     // per-minibatch normalised advantages (async mode, naturecnn:540-541)
   float *adv = nullptr, *target = nullptr, *next_value = nullptr, *stats_dev = nullptr, *loss_partials = nullptr, *norm_partials = nullptr;
   int32_t *perm = nullptr, *perm_tmp = nullptr, *impala_idx = nullptr;
   float* gacc = nullptr;   // MultiSteps running mean (grad_accum_steps > 1)
@@ -130,12 +133,21 @@ static int ctx_create_impl(const cbm_config* cfg, cbm_ctx** out, cbm_ctx** parti
   *partial = c;   // the wrapper releases whatever was allocated if anything below fails
   c->cfg = *cfg;
   c->A = cfg->num_actions; c->E = cfg->local_num_envs; c->S = cfg->num_actor_slots;
-  c->Bdev = c->E * c->S; c->T = cfg->num_steps; c->T1 = c->T + 1;
+  c->T = cfg->num_steps;
+  if (cfg->async_batch_size > 0) {
+    // legacy async mode (naturecnn:65-66,104): a rollout is num_steps*async_update rows of async_batch_size samples, one actor thread
+    if (cfg->algo != CBM_ALGO_PPO) { cbm_set_error("async_batch_size is a PPO option (the IMPALA script already uses recv/send with all envs)"); return -1; }
+    if (cfg->num_actor_slots != 1) { cbm_set_error("async_batch_size supports one actor slot (naturecnn:105)"); return -1; }
+    if (cfg->local_num_envs % cfg->async_batch_size) { cbm_set_error("local_num_envs must be a multiple of async_batch_size"); return -1; }
+    c->asyncB = cfg->async_batch_size; c->NE = cfg->local_num_envs;
+    c->E = c->asyncB; c->T = cfg->num_steps * (c->NE / c->asyncB);
+  }
+  c->Bdev = c->E * c->S; c->T1 = c->T + 1;
   c->nmb = cfg->num_minibatches; c->epochs = is_ppo(c) ? cfg->update_epochs : 1;
   c->accum = cfg->grad_accum_steps > 1 ? cfg->grad_accum_steps : 1;
   c->nmicro = c->nmb * c->accum;   // micro-batches per epoch (ppo:607, impala:627)
   if (c->Bdev > 1024) { cbm_set_error("local_num_envs*slots must be <= 1024 per GPU"); return -1; }
-  if (c->Bdev % c->nmb) { cbm_set_error("local_num_envs*slots must be divisible by num_minibatches (ppo:416-418)"); return -1; }
+  if (!c->asyncB && c->Bdev % c->nmb) { cbm_set_error("local_num_envs*slots must be divisible by num_minibatches (ppo:416-418)"); return -1; }
   if (is_ppo(c) ? (c->T * c->Bdev) % c->nmicro : c->Bdev % c->nmicro) {
     cbm_set_error("the batch does not split into num_minibatches*gradient_accumulation_steps = %d micro-batches", c->nmicro); return -1;
   }
@@ -152,7 +164,10 @@ static int ctx_create_impl(const cbm_config* cfg, cbm_ctx** out, cbm_ctx** parti
   for (int r = 0; r < cfg->ring_depth; ++r) {
     RingEntry& R = c->ring[r];
     if (dalloc(&R.obs, T1 * B * CBM_FRAME) || dalloc(&R.actions, T1 * B) || dalloc(&R.logprobs, T1 * B) || dalloc(&R.values, T1 * B) ||
-        dalloc(&R.rewards, T1 * B) || dalloc(&R.logits, T1 * B * c->A) || dalloc(&R.dones, T1 * B) || dalloc(&R.firststeps, T1 * B)) return -1;
+        dalloc(&R.rewards, T1 * B) || dalloc(&R.logits, T1 * B * c->A) || dalloc(&R.dones, T1 * B) || dalloc(&R.firststeps, T1 * B) ||
+        dalloc(&R.env_ids, T1 * B)) return -1;
+    hipMemset(R.env_ids, 0, T1 * B * 4); hipMemset(R.actions, 0, T1 * B * 4); hipMemset(R.logprobs, 0, T1 * B * 4); hipMemset(R.values, 0, T1 * B * 4);
+    hipMemset(R.logits, 0, T1 * B * c->A * 4);   // rows a rollout never writes (PPO row T) read back as zeros, not as stale HBM
     hipMemset(R.dones, 0, T1 * B); hipMemset(R.firststeps, 0, T1 * B); hipMemset(R.rewards, 0, T1 * B * 4);
     for (int s = 0; s < c->S; ++s) CBM_HIP(hipEventCreateWithFlags(&R.ready[s], hipEventDisableTiming));
     CBM_HIP(hipEventCreateWithFlags(&R.consumed, hipEventDisableTiming));
@@ -177,6 +192,7 @@ static int ctx_create_impl(const cbm_config* cfg, cbm_ctx** out, cbm_ctx** parti
   c->lws.bf16_fwd = cfg->forward_bf16 != 0 && cfg->network == CBM_NET_NATURE;
   c->stat_rows = c->epochs * c->nmicro;
   if (c->accum > 1) { if (dalloc(&c->gacc, P)) return -1; hipMemset(c->gacc, 0, P * 4); }
+  if (c->asyncB && dalloc(&c->advn, T1 * B)) return -1;
   if (dalloc(&c->adv, T1 * B) || dalloc(&c->target, T1 * B) || dalloc(&c->next_value, B) || dalloc(&c->stats_dev, (size_t)c->stat_rows * 8) ||
       dalloc(&c->loss_partials, (size_t)4 * (lmax / 256 + 2) + 3 * B) || dalloc(&c->norm_partials, CBM_NORM_PARTS) ||
       dalloc(&c->perm, T1 * B) || dalloc(&c->perm_tmp, T1 * B) || dalloc(&c->ckeys, 2 * T1 * B)) return -1;
@@ -210,12 +226,12 @@ extern "C" int cbm_ctx_destroy(cbm_ctx* c) {
   hipSetDevice(c->cfg.device);
   hipDeviceSynchronize();
   void* ps[] = {c->params, c->grads, c->opt_m, c->opt_v, c->adv, c->target, c->next_value, c->stats_dev, c->loss_partials, c->norm_partials,
-                c->perm, c->perm_tmp, c->ckeys, c->impala_idx, c->gacc};
+                c->perm, c->perm_tmp, c->ckeys, c->impala_idx, c->gacc, c->advn};
   for (void* p : ps) if (p) hipFree(p);
   for (int i = 0; i < NPV; ++i) { if (c->actor_params[i]) hipFree(c->actor_params[i]); hipEventDestroy(c->params_ready[i]); }
   for (int r = 0; r < c->cfg.ring_depth; ++r) {
     RingEntry& R = c->ring[r];
-    void* qs[] = {R.obs, R.actions, R.logprobs, R.values, R.rewards, R.logits, R.dones, R.firststeps};
+    void* qs[] = {R.obs, R.actions, R.logprobs, R.values, R.rewards, R.logits, R.dones, R.firststeps, R.env_ids};
     for (void* p : qs) if (p) hipFree(p);
     for (int s = 0; s < c->S; ++s) hipEventDestroy(R.ready[s]);
     hipEventDestroy(R.consumed);
@@ -268,7 +284,7 @@ extern "C" int cbm_buffer(cbm_ctx* c, const char* name, int32_t ri, void** p, in
       {"adv", c->adv, TB * 4}, {"target", c->target, TB * 4}, {"perm", c->perm, TB * 4}, {"next_value", c->next_value, (size_t)c->Bdev * 4},
       {"stats", c->stats_dev, (size_t)c->stat_rows * 8 * 4}, {"obs", R.obs, TB * CBM_FRAME}, {"actions", R.actions, TB * 4},
       {"logprobs", R.logprobs, TB * 4}, {"values", R.values, TB * 4}, {"rewards", R.rewards, TB * 4}, {"logits", R.logits, TB * c->A * 4},
-      {"dones", R.dones, TB}, {"firststeps", R.firststeps, TB}, {"lws_logits", c->lws.logits, (size_t)c->lws.maxB * 32 * 4},
+      {"dones", R.dones, TB}, {"firststeps", R.firststeps, TB}, {"env_ids", R.env_ids, TB * 4}, {"adv_norm", c->advn, c->advn ? TB * 4 : 0}, {"lws_logits", c->lws.logits, (size_t)c->lws.maxB * 32 * 4},
       {"lws_value", c->lws.value, (size_t)c->lws.maxB * 4}};
   for (auto& e : tab)
     if (n == e.k) { *p = e.ptr; if (nbytes) *nbytes = (int64_t)e.sz; return 0; }
@@ -324,7 +340,7 @@ extern "C" int cbm_actor_begin_rollout(cbm_ctx* c, int32_t s, int32_t concurrenc
   sl.pver = need;
   sl.ring = ri;
   sl.t = 0;
-  if (u >= 2) {
+  if (u >= 2 && !c->asyncB) {   // (async rollouts start from whatever recv() returns next: nothing is carried, naturecnn:306-311)
     // carry the last row of the previous rollout to the head of this one: PPO next_obs/next_done (ppo:308-310),
     // IMPALA the whole bootstrap transition (impala:416)
     RingEntry& Pv = c->ring[(u - 2) % depth];
@@ -379,6 +395,29 @@ extern "C" int cbm_actor_step_host(cbm_ctx* c, int32_t s, const uint8_t* obs, co
   sl.t += 1;
   return 0;
 }
+// Async host-env step (naturecnn:346-367): the batch envpool.recv() returned — observations of `async_batch_size` envs, the reward /
+// done that arrived WITH them and their env ids — goes into ring row t; get_action_and_value runs on it; actions come back for
+// envs.send(action, env_id).
+extern "C" int cbm_actor_step_async(cbm_ctx* c, int32_t s, const uint8_t* obs, const float* reward, const uint8_t* done, const int32_t* env_id,
+                                    int32_t* actions_out) {
+  if (!c->asyncB) { cbm_set_error("context was created without async_batch_size"); return -1; }
+  Slot& sl = c->slots[s];
+  CBM_HIP(hipSetDevice(c->cfg.device));
+  if (sl.t >= c->T) { cbm_set_error("rollout overrun: row %d of %d", sl.t, c->T); return -1; }
+  for (int j = 0; j < c->E; ++j)
+    if (env_id[j] < 0 || env_id[j] >= c->NE) { cbm_set_error("env_id %d outside [0,%d)", env_id[j], c->NE); return -1; }
+  RingEntry& R = c->ring[sl.ring];
+  const size_t o = row_off(c, sl.t, s), E = (size_t)c->E;
+  CBM_HIP(hipMemcpyAsync(R.obs + o * CBM_FRAME, obs, E * CBM_FRAME, hipMemcpyHostToDevice, sl.stream));
+  CBM_HIP(hipMemcpyAsync(R.dones + o, done, E, hipMemcpyHostToDevice, sl.stream));
+  CBM_HIP(hipMemcpyAsync(R.rewards + o, reward, E * 4, hipMemcpyHostToDevice, sl.stream));
+  CBM_HIP(hipMemcpyAsync(R.env_ids + o, env_id, E * 4, hipMemcpyHostToDevice, sl.stream));
+  actor_infer_row(c, s, sl.t);
+  CBM_HIP(hipMemcpyAsync(actions_out, R.actions + o, E * 4, hipMemcpyDeviceToHost, sl.stream));
+  CBM_HIP(hipStreamSynchronize(sl.stream));
+  sl.t += 1;
+  return 0;
+}
 extern "C" int cbm_actor_record_host(cbm_ctx* c, int32_t s, const float* reward) {
   Slot& sl = c->slots[s];
   CBM_HIP(hipSetDevice(c->cfg.device));
@@ -392,6 +431,7 @@ extern "C" int cbm_actor_rollout_device(cbm_ctx* c, int32_t s, int32_t nsteps) {
   Slot& sl = c->slots[s];
   CBM_HIP(hipSetDevice(c->cfg.device));
   if (!sl.env_inited) { cbm_set_error("device env not reset: call cbm_actor_env_reset_device first"); return -1; }
+  if (c->asyncB) { cbm_set_error("async_batch_size runs with a host env (cbm_actor_step_async); the device env is synchronous"); return -1; }
   RingEntry& R = c->ring[sl.ring];
   const int max_steps = 27000;  // ATARI_MAX_FRAMES ppo:121-123
   if (is_ppo(c)) {
@@ -527,6 +567,10 @@ extern "C" int cbm_learner_prepare(cbm_ctx* c, uint32_t key[2]) {
   if (!is_ppo(c)) return 0;
   RingEntry& R = cur_ring(c);
   const int B = c->Bdev, T = c->T;
+  if (c->asyncB) {   // no bootstrap observation, env-id-indexed returns, normalisation per minibatch later (naturecnn:254-256,540)
+    launch_gae_async(R.env_ids, R.rewards, R.values, R.dones, T, B, c->NE, c->cfg.gamma, c->cfg.gae_lambda, c->adv, c->target, c->lstream);
+    return 0;
+  }
   // compute_gae ppo:543-560: bootstrap value with the LEARNER's params on next_obs (row T)
   nature_forward(c->L, c->params, R.obs + (size_t)T * B * CBM_FRAME, nullptr, B, c->cfg.actor_dense_ksplit, c->lws, c->lstream);
   CBM_HIP(hipMemcpyAsync(c->next_value, c->lws.value, (size_t)B * 4, hipMemcpyDeviceToDevice, c->lstream));
@@ -557,7 +601,9 @@ extern "C" int cbm_learner_minibatch_grad(cbm_ctx* c, int32_t epoch, int32_t mb)
   if (is_ppo(c)) {
     const int32_t* idx = c->perm + (size_t)mb * c->MB;
     nature_forward(c->L, c->params, R.obs, idx, c->MB, learner_ksplit(c), c->lws, c->lstream);
-    launch_ppo_loss(c->lws.logits, c->lws.value, c->MB, c->A, idx, R.actions, R.logprobs, c->adv, c->target, c->cfg.clip_coef, c->cfg.ent_coef,
+    const float* adv = c->adv;
+    if (c->asyncB && c->cfg.norm_adv) { launch_mb_advnorm(c->adv, idx, c->MB, c->advn, c->lstream); adv = c->advn; }
+    launch_ppo_loss(c->lws.logits, c->lws.value, c->MB, c->A, idx, R.actions, R.logprobs, adv, c->target, c->cfg.clip_coef, c->cfg.ent_coef,
                     c->cfg.vf_coef, c->lws.dzv, c->loss_partials, stats, c->lstream);
     nature_backward(c->L, c->params, R.obs, idx, c->MB, c->lws, c->grads, c->lstream);
   } else {
@@ -697,6 +743,19 @@ extern "C" int cbm_gae(cbm_ctx* c, const float* rewards, const float* values, co
                        const uint8_t* next_done, int32_t T, int32_t B, float* adv, float* target) {
   CBM_HIP(hipSetDevice(c->cfg.device));
   launch_gae(rewards, values, dones, next_value, next_done, T, B, c->cfg.gamma, c->cfg.gae_lambda, adv, target, c->lstream);
+  CBM_HIP(hipStreamSynchronize(c->lstream));
+  return 0;
+}
+extern "C" int cbm_gae_async(cbm_ctx* c, const int32_t* env_ids, const float* rewards, const float* values, const uint8_t* dones, int32_t R,
+                             int32_t B, int32_t num_envs, float* adv, float* target) {
+  CBM_HIP(hipSetDevice(c->cfg.device));
+  launch_gae_async(env_ids, rewards, values, dones, R, B, num_envs, c->cfg.gamma, c->cfg.gae_lambda, adv, target, c->lstream);
+  CBM_HIP(hipStreamSynchronize(c->lstream));
+  return 0;
+}
+extern "C" int cbm_mb_advnorm(cbm_ctx* c, const float* adv, const int32_t* idx, int32_t n, float* out) {
+  CBM_HIP(hipSetDevice(c->cfg.device));
+  launch_mb_advnorm(adv, idx, n, out, c->lstream);
   CBM_HIP(hipStreamSynchronize(c->lstream));
   return 0;
 }

@@ -230,21 +230,34 @@ extern "C" int cbm_synth_env_reset_host_games(uint32_t seed, int32_t n, int32_t 
   }
   return 0;
 }
+static void host_step_one(uint32_t seed, int e, int32_t action, int32_t max_episode_steps, cbm_env_state* st, uint8_t* obs, float* reward,
+                          uint8_t* done, uint8_t* terminated, int32_t* elapsed_step) {
+  cbm_env_state s = st[e];
+  const EnvGame gm = env_game(s.game);
+  const EnvOut out = env_transition(&s, seed, (uint32_t)e, action, max_episode_steps);
+  st[e] = s;
+  *reward = out.reward; *done = out.done; *terminated = out.terminated; *elapsed_step = out.elapsed;
+  uint8_t* o = obs + (size_t)e * CBM_FRAME;
+  if (!out.was_reset) memmove(o, o + 7056, 3 * 7056);
+  for (int i = 0; i < 7056; ++i) {
+    const uint8_t v = env_pixel(&s, gm, i / 84, i % 84);
+    o[3 * 7056 + i] = v;
+    if (out.was_reset) { o[i] = v; o[7056 + i] = v; o[2 * 7056 + i] = v; }
+  }
+}
 extern "C" int cbm_synth_env_step_host(uint32_t seed, int32_t n, int32_t max_episode_steps, const int32_t* actions, cbm_env_state* st,
                                        uint8_t* obs, float* reward, uint8_t* done, uint8_t* terminated, int32_t* elapsed_step) {
-  for (int e = 0; e < n; ++e) {
-    cbm_env_state s = st[e];
-    const EnvGame gm = env_game(s.game);
-    const EnvOut out = env_transition(&s, seed, (uint32_t)e, actions[e], max_episode_steps);
-    st[e] = s;
-    reward[e] = out.reward; done[e] = out.done; terminated[e] = out.terminated; elapsed_step[e] = out.elapsed;
-    uint8_t* o = obs + (size_t)e * CBM_FRAME;
-    if (!out.was_reset) memmove(o, o + 7056, 3 * 7056);
-    for (int i = 0; i < 7056; ++i) {
-      const uint8_t v = env_pixel(&s, gm, i / 84, i % 84);
-      o[3 * 7056 + i] = v;
-      if (out.was_reset) { o[i] = v; o[7056 + i] = v; o[2 * 7056 + i] = v; }
-    }
+  for (int e = 0; e < n; ++e) host_step_one(seed, e, actions[e], max_episode_steps, st, obs, reward + e, done + e, terminated + e, elapsed_step + e);
+  return 0;
+}
+// envpool's send(action, env_id) for a subset: steps the k envs listed in env_ids (indices into st / obs, which hold ALL envs); the per-env
+// outputs are written in list order.  An env's trajectory depends only on its own id, seed and actions, not on who is stepped with it.
+extern "C" int cbm_synth_env_step_host_ids(uint32_t seed, int32_t num_envs, int32_t k, int32_t max_episode_steps, const int32_t* env_ids,
+                                           const int32_t* actions, cbm_env_state* st, uint8_t* obs, float* reward, uint8_t* done,
+                                           uint8_t* terminated, int32_t* elapsed_step) {
+  for (int j = 0; j < k; ++j) {
+    if (env_ids[j] < 0 || env_ids[j] >= num_envs) { cbm_set_error("env_id %d outside [0,%d)", env_ids[j], num_envs); return -1; }
+    host_step_one(seed, env_ids[j], actions[j], max_episode_steps, st, obs, reward + j, done + j, terminated + j, elapsed_step + j);
   }
   return 0;
 }

@@ -60,8 +60,8 @@ __global__ __launch_bounds__(256, P::Tile::MINW) void igemm_kernel(const P p) {
   constexpr int TM = BX / WX / 32, TN = BY / WY / 32;
   constexpr int PA = A_RX ? BX : (BR + 1);
   constexpr int ASZ = A_RX ? BR * BX : BX * (BR + 1);
-  constexpr int PB = BY;
-  constexpr int BSZ = BR * BY;
+  constexpr int PB = (B_YR && IGEMM_BYR_YFAST == 2) ? BY + 4 : BY;
+  constexpr int BSZ = BR * PB;
   constexpr int NVA = (BX * BR / 4 + 255) / 256;
   constexpr int NVB = (BR * BY / 4 + 255) / 256;
   constexpr int RED = P::BIAS_GRAD ? 256 : 0;
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256, P::Tile::MINW) void igemm_kernel(const P p) {
       const int v = tid + 256 * j;
       if (BR * BY / 4 % 256 == 0 || v < BR * BY / 4) {
         if (B_YR) {
-#if IGEMM_BYR_YFAST
+#if IGEMM_BYR_YFAST == 1
           const int yl = v % BY, rq = v / BY;   // consecutive lanes -> consecutive y: the transposing LDS stores below are conflict-free
 #else
           const int rq = v % (BR / 4), yl = v / (BR / 4);
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256, P::Tile::MINW) void igemm_kernel(const P p) {
       const int v = tid + 256 * j;
       if (BR * BY / 4 % 256 == 0 || v < BR * BY / 4) {
         if (B_YR) {
-#if IGEMM_BYR_YFAST
+#if IGEMM_BYR_YFAST == 1
           const int yl = v % BY, rq = v / BY;
 #else
           const int rq = v % (BR / 4), yl = v / (BR / 4);
@@ -281,10 +281,13 @@ static inline void igemm_launch(const P& p, int nsplit, hipStream_t stream) {
 // Same math and the same k-ascending accumulation order as igemm_kernel (bit-identical results), but the LDS tiles are filled by
 // global_load_lds_dwordx4: the load unit writes 16 bytes per lane straight into LDS (wave-uniform base + lane*16) — no staging
 // VGPRs, no ds_write instructions, no select/convert VALU work between the global load and the tile.  That fixes the tile layouts:
-//   A[r/4][x][4]   one instruction = 64 rows x of one k-quad (the functor returns the address of A[x][r..r+3])
+//   A[x][BR]       row-major, the BR/4 k-quads of row x stored in slot (quad ^ f(x)); the DMA writes lane-linear, so the swizzle is applied
+//                  on the source side (lane l fetches the quad that belongs in slot l % QPR of row l / QPR).  One instruction touches
+//                  64/QPR rows with QPR*16 contiguous bytes each — a quad-major A[r/4][x][4] tile (64 rows x 16 B per instruction)
+//                  cost 4x the cache-line touches and measured 15 % slower on the dense layer.
 //   B[r][y]        one instruction = 64 consecutive 16-byte pieces of the row-major [BR][BY] tile
-// A fragments are ds_read_b32 at a 16-byte lane stride (4-way bank conflict; a ds_read_b128 + v_permlane32_swap variant was not
-// faster — tools/ubench/gemm_dma.hip).  Usable when the gather needs no zero fill or conversion: P::DMA_OK, a_ptr(), b_ptr().
+// A fragments are ds_read_b32 (2-way bank conflict, inherent to reading one dword of each 16-byte granule; a ds_read_b128 +
+// v_permlane32_swap variant was not faster — tools/ubench/gemm_dma.hip).  Usable when the gather needs no zero fill or conversion: P::DMA_OK, a_ptr(), b_ptr().
 static __device__ __forceinline__ void ig_glds16(const float* g_lane, float* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g_lane, (__attribute__((address_space(3))) void*)lds_wave_base, 16,
                                    0, 0);
@@ -294,7 +297,7 @@ template <class P>
 __global__ __launch_bounds__(256, P::Tile::MINW) void igemm_dma_kernel(const P p) {
   using T = typename P::Tile;
   constexpr int BX = T::BX, BY = T::BY, BR = T::BR, WX = T::WX, WY = T::WY;
-  static_assert(P::DMA_OK && !P::A_RX && !P::B_YR && !P::BIAS_GRAD && P::NCLS == 1 && BX % 64 == 0 && BY % 4 == 0 && BR % 4 == 0, "DMA tile shape");
+  static_assert(P::DMA_OK && !P::A_RX && !P::B_YR && !P::BIAS_GRAD && P::NCLS == 1 && BX % 64 == 0 && BY % 4 == 0 && (BR == 16 || BR == 32 || BR == 64), "DMA tile shape");
   constexpr int TM = BX / WX / 32, TN = BY / WY / 32;
   constexpr int ASZ = BR * BX, BSZ = BR * BY, PB = BY;
   constexpr int NIA = (BR / 4) * (BX / 64), NIB = BR * BY / 4 / 64;     // wave-instructions per tile
@@ -323,13 +326,15 @@ __global__ __launch_bounds__(256, P::Tile::MINW) void igemm_dma_kernel(const P p
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
+  constexpr int QPR = BR / 4, RPI = 64 / QPR;            // k-quads per row, rows per wave-instruction
+  auto swz = [](int row) { return (row / (16 / QPR)) & (QPR - 1); };
   auto dma = [&](int r0, int buf) {
     float* A_ = As + buf * ASZ;
     float* B_ = Bs + buf * BSZ;
 #pragma unroll
     for (int i = 0; i < NIA / 4; ++i) {
-      const int t = wave + 4 * i, rq = t / (BX / 64), xb = t % (BX / 64);
-      ig_glds16(p.a_ptr(x0 + xb * 64 + lane, r0 + 4 * rq, 0), A_ + (rq * BX + xb * 64) * 4);
+      const int t = wave + 4 * i, row = t * RPI + lane / QPR, q = (lane % QPR) ^ swz(row);
+      ig_glds16(p.a_ptr(x0 + row, r0 + 4 * q, 0), A_ + t * 256);
     }
 #pragma unroll
     for (int i = 0; i < NIB / 4; ++i) {
@@ -354,7 +359,10 @@ __global__ __launch_bounds__(256, P::Tile::MINW) void igemm_dma_kernel(const P p
         for (int q = 0; q < G; ++q) {
           const int rr = 2 * (g * G + q);
 #pragma unroll
-          for (int i = 0; i < TM; ++i) fa[set][q][i] = A_[((rr >> 2) * BX + wx * (BX / WX) + i * 32 + li) * 4 + (rr & 3) + h];
+          for (int i = 0; i < TM; ++i) {
+            const int row = wx * (BX / WX) + i * 32 + li;
+            fa[set][q][i] = A_[row * BR + (((rr >> 2) ^ swz(row)) << 2) + (rr & 3) + h];
+          }
 #pragma unroll
           for (int j = 0; j < TN; ++j) fb[set][q][j] = B_[(rr + h) * PB + wy * (BY / WY) + j * 32 + li];
         }

@@ -109,6 +109,77 @@ void launch_advnorm(float* adv, int T, int B, int groups, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Async rollouts (legacy `--async-batch-size`): prepare_data's reward re-index (naturecnn:232-255) + env-id-indexed compute_gae
+// (naturecnn:467-531) in one pass.  One block per env: 1024 rows at a time (from the end), each thread looks its env up in one row's B
+// ids and parks (value, done, reward, flat index) in LDS; thread 0 then runs the serial recursion over the parked samples.  The "next
+// sample of the same env" the reference finds through next_index_ranges is simply the sample visited just before in this reverse walk:
+// its reward / done / value are the carries.  An env's last sample gets delta = 0 and, with the done carry starting at 1, advantage 0.
+#define GA_ROWS 1024
+__global__ __launch_bounds__(GA_ROWS) void gae_async_kernel(const int32_t* env_ids, const float* rewards, const float* values, const uint8_t* dones,
+                                                            int R, int B, float gamma, float gl, float* adv, float* target) {
+  __shared__ float sv[GA_ROWS], sr[GA_ROWS];
+  __shared__ int32_t si[GA_ROWS];   // flat index << 1 | done, or -1 when the env is not in that row
+  const int e = blockIdx.x;
+  float nv = 0.0f, nd = 1.0f, nr = 0.0f, a = 0.0f;
+  bool first = true;
+  for (int rhi = R; rhi > 0; rhi -= GA_ROWS) {
+    const int r = rhi - 1 - (int)threadIdx.x;   // thread 0 holds the latest row of the chunk
+    int32_t tag = -1;
+    if (r >= 0) {
+      const int32_t* row = env_ids + (size_t)r * B;
+      int c = -1;
+      for (int j = 0; j < B; ++j) c = row[j] == e ? j : c;
+      if (c >= 0) {
+        const int i = r * B + c;
+        sv[threadIdx.x] = values[i];
+        sr[threadIdx.x] = rewards[i];
+        tag = (i << 1) | (dones[i] ? 1 : 0);
+      }
+    }
+    si[threadIdx.x] = tag;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int n = rhi < GA_ROWS ? rhi : GA_ROWS;
+      for (int k = 0; k < n; ++k) {
+        const int32_t t = si[k];
+        if (t < 0) continue;
+        const int i = t >> 1;
+        const float v = sv[k];
+        const float nnt = 1.0f - nd;
+        const float delta = first ? 0.0f : (nr + (gamma * nv) * nnt) - v;
+        a = delta + ((gl * nnt) * a);
+        adv[i] = a;
+        target[i] = a + v;
+        nv = v; nd = (float)(t & 1); nr = sr[k];
+        first = false;
+      }
+    }
+    __syncthreads();
+  }
+}
+void launch_gae_async(const int32_t* env_ids, const float* rewards, const float* values, const uint8_t* dones, int R, int B, int num_envs,
+                      float gamma, float lambda, float* adv, float* target, hipStream_t st) {
+  const float gl = (float)((double)gamma * (double)lambda);
+  hipLaunchKernelGGL(gae_async_kernel, dim3(num_envs), dim3(GA_ROWS), 0, st, env_ids, rewards, values, dones, R, B, gamma, gl, adv, target);
+}
+
+// naturecnn:540-541: the legacy ppo_loss normalises the advantages of each minibatch (population std).  out[idx[i]] gets the normalised
+// value, so the loss kernel keeps reading "adv[n]" — minibatches partition the permutation, the scattered writes never collide.
+__global__ __launch_bounds__(1024) void mb_advnorm_kernel(const float* adv, const int32_t* idx, int n, float* out) {
+  __shared__ float red[16];
+  float s = 0.0f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) s += adv[idx ? idx[i] : i];
+  const float mean = block_sum_1024(s, red) / (float)n;
+  float v = 0.0f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) { const float d = adv[idx ? idx[i] : i] - mean; v += d * d; }
+  const float sd = sqrtf(block_sum_1024(v, red) / (float)n);
+  for (int i = threadIdx.x; i < n; i += blockDim.x) { const int k = idx ? idx[i] : i; out[k] = (adv[k] - mean) / (sd + 1e-8f); }
+}
+void launch_mb_advnorm(const float* adv, const int32_t* idx, int n, float* out, hipStream_t st) {
+  hipLaunchKernelGGL(mb_advnorm_kernel, dim3(1), dim3(1024), 0, st, adv, idx, n, out);
+}
+
+// ------------------------------------------------------------------------------------------
 // jax.random.permutation (ppo:606): per round, composite key (random_bits << 32 | position) makes the
 // sort stable by construction; rank by counting (n^2 compares, n = 15360: ~20 us) then scatter.
 __global__ void perm_keys_kernel(uint32_t sk0, uint32_t sk1, int n, uint64_t* ckeys) {

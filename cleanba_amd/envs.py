@@ -32,8 +32,10 @@ def is_atari57_mix(env_id):
 
 
 class SyntheticAtariEnv:
-    def __init__(self, env_id="Breakout-v5", num_envs=8, seed=1, max_episode_steps=ATARI_MAX_FRAMES, num_actions=18, **_):
+    def __init__(self, env_id="Breakout-v5", num_envs=8, seed=1, max_episode_steps=ATARI_MAX_FRAMES, num_actions=18, batch_size=None, **_):
         self.env_id, self.num_envs, self.seed = env_id, int(num_envs), int(seed)
+        self.batch_size = int(batch_size or num_envs)   # envpool async mode: recv() hands back this many envs (naturecnn:119-125)
+        assert 0 < self.batch_size <= self.num_envs
         self.action_space = _Space(n=num_actions)
         self.observation_space = _Space(shape=(4, 84, 84))
         self.single_action_space, self.single_observation_space = self.action_space, self.observation_space
@@ -56,39 +58,74 @@ class SyntheticAtariEnv:
         r, d, term, el = L.synth_env_step_host(self.seed, self._st, self._obs, actions, self.spec.config.max_episode_steps)
         return self._obs.copy(), r, d.astype(bool), self._info(r, term, el)
 
-    # async API (impala:308,352,365): batch_size == num_envs, results sorted by env_id
+    # async API (impala:308,352,365).  batch_size == num_envs: every recv() returns all envs sorted by env_id (what cleanba_impala.py
+    # relies on).  batch_size < num_envs (legacy --async-batch-size, naturecnn:119-133): recv() returns the batch_size envs whose step
+    # finished first, in completion order; completion times come from a deterministic integer latency per (seed, env, step), so runs are
+    # reproducible while the env-id pattern is irregular like a real pool's.
     def async_reset(self):
         obs = self.reset()
-        z = np.zeros(self.num_envs, np.float32)
-        self._pending = (obs, z, np.zeros(self.num_envs, bool), self._info(z, np.zeros(self.num_envs, np.uint8), np.zeros(self.num_envs, np.int32)))
+        n = self.num_envs
+        z = np.zeros(n, np.float32)
+        if self.batch_size == n:
+            self._pending = (obs, z, np.zeros(n, bool), self._info(z, np.zeros(n, np.uint8), np.zeros(n, np.int32)))
+            return
+        self._res = dict(reward=z.copy(), done=np.zeros(n, bool), term=np.zeros(n, np.uint8), elapsed=np.zeros(n, np.int32))
+        self._waiting = np.ones(n, bool)            # env has a finished step nobody received yet
+        self._nsteps = np.zeros(n, np.int64)
+        self._clock = 0
+        self._ready_at = np.array([self._latency(e, 0) for e in range(n)], np.int64)
+
+    def _latency(self, e, k):
+        return ((e * 2654435761 + k * 40503 + self.seed * 97) >> 7) % 5
 
     def recv(self):
-        out, self._pending = self._pending, None
-        return out
+        if self.batch_size == self.num_envs:
+            out, self._pending = self._pending, None
+            return out
+        cand = np.nonzero(self._waiting)[0]
+        assert cand.size >= self.batch_size, "recv() without enough outstanding send()s"
+        ids = cand[np.argsort(self._ready_at[cand], kind="stable")[:self.batch_size]].astype(np.int32)
+        self._waiting[ids] = False
+        self._clock = max(self._clock + 1, int(self._ready_at[ids].max()))
+        r = self._res
+        info = {"env_id": ids, "reward": r["reward"][ids].copy(), "terminated": r["term"][ids].astype(np.int32), "elapsed_step": r["elapsed"][ids].copy(),
+                "TimeLimit.truncated": r["elapsed"][ids] >= self.spec.config.max_episode_steps}
+        return self._obs[ids].copy(), r["reward"][ids].copy(), r["done"][ids].copy(), info
 
     def send(self, actions, env_id=None):
         a = np.asarray(actions, np.int32)
-        if env_id is not None:
-            b = np.zeros_like(a)
-            b[np.asarray(env_id)] = a
-            a = b
-        self._pending = self.step(a)
+        if self.batch_size == self.num_envs:
+            if env_id is not None:
+                b = np.zeros_like(a)
+                b[np.asarray(env_id)] = a
+                a = b
+            self._pending = self.step(a)
+            return
+        ids = np.asarray(env_id, np.int32)
+        assert not self._waiting[ids].any(), "send() for an env whose last result was not received"
+        rw, d, term, el = L.synth_env_step_host_ids(self.seed, self._st, self._obs, ids, a, self.spec.config.max_episode_steps)
+        r = self._res
+        r["reward"][ids], r["done"][ids], r["term"][ids], r["elapsed"][ids] = rw, d.astype(bool), term, el
+        self._nsteps[ids] += 1
+        self._ready_at[ids] = self._clock + 1 + np.array([self._latency(int(e), int(self._nsteps[e])) for e in ids], np.int64)
+        self._waiting[ids] = True
 
     def close(self):
         self._st = None
 
 
-def make_env(env_id, seed, num_envs, backend="host", num_actions=18):
-    """Same thunk contract as the reference's make_env (ppo:126-146)."""
+def make_env(env_id, seed, num_envs, backend="host", num_actions=18, async_batch_size=None):
+    """Same thunk contract as the reference's make_env (ppo:126-146); async_batch_size = envpool's batch_size (naturecnn:119-125)."""
     def thunk():
         if backend == "envpool":
             import envpool  # noqa: F401  (not installed in this image; kept for drop-in use elsewhere)
+            kw = dict(batch_size=async_batch_size) if async_batch_size else {}
             envs = envpool.make(env_id, env_type="gym", num_envs=num_envs, episodic_life=False, repeat_action_probability=0.25,
-                                noop_max=1, full_action_space=True, max_episode_steps=ATARI_MAX_FRAMES, reward_clip=True, seed=seed)
+                                noop_max=1, full_action_space=True, max_episode_steps=ATARI_MAX_FRAMES, reward_clip=True, seed=seed, **kw)
             envs.num_envs = num_envs
             envs.single_action_space = envs.action_space
             envs.single_observation_space = envs.observation_space
             envs.is_vector_env = True
             return envs
-        return SyntheticAtariEnv(env_id, num_envs, seed, num_actions=num_actions)
+        return SyntheticAtariEnv(env_id, num_envs, seed, num_actions=num_actions, batch_size=async_batch_size)
     return thunk

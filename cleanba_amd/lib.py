@@ -28,7 +28,8 @@ class Config(C.Structure):
                 ("norm_adv", C.c_int32), ("ring_depth", C.c_int32), ("gamma", C.c_float), ("gae_lambda", C.c_float),
                 ("clip_coef", C.c_float), ("ent_coef", C.c_float), ("vf_coef", C.c_float), ("max_grad_norm", C.c_float),
                 ("adam_b1", C.c_float), ("adam_b2", C.c_float), ("adam_eps", C.c_float), ("rms_decay", C.c_float),
-                ("rms_eps", C.c_float), ("actor_dense_ksplit", C.c_int32), ("forward_bf16", C.c_int32), ("grad_accum_steps", C.c_int32), ("reserved", C.c_int32 * 5)]
+                ("rms_eps", C.c_float), ("actor_dense_ksplit", C.c_int32), ("forward_bf16", C.c_int32), ("grad_accum_steps", C.c_int32), ("async_batch_size", C.c_int32),
+                ("reserved", C.c_int32 * 4)]
 
 
 class EnvState(C.Structure):
@@ -49,7 +50,8 @@ SYMBOLS = [
     "cbm_forward", "cbm_sample", "cbm_gae", "cbm_advnorm", "cbm_permutation", "cbm_ppo_loss_grad",
     "cbm_impala_loss_grad", "cbm_adam_step", "cbm_rmsprop_step", "cbm_synth_env_reset_host", "cbm_synth_env_reset_host_games", "cbm_synth_env_step_host", "cbm_actor_env_reset_device_games",
     "cbm_actor_env_reset_device", "cbm_profile_select", "cbm_profile_read", "cbm_ingest_begin", "cbm_ingest_commit",
-    "cbm_params_publish_external", "cbm_actor_stream", "cbm_actor_ring_index",
+    "cbm_params_publish_external", "cbm_actor_stream", "cbm_actor_ring_index", "cbm_actor_step_async", "cbm_gae_async", "cbm_mb_advnorm",
+    "cbm_synth_env_step_host_ids",
 ]
 
 _lib = None
@@ -230,6 +232,20 @@ class Context:
         _chk(self.lib.cbm_actor_step_host(self.h, int(slot), _p(obs), _p(done), _p(fs), _p(rw), _p(actions_out)))
         return actions_out
 
+    def actor_step_async(self, slot, obs, reward, done, env_id, actions_out=None):
+        """One envpool.recv() batch of the legacy async loop (naturecnn:346-367) -> actions for envs.send(actions, env_id)."""
+        Ba = self.cfg.async_batch_size
+        if actions_out is None:
+            actions_out = np.empty(Ba, np.int32)
+        obs = np.ascontiguousarray(obs, np.uint8)
+        rw = np.ascontiguousarray(reward, np.float32)
+        done = np.ascontiguousarray(done, np.uint8)
+        eid = np.ascontiguousarray(env_id, np.int32)
+        if obs.shape[0] != Ba or eid.size != Ba:
+            raise ValueError(f"async step expects batches of async_batch_size={Ba} envs, got {obs.shape[0]}")
+        _chk(self.lib.cbm_actor_step_async(self.h, int(slot), _p(obs), _p(rw), _p(done), _p(eid), _p(actions_out)))
+        return actions_out
+
     def actor_record_host(self, slot, reward):
         r = np.ascontiguousarray(reward, np.float32)
         _chk(self.lib.cbm_actor_record_host(self.h, int(slot), _p(r)))
@@ -330,4 +346,18 @@ def synth_env_step_host(seed, st, obs, actions, max_episode_steps=27000):
     elapsed = np.zeros(n, np.int32)
     _chk(load().cbm_synth_env_step_host(C.c_uint32(int(seed) & 0xFFFFFFFF), int(n), int(max_episode_steps), _p(actions), st,
                                         _p(obs), _p(reward), _p(done), _p(term), _p(elapsed)))
+    return reward, done, term, elapsed
+
+
+def synth_env_step_host_ids(seed, st, obs, env_ids, actions, max_episode_steps=27000):
+    """Steps only the listed envs of the (st, obs) arrays that hold all of them — envpool's send(action, env_id) in async mode."""
+    env_ids = np.ascontiguousarray(env_ids, np.int32)
+    actions = np.ascontiguousarray(actions, np.int32)
+    k = env_ids.size
+    reward = np.zeros(k, np.float32)
+    done = np.zeros(k, np.uint8)
+    term = np.zeros(k, np.uint8)
+    elapsed = np.zeros(k, np.int32)
+    _chk(load().cbm_synth_env_step_host_ids(C.c_uint32(int(seed) & 0xFFFFFFFF), int(obs.shape[0]), int(k), int(max_episode_steps), _p(env_ids),
+                                            _p(actions), st, _p(obs), _p(reward), _p(done), _p(term), _p(elapsed)))
     return reward, done, term, elapsed

@@ -64,6 +64,7 @@ def make_config(args, algo):
     cfg.num_steps = args.num_steps
     cfg.num_minibatches = args.num_minibatches
     cfg.grad_accum_steps = args.gradient_accumulation_steps   # optax.MultiSteps(every_k_schedule) ppo:492-500
+    cfg.async_batch_size = int(getattr(args, "async_batch_size", 0) or 0)   # legacy envpool async mode (naturecnn:65-66)
     cfg.update_epochs = args.update_epochs if algo == "ppo" else 1
     cfg.norm_adv = int(args.norm_adv) if algo == "ppo" else 0
     cfg.gamma, cfg.gae_lambda = args.gamma, args.gae_lambda
@@ -81,7 +82,79 @@ def rollout(key, args, algo, engine, writer, device_thread_id, world_size, proce
         raise
 
 
+def _rollout_async(key, args, engine, writer, slot, world_size, process_index, stop_event):
+    """The legacy script's rollout() with envpool in async mode (naturecnn:283-446): every recv() returns `async_batch_size` of the
+    `local_num_envs` envs; a rollout is num_steps*async_update such batches, stored with their env ids; nothing is carried between rollouts."""
+    E, Ba = args.local_num_envs, args.async_batch_size
+    async_update = E // Ba
+    env_seed = args.seed + (0 if args.same_env_seed_all_ranks else process_index)  # naturecnn:290
+    engine.actor_set_key(slot, key)
+    envs = make_env(args.env_id, env_seed, E, backend=args.env_backend, num_actions=args.num_actions, async_batch_size=Ba)()
+    global_step = 0
+    start_time = time.time()
+    episode_returns = np.zeros((E,), dtype=np.float32)
+    returned_episode_returns = np.zeros((E,), dtype=np.float32)
+    episode_lengths = np.zeros((E,), dtype=np.float32)
+    returned_episode_lengths = np.zeros((E,), dtype=np.float32)
+    params_queue_get_time, rollout_time, rollout_queue_put_time = deque(maxlen=10), deque(maxlen=10), deque(maxlen=10)
+    actions = np.empty(Ba, np.int32)
+    envs.async_reset()
+    for update in range(1, args.num_updates + 2):
+        if stop_event.is_set():
+            return
+        update_time_start = time.time()
+        env_recv_time = inference_time = storage_time = env_send_time = 0.0
+        t0 = time.time()
+        engine.actor_begin_rollout(slot, args.concurrency)
+        params_queue_get_time.append(time.time() - t0)
+        rollout_time_start = time.time()
+        truncations = terminations = 0
+        for _ in range(async_update, (args.num_steps + 1) * async_update):   # naturecnn:343-345
+            t1 = time.time()
+            next_obs, next_reward, next_done, info = envs.recv()
+            env_recv_time += time.time() - t1
+            global_step += len(next_done) * len(args.actor_device_ids) * world_size
+            env_id = info["env_id"]
+            t1 = time.time()
+            engine.actor_step_async(slot, next_obs, next_reward, next_done, env_id, actions)
+            inference_time += time.time() - t1
+            t1 = time.time()
+            envs.send(actions, env_id)
+            env_send_time += time.time() - t1
+            t1 = time.time()
+            truncated = info["elapsed_step"] >= envs.spec.config.max_episode_steps
+            ended = (info["terminated"] + truncated) > 0
+            truncations += int(np.sum(truncated))
+            terminations += int(np.sum(info["terminated"]))
+            episode_returns[env_id] += info["reward"]
+            returned_episode_returns[env_id] = np.where(ended, episode_returns[env_id], returned_episode_returns[env_id])
+            episode_returns[env_id] *= (1 - info["terminated"]) * (1 - truncated)
+            episode_lengths[env_id] += 1
+            returned_episode_lengths[env_id] = np.where(ended, episode_lengths[env_id], returned_episode_lengths[env_id])
+            episode_lengths[env_id] *= (1 - info["terminated"]) * (1 - truncated)
+            storage_time += time.time() - t1
+        rollout_time.append(time.time() - rollout_time_start)
+        t0 = time.time()
+        engine.actor_commit(slot, None, None)
+        rollout_queue_put_time.append(time.time() - t0)
+        if update % args.log_frequency == 0:
+            avg_episodic_return = float(np.mean(returned_episode_returns))
+            print(f"global_step={global_step}, avg_episodic_return={avg_episodic_return}")
+            print("SPS:", int(global_step / (time.time() - start_time)))
+            for tag, val in (("stats/rollout_time", np.mean(rollout_time)), ("charts/avg_episodic_return", avg_episodic_return),
+                             ("charts/avg_episodic_length", float(np.mean(returned_episode_lengths))),
+                             ("stats/params_queue_get_time", np.mean(params_queue_get_time)), ("stats/truncations", truncations),
+                             ("stats/terminations", terminations), ("stats/env_recv_time", env_recv_time),
+                             ("stats/inference_time", inference_time), ("stats/storage_time", storage_time),
+                             ("stats/env_send_time", env_send_time), ("stats/rollout_queue_put_time", np.mean(rollout_queue_put_time)),
+                             ("charts/SPS", int(global_step / (time.time() - start_time))),
+                             ("charts/SPS_update", int(E * args.num_steps * len(args.actor_device_ids) * world_size / (time.time() - update_time_start)))):
+                writer.add_scalar(tag, val, global_step)
+
+
 def _rollout(key, args, algo, engine, writer, slot, world_size, process_index, stop_event, on_commit=None):
+    if getattr(args, "async_batch_size", 0):
+        return _rollout_async(key, args, engine, writer, slot, world_size, process_index, stop_event)
     len_actor_device_ids = len(args.actor_device_ids)
     E = args.local_num_envs
     env_seed = args.seed + (0 if args.same_env_seed_all_ranks else process_index) + slot  # ppo:238
@@ -240,6 +313,8 @@ def train(args, algo="ppo", engine_factory=None, on_update=None, rendezvous=None
         n_proc, proc_index = lay.groups, lay.group   # the reference's world_size counts actor+learner groups (ppo:425-430)
     else:
         n_proc, proc_index = world_size, rank
+    if getattr(args, "async_batch_size", 0) and algo != "ppo":
+        raise SystemExit("--async-batch-size belongs to the PPO script (cleanba_impala.py already drives envpool through recv/send)")
     finalize(args, n_proc, proc_index)
     if args.distributed and world_size > 1 and dist_module is None:
         import torch.distributed as dist

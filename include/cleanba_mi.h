@@ -57,7 +57,11 @@ typedef struct {
                                  0 = the reference's fp32 everywhere.  Nature-CNN only. */
   int32_t grad_accum_steps;   /* optax.MultiSteps every_k (ppo:79,492-500): each of the num_minibatches*k micro-batches feeds a running
                                  mean; the optimizer steps on every k-th.  0/1 = off. */
-  int32_t reserved[5];
+  int32_t async_batch_size;   /* legacy `--async-batch-size` (naturecnn:65-66): envpool returns this many of the local_num_envs envs per
+                                 recv(); a rollout is num_steps * local_num_envs/async_batch_size rows of async_batch_size samples with env
+                                 ids, returns are env-id-indexed (naturecnn:467-531), advantages normalised per minibatch
+                                 (naturecnn:540-541).  PPO, one actor slot.  0 = synchronous (cleanba_ppo.py). */
+  int32_t reserved[4];
 } cbm_config;
 
 /* Fills cfg with the reference defaults for `algo` (ppo:34-118 / impala:34-110). */
@@ -78,7 +82,7 @@ int cbm_actor_params_get(cbm_ctx* ctx, float* host_params, int64_t n);      /* a
 
 /* ---- named device buffers (for tests, all-reduce plumbing, checkpointing).
  * names: "params", "actor_params", "actor_params_latest", "grads", "opt_m", "opt_v", "adv", "target", "perm",
- *        "obs", "actions", "logprobs", "values", "rewards", "dones", "logits", "stats" ...   */
+ *        "obs", "actions", "logprobs", "values", "rewards", "dones", "env_ids", "logits", "stats" ...   */
 int cbm_buffer(cbm_ctx* ctx, const char* name, int32_t ring_index, void** dev_ptr, int64_t* nbytes);
 int cbm_copy_to_host(cbm_ctx* ctx, void* host_dst, const void* dev_src, int64_t nbytes);
 int cbm_copy_to_device(cbm_ctx* ctx, void* dev_dst, const void* host_src, int64_t nbytes);
@@ -99,6 +103,11 @@ int cbm_actor_begin_rollout(cbm_ctx* ctx, int32_t slot, int32_t concurrency, int
  * runs get_action_and_value (ppo:246-261), returns actions[E] after the 4*E-byte D2H (ppo:317). */
 int cbm_actor_step_host(cbm_ctx* ctx, int32_t slot, const uint8_t* obs, const uint8_t* done,
                         const uint8_t* firststep, const float* reward_with_obs, int32_t* actions_out);
+/* Async host-env step (legacy script, naturecnn:346-367): one envpool.recv() batch — obs[Ba,4,84,84], the reward[Ba] / done[Ba] that
+ * arrived with it, env_id[Ba] — is stored in ring row t, get_action_and_value runs on it, actions_out[Ba] feed envs.send(action, env_id).
+ * A rollout is exactly num_steps*async_update such calls followed by cbm_actor_commit(ctx, slot, NULL, NULL). */
+int cbm_actor_step_async(cbm_ctx* ctx, int32_t slot, const uint8_t* obs, const float* reward, const uint8_t* done, const int32_t* env_id,
+                         int32_t* actions_out);
 /* reward_with_obs: IMPALA stores the reward that arrived WITH obs_t (impala:372-384); NULL for PPO,
  * which instead records what envs.step returned for the action just taken (ppo:321-342): */
 int cbm_actor_record_host(cbm_ctx* ctx, int32_t slot, const float* reward);
@@ -150,6 +159,12 @@ int cbm_sample(cbm_ctx* ctx, const float* logits, int32_t B, const uint32_t subk
 int cbm_gae(cbm_ctx* ctx, const float* rewards, const float* values, const uint8_t* dones, const float* next_value,
             const uint8_t* next_done, int32_t T, int32_t B, float* adv, float* target);             /* ppo:532-560 */
 int cbm_advnorm(cbm_ctx* ctx, float* adv, int32_t T, int32_t B, int32_t groups);                  /* ppo:592-595 */
+/* async returns: env_ids/rewards/values [R,B] (reward and done as they arrived with each observation), dones u8 [R,B] -> adv, target [R,B]:
+ * prepare_data's reward re-index naturecnn:232-255 + env-id-indexed compute_gae naturecnn:467-531 */
+int cbm_gae_async(cbm_ctx* ctx, const int32_t* env_ids, const float* rewards, const float* values, const uint8_t* dones, int32_t R, int32_t B,
+                  int32_t num_envs, float* adv, float* target);
+/* out[idx[i]] = (adv[idx[i]] - mean) / (std + 1e-8) over the n samples of one minibatch (idx NULL = identity), naturecnn:540-541 */
+int cbm_mb_advnorm(cbm_ctx* ctx, const float* adv, const int32_t* idx, int32_t n, float* out);
 int cbm_permutation(cbm_ctx* ctx, const uint32_t key[2], int32_t n, int32_t* perm);               /* ppo:606 */
 int cbm_ppo_loss_grad(cbm_ctx* ctx, const float* params, const uint8_t* obs, const int32_t* idx, int32_t N,
                       const int32_t* actions, const float* old_logprob, const float* adv, const float* target,
@@ -183,6 +198,11 @@ int cbm_synth_env_reset_host_games(uint32_t seed, int32_t n, int32_t atari57_mix
 int cbm_synth_env_step_host(uint32_t seed, int32_t n, int32_t max_episode_steps, const int32_t* actions,
                             cbm_env_state* st, uint8_t* obs, float* reward, uint8_t* done, uint8_t* terminated,
                             int32_t* elapsed_step);
+/* envpool async mode, send(action, env_id) for a subset (impala:365, naturecnn:358): steps the k listed envs of the num_envs held in st / obs;
+ * outputs in list order. */
+int cbm_synth_env_step_host_ids(uint32_t seed, int32_t num_envs, int32_t k, int32_t max_episode_steps, const int32_t* env_ids,
+                                const int32_t* actions, cbm_env_state* st, uint8_t* obs, float* reward, uint8_t* done,
+                                uint8_t* terminated, int32_t* elapsed_step);
 int cbm_actor_env_reset_device(cbm_ctx* ctx, int32_t slot, uint32_t seed);
 int cbm_actor_env_reset_device_games(cbm_ctx* ctx, int32_t slot, uint32_t seed, int32_t atari57_mix);
 

@@ -30,8 +30,11 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(_SO):
-            build()
+        try:
+            build()   # no-op when the .so is newer than its sources
+        except Exception:
+            if not os.path.exists(_SO):
+                raise
         _lib = C.CDLL(_SO)
         _lib.cbo_global_norm.restype = C.c_float
         _lib.cbo_logf.restype = C.c_float
@@ -197,6 +200,31 @@ def advnorm(adv, groups=4):
     T, B = a.shape
     lib().cbo_advnorm(_p(a), T, B, int(groups))
     return a
+
+
+def gae_async(env_ids, rewards, values, dones, num_envs, gamma=0.99, gae_lambda=0.95):
+    """prepare_data's reward re-index + env-id-indexed compute_gae of the legacy async script (naturecnn:232-262, 467-531)."""
+    env_ids = _i32(env_ids)
+    R, B = env_ids.shape
+    adv = np.zeros((R, B), np.float32)
+    tgt = np.zeros((R, B), np.float32)
+    lib().cbo_gae_async(_p(env_ids), _p(_f32(rewards)), _p(_f32(values)), _p(_u8(dones)), R, B, int(num_envs), C.c_float(gamma),
+                        C.c_float(gae_lambda), _p(adv), _p(tgt))
+    return adv, tgt
+
+
+def async_next_index(env_ids, num_envs):
+    env_ids = _i32(env_ids).reshape(-1)
+    out = np.zeros(env_ids.size, np.int32)
+    lib().cbo_async_next_index(_p(env_ids), env_ids.size, int(num_envs), _p(out))
+    return out
+
+
+def mb_advnorm(adv):
+    a = _f32(adv).reshape(-1)
+    out = np.zeros_like(a)
+    lib().cbo_mb_advnorm(_p(a), a.size, _p(out))
+    return out
 
 
 def vtrace(v_tm1, v_t, r_t, disc_t, rho_tm1):

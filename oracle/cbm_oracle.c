@@ -438,6 +438,66 @@ EXPORT void cbo_advnorm(float* adv, int T, int B, int groups) {
   }
 }
 
+/* ============================================================ async rollouts (legacy `--async-batch-size`)
+ * envpool in async mode hands back `async_batch_size` of the `local_num_envs` envs per recv() (naturecnn:119-133, 346-355), so a
+ * rollout is R = num_steps * async_update rows of B = async_batch_size samples and every row carries its env ids.
+ *
+ * cbo_async_next_index — prepare_data's scan, naturecnn:232-252: next_index[i] = flat index of the NEXT sample of the same env
+ * (0 where there is none: the array starts as zeros and the `.at[-1]` write of an env's first sample stores the old value back). */
+EXPORT void cbo_async_next_index(const int32_t* env_ids, int n, int num_envs, int32_t* next_index) {
+  int32_t* last = (int32_t*)malloc((size_t)num_envs * sizeof(int32_t));
+  for (int e = 0; e < num_envs; ++e) last[e] = -1;
+  for (int i = 0; i < n; ++i) next_index[i] = 0;
+  for (int i = 0; i < n; ++i) {
+    const int e = env_ids[i];
+    if (last[e] != -1) next_index[last[e]] = i;
+    last[e] = i;
+  }
+  free(last);
+}
+/* cbo_gae_async — "rewards is off by one time step" gather (naturecnn:254-255) followed by compute_gae (naturecnn:467-531): a reverse
+ * scan over rows with per-env carries lastvalues / lastdones (=1) / lastgaelam; an env's LAST sample of the rollout gets delta = 0 and,
+ * through nextnonterminal = 1 - lastdones = 0, advantage 0 (there is no bootstrap observation in async mode, naturecnn:306-311).
+ * rewards[i] / dones[i] are what arrived WITH obs_i (naturecnn:347,362,367).  returns = advantages + values. */
+EXPORT void cbo_gae_async(const int32_t* env_ids, const float* rewards, const float* values, const uint8_t* dones, int R, int B,
+                          int num_envs, float gamma, float gae_lambda, float* adv, float* target) {
+  const int n = R * B;
+  const float gl = (float)((double)gamma * (double)gae_lambda);
+  int32_t* next_index = (int32_t*)malloc((size_t)n * sizeof(int32_t));
+  float* lastvalues = (float*)calloc((size_t)num_envs, sizeof(float));
+  float* lastdones = (float*)malloc((size_t)num_envs * sizeof(float));
+  float* lastgaelam = (float*)calloc((size_t)num_envs, sizeof(float));
+  int32_t* checked = (int32_t*)malloc((size_t)num_envs * sizeof(int32_t));
+  cbo_async_next_index(env_ids, n, num_envs, next_index);
+  for (int e = 0; e < num_envs; ++e) { lastdones[e] = 1.0f; checked[e] = -1; }
+  for (int r = R - 1; r >= 0; --r) {
+    for (int c = 0; c < B; ++c) {   /* one scan step handles a whole row; env ids within a row are distinct */
+      const int i = r * B + c, e = env_ids[i];
+      const float reward = rewards[next_index[i]];
+      const float nnt = 1.0f - lastdones[e];
+      const float delta = checked[e] == -1 ? 0.0f : (reward + (gamma * lastvalues[e]) * nnt) - values[i];
+      const float a = delta + ((gl * nnt) * lastgaelam[e]);
+      adv[i] = a;
+      target[i] = a + values[i];
+      checked[e] = 1;
+      lastgaelam[e] = a;
+      lastdones[e] = (float)dones[i];
+      lastvalues[e] = values[i];
+    }
+  }
+  free(next_index); free(lastvalues); free(lastdones); free(lastgaelam); free(checked);
+}
+/* per-minibatch advantage normalisation inside the legacy ppo_loss, naturecnn:540-541: (x - mean) / (std + 1e-8), population std */
+EXPORT void cbo_mb_advnorm(const float* adv, int n, float* out) {
+  double s = 0.0;
+  for (int i = 0; i < n; ++i) s += adv[i];
+  const float mean = (float)(s / (double)n);
+  double v = 0.0;
+  for (int i = 0; i < n; ++i) { const float d = adv[i] - mean; v += (double)d * d; }
+  const float sd = sqrtf((float)(v / (double)n));
+  for (int i = 0; i < n; ++i) out[i] = (adv[i] - mean) / (sd + 1e-8f);
+}
+
 /* ============================================================ PPO loss head  (ppo:516-577)
  * From logits/value of a minibatch: the 5 statistics and dL/dlogits, dL/dvalue.
  * stats = [loss, pg_loss, v_loss, entropy, approx_kl]. */

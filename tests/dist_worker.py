@@ -25,6 +25,8 @@ if same:
     argv.append("--same-env-seed-all-ranks")
 if os.environ.get("CBM_TEST_ACCUM"):
     argv += ["--gradient-accumulation-steps", os.environ["CBM_TEST_ACCUM"], "--num-minibatches", "2"]
+if os.environ.get("CBM_TEST_ASYNC"):   # legacy envpool async mode: recv() batches of 2 of the 4 envs
+    argv += ["--async-batch-size", os.environ["CBM_TEST_ASYNC"]]
 args = parse_args(argv, algo)
 os.chdir(os.environ.get("CBM_TEST_TMP", "/tmp"))
 res = train(args, algo, engine_factory=OracleEngine)

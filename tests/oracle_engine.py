@@ -19,7 +19,12 @@ class OracleEngine:
         self.cfg = cfg
         self.ppo = cfg.algo == 0
         self.A, self.E, self.S = cfg.num_actions, cfg.local_num_envs, cfg.num_actor_slots
-        self.B, self.T = self.E * self.S, cfg.num_steps
+        self.T = cfg.num_steps
+        self.asyncB = int(getattr(cfg, "async_batch_size", 0) or 0)
+        if self.asyncB:   # legacy async mode: rows of asyncB samples, num_steps*async_update of them (mirrors csrc/api.hip)
+            assert self.ppo and self.S == 1 and self.E % self.asyncB == 0
+            self.NE, self.E, self.T = self.E, self.asyncB, cfg.num_steps * (self.E // self.asyncB)
+        self.B = self.E * self.S
         self.T1 = self.T + 1
         self.nmb = cfg.num_minibatches
         self.accum = max(1, cfg.grad_accum_steps)
@@ -30,7 +35,8 @@ class OracleEngine:
         z = lambda dt, *shape: np.zeros(shape, dt)
         self.ring = [dict(obs=z(np.uint8, self.T1, self.B, 4, 84, 84), actions=z(np.int32, self.T1, self.B), logprobs=z(np.float32, self.T1, self.B),
                           values=z(np.float32, self.T1, self.B), rewards=z(np.float32, self.T1, self.B), logits=z(np.float32, self.T1, self.B, self.A),
-                          dones=z(np.uint8, self.T1, self.B), firststeps=z(np.uint8, self.T1, self.B)) for _ in range(self.depth)]
+                          dones=z(np.uint8, self.T1, self.B), firststeps=z(np.uint8, self.T1, self.B), env_ids=z(np.int32, self.T1, self.B))
+                     for _ in range(self.depth)]
         self.params = np.zeros(self.P, np.float32)
         self.grads = np.zeros(self.P, np.float32)
         self.m = np.zeros(self.P, np.float32)
@@ -107,6 +113,20 @@ class OracleEngine:
             R["logprobs"][t, c], R["values"][t, c] = lp, value
         else:
             R["logits"][t, c] = logits
+        sl["t"] += 1
+        if actions_out is not None:
+            actions_out[:] = a
+            return actions_out
+        return a
+
+    def actor_step_async(self, s, obs, reward, done, env_id, actions_out=None):
+        sl = self.slot[s]
+        R, t = self.ring[sl["ring"]], sl["t"]
+        assert t < self.T, "rollout overrun"
+        R["obs"][t], R["rewards"][t], R["dones"][t], R["env_ids"][t] = obs, reward, done, env_id
+        logits, value = oracle.nature_forward(self.actor_params[sl["pver"]], self.A, R["obs"][t], ksplit=self.cfg.actor_dense_ksplit)
+        a, lp, self.keys[s] = oracle.sample_actions(logits, self.keys[s])
+        R["actions"][t], R["logprobs"][t], R["values"][t] = a, lp, value
         sl["t"] += 1
         if actions_out is not None:
             actions_out[:] = a
@@ -196,7 +216,11 @@ class OracleEngine:
             self.cv.wait_for(lambda: all(c >= v for c in self.committed))
 
     def learner_prepare(self, key):
-        if self.ppo:
+        if self.asyncB:
+            R = self._cur()
+            self.adv, self.tgt = oracle.gae_async(R["env_ids"][:self.T], R["rewards"][:self.T], R["values"][:self.T], R["dones"][:self.T], self.NE,
+                                                  self.cfg.gamma, self.cfg.gae_lambda)
+        elif self.ppo:
             R = self._cur()
             _, nv = oracle.nature_forward(self.params, self.A, R["obs"][self.T], ksplit=self.cfg.actor_dense_ksplit)
             adv, tgt = oracle.gae(R["rewards"][:self.T], R["values"][:self.T], R["dones"][:self.T], nv, R["dones"][self.T], self.cfg.gamma,
@@ -222,8 +246,11 @@ class OracleEngine:
             MB = N // self.nmicro
             idx = self.perm[mb * MB:(mb + 1) * MB]
             fo = R["obs"][:self.T].reshape(N, 4, 84, 84)
+            mb_adv = self.adv.reshape(N)[idx]
+            if self.asyncB and self.cfg.norm_adv:
+                mb_adv = oracle.mb_advnorm(mb_adv)   # naturecnn:540-541
             st, g, _, _ = oracle.ppo_loss_grad(self.params, self.A, fo, idx, R["actions"][:self.T].reshape(N)[idx],
-                                               R["logprobs"][:self.T].reshape(N)[idx], self.adv.reshape(N)[idx], self.tgt.reshape(N)[idx],
+                                               R["logprobs"][:self.T].reshape(N)[idx], mb_adv, self.tgt.reshape(N)[idx],
                                                c.clip_coef, c.ent_coef, c.vf_coef)
         else:
             Bm = self.B // self.nmicro

@@ -301,3 +301,26 @@ def test_whole_training_runs_match_the_oracle_engine(tmp_path, algo, E, thr, T, 
     d = np.abs(gpu["params"] - cpu["params"]).max()
     assert d <= 2e-5 * max(1.0, np.abs(cpu["params"]).max()), d
     np.testing.assert_allclose(gpu["stats"], cpu["stats"], rtol=5e-4, atol=5e-5)
+
+
+@pytest.mark.parametrize("E,Ba,T,nmb,epochs,conc", [(4, 2, 4, 2, 2, False), (6, 2, 5, 3, 1, True), (12, 4, 6, 4, 2, True)])
+def test_async_batch_size_runs_match_the_oracle_engine(tmp_path, E, Ba, T, nmb, epochs, conc):
+    # legacy `--async-batch-size` (legacy_scripts/..._naturecnn.py): recv() returns Ba of the E envs in completion order, the
+    # rollout carries env ids, returns are env-id-indexed, advantages normalised per minibatch.  Same host program on the HIP library and
+    # on the oracle-backed engine; sampled actions are bit-exact, so both see the same env-id pattern.
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from oracle_engine import OracleEngine
+    from cleanba_amd.args import parse_args
+    from cleanba_amd.trainer import train
+    os.chdir(str(tmp_path))
+    updates = 3
+    argv = ["--local-num-envs", str(E), "--async-batch-size", str(Ba), "--num-steps", str(T), "--num-minibatches", str(nmb), "--update-epochs",
+            str(epochs), "--network", "nature", "--env-backend", "host", "--total-timesteps", str(updates * E * T), "--log-frequency", "1000"] + (
+                ["--concurrency"] if conc else [])
+    gpu = train(parse_args(argv, "ppo"), "ppo")
+    cpu = train(parse_args(argv, "ppo"), "ppo", engine_factory=OracleEngine)
+    assert gpu["updates"] == cpu["updates"] == updates
+    d = np.abs(gpu["params"] - cpu["params"]).max()
+    assert d <= 2e-5 * max(1.0, np.abs(cpu["params"]).max()), d
+    np.testing.assert_allclose(gpu["stats"], cpu["stats"], rtol=5e-4, atol=5e-5)

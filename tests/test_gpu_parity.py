@@ -90,6 +90,36 @@ def test_gae_advnorm_permutation(ctx, oracle):
         dPm.free()
 
 
+def test_async_gae_and_minibatch_advnorm(ctx, oracle):
+    """legacy --async-batch-size: env-id-indexed returns (naturecnn:232-262, 467-531) bit-exact (same serial recursion per env), the
+    per-minibatch advantage normalisation (naturecnn:540-541) within 1e-5.  R > 1024 exercises the kernel's row chunking."""
+    from test_oracle_async import make_async_rollout
+    for (R, B, NE, seed) in [(60, 4, 12, 1), (384, 20, 60, 2), (33, 5, 5, 3), (2560, 6, 120, 4), (1025, 3, 7, 5), (7, 1, 3, 6)]:
+        env_ids, r, v, d = make_async_rollout(R, B, NE, seed)
+        bufs = [L.DevBuf(ctx, x) for x in (env_ids, r, v, d)]
+        dA = L.DevBuf(ctx, nbytes=R * B * 4, dtype=np.float32, shape=(R, B))
+        dT = L.DevBuf(ctx, nbytes=R * B * 4, dtype=np.float32, shape=(R, B))
+        L._chk(ctx.lib.cbm_gae_async(ctx.h, *[L._p(b.ptr) for b in bufs], R, B, NE, L._p(dA.ptr), L._p(dT.ptr)))
+        adv_o, tgt_o = oracle.gae_async(env_ids, r, v, d, NE)
+        assert (bits(dA.download()) == bits(adv_o)).all() and (bits(dT.download()) == bits(tgt_o)).all(), (R, B, NE)
+        for b in bufs + [dT]:
+            b.free()
+        n = R * B
+        perm = np.random.default_rng(seed).permutation(n).astype(np.int32)
+        dI = L.DevBuf(ctx, perm)
+        dN = L.DevBuf(ctx, np.zeros(n, np.float32))
+        half = n // 2
+        for lo, hi in ((0, half), (half, n)):   # two "minibatches" partition the permutation
+            L._chk(ctx.lib.cbm_mb_advnorm(ctx.h, L._p(dA.ptr), L._p(dI.ptr + 4 * lo), hi - lo, L._p(dN.ptr)))
+        got = dN.download()
+        flat = adv_o.reshape(-1)
+        for lo, hi in ((0, half), (half, n)):
+            if hi - lo > 1 and flat[perm[lo:hi]].std() > 0:
+                np.testing.assert_allclose(got[perm[lo:hi]], oracle.mb_advnorm(flat[perm[lo:hi]]), rtol=0, atol=2e-5)
+        for b in (dA, dI, dN):
+            b.free()
+
+
 def test_ppo_loss_and_grads(ctx, oracle):
     rng = np.random.default_rng(7)
     N = 64

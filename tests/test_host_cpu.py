@@ -65,6 +65,18 @@ def test_impala_host_loop_cpu(tmp_path):
     assert np.isfinite(p).all()
 
 
+def test_async_batch_size_host_loop_cpu(tmp_path, monkeypatch):
+    """Legacy `--async-batch-size`: recv() batches of 2 of 4 envs, env-id-indexed returns, per-minibatch advantage norm."""
+    monkeypatch.setenv("CBM_TEST_ASYNC", "2")
+    ref = _run(1, True, str(tmp_path), "async1")[0]
+    assert np.isfinite(ref).all()
+    a, b = _run(2, True, str(tmp_path), "async2")     # same env streams on both ranks: dp2 == dp1 bit for bit
+    assert (a == b).all() and (a == ref).all()
+    monkeypatch.delenv("CBM_TEST_ASYNC")
+    sync = _run(1, True, str(tmp_path), "sync1")[0]
+    assert np.abs(sync - ref).max() > 0                 # and it is not silently the synchronous path
+
+
 def test_cli_and_schedules():
     from cleanba_amd.args import parse_args, finalize
     import cleanba_amd.model as M
