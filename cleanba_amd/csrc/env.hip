@@ -9,6 +9,9 @@
 // observation of the new episode with reward 0 and elapsed_step 0), `terminated` w.p. ~1/800 per step,
 // clipped reward in {0,1} w.p. ~0.02, truncation at max_episode_steps (ppo:121-123,328).
 #include "cbm_internal.h"
+#include <stdlib.h>
+#include <thread>
+#include <vector>
 #include <string.h>
 
 #define PADDLE_W 12
@@ -245,19 +248,40 @@ static void host_step_one(uint32_t seed, int e, int32_t action, int32_t max_epis
     if (out.was_reset) { o[i] = v; o[7056 + i] = v; o[2 * 7056 + i] = v; }
   }
 }
+// envpool steps its envs on a C++ thread pool; the twin does the same so that host-env runs are not bound by one core: the k envs of a call
+// are cut into contiguous chunks, one std::thread each (an env's trajectory depends only on its own id, seed and actions — any
+// partition gives the same bytes).  CBM_ENV_THREADS overrides the thread count (default min(8, cores), at least 8 envs per thread).
+template <class F>
+static void host_parallel_for(int k, F body) {
+  static const int max_threads = [] {
+    const char* e = getenv("CBM_ENV_THREADS");
+    int n = e ? atoi(e) : (int)std::thread::hardware_concurrency();
+    return n < 1 ? 1 : (n > 8 && !e ? 8 : n);
+  }();
+  int nt = k / 8 < max_threads ? k / 8 : max_threads;
+  if (nt <= 1) { for (int j = 0; j < k; ++j) body(j); return; }
+  std::vector<std::thread> th;
+  th.reserve(nt);
+  for (int t = 0; t < nt; ++t) {
+    const int lo = (int)((int64_t)k * t / nt), hi = (int)((int64_t)k * (t + 1) / nt);
+    th.emplace_back([=] { for (int j = lo; j < hi; ++j) body(j); });
+  }
+  for (auto& x : th) x.join();
+}
 extern "C" int cbm_synth_env_step_host(uint32_t seed, int32_t n, int32_t max_episode_steps, const int32_t* actions, cbm_env_state* st,
                                        uint8_t* obs, float* reward, uint8_t* done, uint8_t* terminated, int32_t* elapsed_step) {
-  for (int e = 0; e < n; ++e) host_step_one(seed, e, actions[e], max_episode_steps, st, obs, reward + e, done + e, terminated + e, elapsed_step + e);
+  host_parallel_for(n, [=](int e) { host_step_one(seed, e, actions[e], max_episode_steps, st, obs, reward + e, done + e, terminated + e, elapsed_step + e); });
   return 0;
 }
 // envpool's send(action, env_id) for a subset: steps the k envs listed in env_ids (indices into st / obs, which hold ALL envs); the per-env
-// outputs are written in list order.  An env's trajectory depends only on its own id, seed and actions, not on who is stepped with it.
+// outputs are written in list order.
 extern "C" int cbm_synth_env_step_host_ids(uint32_t seed, int32_t num_envs, int32_t k, int32_t max_episode_steps, const int32_t* env_ids,
                                            const int32_t* actions, cbm_env_state* st, uint8_t* obs, float* reward, uint8_t* done,
                                            uint8_t* terminated, int32_t* elapsed_step) {
-  for (int j = 0; j < k; ++j) {
+  for (int j = 0; j < k; ++j)
     if (env_ids[j] < 0 || env_ids[j] >= num_envs) { cbm_set_error("env_id %d outside [0,%d)", env_ids[j], num_envs); return -1; }
+  host_parallel_for(k, [=](int j) {
     host_step_one(seed, env_ids[j], actions[j], max_episode_steps, st, obs, reward + j, done + j, terminated + j, elapsed_step + j);
-  }
+  });
   return 0;
 }

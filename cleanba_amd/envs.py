@@ -70,10 +70,14 @@ class SyntheticAtariEnv:
             self._pending = (obs, z, np.zeros(n, bool), self._info(z, np.zeros(n, np.uint8), np.zeros(n, np.int32)))
             return
         self._res = dict(reward=z.copy(), done=np.zeros(n, bool), term=np.zeros(n, np.uint8), elapsed=np.zeros(n, np.int32))
-        self._waiting = np.ones(n, bool)            # env has a finished step nobody received yet
+        self._waiting = np.ones(n, bool)            # env has a (possibly still running) step whose result nobody received yet
+        self._futs = {}                             # env id -> future of the send() batch that is stepping it
+        if getattr(self, "_pool", None) is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._pool = ThreadPoolExecutor(1)      # like envpool, send() returns at once and the envs step in the background
         self._nsteps = np.zeros(n, np.int64)
         self._clock = 0
-        self._ready_at = np.array([self._latency(e, 0) for e in range(n)], np.int64)
+        self._ready_at = self._latency(np.arange(n, dtype=np.int64), 0)
 
     def _latency(self, e, k):
         return ((e * 2654435761 + k * 40503 + self.seed * 97) >> 7) % 5
@@ -85,12 +89,15 @@ class SyntheticAtariEnv:
         cand = np.nonzero(self._waiting)[0]
         assert cand.size >= self.batch_size, "recv() without enough outstanding send()s"
         ids = cand[np.argsort(self._ready_at[cand], kind="stable")[:self.batch_size]].astype(np.int32)
-        self._waiting[ids] = False
+        for f in {id(f): f for f in (self._futs.pop(int(e), None) for e in ids) if f is not None}.values():
+            self._apply(f)                          # WHO is returned is decided by the simulated latencies above (deterministic);
+        self._waiting[ids] = False                  # the real threads only have to be done with those envs
         self._clock = max(self._clock + 1, int(self._ready_at[ids].max()))
         r = self._res
-        info = {"env_id": ids, "reward": r["reward"][ids].copy(), "terminated": r["term"][ids].astype(np.int32), "elapsed_step": r["elapsed"][ids].copy(),
-                "TimeLimit.truncated": r["elapsed"][ids] >= self.spec.config.max_episode_steps}
-        return self._obs[ids].copy(), r["reward"][ids].copy(), r["done"][ids].copy(), info
+        rw, el = r["reward"][ids], r["elapsed"][ids]   # fancy indexing copies
+        info = {"env_id": ids, "reward": rw.copy(), "terminated": r["term"][ids].astype(np.int32), "elapsed_step": el,
+                "TimeLimit.truncated": el >= self.spec.config.max_episode_steps}
+        return self._obs[ids], rw, r["done"][ids], info
 
     def send(self, actions, env_id=None):
         a = np.asarray(actions, np.int32)
@@ -101,16 +108,28 @@ class SyntheticAtariEnv:
                 a = b
             self._pending = self.step(a)
             return
-        ids = np.asarray(env_id, np.int32)
+        ids, a = np.array(env_id, np.int32), np.array(a, np.int32)   # copies: the caller reuses its buffers while the envs step
         assert not self._waiting[ids].any(), "send() for an env whose last result was not received"
-        rw, d, term, el = L.synth_env_step_host_ids(self.seed, self._st, self._obs, ids, a, self.spec.config.max_episode_steps)
-        r = self._res
-        r["reward"][ids], r["done"][ids], r["term"][ids], r["elapsed"][ids] = rw, d.astype(bool), term, el
+        fut = self._pool.submit(lambda: (ids,) + tuple(L.synth_env_step_host_ids(self.seed, self._st, self._obs, ids, a,
+                                                                                    self.spec.config.max_episode_steps)))
+        for e in ids:
+            self._futs[int(e)] = fut
         self._nsteps[ids] += 1
-        self._ready_at[ids] = self._clock + 1 + np.array([self._latency(int(e), int(self._nsteps[e])) for e in ids], np.int64)
+        self._ready_at[ids] = self._clock + 1 + self._latency(ids.astype(np.int64), self._nsteps[ids])
         self._waiting[ids] = True
 
+    def _apply(self, fut):
+        """Fold one finished send() batch into the per-env result table — once, even when its envs are received in different recv()s."""
+        ids, rw, d, term, el = fut.result()
+        if not getattr(fut, "_applied", False):
+            fut._applied = True
+            r = self._res
+            r["reward"][ids], r["done"][ids], r["term"][ids], r["elapsed"][ids] = rw, d.astype(bool), term, el
+
     def close(self):
+        if getattr(self, "_pool", None) is not None:
+            self._pool.shutdown(wait=True)
+            self._pool = None
         self._st = None
 
 

@@ -63,3 +63,15 @@ out.update(imp_logits=lg3, imp_mu=mu3, imp_value=v3, imp_actions=a3, imp_rewards
            imp_dvalue=dv)
 np.savez_compressed(os.path.join(HERE, "oracle_vectors.npz"), **out)
 print("wrote", os.path.join(HERE, "oracle_vectors.npz"), {k: v.shape for k, v in out.items() if k.startswith(("fwd", "ppo_stats", "imp_stats"))})
+
+# legacy --async-batch-size returns: env-id-indexed GAE + per-minibatch advantage normalisation, own file
+from test_oracle_async import make_async_rollout  # noqa: E402
+asy = {}
+for tag, (R, B, NE, seed) in {"a": (24, 3, 7, 11), "b": (128, 20, 60, 12)}.items():
+    env_ids, r, v, d = make_async_rollout(R, B, NE, seed)
+    adv, tgt = oracle.gae_async(env_ids, r, v, d, NE)
+    asy.update({f"{tag}_env_ids": env_ids, f"{tag}_r": r, f"{tag}_v": v, f"{tag}_d": d, f"{tag}_adv": adv, f"{tag}_tgt": tgt,
+                f"{tag}_num_envs": np.int32(NE), f"{tag}_next_index": oracle.async_next_index(env_ids, NE),
+                f"{tag}_mbnorm": oracle.mb_advnorm(adv.reshape(-1)[: R * B // 2])})
+np.savez_compressed(os.path.join(HERE, "async_vectors.npz"), **asy)
+print("wrote", os.path.join(HERE, "async_vectors.npz"))

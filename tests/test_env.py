@@ -67,3 +67,40 @@ def test_atari57_mix_presets():
     rate = (rew[:57] + rew[57:]) / (2 * steps)
     assert 0.002 < rate.min() and rate.max() < 0.07 and rate.max() > 2 * rate.min()
     assert done.sum() > 0
+
+
+def test_async_batches_are_the_same_trajectories_in_a_different_order():
+    """envpool async mode (batch_size < num_envs): recv() hands back batch_size envs in completion order.  Whatever the
+    order, every env must live exactly the trajectory it has in the synchronous env when it is fed the same actions — observation,
+    and the reward / done / elapsed_step that arrive WITH that observation."""
+    import zlib
+    from cleanba_amd.envs import SyntheticAtariEnv
+    E, Ba, steps = 12, 4, 40
+    policy = lambda e, k: (e * 5 + k * 3) % 6
+    sync = SyntheticAtariEnv(num_envs=E, seed=9)
+    obs = sync.reset()
+    want = [[(zlib.crc32(obs[e].tobytes()), 0.0, False, 0)] for e in range(E)]
+    for k in range(steps):
+        obs, r, d, info = sync.step(np.array([policy(e, k) for e in range(E)], np.int32))
+        for e in range(E):
+            want[e].append((zlib.crc32(obs[e].tobytes()), float(r[e]), bool(d[e]), int(info["elapsed_step"][e])))
+    asy = SyntheticAtariEnv(num_envs=E, seed=9, batch_size=Ba)
+    asy.async_reset()
+    seen = [0] * E
+    orders = set()
+    buf = np.zeros(Ba, np.int32)
+    while min(seen) < steps:
+        o, r, d, info = asy.recv()
+        ids = info["env_id"]
+        assert len(set(ids.tolist())) == Ba
+        orders.add(tuple(ids.tolist()))
+        live = []
+        for j, e in enumerate(ids):
+            if seen[e] <= steps:
+                assert (zlib.crc32(o[j].tobytes()), float(r[j]), bool(d[j]), int(info["elapsed_step"][j])) == want[e][seen[e]], (e, seen[e])
+            buf[j] = policy(int(e), seen[e])
+            seen[e] += 1
+        asy.send(buf, ids)
+        buf[:] = -7          # the caller may reuse its action buffer right after send()
+    asy.close()
+    assert len(orders) > 10   # the batches are not a fixed round-robin
