@@ -205,3 +205,26 @@ def test_split_fan_out_plan_follows_the_reference_recipes():
     # workers (RANK set) and non-split runs are left alone
     assert plan(a, dict(slurm, RANK="4", WORLD_SIZE="8")) is None
     assert plan(parse_args([], "ppo"), {}) is None
+
+
+def test_benchmark_fan_out_matrix_and_slurm_render(tmp_path, monkeypatch):
+    """cleanrl_utils.benchmark counterpart (README.md:74-83): command matrix order, local workers, SLURM template placeholders."""
+    import cleanba_amd.benchmark as B
+    cmds = B.command_matrix("python x.py --a 1", ["Breakout-v5", "Pong-v5"], 2, start_seed=3)
+    assert cmds == ["python x.py --a 1 --env-id Breakout-v5 --seed 3", "python x.py --a 1 --env-id Pong-v5 --seed 3",
+                    "python x.py --a 1 --env-id Breakout-v5 --seed 4", "python x.py --a 1 --env-id Pong-v5 --seed 4"]
+    monkeypatch.chdir(tmp_path)
+    marker = tmp_path / "ran.txt"
+    prog = tmp_path / "w.py"
+    prog.write_text("import sys\nopen(%r, 'a').write(' '.join(sys.argv[1:]) + '\\n')\n" % str(marker))
+    B.main(["--command", f"{sys.executable} {prog}", "--env-ids", "A-v5", "B-v5", "--num-seeds", "2", "--workers", "2"])
+    assert sorted(marker.read_text().split("\n")[:-1]) == ["--env-id A-v5 --seed 1", "--env-id A-v5 --seed 2", "--env-id B-v5 --seed 1", "--env-id B-v5 --seed 2"]
+    tpl = tmp_path / "t.slurm"
+    tpl.write_text("#SBATCH --gpus-per-task={{gpus_per_task}}\n#SBATCH --cpus-per-gpu={{cpus_per_gpu}}\n#SBATCH --ntasks={{ntasks}}\n#SBATCH --array={{array}}\n{{nodes}}\n"
+                   "env_ids={{env_ids}}\nseeds={{seeds}}\nn={{len_seeds}}\nsrun {{command}} --env-id $env_id --seed $seed\n")
+    path = B.main(["--command", "python -m cleanba_amd.cleanba_ppo --distributed --learner-device-ids 1 2 3", "--env-ids", "Breakout-v5", "--num-seeds", "1",
+                   "--workers", "0", "--slurm-gpus-per-task", "4", "--slurm-ntasks", "2", "--slurm-nodes", "1", "--slurm-template-path", str(tpl)])
+    out = open(path).read()
+    assert "--gpus-per-task=4" in out and "--cpus-per-gpu=7" in out and "--ntasks=2" in out and "--array=0-0%0" in out and "#SBATCH --nodes=1" in out
+    assert "env_ids=(Breakout-v5)" in out and "seeds=(1)" in out and "{{" not in out
+    assert "srun python -m cleanba_amd.cleanba_ppo --distributed --learner-device-ids 1 2 3 --env-id $env_id --seed $seed" in out
