@@ -98,7 +98,8 @@ def main():
     ctx.actor_set_key(0, key)
     ctx.actor_env_reset_device(0, 1 + rank)  # env seed = seed + process_index + thread id (ppo:238)
     lkey = key.copy()
-    grads_t = ctx.grads_tensor() if dist is not None else None
+    from cleanba_amd.trainer import GradAllReducer
+    allreduce = GradAllReducer(ctx, world, dist_module=dist, active=dist is not None)   # tail of the gradient overlaps the conv backward
     n_opt = EPOCHS * NMB
     total_updates = a.warmup + a.steps
     opt_count = 0
@@ -122,9 +123,8 @@ def main():
                 lkey = ctx.learner_epoch_begin(lkey)
                 for mb in range(NMB):
                     ctx.learner_minibatch_grad(e, mb)
-                    with ctx.stream_context():
-                        dist.all_reduce(grads_t)
-                    ctx.learner_optimizer_step(float(lrs[i]), float(bcs[i][0]), float(bcs[i][1]), float(world))
+                    grad_div = allreduce()
+                    ctx.learner_optimizer_step(float(lrs[i]), float(bcs[i][0]), float(bcs[i][1]), grad_div)
                     i += 1
             ctx.learner_finish(n_opt, want_stats=False)
         opt_count += n_opt
@@ -180,11 +180,32 @@ def main():
                 "roofline": roof}
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(params)
-        print(json.dumps(line))
+        _emit(json.dumps(line))
     ctx.close()
     if dist is not None:
         dist.destroy_process_group()
 
 
+_REAL_STDOUT = None
+
+
+def _emit(text):
+    """The one JSON line goes to the process's ORIGINAL stdout; see _quiet_stdout."""
+    if _REAL_STDOUT is None:
+        print(text, flush=True)
+    else:
+        os.write(_REAL_STDOUT, (text + "\n").encode())
+
+
+def _quiet_stdout():
+    """Everything else that writes to fd 1 — RCCL's start-up banner (C stdio, flushed at exit, i.e. AFTER the result line), library warnings,
+    the other ranks under torchrun — is sent to stderr, so stdout carries exactly one line: rank 0's JSON."""
+    global _REAL_STDOUT
+    sys.stdout.flush()
+    _REAL_STDOUT = os.dup(1)
+    os.dup2(2, 1)
+
+
 if __name__ == "__main__":
+    _quiet_stdout()
     main()

@@ -77,6 +77,7 @@ struct cbm_ctx {
   int updates_done = 0;
   int stat_rows = 0;
   CbmProf prof;
+  hipEvent_t tail_ev = nullptr, ext_ev = nullptr;   // gradient-tail hand-off to an external communication stream
 };
 
 static bool is_ppo(const cbm_ctx* c) { return c->cfg.algo == CBM_ALGO_PPO; }
@@ -190,6 +191,9 @@ static int ctx_create_impl(const cbm_config* cfg, cbm_ctx** out, cbm_ctx** parti
   const int lmax = c->MB > c->Bdev ? c->MB : c->Bdev;
   if (nature_ws_alloc(c->lws, lmax, true, cfg->actor_dense_ksplit, cfg->network)) return -1;
   c->lws.bf16_fwd = cfg->forward_bf16 != 0 && cfg->network == CBM_NET_NATURE;
+  CBM_HIP(hipEventCreateWithFlags(&c->tail_ev, hipEventDisableTiming));
+  CBM_HIP(hipEventCreateWithFlags(&c->ext_ev, hipEventDisableTiming));
+  c->lws.tail_ev = c->tail_ev;
   c->stat_rows = c->epochs * c->nmicro;
   if (c->accum > 1) { if (dalloc(&c->gacc, P)) return -1; hipMemset(c->gacc, 0, P * 4); }
   if (c->asyncB && dalloc(&c->advn, T1 * B)) return -1;
@@ -243,6 +247,8 @@ extern "C" int cbm_ctx_destroy(cbm_ctx* c) {
     hipStreamDestroy(c->slots[s].stream);
   }
   nature_ws_free(c->lws);
+  if (c->tail_ev) hipEventDestroy(c->tail_ev);
+  if (c->ext_ev) hipEventDestroy(c->ext_ev);
   hipStreamDestroy(c->lstream);
   delete c;
   return 0;
@@ -614,6 +620,23 @@ extern "C" int cbm_learner_minibatch_grad(cbm_ctx* c, int32_t epoch, int32_t mb)
                        c->cfg.gamma, c->cfg.vf_coef, c->cfg.ent_coef, c->lws.dzv, c->loss_partials, stats, c->lstream);
     nature_backward(c->L, c->params, R.obs, idx, c->MB, c->lws, c->grads, c->lstream);
   }
+  return 0;
+}
+
+// Overlapping pmean(grads) (ppo:628) with the backward pass.  The flat gradient is laid out conv1 | conv2 | conv3 | dense | actor | critic and
+// the backward pass produces it from the back: once the dense weight gradient is reduced, the tail [grad_tail_offset, P) — 95 % of the
+// bytes (Nature) / 91 % (ResNet) — is final while the conv dgrad / wgrad kernels are still to run.  A data-parallel host all-reduces that
+// tail on its own communication stream as soon as the event fires, the small head after the backward pass, and joins the streams.
+extern "C" int64_t cbm_learner_grad_tail_offset(cbm_ctx* c) { return c->L.w[3]; }
+extern "C" int cbm_learner_stream_wait_tail(cbm_ctx* c, void* stream) {   // call after cbm_learner_minibatch_grad
+  CBM_HIP(hipSetDevice(c->cfg.device));
+  CBM_HIP(hipStreamWaitEvent((hipStream_t)stream, c->tail_ev, 0));
+  return 0;
+}
+extern "C" int cbm_learner_wait_stream(cbm_ctx* c, void* stream) {        // learner stream waits for everything enqueued on `stream` so far
+  CBM_HIP(hipSetDevice(c->cfg.device));
+  CBM_HIP(hipEventRecord(c->ext_ev, (hipStream_t)stream));
+  CBM_HIP(hipStreamWaitEvent(c->lstream, c->ext_ev, 0));
   return 0;
 }
 

@@ -36,6 +36,7 @@ struct NatureWs {
   CbmProf* prof = nullptr;
   int maxB = 0;
   bool with_grad = false;
+  hipEvent_t tail_ev = nullptr;   // when set: recorded by the backward pass once the gradients of dense + heads (the flat tail [w[3], total)) are final
   bool bf16_fwd = false;   // cbm_config.forward_bf16: conv2/conv3/dense forward on bf16 MFMA (Nature-CNN)
   float *act1 = nullptr, *act2 = nullptr, *act3 = nullptr, *hid = nullptr;
   float *logits = nullptr, *value = nullptr;

@@ -591,6 +591,7 @@ void nature_backward(const NatureLayout& L, const float* P, const uint8_t* obs, 
     launch_reduce(ws.wg_part, nz, 3136 * 512, 512, 0, A, grads + L.w[3], (float*)nullptr, st);
     launch_reduce(ws.bias_part, nz, 512, 512, 0, A, grads + L.b[3], (float*)nullptr, st);
   }
+  if (ws.tail_ev) hipEventRecord(ws.tail_ev, st);   // 95 % of the flat gradient is final here: its all-reduce can overlap the conv backward
   // conv3: dgrad -> dact2pad, wgrad
   {
     Conv3Dgrad<T128x64> pd{ws.dact3pad, P + L.w[2], ws.act2, ws.dact2pad, B * 81};

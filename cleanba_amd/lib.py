@@ -51,7 +51,7 @@ SYMBOLS = [
     "cbm_impala_loss_grad", "cbm_adam_step", "cbm_rmsprop_step", "cbm_synth_env_reset_host", "cbm_synth_env_reset_host_games", "cbm_synth_env_step_host", "cbm_actor_env_reset_device_games",
     "cbm_actor_env_reset_device", "cbm_profile_select", "cbm_profile_read", "cbm_ingest_begin", "cbm_ingest_commit",
     "cbm_params_publish_external", "cbm_actor_stream", "cbm_actor_ring_index", "cbm_actor_step_async", "cbm_gae_async", "cbm_mb_advnorm",
-    "cbm_synth_env_step_host_ids",
+    "cbm_synth_env_step_host_ids", "cbm_learner_grad_tail_offset", "cbm_learner_stream_wait_tail", "cbm_learner_wait_stream",
 ]
 
 _lib = None
@@ -92,6 +92,7 @@ def load():
     lib.cbm_last_error.restype = C.c_char_p
     lib.cbm_build_info.restype = C.c_char_p
     lib.cbm_param_count.restype = C.c_int64
+    lib.cbm_learner_grad_tail_offset.restype = C.c_int64
     lib.cbm_learner_stream.restype = C.c_void_p
     lib.cbm_learner_stream.argtypes = [C.c_void_p]
     lib.cbm_actor_stream.restype = C.c_void_p
@@ -315,6 +316,15 @@ class Context:
 
     def learner_minibatch_grad(self, epoch, mb):
         _chk(self.lib.cbm_learner_minibatch_grad(self.h, int(epoch), int(mb)))
+
+    def grad_tail_offset(self):
+        return int(self.lib.cbm_learner_grad_tail_offset(self.h))
+
+    def learner_stream_wait_tail(self, stream_handle):
+        _chk(self.lib.cbm_learner_stream_wait_tail(self.h, C.c_void_p(int(stream_handle))))
+
+    def learner_wait_stream(self, stream_handle):
+        _chk(self.lib.cbm_learner_wait_stream(self.h, C.c_void_p(int(stream_handle))))
 
     def learner_accumulate(self, mini_step, grad_div=1.0):
         _chk(self.lib.cbm_learner_accumulate(self.h, int(mini_step), C.c_float(grad_div)))

@@ -271,18 +271,44 @@ def _rollout(key, args, algo, engine, writer, slot, world_size, process_index, s
 
 
 class GradAllReducer:
-    """pmean(grads) over all learner processes (ppo:628) = one flat all-reduce on the library's grad
-    buffer.  RCCL via torch.distributed when the engine exposes a device buffer, gloo on CPU in tests."""
+    """pmean(grads) over all learner processes (ppo:628) = all-reduce(SUM) of the library's flat gradient buffer, divided by the world
+    size inside the optimizer kernel.  RCCL via torch.distributed on the HIP engine, gloo on CPU in tests.
 
-    def __init__(self, engine, world_size, group=None):
+    On the HIP engine the all-reduce is split in two so that most of it hides under the backward pass: the gradient is produced from the
+    back, and the tail [grad_tail_offset, P) — dense layer + heads, 95 % of the bytes — is final long before the conv kernels are done.
+    `cbm_learner_minibatch_grad` only enqueues work, so by the time this is called the GPU is still inside the backward pass: the tail is
+    all-reduced on a communication stream that waits for the library's tail event, the small head on the learner stream after the
+    backward pass, and the learner stream joins the communication stream before the optimizer step.  `overlap=False` (or an engine without
+    the hooks) gives the single flat all-reduce."""
+
+    def __init__(self, engine, world_size, group=None, dist_module=None, overlap=None, active=None):
         self.engine, self.world, self.group = engine, world_size, group
-        self.tensor = engine.grads_tensor() if world_size > 1 else None
+        self.active = world_size > 1 if active is None else bool(active)   # active=True at world 1: exercise the path on one GPU
+        self.tensor = engine.grads_tensor() if self.active else None
+        self.dist = dist_module
+        want = os.environ.get("CBM_ALLREDUCE_OVERLAP", "1") != "0" if overlap is None else overlap
+        self.overlap = bool(want and self.active and hasattr(engine, "learner_stream_wait_tail"))
+        if self.overlap:
+            import torch
+            self.comm = torch.cuda.Stream(device=self.tensor.device)
+            self.tail = engine.grad_tail_offset()
 
     def __call__(self):
-        if self.world > 1:
-            import torch.distributed as dist
-            with self.engine.stream_context():
-                dist.all_reduce(self.tensor, op=dist.ReduceOp.SUM, group=self.group)
+        if self.active:
+            dist = self.dist
+            if dist is None:
+                import torch.distributed as dist
+            if self.overlap:
+                import torch
+                with torch.cuda.stream(self.comm):
+                    self.engine.learner_stream_wait_tail(self.comm.cuda_stream)
+                    dist.all_reduce(self.tensor[self.tail:], op=dist.ReduceOp.SUM, group=self.group)
+                with self.engine.stream_context():
+                    dist.all_reduce(self.tensor[:self.tail], op=dist.ReduceOp.SUM, group=self.group)
+                self.engine.learner_wait_stream(self.comm.cuda_stream)
+            else:
+                with self.engine.stream_context():
+                    dist.all_reduce(self.tensor, op=dist.ReduceOp.SUM, group=self.group)
         return float(self.world)  # grad_div: the mean is taken inside the optimizer kernel
 
 

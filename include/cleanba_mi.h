@@ -144,6 +144,14 @@ int cbm_learner_update(cbm_ctx* ctx, uint32_t key[2], const float* lrs, const fl
 int cbm_learner_prepare(cbm_ctx* ctx, uint32_t key[2]);
 int cbm_learner_epoch_begin(cbm_ctx* ctx, uint32_t key[2]);   /* key,subkey = split(key); perm = permutation(subkey) ppo:599-606 */
 int cbm_learner_minibatch_grad(cbm_ctx* ctx, int32_t epoch, int32_t minibatch);
+/* Overlap of the gradient all-reduce with the backward pass (pmean, ppo:628): the flat gradient is produced from the back; once the dense
+ * layer's weight gradient exists, the tail [cbm_learner_grad_tail_offset, P) — dense + heads, 95 % of the bytes — is final.  After
+ * cbm_learner_minibatch_grad (which only enqueues work), cbm_learner_stream_wait_tail makes the caller's communication stream wait for
+ * that point so the tail's all-reduce runs under the conv backward; the head [0, offset) is all-reduced on the learner stream as before;
+ * cbm_learner_wait_stream then makes the learner stream wait for the communication stream before the optimizer step. */
+int64_t cbm_learner_grad_tail_offset(cbm_ctx* ctx);
+int cbm_learner_stream_wait_tail(cbm_ctx* ctx, void* hip_stream);
+int cbm_learner_wait_stream(cbm_ctx* ctx, void* hip_stream);
 /* gradient accumulation (grad_accum_steps = k > 1), split form: after each micro-batch's all-reduce call cbm_learner_accumulate with
  * mini_step = micro_batch % k; it folds "grads"/grad_div into the running mean and, on mini_step == k-1, leaves that mean in "grads" for
  * cbm_learner_optimizer_step(..., grad_div = 1). */
