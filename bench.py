@@ -34,9 +34,12 @@ MB = E * T // NMB
 KERNELS = {
     0: ("conv1_fwd", 2.0 * MB * 400 * 32 * 256), 1: ("conv2_fwd", 2.0 * MB * 81 * 64 * 512), 2: ("conv3_fwd", 2.0 * MB * 49 * 64 * 576),
     3: ("dense_fwd", 2.0 * MB * 512 * 3136), 4: ("heads_wgrad", 2.0 * MB * 512 * 32), 5: ("dense_dgrad", 2.0 * MB * 3136 * 512),
-    6: ("dense_wgrad", 2.0 * MB * 3136 * 512), 7: ("conv3_dgrad", 2.0 * MB * 81 * 64 * 576), 8: ("conv3_wgrad", 2.0 * MB * 49 * 576 * 64),
-    9: ("conv2_dgrad", 2.0 * MB * 400 * 32 * 256), 10: ("conv2_wgrad", 2.0 * MB * 81 * 512 * 64), 11: ("conv1_wgrad", 2.0 * MB * 400 * 256 * 32),
+    6: ("dense_wgrad", 2.0 * MB * 3136 * 512), 7: ("conv3_dgrad", 2.0 * MB * 49 * 64 * 576), 8: ("conv3_wgrad", 2.0 * MB * 49 * 576 * 64),
+    9: ("conv2_dgrad", 2.0 * MB * 81 * 64 * 512), 10: ("conv2_wgrad", 2.0 * MB * 81 * 512 * 64), 11: ("conv1_wgrad", 2.0 * MB * 400 * 256 * 32),
 }
+# flops are ALGORITHMIC (a layer's dgrad and wgrad each cost its forward flops).  The conv2 dgrad EXECUTES 2*MB*400*32*256
+# (x1.23: its four parity classes run over a 10x10 half-resolution grid whose border taps hit zero padding); the conv3 dgrad executes
+# exactly the algorithmic count since it skips the taps that fall into the zero border.
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 
 

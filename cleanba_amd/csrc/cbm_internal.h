@@ -45,6 +45,8 @@ struct NatureWs {
   // backward
   float *dzv = nullptr, *dhid = nullptr, *dact3pad = nullptr, *dact2pad = nullptr, *dact1 = nullptr;
   float *wg_part = nullptr, *bias_part = nullptr;
+  int32_t* c3_order = nullptr;   // conv3 dgrad tile order (position-major tiles, heavy taps first at the end of each XCD's run)
+  int c3_order_S = -1;
   int64_t wg_part_floats = 0, bias_part_floats = 0;
   // IMPALA-ResNet activations (resnet_layers.inc): per sequence {c0, p, b0y1, b0out, b1y1, b1out}, pool arg-max, grad ping-pong
   int kind = 0;

@@ -22,6 +22,7 @@
 #endif
 #include "igemm.h"
 #include <algorithm>
+#include <vector>
 #include <type_traits>
 
 NatureLayout nature_layout(int A) {
@@ -243,6 +244,60 @@ struct Conv3Dgrad {
   }
 };
 
+// conv3 dgrad, position-major: the frame-major form above multiplies all 9 taps for every output pixel although the 7x7 dY sits in a
+// zero border — only 49/81 of its flops touch data.  Here an x-tile is ONE output pixel (ih, iw) of BX consecutive frames, so the taps
+// that can be non-zero are the same for all its rows (jh in [max(0,2-ih), min(2,8-ih)], same for jw: 1, 2 or 3 per axis) and the block
+// reduces over exactly those (igemm.h KSKIP): 441 instead of 729 tap-tiles per frame tile.  Tiles are ordered frame-tile-major, pixel-minor, so
+// the 81 blocks that read the same BX frames of dY run back to back on one XCD.  Rows beyond S (last frame tile) load frame S-1 and store nothing.
+template <class TileT>
+struct Conv3DgradPos {
+  using Tile = TileT;
+  static constexpr bool A_RX = false, B_YR = true, BIAS_GRAD = false, KSKIP = true;
+  static constexpr int NCLS = 1;
+  const float* dypad; const float* W; const float* act2; float* dxpad; int S;
+  const int32_t* order;   // x-tile index (after the kernel's XCD remap) -> frame_tile * 81 + pixel
+  __host__ __device__ int X() const { return ((S + Tile::BX - 1) / Tile::BX) * 81 * Tile::BX; }
+  __host__ __device__ int Y() const { return 64; }
+  __device__ void r_range(int, int& lo, int& hi) const { lo = 0; hi = 576; }
+  __device__ int block_ctx(int x0, int) const {
+    const int p = order[x0 / Tile::BX] % 81, ih = p / 9, iw = p - ih * 9;
+#if CONV3_DGRAD_POS == 2   // experiment: position-major order without the tap skipping
+    const int jh0 = 0, jh1 = 2, jw0 = 0, jw1 = 2;
+#else
+    const int jh0 = max(0, 2 - ih), jh1 = min(2, 8 - ih), jw0 = max(0, 2 - iw), jw1 = min(2, 8 - iw);
+#endif
+    const int njw = jw1 - jw0 + 1, nt = (jh1 - jh0 + 1) * njw;
+    return jh0 | (jw0 << 2) | (njw << 4) | (nt << 8);
+  }
+  __device__ int block_k(int ctx) const { return (ctx >> 8) * 64; }
+  __device__ int r_map(int ctx, int rc) const {
+    const int t = rc >> 6, njw = (ctx >> 4) & 15, q = t / njw;
+    return ((ctx & 3) + q) * 192 + (((ctx >> 2) & 3) + (t - q * njw)) * 64 + (rc & 63);
+  }
+  __device__ void decode(int x, int& s, int& ih, int& iw) const {
+    const int xt = x / Tile::BX, tile = order[xt], t = tile / 81, p = tile - t * 81;
+    s = t * Tile::BX + (x - xt * Tile::BX); ih = p / 9; iw = p - ih * 9;
+  }
+  __device__ float4 load_a(int x, int r, int, int) const {
+    int s, ih, iw;
+    decode(x, s, ih, iw);
+    s = min(s, S - 1);
+    const int jh = r / 192, rem = r - jh * 192;
+    return *reinterpret_cast<const float4*>(dypad + ((size_t)(s * 11 + ih + jh) * 11 + iw) * 64 + rem);
+  }
+  __device__ float4 load_b(int r, int ci, int, int) const {
+    const int jh = r / 192, rem = r - jh * 192, jw = rem >> 6, co = rem & 63;
+    return *reinterpret_cast<const float4*>(W + ((size_t)((2 - jh) * 3 + (2 - jw)) * 64 + ci) * 64 + co);
+  }
+  __device__ void store(int x, int ci, float v, int, int) const {
+    int s, ih, iw;
+    decode(x, s, ih, iw);
+    if (s >= S) return;
+    const bool on = act2[((size_t)s * 81 + ih * 9 + iw) * 64 + ci] > 0.0f;
+    dxpad[((size_t)(s * 11 + ih + 1) * 11 + iw + 1) * 64 + ci] = on ? v : 0.0f;
+  }
+};
+
 // conv2 dgrad (4x4 s2) as 4 parity classes (ph,pw): X = (s, ih', iw') over 10x10, Y = ci (32),
 // r = (jh, jw, co) with kh = ph + 2(1-jh), kw = pw + 2(1-jw); reads dact2pad, writes masked dact1.
 template <class TileT>
@@ -416,6 +471,7 @@ int nature_ws_alloc(NatureWs& ws, int maxB, bool with_grad, int dense_ksplit_sma
   if (with_grad) {
     if (dmalloc(&ws.dzv, B * 32) || dmalloc(&ws.dhid, B * 512) || dmalloc(&ws.dact3pad, B * 7744) || dmalloc(&ws.dact2pad, B * 7744) ||
         dmalloc(&ws.dact1, B * 12800)) return -1;
+    if (hipMalloc((void**)&ws.c3_order, ((B + 127) / 128) * 81 * sizeof(int32_t)) != hipSuccess) { cbm_set_error("hipMalloc failed"); return -1; }
     hipMemset(ws.dact3pad, 0, B * 7744 * sizeof(float));
     hipMemset(ws.dact2pad, 0, B * 7744 * sizeof(float));
     hipMemset(ws.dzv, 0, B * 32 * sizeof(float));
@@ -444,6 +500,8 @@ void nature_ws_free(NatureWs& ws) {
   }
   for (int j = 0; j < 2; ++j) { if (ws.rn_g[j]) hipFree(ws.rn_g[j]); ws.rn_g[j] = nullptr; }
   if (ws.rn_wT) { hipFree(ws.rn_wT); ws.rn_wT = nullptr; }
+  if (ws.c3_order) { hipFree(ws.c3_order); ws.c3_order = nullptr; }
+  ws.c3_order_S = -1;
 }
 
 // ------------------------------------------------------------------------------------------ drivers
@@ -481,6 +539,9 @@ static inline void plaunch_fwd(NatureWs& ws, int kid, const P& p, int nz, hipStr
   igemm_bf16_launch(p, nz, st);
   if (on) { hipEventRecord(pf->ev[2 * pf->n + 1], st); pf->n += 1; }
 }
+#ifndef CONV3_DGRAD_POS
+#define CONV3_DGRAD_POS 1   // position-major conv3 dgrad with tap skipping
+#endif
 template <class F>
 static inline void plaunch_fn(NatureWs& ws, int kid, hipStream_t st, F&& launch) {
   CbmProf* pf = ws.prof;
@@ -566,6 +627,31 @@ void nature_forward(const NatureLayout& L, const float* P, const uint8_t* obs, c
   launch_heads_fwd(ws.hid, P + L.w[4], P + L.b[4], P + L.w[5], P + L.b[5], B, L.A, 512, ws.logits, ws.value, st);
 }
 
+// Tile order of the position-major conv3 dgrad.  igemm_kernel hands XCD k the contiguous run of x-tiles [start_k, start_k + len_k)
+// (block b runs on XCD b % 8).  Within a run the tiles go frame-tile by frame-tile (81 pixels that read the same BX frames, L2-friendly);
+// the last two frame-tiles' worth of every run is sorted by tap count, heaviest first, so that the blocks still running when the
+// kernel drains are the 1- and 2-tap border pixels (4-8 K-chunks) rather than 9-tap interior ones (36): a lone block is latency-bound,
+// and the drain used to cost as much as the skipped taps saved.
+static void conv3_order_build(NatureWs& ws, int S, int BX, hipStream_t st) {
+  if (ws.c3_order_S == S) return;
+  const int nft = (S + BX - 1) / BX, nb = nft * 81;
+  auto taps = [](int p) {
+    const int ih = p / 9, iw = p % 9;
+    return (std::min(2, 8 - ih) - std::max(0, 2 - ih) + 1) * (std::min(2, 8 - iw) - std::max(0, 2 - iw) + 1);
+  };
+  std::vector<int32_t> h(nb);
+  for (int i = 0; i < nb; ++i) h[i] = i;
+  const int q = nb >> 3, r = nb & 7;
+  for (int k = 0; k < 8; ++k) {
+    const int lo = k < r ? k * (q + 1) : r * (q + 1) + (k - r) * q, len = k < r ? q + 1 : q;
+    const int tail = std::min(len, 162);
+    std::stable_sort(h.begin() + lo + len - tail, h.begin() + lo + len, [&](int a, int b) { return taps(a % 81) > taps(b % 81); });
+  }
+  hipMemcpyAsync(ws.c3_order, h.data(), (size_t)nb * 4, hipMemcpyHostToDevice, st);
+  hipStreamSynchronize(st);   // h goes out of scope; happens once per batch size
+  ws.c3_order_S = S;
+}
+
 void nature_backward(const NatureLayout& L, const float* P, const uint8_t* obs, const int32_t* idx, int B, NatureWs& ws, float* grads,
                      hipStream_t st) {
   if (L.kind == CBM_NET_IMPALA_RESNET) { resnet_backward(L, P, obs, idx, B, ws, grads, st); return; }
@@ -594,7 +680,12 @@ void nature_backward(const NatureLayout& L, const float* P, const uint8_t* obs, 
   if (ws.tail_ev) hipEventRecord(ws.tail_ev, st);   // 95 % of the flat gradient is final here: its all-reduce can overlap the conv backward
   // conv3: dgrad -> dact2pad, wgrad
   {
+#if CONV3_DGRAD_POS
+    conv3_order_build(ws, B, T128x64::BX, st);
+    Conv3DgradPos<T128x64> pd{ws.dact3pad, P + L.w[2], ws.act2, ws.dact2pad, B, ws.c3_order};
+#else
     Conv3Dgrad<T128x64> pd{ws.dact3pad, P + L.w[2], ws.act2, ws.dact2pad, B * 81};
+#endif
     plaunch(ws, K_CONV3_DGRAD, pd, 1, st);
     const int M = B * 49, nz = ceil_div(M, RPS_C3);
     ConvWgrad<TILE_C3W, 3, 3, 1, 64, 64, 9, 9, 7, 7, 2> pw{ws.act2, ws.dact3pad, ws.wg_part, ws.bias_part, M, RPS_C3};

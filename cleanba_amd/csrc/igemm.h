@@ -25,6 +25,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef IGEMM_BYR_YFAST
 #define IGEMM_BYR_YFAST 1
 #endif
+// Functors with KSKIP = true give every x-tile its own compressed reduction range: block_ctx(x0, cls) packs what the block needs,
+// block_k(ctx) is the length of its range, r_map(ctx, r) turns a chunk-aligned compressed r into the real one (the chunk never
+// straddles a 64-wide tap).  Used by the position-major dgrads, whose border tiles multiply only the taps that can be non-zero.
+template <class P, class = void>
+struct igemm_kskip { static constexpr bool value = false; };
+template <class P>
+struct igemm_kskip<P, decltype((void)P::KSKIP)> { static constexpr bool value = P::KSKIP; };
 #ifndef IGEMM_MIN_WAVES
 #define IGEMM_MIN_WAVES 4
 #endif
@@ -100,6 +107,9 @@ __global__ __launch_bounds__(256, P::Tile::MINW) void igemm_kernel(const P p) {
   }
   int rlo, rhi;
   p.r_range(z, rlo, rhi);
+  constexpr bool KSKIP = igemm_kskip<P>::value;
+  int kctx = 0;
+  if constexpr (KSKIP) { kctx = p.block_ctx(x0, cls); rlo = 0; rhi = p.block_k(kctx); }
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -112,7 +122,9 @@ __global__ __launch_bounds__(256, P::Tile::MINW) void igemm_kernel(const P p) {
   float4 ra[NVA], rb[NVB];
   float bsum = 0.0f;
 
-  auto gload = [&](int r0) {
+  auto gload = [&](int rc) {
+    int r0 = rc;
+    if constexpr (KSKIP) r0 = p.r_map(kctx, rc);
 #pragma unroll
     for (int j = 0; j < NVA; ++j) {
       const int v = tid + 256 * j;
