@@ -769,6 +769,13 @@ extern "C" int cbm_gae(cbm_ctx* c, const float* rewards, const float* values, co
   CBM_HIP(hipStreamSynchronize(c->lstream));
   return 0;
 }
+extern "C" int cbm_vtrace(cbm_ctx* c, const float* v_tm1, const float* v_t, const float* r_t, const float* disc_t, const float* rho_tm1, int32_t T,
+                          int32_t B, float* errors, float* pg_adv, float* q_est) {
+  CBM_HIP(hipSetDevice(c->cfg.device));
+  launch_vtrace(v_tm1, v_t, r_t, disc_t, rho_tm1, T, B, errors, pg_adv, q_est, c->lstream);
+  CBM_HIP(hipStreamSynchronize(c->lstream));
+  return 0;
+}
 extern "C" int cbm_gae_async(cbm_ctx* c, const int32_t* env_ids, const float* rewards, const float* values, const uint8_t* dones, int32_t R,
                              int32_t B, int32_t num_envs, float* adv, float* target) {
   CBM_HIP(hipSetDevice(c->cfg.device));

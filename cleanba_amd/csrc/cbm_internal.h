@@ -79,6 +79,8 @@ void launch_gae(const float* rewards, const float* values, const uint8_t* dones,
 void launch_advnorm(float* adv, int T, int B, int groups, hipStream_t st);
 void launch_gae_async(const int32_t* env_ids, const float* rewards, const float* values, const uint8_t* dones, int R, int B, int num_envs,
                       float gamma, float lambda, float* adv, float* target, hipStream_t st);
+void launch_vtrace(const float* v_tm1, const float* v_t, const float* r_t, const float* disc_t, const float* rho_tm1, int T, int B, float* errors,
+                   float* pg_adv, float* q_est, hipStream_t st);
 void launch_mb_advnorm(const float* adv, const int32_t* idx, int n, float* out, hipStream_t st);
 // perm = jax.random.permutation(key, n): host does the key splits, device the bits + stable sorts.
 void launch_permutation(const uint32_t key[2], int n, int32_t* perm, int32_t* tmp, uint64_t* ckeys, hipStream_t st);

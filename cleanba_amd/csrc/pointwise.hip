@@ -109,6 +109,36 @@ void launch_advnorm(float* adv, int T, int B, int groups, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------
+// rlax.vtrace_td_error_and_advantage (impala:559-567) on its own, lambda = 1, clip thresholds 1: one thread per env column, the serial
+// reverse recursion and then the q / pg-advantage pass — the same expressions, in the same order, as the loop inside impala_loss_kernel
+// and as the oracle, so the three agree bit for bit.  Used by the parity tests (cbm_vtrace); the training path keeps the fused kernel.
+__global__ void vtrace_kernel(const float* v_tm1, const float* v_t, const float* r_t, const float* disc_t, const float* rho_tm1, int T, int B,
+                              float* errors, float* pg_adv, float* q_est) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  float e = 0.0f;
+  for (int t = T - 1; t >= 0; --t) {
+    const size_t i = (size_t)t * B + b;
+    const float cr = rho_tm1[i] < 1.0f ? rho_tm1[i] : 1.0f;
+    const float td = cr * ((r_t[i] + disc_t[i] * v_t[i]) - v_tm1[i]);
+    e = td + (disc_t[i] * cr) * e;
+    errors[i] = (e + v_tm1[i]) - v_tm1[i];
+  }
+  for (int t = 0; t < T; ++t) {
+    const size_t i = (size_t)t * B + b;
+    const float cr = rho_tm1[i] < 1.0f ? rho_tm1[i] : 1.0f;
+    const float qb = (t == T - 1) ? v_t[i] : (errors[i + B] + v_tm1[i + B]);
+    const float q = r_t[i] + disc_t[i] * qb;
+    q_est[i] = q;
+    pg_adv[i] = cr * (q - v_tm1[i]);
+  }
+}
+void launch_vtrace(const float* v_tm1, const float* v_t, const float* r_t, const float* disc_t, const float* rho_tm1, int T, int B, float* errors,
+                   float* pg_adv, float* q_est, hipStream_t st) {
+  hipLaunchKernelGGL(vtrace_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, st, v_tm1, v_t, r_t, disc_t, rho_tm1, T, B, errors, pg_adv, q_est);
+}
+
+// ------------------------------------------------------------------------------------------
 // Async rollouts (legacy `--async-batch-size`): prepare_data's reward re-index (naturecnn:232-255) + env-id-indexed compute_gae
 // (naturecnn:467-531) in one pass.  One block per env: 1024 rows at a time (from the end), each thread looks its env up in one row's B
 // ids and parks (value, done, reward, flat index) in LDS; thread 0 then runs the serial recursion over the parked samples.  The "next

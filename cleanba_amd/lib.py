@@ -51,7 +51,7 @@ SYMBOLS = [
     "cbm_impala_loss_grad", "cbm_adam_step", "cbm_rmsprop_step", "cbm_synth_env_reset_host", "cbm_synth_env_reset_host_games", "cbm_synth_env_step_host", "cbm_actor_env_reset_device_games",
     "cbm_actor_env_reset_device", "cbm_profile_select", "cbm_profile_read", "cbm_ingest_begin", "cbm_ingest_commit",
     "cbm_params_publish_external", "cbm_actor_stream", "cbm_actor_ring_index", "cbm_actor_step_async", "cbm_gae_async", "cbm_mb_advnorm",
-    "cbm_synth_env_step_host_ids", "cbm_learner_grad_tail_offset", "cbm_learner_stream_wait_tail", "cbm_learner_wait_stream",
+    "cbm_synth_env_step_host_ids", "cbm_learner_grad_tail_offset", "cbm_learner_stream_wait_tail", "cbm_learner_wait_stream", "cbm_vtrace",
 ]
 
 _lib = None

@@ -167,6 +167,10 @@ int cbm_sample(cbm_ctx* ctx, const float* logits, int32_t B, const uint32_t subk
 int cbm_gae(cbm_ctx* ctx, const float* rewards, const float* values, const uint8_t* dones, const float* next_value,
             const uint8_t* next_done, int32_t T, int32_t B, float* adv, float* target);             /* ppo:532-560 */
 int cbm_advnorm(cbm_ctx* ctx, float* adv, int32_t T, int32_t B, int32_t groups);                  /* ppo:592-595 */
+/* rlax.vtrace_td_error_and_advantage with lambda = 1 and all clip thresholds 1 (impala:559-567): inputs [T,B] (v_tm1 = V[:-1], v_t = V[1:],
+ * rewards, discounts, rho = pi(a)/mu(a)), outputs [T,B]: errors (= stop-gradient targets minus v_tm1), pg advantages, q estimates. */
+int cbm_vtrace(cbm_ctx* ctx, const float* v_tm1, const float* v_t, const float* r_t, const float* disc_t, const float* rho_tm1, int32_t T,
+               int32_t B, float* errors, float* pg_adv, float* q_est);
 /* async returns: env_ids/rewards/values [R,B] (reward and done as they arrived with each observation), dones u8 [R,B] -> adv, target [R,B]:
  * prepare_data's reward re-index naturecnn:232-255 + env-id-indexed compute_gae naturecnn:467-531 */
 int cbm_gae_async(cbm_ctx* ctx, const int32_t* env_ids, const float* rewards, const float* values, const uint8_t* dones, int32_t R, int32_t B,

@@ -90,6 +90,37 @@ def test_gae_advnorm_permutation(ctx, oracle):
         dPm.free()
 
 
+def test_vtrace_bit_exact(ctx, oracle):
+    """rlax.vtrace_td_error_and_advantage (impala:559-567) as a pure function: same serial recursion as the oracle -> same bits; and at
+    rho = 1 the errors are the lambda = 1 GAE advantages (the analytic pin of tests/test_oracle_network.py, here on the GPU)."""
+    rng = np.random.default_rng(12)
+    for T, B in ((20, 120), (128, 30), (1, 7), (1999, 3)):
+        v = rng.normal(size=(T + 1, B)).astype(np.float32)
+        r = (rng.random((T, B)) < 0.1).astype(np.float32)
+        disc = ((rng.random((T, B)) > 0.05) * 0.99).astype(np.float32)
+        rho = np.exp(rng.normal(0, 0.5, size=(T, B))).astype(np.float32)
+        ins = [np.ascontiguousarray(x) for x in (v[:-1], v[1:], r, disc, rho)]
+        bufs = [L.DevBuf(ctx, x) for x in ins]
+        outs = [L.DevBuf(ctx, nbytes=T * B * 4, dtype=np.float32, shape=(T, B)) for _ in range(3)]
+        L._chk(ctx.lib.cbm_vtrace(ctx.h, *[L._p(b.ptr) for b in bufs], T, B, *[L._p(o.ptr) for o in outs]))
+        want = oracle.vtrace(*ins)
+        for o, w in zip(outs, want):
+            assert (bits(o.download()) == bits(w)).all(), (T, B)
+        for b in bufs + outs:
+            b.free()
+    T, B = 16, 5
+    v = rng.normal(size=(T + 1, B)).astype(np.float32)
+    r = rng.random((T, B)).astype(np.float32)
+    d = (rng.random((T + 1, B)) < 0.2).astype(np.uint8)
+    disc = ((1 - d[1:]) * np.float32(0.99)).astype(np.float32)
+    ins = [np.ascontiguousarray(x) for x in (v[:-1], v[1:], r, disc, np.ones((T, B), np.float32))]
+    bufs = [L.DevBuf(ctx, x) for x in ins]
+    outs = [L.DevBuf(ctx, nbytes=T * B * 4, dtype=np.float32, shape=(T, B)) for _ in range(3)]
+    L._chk(ctx.lib.cbm_vtrace(ctx.h, *[L._p(b.ptr) for b in bufs], T, B, *[L._p(o.ptr) for o in outs]))
+    adv, _ = oracle.gae(r, v[:-1], d[:-1], v[-1], d[-1], gamma=0.99, gae_lambda=1.0)
+    np.testing.assert_allclose(outs[0].download(), adv, rtol=1e-5, atol=1e-5)
+
+
 def test_async_gae_and_minibatch_advnorm(ctx, oracle):
     """legacy --async-batch-size: env-id-indexed returns (naturecnn:232-262, 467-531) bit-exact (same serial recursion per env), the
     per-minibatch advantage normalisation (naturecnn:540-541) within 1e-5.  R > 1024 exercises the kernel's row chunking."""
