@@ -43,7 +43,7 @@ KERNELS = {
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 
 
-def cpu_baseline(params, n_frames=192):
+def cpu_baseline(params, n_frames=768):
     """The CPU restatement (oracle/, 'port') timed on a bounded sample of the same per-env-step work:
     t_fwd (actor forward+sampling) and t_fb (learner forward+loss+backward) per frame on n_frames
     Breakout-shaped frames; env-steps/s = 1 / (t_fwd*(1+1/T) + EPOCHS*t_fb)."""
@@ -63,8 +63,22 @@ def cpu_baseline(params, n_frames=192):
     oracle.ppo_loss_grad(params, A, obs, None, actions, lp, adv, value + adv)
     t_fb = (time.time() - t0) / n_frames
     sps = 1.0 / (t_fwd * (1.0 + 1.0 / T) + EPOCHS * t_fb)
+    # SURVEY section 8d row (A), "reference-faithful threading": the reference pins XLA-CPU to one intra-op thread per computation
+    # (ppo:28), i.e. one busy core for the actor thread and one for the learner, running concurrently -> the slower of the two bounds it
     oracle.set_threads(1)
+    n1 = 24
+    t0 = time.time()
+    lg1, v1 = oracle.nature_forward(params, A, obs[:n1], ksplit=14)
+    a1, lp1, _ = oracle.sample_actions(lg1, prng.prng_key(1))
+    t_fwd1 = (time.time() - t0) / n1
+    t0 = time.time()
+    oracle.ppo_loss_grad(params, A, obs[:n1], None, a1, lp1, adv[:n1], v1 + adv[:n1])
+    t_fb1 = (time.time() - t0) / n1
+    sps_ref_threads = 1.0 / max(t_fwd1 * (1.0 + 1.0 / T), EPOCHS * t_fb1)
     return {"value": round(sps, 2), "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "reference_threading": {"value": round(sps_ref_threads, 2), "cores": 2,
+                                    "note": f"one thread per role like the reference (ppo:28): actor {t_fwd1 * 1e3:.1f} ms/frame and learner "
+                                            f"{t_fb1 * 1e3:.1f} ms/frame on one core each, overlapped; {n1}-frame sample"},
             "sample": f"{n_frames} synthetic frames: oracle actor forward+sampling ({t_fwd * 1e3:.2f} ms/frame) and PPO "
                       f"forward+loss+backward ({t_fb * 1e3:.2f} ms/frame) with OpenMP over frames; per-env-step cost = "
                       f"t_fwd*(1+1/{T}) + {EPOCHS}*t_fb (Adam/GAE/shuffle excluded: <1%)"}

@@ -351,6 +351,13 @@ def train(args, algo="ppo", engine_factory=None, on_update=None, rendezvous=None
                 torch.cuda.set_device(local_rank)
             dist.init_process_group(backend, init_method=f"tcp://{master_addr}:{master_port}", rank=rank, world_size=world_size)
     run_name = f"{args.env_id}__{args.exp_name}__{args.seed}__{uuid.uuid4()}"
+    if args.track and rank == 0:   # ppo:447-458 — same wandb.init call when wandb is importable; never a silent no-op
+        try:
+            import wandb
+            wandb.init(project=args.wandb_project_name, entity=args.wandb_entity, sync_tensorboard=True, config=vars(args), name=run_name,
+                       monitor_gym=True, save_code=True)
+        except ImportError:
+            print("--track: wandb is not installed here; scalars are written to TensorBoard event files under runs/ only")
     writer = JsonlWriter(f"runs/{run_name}") if rank == 0 else SimpleNamespace(add_scalar=lambda *a: None, add_text=lambda *a: None, close=lambda: None)
     writer.add_text("hyperparameters", "|param|value|\n|-|-|\n%s" % ("\n".join([f"|{k}|{v}|" for k, v in vars(args).items()])))
 
@@ -462,6 +469,14 @@ def train(args, algo="ppo", engine_factory=None, on_update=None, rendezvous=None
             for idx, r in enumerate(rets):
                 writer.add_scalar("eval/episodic_return", r, idx)
             result["eval_returns"] = rets
+            if args.upload_model:   # ppo:785-799
+                try:
+                    from cleanrl_utils.huggingface import push_to_hub
+                    repo_name = f"{args.env_id}-{args.exp_name}-seed{args.seed}"
+                    push_to_hub(args, rets, f"{args.hf_entity}/{repo_name}" if args.hf_entity else repo_name, "PPO" if algo == "ppo" else "IMPALA",
+                                f"runs/{run_name}", f"videos/{run_name}-eval", extra_dependencies=["cleanba_amd"])
+                except ImportError:
+                    print("--upload-model: cleanrl_utils.huggingface is not installed here; the model stays at", path)
     writer.close()
     engine.close()
     return result
