@@ -45,6 +45,9 @@ struct NatureWs {
   // backward
   float *dzv = nullptr, *dhid = nullptr, *dact3pad = nullptr, *dact2pad = nullptr, *dact1 = nullptr;
   float *wg_part = nullptr, *bias_part = nullptr;
+  // ReLU masks as bits, written by the forward epilogues (one 32-bit word per 32 channels of an output row) and read by the dgrad
+  // epilogues instead of the fp32 activations: act1 [B*400] words, act2 [B*81][2], act3 [B*49][2]
+  uint32_t *mask1 = nullptr, *mask2 = nullptr, *mask3 = nullptr;
   int32_t* c3_order = nullptr;   // conv3 dgrad tile order (position-major tiles, heavy taps first at the end of each XCD's run)
   int c3_order_S = -1;
   int64_t wg_part_floats = 0, bias_part_floats = 0;
@@ -66,7 +69,8 @@ void nature_backward(const NatureLayout& L, const float* P, const uint8_t* obs, 
                      NatureWs& ws, float* grads, hipStream_t st);
 
 // frame-resident conv1 kernels (conv1.hip)
-void launch_conv1_fwd_frames(const uint8_t* obs, const int32_t* idx, const float* W, const float* bias, float* out, int S, hipStream_t st);
+void launch_conv1_fwd_frames(const uint8_t* obs, const int32_t* idx, const float* W, const float* bias, float* out, uint32_t* mask, int S,
+                             hipStream_t st);
 int conv1_wgrad_frames_splits(int S);
 void launch_conv1_wgrad_frames(const uint8_t* obs, const int32_t* idx, const float* dy, float* part, float* bpart, int S, hipStream_t st);
 

@@ -40,7 +40,7 @@ static __device__ __forceinline__ void frame_to_lds(const uint8_t* frame, unsign
 // waves per SIMD whose conversion chains and MFMAs interleave.  A frame is 400 positions = 12.5 tiles of 32: wave
 // (w + f) % 4 takes tiles {first, first+4, first+8, (12)}; the rotation evens out who owns the 13th half tile.
 __global__ __launch_bounds__(256, 2) void conv1_fwd_frames_kernel(const uint8_t* obs, const int32_t* idx, const float* W, const float* bias,
-                                                                  float* out, int S, int frames_per_block) {
+                                                                  float* out, uint32_t* mask, int S, int frames_per_block) {
   __shared__ __attribute__((aligned(16))) unsigned char smem_raw[256 * 32 * 4 + FR];
   float* Wl = reinterpret_cast<float*>(smem_raw);            // [256][32]
   unsigned char* F = smem_raw + 256 * 32 * 4;                // [28224]
@@ -133,7 +133,14 @@ __global__ __launch_bounds__(256, 2) void conv1_fwd_frames_kernel(const uint8_t*
 #if defined(C1_ABL) && C1_ABL == 1
           if (m < 400 && acc[t][e] == 123.456f) o[m * 32] = relu_(acc[t][e] + bn);
 #else
-          if (m < 400) o[m * 32] = relu_(acc[t][e] + bn);
+          if (m < 400) {
+            const float v = relu_(acc[t][e] + bn);
+            o[m * 32] = v;
+            if (mask) {   // ReLU mask of this output pixel's 32 channels as one word (read by the conv2 dgrad epilogue)
+              const unsigned long long bal = __ballot(v > 0.0f);
+              if (li == 0) mask[(size_t)s * 400 + m] = (uint32_t)(bal >> (32 * h));
+            }
+          }
 #endif
         }
       }
@@ -143,12 +150,13 @@ __global__ __launch_bounds__(256, 2) void conv1_fwd_frames_kernel(const uint8_t*
   }
 }
 
-void launch_conv1_fwd_frames(const uint8_t* obs, const int32_t* idx, const float* W, const float* bias, float* out, int S, hipStream_t st) {
+void launch_conv1_fwd_frames(const uint8_t* obs, const int32_t* idx, const float* W, const float* bias, float* out, uint32_t* mask, int S,
+                             hipStream_t st) {
   int blocks = 512;
   if (S < blocks) blocks = S;
   const int fpb = (S + blocks - 1) / blocks;
   blocks = (S + fpb - 1) / fpb;
-  hipLaunchKernelGGL(conv1_fwd_frames_kernel, dim3(blocks), dim3(256), 0, st, obs, idx, W, bias, out, S, fpb);
+  hipLaunchKernelGGL(conv1_fwd_frames_kernel, dim3(blocks), dim3(256), 0, st, obs, idx, W, bias, out, mask, S, fpb);
 }
 
 // ------------------------------------------------------------------------------------------ wgrad

@@ -44,6 +44,14 @@ static __device__ __forceinline__ float4 f4sel(bool ok, float4 v) {
   return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
 }
 
+// ReLU masks as bits.  In every igemm epilogue call the 32 lanes of a wave half hold 32 consecutive columns of ONE output row, so a
+// ballot gives that row's mask word; lane 0 of the half writes it.  words_per_row = channels / 32.
+static __device__ __forceinline__ void put_mask_word(uint32_t* mask, size_t row, int words_per_row, int col, bool on) {
+  const unsigned long long bal = __ballot(on);
+  const int lane = threadIdx.x & 63;
+  if ((lane & 31) == 0) mask[row * words_per_row + (col >> 5)] = (uint32_t)(bal >> (lane & 32));
+}
+
 // ------------------------------------------------------------------------------------------
 // conv1: uint8 NCHW frames -> act1 [M=S*400][32].  k = (c, kh, kw), 8 contiguous bytes per (c,kh).
 template <class TileT>
@@ -51,7 +59,7 @@ struct Conv1Fwd {
   using Tile = TileT;
   static constexpr bool A_RX = false, B_YR = false, BIAS_GRAD = false;
   static constexpr int NCLS = 1;
-  const uint8_t* obs; const int32_t* idx; const float* W; const float* bias; float* out; int M;
+  const uint8_t* obs; const int32_t* idx; const float* W; const float* bias; float* out; int M; uint32_t* mask;
   __host__ __device__ int X() const { return M; }
   __host__ __device__ int Y() const { return 32; }
   __device__ void r_range(int, int& lo, int& hi) const { lo = 0; hi = 256; }
@@ -68,7 +76,11 @@ struct Conv1Fwd {
     return *reinterpret_cast<const float4*>(W + ((kh * 8 + kw) * 4 + c) * 32 + y);
   }
   __device__ void store(int m, int n, float v, int, int) const {
-    if (m < M) out[(size_t)m * 32 + n] = relu(v + bias[n]);
+    if (m < M) {
+      const float o = relu(v + bias[n]);
+      out[(size_t)m * 32 + n] = o;
+      if (mask) put_mask_word(mask, (size_t)m, 1, n, o > 0.0f);
+    }
   }
 };
 
@@ -78,7 +90,7 @@ struct ConvFwd {
   using Tile = TileT;
   static constexpr bool A_RX = false, B_YR = false, BIAS_GRAD = false;
   static constexpr int NCLS = 1;
-  const float* in; const float* W; const float* bias; float* out; int M;
+  const float* in; const float* W; const float* bias; float* out; int M; uint32_t* mask;
   __host__ __device__ int X() const { return M; }
   __host__ __device__ int Y() const { return CO; }
   __device__ void r_range(int, int& lo, int& hi) const { lo = 0; hi = KH * KW * CI; }
@@ -100,7 +112,11 @@ struct ConvFwd {
   }
   __device__ const float* b_ptr(int r, int y, int) const { return W + (size_t)r * CO + y; }
   __device__ void store(int m, int n, float v, int, int) const {
-    if (m < M) out[(size_t)m * CO + n] = relu(v + bias[n]);
+    if (m < M) {
+      const float o = relu(v + bias[n]);
+      out[(size_t)m * CO + n] = o;
+      if (mask) put_mask_word(mask, (size_t)m, CO / 32, n, o > 0.0f);
+    }
   }
 };
 
@@ -213,6 +229,15 @@ struct DenseDgrad {
     const bool on = act3[(size_t)m * 3136 + j] > 0.0f;
     dact3pad[((size_t)(m * 11 + hh + 2) * 11 + ww + 2) * 64 + c] = on ? v : 0.0f;
   }
+  // bit-mask epilogue (igemm.h BITMASK): the ReLU mask of act3 comes as one word per (frame, 32 flatten columns)
+  static constexpr bool BITMASK = true;
+  const uint32_t* mask;
+  __device__ uint32_t mask_word(int m, int j32, int) const { return mask[(size_t)min(m, M - 1) * 98 + (min(j32, 3135) >> 5)]; }
+  __device__ void store_on(int m, int j, float v, bool on, int, int) const {
+    if (m >= M || j >= 3136) return;
+    const int pos = j >> 6, c = j & 63, hh = pos / 7, ww = pos - hh * 7;
+    dact3pad[((size_t)(m * 11 + hh + 2) * 11 + ww + 2) * 64 + c] = on ? v : 0.0f;
+  }
 };
 
 // conv3 dgrad (3x3 s1): X = (s, ih, iw) over 9x9, Y = ci (64), r = (jh, jw, co), reads dact3pad,
@@ -263,6 +288,8 @@ struct Conv3DgradPos {
     const int p = order[x0 / Tile::BX] % 81, ih = p / 9, iw = p - ih * 9;
 #if CONV3_DGRAD_POS == 2   // experiment: position-major order without the tap skipping
     const int jh0 = 0, jh1 = 2, jw0 = 0, jw1 = 2;
+#elif CONV3_DGRAD_POS == 4   // timing experiment (wrong results): every tile multiplies 1 tap
+    const int jh0 = 0, jh1 = 0, jw0 = 0, jw1 = 0;
 #else
     const int jh0 = max(0, 2 - ih), jh1 = min(2, 8 - ih), jw0 = max(0, 2 - iw), jw1 = min(2, 8 - iw);
 #endif
@@ -293,7 +320,26 @@ struct Conv3DgradPos {
     int s, ih, iw;
     decode(x, s, ih, iw);
     if (s >= S) return;
+#if defined(CONV3_EPI) && CONV3_EPI == 2
+    if (v == 12345.678f) dxpad[0] = v;
+#elif defined(CONV3_EPI) && CONV3_EPI == 1
+    dxpad[((size_t)(s * 11 + ih + 1) * 11 + iw + 1) * 64 + ci] = v;
+#else
     const bool on = act2[((size_t)s * 81 + ih * 9 + iw) * 64 + ci] > 0.0f;
+    dxpad[((size_t)(s * 11 + ih + 1) * 11 + iw + 1) * 64 + ci] = on ? v : 0.0f;
+#endif
+  }
+  static constexpr bool BITMASK = true;
+  const uint32_t* mask;   // act2 ReLU bits [S*81][2]
+  __device__ uint32_t mask_word(int x, int ci32, int) const {
+    int s, ih, iw;
+    decode(x, s, ih, iw);
+    return mask[((size_t)min(s, S - 1) * 81 + ih * 9 + iw) * 2 + (ci32 >> 5)];
+  }
+  __device__ void store_on(int x, int ci, float v, bool on, int, int) const {
+    int s, ih, iw;
+    decode(x, s, ih, iw);
+    if (s >= S) return;
     dxpad[((size_t)(s * 11 + ih + 1) * 11 + iw + 1) * 64 + ci] = on ? v : 0.0f;
   }
 };
@@ -326,6 +372,17 @@ struct Conv2Dgrad {
     const int s = m / 100, p = m - s * 100, ihh = p / 10, iwh = p - ihh * 10;
     const size_t pos = ((size_t)(s * 20 + 2 * ihh + (cls >> 1)) * 20 + 2 * iwh + (cls & 1)) * 32 + ci;
     dact1[pos] = act1[pos] > 0.0f ? v : 0.0f;
+  }
+  static constexpr bool BITMASK = true;
+  const uint32_t* mask;   // act1 ReLU bits, one word per output pixel [S*400]
+  __device__ size_t pixel(int m, int cls) const {
+    const int s = m / 100, p = m - s * 100, ihh = p / 10, iwh = p - ihh * 10;
+    return (size_t)(s * 20 + 2 * ihh + (cls >> 1)) * 20 + 2 * iwh + (cls & 1);
+  }
+  __device__ uint32_t mask_word(int m, int, int cls) const { return mask[pixel(min(m, M - 1), cls)]; }
+  __device__ void store_on(int m, int ci, float v, bool on, int, int cls) const {
+    if (m >= M) return;
+    dact1[pixel(m, cls) * 32 + ci] = on ? v : 0.0f;
   }
 };
 
@@ -471,6 +528,10 @@ int nature_ws_alloc(NatureWs& ws, int maxB, bool with_grad, int dense_ksplit_sma
   if (with_grad) {
     if (dmalloc(&ws.dzv, B * 32) || dmalloc(&ws.dhid, B * 512) || dmalloc(&ws.dact3pad, B * 7744) || dmalloc(&ws.dact2pad, B * 7744) ||
         dmalloc(&ws.dact1, B * 12800)) return -1;
+#if IGEMM_USE_BITMASK
+    if (hipMalloc((void**)&ws.mask1, B * 400 * 4) != hipSuccess || hipMalloc((void**)&ws.mask2, B * 81 * 2 * 4) != hipSuccess ||
+        hipMalloc((void**)&ws.mask3, B * 49 * 2 * 4) != hipSuccess) { cbm_set_error("hipMalloc failed"); return -1; }
+#endif
     if (hipMalloc((void**)&ws.c3_order, ((B + 127) / 128) * 81 * sizeof(int32_t)) != hipSuccess) { cbm_set_error("hipMalloc failed"); return -1; }
     hipMemset(ws.dact3pad, 0, B * 7744 * sizeof(float));
     hipMemset(ws.dact2pad, 0, B * 7744 * sizeof(float));
@@ -501,6 +562,7 @@ void nature_ws_free(NatureWs& ws) {
   for (int j = 0; j < 2; ++j) { if (ws.rn_g[j]) hipFree(ws.rn_g[j]); ws.rn_g[j] = nullptr; }
   if (ws.rn_wT) { hipFree(ws.rn_wT); ws.rn_wT = nullptr; }
   if (ws.c3_order) { hipFree(ws.c3_order); ws.c3_order = nullptr; }
+  for (uint32_t** m : {&ws.mask1, &ws.mask2, &ws.mask3}) { if (*m) hipFree(*m); *m = nullptr; }
   ws.c3_order_S = -1;
 }
 
@@ -587,13 +649,13 @@ void nature_forward(const NatureLayout& L, const float* P, const uint8_t* obs, c
   const bool small = B <= 512;
   if (small) {
 #if ACTOR_K16
-    Conv1Fwd<T128x32k16> p{obs, idx, P + L.w[0], P + L.b[0], ws.act1, B * 400};
+    Conv1Fwd<T128x32k16> p{obs, idx, P + L.w[0], P + L.b[0], ws.act1, B * 400, ws.mask1};
 #else
-    Conv1Fwd<T128x32> p{obs, idx, P + L.w[0], P + L.b[0], ws.act1, B * 400};
+    Conv1Fwd<T128x32> p{obs, idx, P + L.w[0], P + L.b[0], ws.act1, B * 400, ws.mask1};
 #endif
     plaunch(ws, K_CONV1_FWD, p, 1, st);
   } else {
-    plaunch_fn(ws, K_CONV1_FWD, st, [&] { launch_conv1_fwd_frames(obs, idx, P + L.w[0], P + L.b[0], ws.act1, B, st); });
+    plaunch_fn(ws, K_CONV1_FWD, st, [&] { launch_conv1_fwd_frames(obs, idx, P + L.w[0], P + L.b[0], ws.act1, ws.mask1, B, st); });
   }
   if (small) {
 #if ACTOR_K16
@@ -601,14 +663,14 @@ void nature_forward(const NatureLayout& L, const float* P, const uint8_t* obs, c
 #else
     using TS = T64x64;
 #endif
-    ConvFwd<TS, 4, 4, 2, 32, 64, 20, 20, 9, 9> p2{ws.act1, P + L.w[1], P + L.b[1], ws.act2, B * 81};
+    ConvFwd<TS, 4, 4, 2, 32, 64, 20, 20, 9, 9> p2{ws.act1, P + L.w[1], P + L.b[1], ws.act2, B * 81, ws.mask2};
     plaunch_fwd(ws, K_CONV2_FWD, p2, 1, st);
-    ConvFwd<TS, 3, 3, 1, 64, 64, 9, 9, 7, 7> p3{ws.act2, P + L.w[2], P + L.b[2], ws.act3, B * 49};
+    ConvFwd<TS, 3, 3, 1, 64, 64, 9, 9, 7, 7> p3{ws.act2, P + L.w[2], P + L.b[2], ws.act3, B * 49, ws.mask3};
     plaunch_fwd(ws, K_CONV3_FWD, p3, 1, st);
   } else {
-    ConvFwd<TILE_C2F, 4, 4, 2, 32, 64, 20, 20, 9, 9> p2{ws.act1, P + L.w[1], P + L.b[1], ws.act2, B * 81};
+    ConvFwd<TILE_C2F, 4, 4, 2, 32, 64, 20, 20, 9, 9> p2{ws.act1, P + L.w[1], P + L.b[1], ws.act2, B * 81, ws.mask2};
     plaunch_fwd(ws, K_CONV2_FWD, p2, 1, st);
-    ConvFwd<T128x64, 3, 3, 1, 64, 64, 9, 9, 7, 7> p3{ws.act2, P + L.w[2], P + L.b[2], ws.act3, B * 49};
+    ConvFwd<T128x64, 3, 3, 1, 64, 64, 9, 9, 7, 7> p3{ws.act2, P + L.w[2], P + L.b[2], ws.act3, B * 49, ws.mask3};
     plaunch_fwd(ws, K_CONV3_FWD, p3, 1, st);
   }
   if (dense_ksplit > 1) {
@@ -668,7 +730,7 @@ void nature_backward(const NatureLayout& L, const float* P, const uint8_t* obs, 
   }
   // dense: dgrad -> dact3pad, wgrad
   {
-    DenseDgrad<T128x64> pd{ws.dhid, P + L.w[3], ws.act3, ws.dact3pad, B};
+    DenseDgrad<T128x64> pd{ws.dhid, P + L.w[3], ws.act3, ws.dact3pad, B, ws.mask3};
     plaunch(ws, K_DENSE_DGRAD, pd, 1, st);
     const int nz = dense_wgrad_splits(B);
     const int rps = round_up(ceil_div(B, nz), 32);
@@ -682,7 +744,7 @@ void nature_backward(const NatureLayout& L, const float* P, const uint8_t* obs, 
   {
 #if CONV3_DGRAD_POS
     conv3_order_build(ws, B, T128x64::BX, st);
-    Conv3DgradPos<T128x64> pd{ws.dact3pad, P + L.w[2], ws.act2, ws.dact2pad, B, ws.c3_order};
+    Conv3DgradPos<T128x64> pd{ws.dact3pad, P + L.w[2], ws.act2, ws.dact2pad, B, ws.c3_order, ws.mask2};
 #else
     Conv3Dgrad<T128x64> pd{ws.dact3pad, P + L.w[2], ws.act2, ws.dact2pad, B * 81};
 #endif
@@ -695,7 +757,7 @@ void nature_backward(const NatureLayout& L, const float* P, const uint8_t* obs, 
   }
   // conv2: dgrad -> dact1, wgrad
   {
-    Conv2Dgrad<TILE_C2D> pd{ws.dact2pad, P + L.w[1], ws.act1, ws.dact1, B * 100};
+    Conv2Dgrad<TILE_C2D> pd{ws.dact2pad, P + L.w[1], ws.act1, ws.dact1, B * 100, ws.mask1};
     plaunch(ws, K_CONV2_DGRAD, pd, 1, st);
     const int M = B * 81, nz = ceil_div(M, RPS_C2);
     ConvWgrad<T128x64, 4, 4, 2, 32, 64, 20, 20, 9, 9, 1> pw{ws.act1, ws.dact2pad, ws.wg_part, ws.bias_part, M, RPS_C2};

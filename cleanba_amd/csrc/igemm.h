@@ -22,6 +22,9 @@
 #include <stdint.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+#ifndef IGEMM_USE_BITMASK
+#define IGEMM_USE_BITMASK 1
+#endif
 #ifndef IGEMM_BYR_YFAST
 #define IGEMM_BYR_YFAST 1
 #endif
@@ -32,6 +35,13 @@ template <class P, class = void>
 struct igemm_kskip { static constexpr bool value = false; };
 template <class P>
 struct igemm_kskip<P, decltype((void)P::KSKIP)> { static constexpr bool value = P::KSKIP; };
+// Functors with BITMASK = true take their ReLU mask as bits: mask_word(x, y32, cls) is the 32-bit word of output row x for the 32 columns
+// starting at y32, store_on(x, y, v, on, z, cls) the store.  Lane r of a wave fetches the word of tile row r ONCE and the epilogue hands
+// it round with ds_bpermute, instead of every lane loading the fp32 activation behind each of its 16-32 outputs.
+template <class P, class = void>
+struct igemm_bitmask { static constexpr bool value = false; };
+template <class P>
+struct igemm_bitmask<P, decltype((void)P::BITMASK)> { static constexpr bool value = P::BITMASK && IGEMM_USE_BITMASK; };
 #ifndef IGEMM_MIN_WAVES
 #define IGEMM_MIN_WAVES 4
 #endif
@@ -261,11 +271,21 @@ __global__ __launch_bounds__(256, P::Tile::MINW) void igemm_kernel(const P p) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int y = y0 + wy * (BY / WY) + j * 32 + li;
+      if constexpr (igemm_bitmask<P>::value) {
+        const uint32_t mw = p.mask_word(x0 + wx * (BX / WX) + i * 32 + li, y0 + wy * (BY / WY) + j * 32, cls);   // lane r holds row r's word
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
-        const int x = x0 + wx * (BX / WX) + i * 32 + row;
-        p.store(x, y, acc[i][j][e], z, cls);
+        for (int e = 0; e < 16; ++e) {
+          const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
+          const uint32_t w = (uint32_t)__shfl((int)mw, row, 64);
+          p.store_on(x0 + wx * (BX / WX) + i * 32 + row, y, acc[i][j][e], (w >> li) & 1u, z, cls);
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
+          const int x = x0 + wx * (BX / WX) + i * 32 + row;
+          p.store(x, y, acc[i][j][e], z, cls);
+        }
       }
     }
 
