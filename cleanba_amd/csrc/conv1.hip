@@ -121,28 +121,31 @@ __global__ __launch_bounds__(256, 2) void conv1_fwd_frames_kernel(const uint8_t*
       const int f = idx ? idx[s + 1] : s + 1;
       frame_to_lds(obs + (size_t)f * FR, F, wave, lane);  // lands while the epilogue stores drain
     }
-    // epilogue: out[s][pos][n] = relu(acc + bias)
+    // epilogue: out[s][pos][n] = relu(acc + bias); the ReLU mask of each output pixel's 32 channels is a ballot word — lane r of the
+    // lower half collects the word of tile row r, one coalesced 128-byte store per tile (read by the conv2 dgrad epilogue)
     float* o = out + (size_t)s * 400 * 32 + li;
 #pragma unroll
     for (int t = 0; t < MAXT; ++t) {
       if (t < 3 || four) {
         const int m0 = (first + 4 * t) * 32 + 4 * h;
+        uint32_t word = 0;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-          const int m = m0 + (e & 3) + 8 * (e >> 2);
+          const int r0 = (e & 3) + 8 * (e >> 2);
+          const int m = m0 + r0;
+          const float v = relu_(acc[t][e] + bn);
 #if defined(C1_ABL) && C1_ABL == 1
-          if (m < 400 && acc[t][e] == 123.456f) o[m * 32] = relu_(acc[t][e] + bn);
+          if (m < 400 && acc[t][e] == 123.456f) o[m * 32] = v;
 #else
-          if (m < 400) {
-            const float v = relu_(acc[t][e] + bn);
-            o[m * 32] = v;
-            if (mask) {   // ReLU mask of this output pixel's 32 channels as one word (read by the conv2 dgrad epilogue)
-              const unsigned long long bal = __ballot(v > 0.0f);
-              if (li == 0) mask[(size_t)s * 400 + m] = (uint32_t)(bal >> (32 * h));
-            }
-          }
+          if (m < 400) o[m * 32] = v;
 #endif
+          const unsigned long long bal = __ballot(v > 0.0f);   // all 64 lanes: rows r0 (lower half) and r0 + 4 (upper half)
+          // lane r0 <- the lower wave half's row, lane r0 + 4 <- the upper half's (no writelane builtin in this clang)
+          asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(word) : "s"((uint32_t)bal), "n"(r0));
+          asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(word) : "s"((uint32_t)(bal >> 32)), "n"(r0 + 4));
         }
+        const int mrow = (first + 4 * t) * 32 + lane;
+        if (mask && lane < 32 && mrow < 400) mask[(size_t)s * 400 + mrow] = word;
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

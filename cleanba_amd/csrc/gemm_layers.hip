@@ -82,6 +82,13 @@ struct Conv1Fwd {
       if (mask) put_mask_word(mask, (size_t)m, 1, n, o > 0.0f);
     }
   }
+  static constexpr bool MASKOUT = true;   // igemm_kernel epilogue: one mask store per 32x32 tile instead of one per element row
+  __device__ bool store_flag(int m, int n, float v, int, int) const {
+    const float o = relu(v + bias[n]);
+    if (m < M) out[(size_t)m * 32 + n] = o;
+    return o > 0.0f;
+  }
+  __device__ void put_mask(int m, int, uint32_t word) const { if (mask && m < M) mask[m] = word; }
 };
 
 // generic VALID NHWC conv forward, k = (kh, kw, ci)
@@ -118,6 +125,13 @@ struct ConvFwd {
       if (mask) put_mask_word(mask, (size_t)m, CO / 32, n, o > 0.0f);
     }
   }
+  static constexpr bool MASKOUT = true;
+  __device__ bool store_flag(int m, int n, float v, int, int) const {
+    const float o = relu(v + bias[n]);
+    if (m < M) out[(size_t)m * CO + n] = o;
+    return o > 0.0f;
+  }
+  __device__ void put_mask(int m, int n32, uint32_t word) const { if (mask && m < M) mask[(size_t)m * (CO / 32) + (n32 >> 5)] = word; }
 };
 
 // dense forward C[m][n] = sum_k A[m][k] W[k][n]; SPLIT: partials [z][M][N], else relu(+bias)

@@ -42,6 +42,12 @@ template <class P, class = void>
 struct igemm_bitmask { static constexpr bool value = false; };
 template <class P>
 struct igemm_bitmask<P, decltype((void)P::BITMASK)> { static constexpr bool value = P::BITMASK && IGEMM_USE_BITMASK; };
+// Functors with MASKOUT = true (forward convs) emit their ReLU mask: store_flag() stores one output and returns "> 0", the epilogue
+// ballots it, lane r of the lower wave half collects the word of tile row r, and put_mask() writes 32 words per 32x32 tile at once.
+template <class P, class = void>
+struct igemm_maskout { static constexpr bool value = false; };
+template <class P>
+struct igemm_maskout<P, decltype((void)P::MASKOUT)> { static constexpr bool value = P::MASKOUT; };
 #ifndef IGEMM_MIN_WAVES
 #define IGEMM_MIN_WAVES 4
 #endif
@@ -279,6 +285,18 @@ __global__ __launch_bounds__(256, P::Tile::MINW) void igemm_kernel(const P p) {
           const uint32_t w = (uint32_t)__shfl((int)mw, row, 64);
           p.store_on(x0 + wx * (BX / WX) + i * 32 + row, y, acc[i][j][e], (w >> li) & 1u, z, cls);
         }
+      } else if constexpr (igemm_maskout<P>::value) {
+        uint32_t word = 0;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int r0 = (e & 3) + 8 * (e >> 2);
+          const bool on = p.store_flag(x0 + wx * (BX / WX) + i * 32 + r0 + 4 * h, y, acc[i][j][e], z, cls);
+          const unsigned long long bal = __ballot(on);
+          // lane r0 <- the lower wave half's row, lane r0 + 4 <- the upper half's (no writelane builtin in this clang)
+          asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(word) : "s"((uint32_t)bal), "n"(r0));
+          asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(word) : "s"((uint32_t)(bal >> 32)), "n"(r0 + 4));
+        }
+        if (lane < 32) p.put_mask(x0 + wx * (BX / WX) + i * 32 + lane, y0 + wy * (BY / WY) + j * 32, word);
       } else {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
