@@ -54,7 +54,9 @@ __global__ __launch_bounds__(256, 2) void conv1_fwd_frames_kernel(const uint8_t*
   }
   const int s_lo = blockIdx.x * frames_per_block, s_hi = min(S, s_lo + frames_per_block);
   const float bn = bias[li];
-  constexpr int MAXT = 4;
+  constexpr int MAXT = 3;
+  typedef float f32x4_t __attribute__((ext_vector_type(4)));
+  const int r16 = lane & 15, g4 = lane >> 4;   // 16x16x4 MFMA roles of the tail tile: position / column r16, k = 4*step + g4
   if (s_lo < s_hi) {
     const int f = idx ? idx[s_lo] : s_lo;
     frame_to_lds(obs + (size_t)f * FR, F, wave, lane);
@@ -63,7 +65,12 @@ __global__ __launch_bounds__(256, 2) void conv1_fwd_frames_kernel(const uint8_t*
   __syncthreads();
   for (int s = s_lo; s < s_hi; ++s) {
     const int first = (wave + (s - s_lo)) & 3;
-    const bool four = first == 0;  // wave-uniform: owns tile 12 (positions 384..399 valid)
+    // 400 positions = 12 tiles of 32 (three per wave) + 16 left over.  A fourth 32-row tile for one wave made that wave 33 % longer than the
+    // others at every per-frame barrier (measured: dropping it took the kernel 310 -> 265 us); the 16 positions are instead a 16x16x4
+    // MFMA tile (two column tiles, k = 4 consecutive kw per instruction: still the oracle's k-ascending chain), half the extra work.
+    // The tail's two 16-column tiles go to two different waves (first == 0 and first == 1): 13 vs 12 MFMA-equivalents per k-row.
+    const bool four = first < 2;   // wave-uniform: owns column tile `first` of the tail tile (positions 384..399)
+    const int tj = first & 1;
     int base[MAXT];
 #pragma unroll
     for (int t = 0; t < MAXT; ++t) {
@@ -76,11 +83,13 @@ __global__ __launch_bounds__(256, 2) void conv1_fwd_frames_kernel(const uint8_t*
     for (int t = 0; t < MAXT; ++t)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[t][e] = 0.0f;
+    f32x4_t tacc = {0.f, 0.f, 0.f, 0.f};
+    const int tbase = ((384 + r16) / 20) * 4 * 84 + ((384 + r16) % 20) * 4;
     // One (c,kh) row of the patch = 8 contiguous pixels per position = one ds_read2_b32 per tile, feeding the four
     // kw-pairs; the reads of row ckh+1 are issued before the MFMAs of row ckh.
-    uint2 pxa[MAXT], pxb[MAXT];
-    float wa[4], wb[4];
-    auto fetch = [&](int ckh, uint2(&px)[MAXT], float(&wv)[4]) __attribute__((always_inline)) {
+    uint2 pxa[MAXT + 1], pxb[MAXT + 1];   // [MAXT] = the tail tile's 8 bytes
+    float wa[6], wb[6];                   // [4..5] = the tail tile's B values of the two k-steps
+    auto fetch = [&](int ckh, uint2(&px)[MAXT + 1], float(&wv)[6]) __attribute__((always_inline)) {
       const int koff = (ckh >> 3) * 7056 + (ckh & 7) * 84;
 #pragma unroll
       for (int t = 0; t < MAXT; ++t) {
@@ -89,18 +98,29 @@ __global__ __launch_bounds__(256, 2) void conv1_fwd_frames_kernel(const uint8_t*
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) wv[j] = Wl[(ckh * 8 + 2 * j + h) * 32 + li];
+      if (four) {
+        const unsigned char* q = F + tbase + koff;
+        px[MAXT] = make_uint2(*reinterpret_cast<const uint32_t*>(q), *reinterpret_cast<const uint32_t*>(q + 4));
+#pragma unroll
+        for (int st = 0; st < 2; ++st) wv[4 + st] = Wl[(ckh * 8 + 4 * st + g4) * 32 + 16 * tj + r16];
+      }
     };
-    auto fma_row = [&](const uint2(&px)[MAXT], const float(&wv)[4]) __attribute__((always_inline)) {
+    auto fma_row = [&](const uint2(&px)[MAXT + 1], const float(&wv)[6]) __attribute__((always_inline)) {
       // kw-pair outer / tile inner: consecutive MFMAs hit different accumulators; each accumulator still sees its
       // k-pairs in ascending order (bit-exact with the oracle's chain).
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
 #pragma unroll
         for (int t = 0; t < MAXT; ++t) {
-          if (t < 3 || four) {
-            const uint32_t w32 = (j < 2 ? px[t].x : px[t].y) >> (8 * h + 16 * (j & 1));  // pixel kw = 2j + h
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(cbm_u8_unit(w32 & 255u), wv[j], acc[t], 0, 0, 0);
-          }
+          const uint32_t w32 = (j < 2 ? px[t].x : px[t].y) >> (8 * h + 16 * (j & 1));  // pixel kw = 2j + h
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(cbm_u8_unit(w32 & 255u), wv[j], acc[t], 0, 0, 0);
+        }
+      }
+      if (four) {   // tail tile: kw = 4*st + g4
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+          const float a = cbm_u8_unit(((st == 0 ? px[MAXT].x : px[MAXT].y) >> (8 * g4)) & 255u);
+          tacc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wv[4 + st], tacc, 0, 0, 0);
         }
       }
     };
@@ -126,27 +146,36 @@ __global__ __launch_bounds__(256, 2) void conv1_fwd_frames_kernel(const uint8_t*
     float* o = out + (size_t)s * 400 * 32 + li;
 #pragma unroll
     for (int t = 0; t < MAXT; ++t) {
-      if (t < 3 || four) {
-        const int m0 = (first + 4 * t) * 32 + 4 * h;
-        uint32_t word = 0;
+      const int m0 = (first + 4 * t) * 32 + 4 * h;
+      uint32_t word = 0;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int r0 = (e & 3) + 8 * (e >> 2);
-          const int m = m0 + r0;
-          const float v = relu_(acc[t][e] + bn);
+      for (int e = 0; e < 16; ++e) {
+        const int r0 = (e & 3) + 8 * (e >> 2);
+        const float v = relu_(acc[t][e] + bn);
 #if defined(C1_ABL) && C1_ABL == 1
-          if (m < 400 && acc[t][e] == 123.456f) o[m * 32] = v;
+        if (acc[t][e] == 123.456f) o[(m0 + r0) * 32] = v;
 #else
-          if (m < 400) o[m * 32] = v;
+        o[(m0 + r0) * 32] = v;
 #endif
-          const unsigned long long bal = __ballot(v > 0.0f);   // all 64 lanes: rows r0 (lower half) and r0 + 4 (upper half)
-          // lane r0 <- the lower wave half's row, lane r0 + 4 <- the upper half's (no writelane builtin in this clang)
-          asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(word) : "s"((uint32_t)bal), "n"(r0));
-          asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(word) : "s"((uint32_t)(bal >> 32)), "n"(r0 + 4));
-        }
-        const int mrow = (first + 4 * t) * 32 + lane;
-        if (mask && lane < 32 && mrow < 400) mask[(size_t)s * 400 + mrow] = word;
+        const unsigned long long bal = __ballot(v > 0.0f);   // all 64 lanes: rows r0 (lower half) and r0 + 4 (upper half)
+        // lane r0 <- the lower wave half's row, lane r0 + 4 <- the upper half's (no writelane builtin in this clang)
+        asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(word) : "s"((uint32_t)bal), "n"(r0));
+        asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(word) : "s"((uint32_t)(bal >> 32)), "n"(r0 + 4));
       }
+      if (mask && lane < 32) mask[(size_t)s * 400 + (first + 4 * t) * 32 + lane] = word;
+    }
+    if (four) {   // tail tile: lane (g4, r16) holds rows 384 + 4*g4 + i, column 16*tj + r16; its 16 mask bits go to half a word
+      const float bt = bias[16 * tj + r16];
+      uint32_t word = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float v = relu_(tacc[i] + bt);
+        out[((size_t)s * 400 + 384 + 4 * g4 + i) * 32 + 16 * tj + r16] = v;
+        const unsigned long long bal = __ballot(v > 0.0f);   // 16 bits per row group g4
+#pragma unroll
+        for (int g = 0; g < 4; ++g) asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(word) : "s"((uint32_t)((bal >> (16 * g)) & 0xFFFFull)), "n"(4 * g + i));
+      }
+      if (mask && lane < 16) reinterpret_cast<uint16_t*>(mask + (size_t)s * 400 + 384 + lane)[tj] = (uint16_t)word;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
