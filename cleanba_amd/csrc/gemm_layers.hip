@@ -514,6 +514,48 @@ static void launch_reduce(const float* part, int nz, int XY, int Ycols, int mode
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((XY + ow - 1) / ow), dim3(256), 0, st, part, nz, XY, Ycols, mode, A, zg, scale, gw, gw2);
 }
 
+// The backward pass has ten of these reductions (weights and biases of five layers).  As ten launches they cost ~86 us per minibatch on
+// the learner stream (most of them a few microseconds of work behind a launch); the partials of every layer now live in their own region
+// and the reductions run as TWO launches: {heads, dense} right after the dense weight gradient (their result is the tail the data-parallel
+// all-reduce waits for) and {conv3, conv2, conv1} at the end.  Same per-output summation order as the single launches -> same bits.
+struct RedJob { const float* part; float* gw; float* gw2; int nz, XY, Ycols, mode, zg, block0; float scale; };
+#define RED_MAX_JOBS 6
+struct RedJobs { RedJob j[RED_MAX_JOBS]; int n, A; };
+__global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const RedJobs jobs) {
+  __shared__ float red[256];
+  int q = 0;
+#pragma unroll
+  for (int k = 1; k < RED_MAX_JOBS; ++k) if (k < jobs.n && (int)blockIdx.x >= jobs.j[k].block0) q = k;
+  const RedJob& J = jobs.j[q];
+  const int zg = J.zg, ow = 256 / zg, nz = J.nz, XY = J.XY;
+  const int o = threadIdx.x % ow, g = threadIdx.x / ow;
+  const int i = ((int)blockIdx.x - J.block0) * ow + o;
+  float s = 0.0f;
+  if (i < XY)
+    for (int z = g; z < nz; z += zg) s += J.part[(size_t)z * XY + i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (g != 0 || i >= XY) return;
+  for (int r = 1; r < zg; ++r) s += red[r * ow + o];
+  s *= J.scale;
+  const int x = i / J.Ycols, y = i - x * J.Ycols, A = jobs.A;
+  if (J.mode == 0) J.gw[i] = s;
+  else if (J.mode == 1) { const int c = x >> 6, kh = (x >> 3) & 7, kw = x & 7; J.gw[((kh * 8 + kw) * 4 + c) * 32 + y] = s; }
+  else if (J.mode == 2) { if (y < A) J.gw[x * A + y] = s; else if (y == A) J.gw2[x] = s; }
+  else { if (y < A) J.gw[y] = s; else if (y == A) J.gw2[0] = s; }
+}
+struct RedBatch {
+  RedJobs jobs;
+  int blocks = 0;
+  explicit RedBatch(int A) { jobs.n = 0; jobs.A = A; }
+  void add(const float* part, int nz, int XY, int Ycols, int mode, float* gw, float* gw2, float scale = 1.0f) {
+    const int zg = nz >= 64 ? 16 : (nz >= 8 ? 4 : 1), ow = 256 / zg;
+    jobs.j[jobs.n++] = RedJob{part, gw, gw2, nz, XY, Ycols, mode, zg, blocks, scale};
+    blocks += (XY + ow - 1) / ow;
+  }
+  void launch(hipStream_t st) { hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3(blocks), dim3(256), 0, st, jobs); }
+};
+
 // ------------------------------------------------------------------------------------------ workspace
 static int dmalloc(float** p, size_t nfloats) {
   if (hipMalloc((void**)p, nfloats * sizeof(float)) != hipSuccess) { cbm_set_error("hipMalloc of %zu floats failed", nfloats); return -1; }
@@ -528,6 +570,20 @@ static const int RPS_C1 = 1600, RPS_C2 = 1280, RPS_C3 = 1664, RPS_HEADS = 128;
 #define DENSE_WGRAD_NZ 2
 #endif
 static int dense_wgrad_splits(int B) { return B >= 2048 ? DENSE_WGRAD_NZ : 1; }
+
+// offsets (floats) of the per-layer partial regions inside ws.wg_part / ws.bias_part for a batch of B frames
+struct WgRegions {
+  int nz[5];            // 0 heads, 1 dense, 2 conv3, 3 conv2, 4 conv1
+  size_t w[5], b[5], w_total, b_total;
+  explicit WgRegions(int B) {
+    nz[0] = ceil_div(B, RPS_HEADS); nz[1] = dense_wgrad_splits(B); nz[2] = ceil_div(B * 49, RPS_C3); nz[3] = ceil_div(B * 81, RPS_C2);
+    nz[4] = std::max(ceil_div(B * 400, RPS_C1), conv1_wgrad_frames_splits(B));
+    const size_t wsz[5] = {512 * 32, 3136 * 512, 576 * 64, 512 * 64, 256 * 32}, bsz[5] = {32, 512, 64, 64, 32};
+    size_t ow = 0, ob = 0;
+    for (int i = 0; i < 5; ++i) { w[i] = ow; b[i] = ob; ow += (size_t)nz[i] * wsz[i]; ob += (size_t)nz[i] * bsz[i] + 64; }
+    w_total = ow; b_total = ob;
+  }
+};
 
 static int rn_ws_alloc(NatureWs& ws, int maxB, bool with_grad, int dense_ksplit_small);
 int nature_ws_alloc(NatureWs& ws, int maxB, bool with_grad, int dense_ksplit_small, int kind) {
@@ -550,15 +606,10 @@ int nature_ws_alloc(NatureWs& ws, int maxB, bool with_grad, int dense_ksplit_sma
     hipMemset(ws.dact3pad, 0, B * 7744 * sizeof(float));
     hipMemset(ws.dact2pad, 0, B * 7744 * sizeof(float));
     hipMemset(ws.dzv, 0, B * 32 * sizeof(float));
-    size_t need = 0;
-    auto mx = [&](size_t v) { if (v > need) need = v; };
-    mx((size_t)std::max(ceil_div(maxB * 400, RPS_C1), conv1_wgrad_frames_splits(maxB)) * 256 * 32);  // generic or frame-resident conv1 wgrad
-    mx((size_t)ceil_div(maxB * 81, RPS_C2) * 512 * 64);
-    mx((size_t)ceil_div(maxB * 49, RPS_C3) * 576 * 64);
-    mx((size_t)dense_wgrad_splits(maxB) * 3136 * 512);
-    mx((size_t)ceil_div(maxB, RPS_HEADS) * 512 * 32);
+    // split-K partials: one region per layer (WgRegions), so that the reductions can be deferred and batched
+    const WgRegions rg(maxB);
+    const size_t need = rg.w_total, bneed = rg.b_total;
     ws.wg_part_floats = (int64_t)need;
-    size_t bneed = (size_t)std::max(ceil_div(maxB * 400, RPS_C1), conv1_wgrad_frames_splits(maxB)) * 512 + 4096;
     ws.bias_part_floats = (int64_t)bneed;
     if (dmalloc(&ws.wg_part, need) || dmalloc(&ws.bias_part, bneed)) return -1;
   }
@@ -732,15 +783,19 @@ void nature_backward(const NatureLayout& L, const float* P, const uint8_t* obs, 
                      hipStream_t st) {
   if (L.kind == CBM_NET_IMPALA_RESNET) { resnet_backward(L, P, obs, idx, B, ws, grads, st); return; }
   const int A = L.A;
+  const WgRegions rg(B);
+  float* const wp = ws.wg_part;
+  float* const bp = ws.bias_part;
+  RedBatch tail_red(A), conv_red(A);
   // heads: dgrad (VALU) and wgrad (MFMA, Y = A+1 padded to 32)
   hipLaunchKernelGGL(heads_dgrad_kernel, dim3(ceil_div(B * 512, 256)), dim3(256), 0, st, ws.dzv, P + L.w[4], P + L.w[5], ws.hid, B, A, 512,
                      ws.dhid);
   {
     const int nz = ceil_div(B, RPS_HEADS);
-    MatWgrad<T128x32> p{ws.hid, ws.dzv, ws.wg_part, ws.bias_part, B, 512, 32, 32, RPS_HEADS};
+    MatWgrad<T128x32> p{ws.hid, ws.dzv, wp + rg.w[0], bp + rg.b[0], B, 512, 32, 32, RPS_HEADS};
     plaunch(ws, K_HEADS_WGRAD, p, nz, st);
-    launch_reduce(ws.wg_part, nz, 512 * 32, 32, 2, A, grads + L.w[4], grads + L.w[5], st);
-    launch_reduce(ws.bias_part, nz, 32, 32, 3, A, grads + L.b[4], grads + L.b[5], st);
+    tail_red.add(wp + rg.w[0], nz, 512 * 32, 32, 2, grads + L.w[4], grads + L.w[5]);
+    tail_red.add(bp + rg.b[0], nz, 32, 32, 3, grads + L.b[4], grads + L.b[5]);
   }
   // dense: dgrad -> dact3pad, wgrad
   {
@@ -748,10 +803,11 @@ void nature_backward(const NatureLayout& L, const float* P, const uint8_t* obs, 
     plaunch(ws, K_DENSE_DGRAD, pd, 1, st);
     const int nz = dense_wgrad_splits(B);
     const int rps = round_up(ceil_div(B, nz), 32);
-    MatWgrad<TILE_DW> pw{ws.act3, ws.dhid, ws.wg_part, ws.bias_part, B, 3136, 512, 512, rps};
+    MatWgrad<TILE_DW> pw{ws.act3, ws.dhid, wp + rg.w[1], bp + rg.b[1], B, 3136, 512, 512, rps};
     plaunch(ws, K_DENSE_WGRAD, pw, nz, st);
-    launch_reduce(ws.wg_part, nz, 3136 * 512, 512, 0, A, grads + L.w[3], (float*)nullptr, st);
-    launch_reduce(ws.bias_part, nz, 512, 512, 0, A, grads + L.b[3], (float*)nullptr, st);
+    tail_red.add(wp + rg.w[1], nz, 3136 * 512, 512, 0, grads + L.w[3], nullptr);
+    tail_red.add(bp + rg.b[1], nz, 512, 512, 0, grads + L.b[3], nullptr);
+    tail_red.launch(st);
   }
   if (ws.tail_ev) hipEventRecord(ws.tail_ev, st);   // 95 % of the flat gradient is final here: its all-reduce can overlap the conv backward
   // conv3: dgrad -> dact2pad, wgrad
@@ -764,26 +820,27 @@ void nature_backward(const NatureLayout& L, const float* P, const uint8_t* obs, 
 #endif
     plaunch(ws, K_CONV3_DGRAD, pd, 1, st);
     const int M = B * 49, nz = ceil_div(M, RPS_C3);
-    ConvWgrad<TILE_C3W, 3, 3, 1, 64, 64, 9, 9, 7, 7, 2> pw{ws.act2, ws.dact3pad, ws.wg_part, ws.bias_part, M, RPS_C3};
+    ConvWgrad<TILE_C3W, 3, 3, 1, 64, 64, 9, 9, 7, 7, 2> pw{ws.act2, ws.dact3pad, wp + rg.w[2], bp + rg.b[2], M, RPS_C3};
     plaunch(ws, K_CONV3_WGRAD, pw, nz, st);
-    launch_reduce(ws.wg_part, nz, 576 * 64, 64, 0, A, grads + L.w[2], (float*)nullptr, st);
-    launch_reduce(ws.bias_part, nz, 64, 64, 0, A, grads + L.b[2], (float*)nullptr, st);
+    conv_red.add(wp + rg.w[2], nz, 576 * 64, 64, 0, grads + L.w[2], nullptr);
+    conv_red.add(bp + rg.b[2], nz, 64, 64, 0, grads + L.b[2], nullptr);
   }
   // conv2: dgrad -> dact1, wgrad
   {
     Conv2Dgrad<TILE_C2D> pd{ws.dact2pad, P + L.w[1], ws.act1, ws.dact1, B * 100, ws.mask1};
     plaunch(ws, K_CONV2_DGRAD, pd, 1, st);
     const int M = B * 81, nz = ceil_div(M, RPS_C2);
-    ConvWgrad<T128x64, 4, 4, 2, 32, 64, 20, 20, 9, 9, 1> pw{ws.act1, ws.dact2pad, ws.wg_part, ws.bias_part, M, RPS_C2};
+    ConvWgrad<T128x64, 4, 4, 2, 32, 64, 20, 20, 9, 9, 1> pw{ws.act1, ws.dact2pad, wp + rg.w[3], bp + rg.b[3], M, RPS_C2};
     plaunch(ws, K_CONV2_WGRAD, pw, nz, st);
-    launch_reduce(ws.wg_part, nz, 512 * 64, 64, 0, A, grads + L.w[1], (float*)nullptr, st);
-    launch_reduce(ws.bias_part, nz, 64, 64, 0, A, grads + L.b[1], (float*)nullptr, st);
+    conv_red.add(wp + rg.w[3], nz, 512 * 64, 64, 0, grads + L.w[1], nullptr);
+    conv_red.add(bp + rg.b[3], nz, 64, 64, 0, grads + L.b[1], nullptr);
   }
   // conv1: wgrad only (frames need no gradient); frame-resident kernel, pixels as integers, 1/255 in the reduce
   {
     const int nz = conv1_wgrad_frames_splits(B);
-    plaunch_fn(ws, K_CONV1_WGRAD, st, [&] { launch_conv1_wgrad_frames(obs, idx, ws.dact1, ws.wg_part, ws.bias_part, B, st); });
-    launch_reduce(ws.wg_part, nz, 256 * 32, 32, 1, A, grads + L.w[0], (float*)nullptr, st, 1.0f / 255.0f);
-    launch_reduce(ws.bias_part, nz, 32, 32, 0, A, grads + L.b[0], (float*)nullptr, st);
+    plaunch_fn(ws, K_CONV1_WGRAD, st, [&] { launch_conv1_wgrad_frames(obs, idx, ws.dact1, wp + rg.w[4], bp + rg.b[4], B, st); });
+    conv_red.add(wp + rg.w[4], nz, 256 * 32, 32, 1, grads + L.w[0], nullptr, 1.0f / 255.0f);
+    conv_red.add(bp + rg.b[4], nz, 32, 32, 0, grads + L.b[0], nullptr);
+    conv_red.launch(st);
   }
 }
