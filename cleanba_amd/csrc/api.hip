@@ -291,7 +291,11 @@ extern "C" int cbm_buffer(cbm_ctx* c, const char* name, int32_t ri, void** p, in
       {"stats", c->stats_dev, (size_t)c->stat_rows * 8 * 4}, {"obs", R.obs, TB * CBM_FRAME}, {"actions", R.actions, TB * 4},
       {"logprobs", R.logprobs, TB * 4}, {"values", R.values, TB * 4}, {"rewards", R.rewards, TB * 4}, {"logits", R.logits, TB * c->A * 4},
       {"dones", R.dones, TB}, {"firststeps", R.firststeps, TB}, {"env_ids", R.env_ids, TB * 4}, {"adv_norm", c->advn, c->advn ? TB * 4 : 0}, {"lws_logits", c->lws.logits, (size_t)c->lws.maxB * 32 * 4},
-      {"lws_value", c->lws.value, (size_t)c->lws.maxB * 4}};
+      {"lws_value", c->lws.value, (size_t)c->lws.maxB * 4},
+      // learner-workspace activations and their ReLU bit masks (tests / debugging)
+      {"lws_act1", c->lws.act1, (size_t)c->lws.maxB * 12800 * 4}, {"lws_act2", c->lws.act2, (size_t)c->lws.maxB * 5184 * 4},
+      {"lws_act3", c->lws.act3, (size_t)c->lws.maxB * 3136 * 4}, {"lws_mask1", c->lws.mask1, c->lws.mask1 ? (size_t)c->lws.maxB * 400 * 4 : 0},
+      {"lws_mask2", c->lws.mask2, c->lws.mask2 ? (size_t)c->lws.maxB * 162 * 4 : 0}, {"lws_mask3", c->lws.mask3, c->lws.mask3 ? (size_t)c->lws.maxB * 98 * 4 : 0}};
   for (auto& e : tab)
     if (n == e.k) { *p = e.ptr; if (nbytes) *nbytes = (int64_t)e.sz; return 0; }
   cbm_set_error("unknown buffer '%s'", name);

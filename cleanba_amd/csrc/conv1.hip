@@ -159,8 +159,8 @@ __global__ __launch_bounds__(256, 2) void conv1_fwd_frames_kernel(const uint8_t*
 #endif
         const unsigned long long bal = __ballot(v > 0.0f);   // all 64 lanes: rows r0 (lower half) and r0 + 4 (upper half)
         // lane r0 <- the lower wave half's row, lane r0 + 4 <- the upper half's (no writelane builtin in this clang)
-        asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(word) : "s"((uint32_t)bal), "n"(r0));
-        asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(word) : "s"((uint32_t)(bal >> 32)), "n"(r0 + 4));
+        asm volatile("s_nop 4\n\tv_writelane_b32 %0, %1, %2" : "+v"(word) : "s"((uint32_t)bal), "n"(r0));
+        asm volatile("s_nop 4\n\tv_writelane_b32 %0, %1, %2" : "+v"(word) : "s"((uint32_t)(bal >> 32)), "n"(r0 + 4));
       }
       if (mask && lane < 32) mask[(size_t)s * 400 + (first + 4 * t) * 32 + lane] = word;
     }
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256, 2) void conv1_fwd_frames_kernel(const uint8_t*
         out[((size_t)s * 400 + 384 + 4 * g4 + i) * 32 + 16 * tj + r16] = v;
         const unsigned long long bal = __ballot(v > 0.0f);   // 16 bits per row group g4
 #pragma unroll
-        for (int g = 0; g < 4; ++g) asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(word) : "s"((uint32_t)((bal >> (16 * g)) & 0xFFFFull)), "n"(4 * g + i));
+        for (int g = 0; g < 4; ++g) asm volatile("s_nop 4\n\tv_writelane_b32 %0, %1, %2" : "+v"(word) : "s"((uint32_t)((bal >> (16 * g)) & 0xFFFFull)), "n"(4 * g + i));
       }
       if (mask && lane < 16) reinterpret_cast<uint16_t*>(mask + (size_t)s * 400 + 384 + lane)[tj] = (uint16_t)word;
     }

@@ -153,3 +153,22 @@ def test_resnet_large_batch_properties():
         assert np.abs(g1).max() > 1e-6 * scale and np.abs(g12 - (g1 + g2)).max() <= 2e-5 * scale
     finally:
         ctx.close()
+
+
+def test_relu_bit_masks_equal_the_activations(big):
+    """The forward epilogues emit the ReLU masks as bits (ballot words collected with v_writelane — inline asm, so the hazard wait states
+    are ours to keep); the dgrad epilogues trust them.  After a full-size forward every word must equal (activation > 0)."""
+    P = make_params(A, 51)
+    for rep, n in enumerate((MB, 1000, MB)):
+        obs = make_frames(n, 52 + rep)
+        dP, dO = L.DevBuf(big, P), L.DevBuf(big, obs)
+        L._chk(big.lib.cbm_forward(big.h, L._p(dP.ptr), L._p(dO.ptr), None, n, 1 if n > 1024 else 14, None, None))
+        for name, ch, rows in (("1", 32, n * 400), ("2", 64, n * 81), ("3", 64, n * 49)):
+            act = big.read("lws_act" + name, np.float32).reshape(-1, ch)[:rows]
+            m = big.read("lws_mask" + name, np.uint32).reshape(-1, ch // 32)[:rows]
+            for w in range(ch // 32):
+                bits = (act[:, 32 * w:32 * w + 32] > 0).astype(np.uint64)
+                want = (bits << np.arange(32, dtype=np.uint64)).sum(1).astype(np.uint32)
+                bad = np.nonzero(want != m[:, w])[0]
+                assert bad.size == 0, (n, name, w, bad[:8])
+        dP.free(); dO.free()
