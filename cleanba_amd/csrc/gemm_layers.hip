@@ -666,14 +666,6 @@ static inline void plaunch_fwd(NatureWs& ws, int kid, const P& p, int nz, hipStr
   igemm_bf16_launch(p, nz, st);
   if (on) { hipEventRecord(pf->ev[2 * pf->n + 1], st); pf->n += 1; }
 }
-#ifndef WAVE_C3F
-#define WAVE_C3F 0   // experiment: conv3 forward on the wave-private kernel
-#endif
-#ifndef WAVE_TM
-#define WAVE_TM 2
-#define WAVE_TN 2
-#define WAVE_MINW 2
-#endif
 #ifndef CONV3_DGRAD_POS
 #define CONV3_DGRAD_POS 1   // position-major conv3 dgrad with tap skipping
 #endif
@@ -744,10 +736,6 @@ void nature_forward(const NatureLayout& L, const float* P, const uint8_t* obs, c
     ConvFwd<TILE_C2F, 4, 4, 2, 32, 64, 20, 20, 9, 9> p2{ws.act1, P + L.w[1], P + L.b[1], ws.act2, B * 81, ws.mask2};
     plaunch_fwd(ws, K_CONV2_FWD, p2, 1, st);
     ConvFwd<T128x64, 3, 3, 1, 64, 64, 9, 9, 7, 7> p3{ws.act2, P + L.w[2], P + L.b[2], ws.act3, B * 49, ws.mask3};
-#if WAVE_C3F
-    if (!ws.bf16_fwd) plaunch_fn(ws, K_CONV3_FWD, st, [&] { igemm_wave_launch<decltype(p3), WAVE_TM, WAVE_TN, WAVE_MINW>(p3, 1, st); });
-    else
-#endif
     plaunch_fwd(ws, K_CONV3_FWD, p3, 1, st);
   }
   if (dense_ksplit > 1) {

@@ -327,156 +327,6 @@ static inline void igemm_launch(const P& p, int nsplit, hipStream_t stream) {
   hipLaunchKernelGGL(igemm_kernel<P>, grid, dim3(256), 0, stream, p);
 }
 
-// ------------------------------------------------------------------------------------------------ wave-private variant (no block barrier)
-// igemm_kernel synchronises its four waves at every K chunk; PMC shows the waves parked at that barrier / waitcnt ~40 % of the time.
-// Here every wave owns a (32*TM) x (32*TN) output tile outright: it stages ITS rows of A and ITS columns of B into a private LDS slice,
-// prefetches the next chunk into registers, and never executes s_barrier — LDS operations of one wave are processed in order, so
-// "write chunk, then read fragments" needs no hardware barrier, only a compiler fence.  The four waves of a block sit side by side along x
-// and read the same B columns from global memory (L1/L2 hits), so global traffic grows by the B tile only.  Same math and the same
-// k-ascending chain per accumulator as igemm_kernel: bit-identical results.
-template <class P, int TM, int TN, int MINW>
-__global__ __launch_bounds__(256, MINW) void igemm_wave_kernel(const P p) {
-  constexpr bool A_RX = P::A_RX, B_YR = P::B_YR;
-  static_assert(!A_RX && !P::BIAS_GRAD, "wave-private variant: row-gather A, no fused bias gradient");
-  constexpr int WXR = 32 * TM, WYC = 32 * TN, BR = 16;        // wave tile, K chunk
-  constexpr int PA = BR + 1, ASZ = WXR * PA, PB = WYC, BSZ = BR * PB;
-  constexpr int NVA = WXR * BR / 4 / 64, NVB = BR * WYC / 4 / 64;
-  __shared__ __attribute__((aligned(16))) float smem[4 * (ASZ + BSZ)];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int li = lane & 31, h = lane >> 5;
-  float* A_ = smem + wave * (ASZ + BSZ);
-  float* B_ = A_ + ASZ;
-  const int cls = P::NCLS > 1 ? (int)(blockIdx.y % P::NCLS) : 0;
-  int bx = blockIdx.x;
-  {
-    const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = bx & 7, k = bx >> 3;
-    bx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
-  }
-  const int x0 = (bx * 4 + wave) * WXR;
-  const int y0 = (P::NCLS > 1 ? (int)(blockIdx.y / P::NCLS) : (int)blockIdx.y) * WYC;
-  const int z = blockIdx.z;
-  int rlo, rhi;
-  p.r_range(z, rlo, rhi);
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
-
-  float4 ra[NVA], rb[NVB];
-  auto gload = [&](int r0) {
-#pragma unroll
-    for (int j = 0; j < NVA; ++j) {
-      const int v = lane + 64 * j, rq = v % (BR / 4), xl = v / (BR / 4);
-      ra[j] = p.load_a(x0 + xl, r0 + 4 * rq, rhi, cls);
-    }
-#pragma unroll
-    for (int j = 0; j < NVB; ++j) {
-      const int v = lane + 64 * j;
-      if (B_YR) { const int yl = v % WYC, rq = v / WYC; rb[j] = p.load_b(r0 + 4 * rq, y0 + yl, rhi, cls); }
-      else { const int yq = v % (WYC / 4), rl = v / (WYC / 4); rb[j] = p.load_b(r0 + rl, y0 + 4 * yq, rhi, cls); }
-    }
-  };
-  auto sstore = [&]() {
-#pragma unroll
-    for (int j = 0; j < NVA; ++j) {
-      const int v = lane + 64 * j, rq = v % (BR / 4), xl = v / (BR / 4);
-      float* d = A_ + xl * PA + 4 * rq;
-      d[0] = ra[j].x; d[1] = ra[j].y; d[2] = ra[j].z; d[3] = ra[j].w;
-    }
-#pragma unroll
-    for (int j = 0; j < NVB; ++j) {
-      const int v = lane + 64 * j;
-      if (B_YR) { const int yl = v % WYC, rq = v / WYC; float* d = B_ + (4 * rq) * PB + yl; d[0] = rb[j].x; d[PB] = rb[j].y; d[2 * PB] = rb[j].z; d[3 * PB] = rb[j].w; }
-      else { const int yq = v % (WYC / 4), rl = v / (WYC / 4); *reinterpret_cast<float4*>(B_ + rl * PB + 4 * yq) = rb[j]; }
-    }
-  };
-  auto wave_fence = [] { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); };
-
-  gload(rlo);
-  sstore();
-  wave_fence();
-  for (int r0 = rlo; r0 < rhi; r0 += BR) {
-    const bool more = (r0 + BR) < rhi;
-    if (more) gload(r0 + BR);
-    {
-      constexpr int G = 2, NG = BR / 2 / G;
-      float fa[2][G][TM], fb[2][G][TN];
-      auto frag = [&](int g, int set) {
-#pragma unroll
-        for (int q = 0; q < G; ++q) {
-          const int rr = 2 * (g * G + q);
-#pragma unroll
-          for (int i = 0; i < TM; ++i) fa[set][q][i] = A_[(i * 32 + li) * PA + rr + h];
-#pragma unroll
-          for (int j = 0; j < TN; ++j) fb[set][q][j] = B_[(rr + h) * PB + j * 32 + li];
-        }
-      };
-      frag(0, 0);
-#pragma unroll
-      for (int g = 0; g < NG; ++g) {
-        if (g + 1 < NG) frag(g + 1, (g + 1) & 1);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int q = 0; q < G; ++q)
-#pragma unroll
-          for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g & 1][q][i], fb[g & 1][q][j], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-    wave_fence();            // my fragment reads of this chunk are done (in-order LDS) before the next chunk overwrites the slice
-    if (more) sstore();
-    wave_fence();
-  }
-
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int y = y0 + j * 32 + li;
-      if constexpr (igemm_bitmask<P>::value) {
-        const uint32_t mw = p.mask_word(x0 + i * 32 + li, y0 + j * 32, cls);
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
-          const uint32_t w = (uint32_t)__shfl((int)mw, row, 64);
-          p.store_on(x0 + i * 32 + row, y, acc[i][j][e], (w >> li) & 1u, z, cls);
-        }
-      } else if constexpr (igemm_maskout<P>::value) {
-        uint32_t word = 0;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int r0 = (e & 3) + 8 * (e >> 2);
-          const bool on = p.store_flag(x0 + i * 32 + r0 + 4 * h, y, acc[i][j][e], z, cls);
-          const unsigned long long bal = __ballot(on);
-          asm volatile("s_nop 4\n\tv_writelane_b32 %0, %1, %2" : "+v"(word) : "s"((uint32_t)bal), "n"(r0));
-          asm volatile("s_nop 4\n\tv_writelane_b32 %0, %1, %2" : "+v"(word) : "s"((uint32_t)(bal >> 32)), "n"(r0 + 4));
-        }
-        if (lane < 32) p.put_mask(x0 + i * 32 + lane, y0 + j * 32, word);
-      } else {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
-          p.store(x0 + i * 32 + row, y, acc[i][j][e], z, cls);
-        }
-      }
-    }
-}
-
-template <class P, int TM, int TN, int MINW = 2>
-static inline void igemm_wave_launch(const P& p, int nsplit, hipStream_t stream) {
-  constexpr int BXB = 4 * 32 * TM, WYC = 32 * TN;
-  dim3 grid((p.X() + BXB - 1) / BXB, ((p.Y() + WYC - 1) / WYC) * P::NCLS, nsplit);
-  hipLaunchKernelGGL((igemm_wave_kernel<P, TM, TN, MINW>), grid, dim3(256), 0, stream, p);
-}
-
 // ------------------------------------------------------------------------------------------------ DMA-staged variant
 // Same math and the same k-ascending accumulation order as igemm_kernel (bit-identical results), but the LDS tiles are filled by
 // global_load_lds_dwordx4: the load unit writes 16 bytes per lane straight into LDS (wave-uniform base + lane*16) — no staging
