@@ -307,3 +307,34 @@ def test_other_action_set_sizes(oracle, na):
         assert np.abs(p_g - p_o).max() <= 1e-5 * max(1.0, np.abs(p_o).max())
     finally:
         ctx.close()
+
+
+def test_ppo_grads_at_ragged_batch_sizes(oracle):
+    """Backward parity at sizes that do not fill the position-major conv3 dgrad's 128-frame tiles (130 = one full tile + 2 frames, 7 = a
+    sliver), with a gather index — the masked rows of the last frame tile, the K-skip table and the bit-mask epilogues all take their edge paths."""
+    cfg = L.default_config(L.ALGO_PPO)
+    cfg.local_num_envs, cfg.num_actor_slots, cfg.num_steps = 68, 1, 8      # MB = 136 frames of workspace
+    c = L.Context(cfg)
+    rng = np.random.default_rng(70)
+    P = make_params(A, 71)
+    pool = make_frames(200, 72)
+    dP, dO = L.DevBuf(c, P), L.DevBuf(c, pool)
+    for N in (130, 7):
+        idx = rng.permutation(200)[:N].astype(np.int32)
+        actions = rng.integers(0, A, N).astype(np.int32)
+        old_lp = (-np.log(A) + 0.2 * rng.normal(size=N)).astype(np.float32)
+        adv = rng.normal(size=N).astype(np.float32)
+        tgt = rng.normal(size=N).astype(np.float32)
+        d = [L.DevBuf(c, x) for x in (idx, actions, old_lp, adv, tgt)]
+        dS = L.DevBuf(c, nbytes=32, dtype=np.float32)
+        dG = L.DevBuf(c, nbytes=P.size * 4, dtype=np.float32)
+        L._chk(c.lib.cbm_ppo_loss_grad(c.h, L._p(dP.ptr), L._p(dO.ptr), L._p(d[0].ptr), N, L._p(d[1].ptr), L._p(d[2].ptr), L._p(d[3].ptr),
+                                       L._p(d[4].ptr), L._p(dS.ptr), L._p(dG.ptr), None, None))
+        stats_o, grads_o, _, _ = oracle.ppo_loss_grad(P, A, pool, idx, actions, old_lp, adv, tgt)
+        np.testing.assert_allclose(dS.download()[:5], stats_o, rtol=1e-5, atol=1e-6)
+        g = dG.download()
+        for name, (o, shp) in oracle.nature_layout(A).items():
+            n = int(np.prod(shp))
+            ref = grads_o[o:o + n]
+            assert np.abs(g[o:o + n] - ref).max() <= 1e-5 * max(np.abs(ref).max(), 1e-7), (N, name)
+    c.close()
