@@ -91,6 +91,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--prof-kernel", type=int, default=9, help="igemm kernel id timed with HIP events for the roofline line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--bwd-split", type=int, default=0, choices=[0, 2, 3],
+                    help="build-only extension (NOT the headline): backward GEMMs on split-bf16 MFMA, see cbm_config.backward_split")
     a = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -106,6 +108,7 @@ def main():
     cfg = L.default_config(L.ALGO_PPO)
     cfg.device = local_rank
     cfg.local_num_envs, cfg.num_actor_slots, cfg.num_steps, cfg.num_actions = E, 1, T, A
+    cfg.backward_split = a.bwd_split
     from cleanba_amd.trainer import HipEngine
     ctx = HipEngine(cfg)
     key = prng.prng_key(1)
@@ -190,7 +193,8 @@ def main():
                     "flops_per_launch": kflops}
         line = {"metric": "env-steps/sec (whole node), Breakout-v5 84x84x4, num_envs=120", "value": round(sps, 1), "unit": "env-steps/s",
                 "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
-                "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "scaling": "weak", "vs_baseline": None,
+                "dtype": "f32" if not a.bwd_split else f"f32 forward / split-bf16 x{a.bwd_split} backward GEMMs (extension, not the headline)", "data": "synthetic",
                 "config": {"workload": "PPO a0-l0-d%d: Nature-CNN fp32, local_num_envs=120, rollout_len=128, 4 epochs x 4 minibatches, A=18, "
                                        "device synthetic Breakout-shaped env, concurrency on" % world,
                            "global_batch": T * E * world, "parallelism": f"dp{world}"},

@@ -59,6 +59,8 @@ class Args:
     eval_max_episode_steps: int = 0  # 0 = the env's own limit (27000 for Atari); smaller values bound smoke runs
     async_batch_size: int = 0  # legacy `--async-batch-size` (legacy_scripts/..._naturecnn.py:65-66): envpool async mode, recv() returns this many
                                # of the local_num_envs envs; env-id-indexed GAE, per-minibatch advantage normalisation.  0 = off (cleanba_ppo.py)
+    backward_split: int = 0  # build-only extension: 0 = backward GEMMs on fp32 MFMA (reference precision); 2 / 3 = fp32 operands split exactly into
+                             # 2 / 3 bf16 terms, products on bf16 MFMA, fp32 accumulate (gradient error ~1e-6 / ~1e-7 of the fp32 path's); Nature-CNN
     bf16_forward: bool = False  # build-only extension (reference is fp32): conv2/conv3/dense forward on bf16 MFMA, fp32 accumulate + fp32 returns (Nature-CNN)
     same_env_seed_all_ranks: bool = False  # testing aid: every process steps identical envs (then dp-N == dp-1 bitwise)
 

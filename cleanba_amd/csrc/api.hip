@@ -126,6 +126,8 @@ static int ctx_create_impl(const cbm_config* cfg, cbm_ctx** out, cbm_ctx** parti
   }
   if (cfg->num_actions < 2 || cfg->num_actions > 28) { cbm_set_error("num_actions must be in [2,28]"); return -1; }
   if (cfg->algo == CBM_ALGO_IMPALA && cfg->num_steps + 1 > 2000) { cbm_set_error("IMPALA num_steps must be <= 1999 (the V-trace kernel keeps 8 floats per step in LDS)"); return -1; }
+  if (cfg->backward_split != 0 && cfg->backward_split != 2 && cfg->backward_split != 3) { cbm_set_error("backward_split must be 0, 2 or 3"); return -1; }
+  if (cfg->backward_split && cfg->network != CBM_NET_NATURE) { cbm_set_error("backward_split is built for the Nature-CNN torso only"); return -1; }
   if (cfg->forward_bf16 && cfg->network != CBM_NET_NATURE) { cbm_set_error("forward_bf16 is built for the Nature-CNN torso only"); return -1; }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { cbm_set_error("no HIP device visible: libcleanba_mi needs an MI355X"); return -3; }
@@ -191,6 +193,7 @@ static int ctx_create_impl(const cbm_config* cfg, cbm_ctx** out, cbm_ctx** parti
   const int lmax = c->MB > c->Bdev ? c->MB : c->Bdev;
   if (nature_ws_alloc(c->lws, lmax, true, cfg->actor_dense_ksplit, cfg->network)) return -1;
   c->lws.bf16_fwd = cfg->forward_bf16 != 0 && cfg->network == CBM_NET_NATURE;
+  c->lws.bwd_split = cfg->backward_split;
   CBM_HIP(hipEventCreateWithFlags(&c->tail_ev, hipEventDisableTiming));
   CBM_HIP(hipEventCreateWithFlags(&c->ext_ev, hipEventDisableTiming));
   c->lws.tail_ev = c->tail_ev;

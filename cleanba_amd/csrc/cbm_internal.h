@@ -37,6 +37,7 @@ struct NatureWs {
   int maxB = 0;
   bool with_grad = false;
   hipEvent_t tail_ev = nullptr;   // when set: recorded by the backward pass once the gradients of dense + heads (the flat tail [w[3], total)) are final
+  int bwd_split = 0;       // cbm_config.backward_split: 0 fp32 MFMA, 2 / 3 split-bf16 backward GEMMs (igemm_split_kernel)
   bool bf16_fwd = false;   // cbm_config.forward_bf16: conv2/conv3/dense forward on bf16 MFMA (Nature-CNN)
   float *act1 = nullptr, *act2 = nullptr, *act3 = nullptr, *hid = nullptr;
   float *logits = nullptr, *value = nullptr;

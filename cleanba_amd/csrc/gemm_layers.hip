@@ -576,7 +576,9 @@ struct WgRegions {
   int nz[5];            // 0 heads, 1 dense, 2 conv3, 3 conv2, 4 conv1
   size_t w[5], b[5], w_total, b_total;
   explicit WgRegions(int B) {
-    nz[0] = ceil_div(B, RPS_HEADS); nz[1] = dense_wgrad_splits(B); nz[2] = ceil_div(B * 49, RPS_C3); nz[3] = ceil_div(B * 81, RPS_C2);
+    nz[0] = ceil_div(B, RPS_HEADS);
+    nz[1] = std::max(dense_wgrad_splits(B), 4);   // room for the split-bf16 mode's 4 splits
+    nz[2] = ceil_div(B * 49, RPS_C3); nz[3] = ceil_div(B * 81, RPS_C2);
     nz[4] = std::max(ceil_div(B * 400, RPS_C1), conv1_wgrad_frames_splits(B));
     const size_t wsz[5] = {512 * 32, 3136 * 512, 576 * 64, 512 * 64, 256 * 32}, bsz[5] = {32, 512, 64, 64, 32};
     size_t ow = 0, ob = 0;
@@ -664,6 +666,18 @@ static inline void plaunch_fwd(NatureWs& ws, int kid, const P& p, int nz, hipStr
   const bool on = pf && pf->sel == kid && pf->n < CBM_PROF_MAX;
   if (on) hipEventRecord(pf->ev[2 * pf->n], st);
   igemm_bf16_launch(p, nz, st);
+  if (on) { hipEventRecord(pf->ev[2 * pf->n + 1], st); pf->n += 1; }
+}
+// backward GEMM launch: fp32 MFMA (default) or, with cbm_config.backward_split = 2 / 3, the split-bf16 kernel
+template <class P>
+static inline void plaunch_bwd(NatureWs& ws, int kid, const P& p, int nz, hipStream_t st) {
+  // (three-term weight gradients measured slower than fp32 MFMA: with backward_split = 3 only the input gradients are split)
+  if (ws.bwd_split == 0 || (P::A_RX && ws.bwd_split != 2)) { plaunch(ws, kid, p, nz, st); return; }
+  CbmProf* pf = ws.prof;
+  const bool on = pf && pf->sel == kid && pf->n < CBM_PROF_MAX;
+  if (on) hipEventRecord(pf->ev[2 * pf->n], st);
+  if constexpr (P::A_RX) igemm_split_wgrad_launch<P, 2>(p, nz, st);
+  else { if (ws.bwd_split == 2) igemm_split_launch<P, 2>(p, nz, st); else igemm_split_launch<P, 3>(p, nz, st); }
   if (on) { hipEventRecord(pf->ev[2 * pf->n + 1], st); pf->n += 1; }
 }
 #ifndef CONV3_DGRAD_POS
@@ -793,18 +807,24 @@ void nature_backward(const NatureLayout& L, const float* P, const uint8_t* obs, 
   {
     const int nz = ceil_div(B, RPS_HEADS);
     MatWgrad<T128x32> p{ws.hid, ws.dzv, wp + rg.w[0], bp + rg.b[0], B, 512, 32, 32, RPS_HEADS};
-    plaunch(ws, K_HEADS_WGRAD, p, nz, st);
+    plaunch(ws, K_HEADS_WGRAD, p, nz, st);   // (fp32 also in split mode: 9 vs 15 us)
     tail_red.add(wp + rg.w[0], nz, 512 * 32, 32, 2, grads + L.w[4], grads + L.w[5]);
     tail_red.add(bp + rg.b[0], nz, 32, 32, 3, grads + L.b[4], grads + L.b[5]);
   }
   // dense: dgrad -> dact3pad, wgrad
   {
     DenseDgrad<T128x64> pd{ws.dhid, P + L.w[3], ws.act3, ws.dact3pad, B, ws.mask3};
-    plaunch(ws, K_DENSE_DGRAD, pd, 1, st);
-    const int nz = dense_wgrad_splits(B);
+    plaunch_bwd(ws, K_DENSE_DGRAD, pd, 1, st);
+    // split-bf16 mode: the staging of a tile is the bottleneck, so it wants the bigger 128x64 tile (and more splits to fill the chip)
+    const int nz = ws.bwd_split == 2 ? (B >= 2048 ? 4 : 1) : dense_wgrad_splits(B);
     const int rps = round_up(ceil_div(B, nz), 32);
-    MatWgrad<TILE_DW> pw{ws.act3, ws.dhid, wp + rg.w[1], bp + rg.b[1], B, 3136, 512, 512, rps};
-    plaunch(ws, K_DENSE_WGRAD, pw, nz, st);
+    if (ws.bwd_split == 2) {
+      MatWgrad<T128x64> pw{ws.act3, ws.dhid, wp + rg.w[1], bp + rg.b[1], B, 3136, 512, 512, rps};
+      plaunch_bwd(ws, K_DENSE_WGRAD, pw, nz, st);
+    } else {
+      MatWgrad<TILE_DW> pw{ws.act3, ws.dhid, wp + rg.w[1], bp + rg.b[1], B, 3136, 512, 512, rps};
+      plaunch(ws, K_DENSE_WGRAD, pw, nz, st);
+    }
     tail_red.add(wp + rg.w[1], nz, 3136 * 512, 512, 0, grads + L.w[3], nullptr);
     tail_red.add(bp + rg.b[1], nz, 512, 512, 0, grads + L.b[3], nullptr);
     tail_red.launch(st);
@@ -818,8 +838,10 @@ void nature_backward(const NatureLayout& L, const float* P, const uint8_t* obs, 
 #else
     Conv3Dgrad<T128x64> pd{ws.dact3pad, P + L.w[2], ws.act2, ws.dact2pad, B * 81};
 #endif
-    plaunch(ws, K_CONV3_DGRAD, pd, 1, st);
+    plaunch_bwd(ws, K_CONV3_DGRAD, pd, 1, st);
     const int M = B * 49, nz = ceil_div(M, RPS_C3);
+    // (fp32 MFMA also in split mode: the split weight-gradient kernel is bound by staging VALU work — im2col address math + conversions —
+    //  and measured 214 us against 162 us here; it pays for the dense layer, 126 vs 159 us, and conv2, 191 vs 252 us)
     ConvWgrad<TILE_C3W, 3, 3, 1, 64, 64, 9, 9, 7, 7, 2> pw{ws.act2, ws.dact3pad, wp + rg.w[2], bp + rg.b[2], M, RPS_C3};
     plaunch(ws, K_CONV3_WGRAD, pw, nz, st);
     conv_red.add(wp + rg.w[2], nz, 576 * 64, 64, 0, grads + L.w[2], nullptr);
@@ -828,10 +850,10 @@ void nature_backward(const NatureLayout& L, const float* P, const uint8_t* obs, 
   // conv2: dgrad -> dact1, wgrad
   {
     Conv2Dgrad<TILE_C2D> pd{ws.dact2pad, P + L.w[1], ws.act1, ws.dact1, B * 100, ws.mask1};
-    plaunch(ws, K_CONV2_DGRAD, pd, 1, st);
+    plaunch_bwd(ws, K_CONV2_DGRAD, pd, 1, st);
     const int M = B * 81, nz = ceil_div(M, RPS_C2);
     ConvWgrad<T128x64, 4, 4, 2, 32, 64, 20, 20, 9, 9, 1> pw{ws.act1, ws.dact2pad, wp + rg.w[3], bp + rg.b[3], M, RPS_C2};
-    plaunch(ws, K_CONV2_WGRAD, pw, nz, st);
+    plaunch_bwd(ws, K_CONV2_WGRAD, pw, nz, st);
     conv_red.add(wp + rg.w[3], nz, 512 * 64, 64, 0, grads + L.w[1], nullptr);
     conv_red.add(bp + rg.b[3], nz, 64, 64, 0, grads + L.b[1], nullptr);
   }

@@ -599,3 +599,340 @@ static inline void igemm_bf16_launch(const P& p, int nsplit, hipStream_t stream)
   dim3 grid((p.X() + T::BX - 1) / T::BX, (p.Y() + T::BY - 1) / T::BY, nsplit);
   hipLaunchKernelGGL(igemm_bf16_kernel<P>, grid, dim3(256), 0, stream, p);
 }
+
+// ------------------------------------------------------------------------------------------------ split-bf16 variant (experiment, backward)
+// fp32 products out of bf16 MFMAs: every fp32 operand is split exactly into NS bf16 terms when the tile is staged (v = v1 + v2 (+ v3) + r,
+// |r| <= 2^-8NS |v|: the subtractions are exact), and the cross products that matter are formed on v_mfma_f32_32x32x16_bf16, 16x the
+// fp32 MFMA rate: NS = 2 -> a1b1 + (a1b2 + a2b1), relative product error ~2^-16;  NS = 3 -> + (a2b2 + a1b3 + a3b1), ~2^-22, i.e. fp32
+// rounding noise.  The leading product and the corrections accumulate in separate fp32 accumulators and are added once at the end.
+// Same functors / gathers / epilogues as igemm_bf16_kernel (row-gather A, dgrad-style problems).
+template <class P, int NS>
+__global__ __launch_bounds__(256, 2) void igemm_split_kernel(const P p) {
+  using T = typename P::Tile;
+  constexpr int BX = T::BX, BY = T::BY, BR = T::BR, WX = T::WX, WY = T::WY;
+  static_assert(!P::A_RX && !P::BIAS_GRAD && BR % 16 == 0 && (NS == 2 || NS == 3), "split variant covers the dgrad style problems");
+  constexpr bool B_YR = P::B_YR;
+  constexpr int TM = BX / WX / 32, TN = BY / WY / 32;
+  constexpr int PH = BR + 8;
+  constexpr int ASZ = BX * PH, BSZ = BY * PH, STG = NS * (ASZ + BSZ);
+  constexpr int NVA = (BX * BR / 4 + 255) / 256;
+  constexpr int NVB = (BR * BY / 4 + 255) / 256;
+  __shared__ __attribute__((aligned(16))) __bf16 hmem[2 * STG];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, h = lane >> 5;
+  const int wx = wave / WY, wy = wave % WY;
+  const int cls = P::NCLS > 1 ? (int)(blockIdx.y % P::NCLS) : 0;
+  int bx = blockIdx.x;
+  {
+    const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = bx & 7, k = bx >> 3;
+    bx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+  }
+  const int x0 = bx * BX, y0 = (P::NCLS > 1 ? (int)(blockIdx.y / P::NCLS) : (int)blockIdx.y) * BY, z = blockIdx.z;
+  int rlo, rhi;
+  p.r_range(z, rlo, rhi);
+  constexpr bool KSKIP = igemm_kskip<P>::value;
+  int kctx = 0;
+  if constexpr (KSKIP) { kctx = p.block_ctx(x0, cls); rlo = 0; rhi = p.block_k(kctx); }
+
+  f32x16 acc[TM][TN], lo[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { acc[i][j][e] = 0.0f; lo[i][j][e] = 0.0f; }
+
+  float4 ra[NVA], rb[NVB];
+  auto gload = [&](int rc) {
+    int r0 = rc;
+    if constexpr (KSKIP) r0 = p.r_map(kctx, rc);
+#pragma unroll
+    for (int j = 0; j < NVA; ++j) {
+      const int v = tid + 256 * j;
+      if (BX * BR / 4 % 256 == 0 || v < BX * BR / 4) {
+        const int rq = v % (BR / 4), xl = v / (BR / 4);
+        ra[j] = p.load_a(x0 + xl, r0 + 4 * rq, rhi, cls);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NVB; ++j) {
+      const int v = tid + 256 * j;
+      if (BR * BY / 4 % 256 == 0 || v < BR * BY / 4) {
+        if (B_YR) { const int rq = v % (BR / 4), yl = v / (BR / 4); rb[j] = p.load_b(r0 + 4 * rq, y0 + yl, rhi, cls); }
+        else { const int yq = v % (BY / 4), rl = v / (BY / 4); rb[j] = p.load_b(r0 + rl, y0 + 4 * yq, rhi, cls); }
+      }
+    }
+  };
+  // v -> NS bf16 planes (plane k of element e in out[k][e])
+  auto split4 = [](float4 v, ig_bf16x4 (&out)[NS]) {
+    float f[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float r = f[e];
+#pragma unroll
+      for (int k = 0; k < NS; ++k) { const __bf16 t = (__bf16)r; out[k][e] = t; r -= (float)t; }
+    }
+  };
+  auto sstore = [&](int buf) {
+    __bf16* base = hmem + buf * STG;
+#pragma unroll
+    for (int j = 0; j < NVA; ++j) {
+      const int v = tid + 256 * j;
+      if (BX * BR / 4 % 256 == 0 || v < BX * BR / 4) {
+        const int rq = v % (BR / 4), xl = v / (BR / 4);
+        ig_bf16x4 pl[NS];
+        split4(ra[j], pl);
+#pragma unroll
+        for (int k = 0; k < NS; ++k) *reinterpret_cast<ig_bf16x4*>(base + k * ASZ + xl * PH + 4 * rq) = pl[k];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NVB; ++j) {
+      const int v = tid + 256 * j;
+      if (BR * BY / 4 % 256 == 0 || v < BR * BY / 4) {
+        ig_bf16x4 pl[NS];
+        split4(rb[j], pl);
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+          __bf16* B_ = base + NS * ASZ + k * BSZ;
+          if (B_YR) { const int rq = v % (BR / 4), yl = v / (BR / 4); *reinterpret_cast<ig_bf16x4*>(B_ + yl * PH + 4 * rq) = pl[k]; }
+          else {
+            const int yq = v % (BY / 4), rl = v / (BY / 4);
+            __bf16* d = B_ + (4 * yq) * PH + rl;
+            d[0] = pl[k][0]; d[PH] = pl[k][1]; d[2 * PH] = pl[k][2]; d[3 * PH] = pl[k][3];
+          }
+        }
+      }
+    }
+  };
+
+  gload(rlo);
+  sstore(0);
+  __syncthreads();
+  int buf = 0;
+  for (int r0 = rlo; r0 < rhi; r0 += BR) {
+    const bool more = (r0 + BR) < rhi;
+    if (more) gload(r0 + BR);
+    const __bf16* Ab = hmem + buf * STG;
+    const __bf16* Bb = Ab + NS * ASZ;
+#pragma unroll
+    for (int g = 0; g < BR / 16; ++g) {
+      ig_bf16x8 fa[NS][TM], fb[NS][TN];
+#pragma unroll
+      for (int k = 0; k < NS; ++k) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[k][i] = *reinterpret_cast<const ig_bf16x8*>(Ab + k * ASZ + (wx * (BX / WX) + i * 32 + li) * PH + 16 * g + 8 * h);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[k][j] = *reinterpret_cast<const ig_bf16x8*>(Bb + k * BSZ + (wy * (BY / WY) + j * 32 + li) * PH + 16 * g + 8 * h);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[0][j], acc[i][j], 0, 0, 0);
+          if constexpr (NS == 3) {
+            lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2][i], fb[0][j], lo[i][j], 0, 0, 0);
+            lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[2][j], lo[i][j], 0, 0, 0);
+            lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][i], fb[1][j], lo[i][j], 0, 0, 0);
+          }
+          lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][i], fb[0][j], lo[i][j], 0, 0, 0);
+          lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[1][j], lo[i][j], 0, 0, 0);
+        }
+    }
+    if (more) sstore(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int y = y0 + wy * (BY / WY) + j * 32 + li;
+      if constexpr (igemm_bitmask<P>::value) {
+        const uint32_t mw = p.mask_word(x0 + wx * (BX / WX) + i * 32 + li, y0 + wy * (BY / WY) + j * 32, cls);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
+          const uint32_t w = (uint32_t)__shfl((int)mw, row, 64);
+          p.store_on(x0 + wx * (BX / WX) + i * 32 + row, y, acc[i][j][e] + lo[i][j][e], (w >> li) & 1u, z, cls);
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
+          p.store(x0 + wx * (BX / WX) + i * 32 + row, y, acc[i][j][e] + lo[i][j][e], z, cls);
+        }
+      }
+    }
+}
+
+template <class P, int NS>
+static inline void igemm_split_launch(const P& p, int nsplit, hipStream_t stream) {
+  using T = typename P::Tile;
+  dim3 grid((p.X() + T::BX - 1) / T::BX, ((p.Y() + T::BY - 1) / T::BY) * P::NCLS, nsplit);
+  hipLaunchKernelGGL((igemm_split_kernel<P, NS>), grid, dim3(256), 0, stream, p);
+}
+
+// Weight-gradient flavour of the split-bf16 kernel: C[x][y] = sum_r A[r][x] * B[r][y] with both operands r-major in memory (x / y
+// contiguous), i.e. the MFMA's k index runs ACROSS global rows.  Every thread takes 4x4 blocks (4 consecutive r, 4 consecutive x or y:
+// four 16-byte loads), transposes them in registers and writes r-contiguous 8-byte pieces, so the tiles land as A[x][r] / B[y][r] without
+// 2-byte scatter stores.  K chunk = 32 rows.  BIAS_GRAD (column sums of B for the x0 == 0 blocks) is taken from the fp32 registers
+// before the split.  Functors: ConvWgrad / MatWgrad (A_RX, !B_YR).
+template <class P, int NS>
+__global__ __launch_bounds__(256, 2) void igemm_split_wgrad_kernel(const P p) {
+  using T = typename P::Tile;
+  constexpr int BX = T::BX, BY = T::BY, WX = T::WX, WY = T::WY, KR = 32;
+  static_assert(P::A_RX && !P::B_YR && P::NCLS == 1 && (NS == 2 || NS == 3), "split wgrad variant");
+  constexpr int TM = BX / WX / 32, TN = BY / WY / 32;
+  constexpr int PH = KR + 8;
+  constexpr int ASZ = BX * PH, BSZ = BY * PH, STG = NS * (ASZ + BSZ);
+  constexpr int NBA = BX / 4 * (KR / 4), NBB = BY / 4 * (KR / 4);       // 4x4 blocks per tile
+  constexpr int NVA = (NBA + 255) / 256, NVB = (NBB + 255) / 256;
+  __shared__ __attribute__((aligned(16))) __bf16 hmem[2 * STG];
+  __shared__ float bred[P::BIAS_GRAD ? 256 * 4 : 1];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, h = lane >> 5;
+  const int wx = wave / WY, wy = wave % WY;
+  int bx = blockIdx.x;
+  {
+    const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = bx & 7, k = bx >> 3;
+    bx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+  }
+  const int x0 = bx * BX, y0 = (int)blockIdx.y * BY, z = blockIdx.z;
+  int rlo, rhi;
+  p.r_range(z, rlo, rhi);
+
+  f32x16 acc[TM][TN], lo[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { acc[i][j][e] = 0.0f; lo[i][j][e] = 0.0f; }
+
+  float4 ra[NVA][4], rb[NVB][4];
+  float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto gload = [&](int r0) {
+#pragma unroll
+    for (int j = 0; j < NVA; ++j) {
+      const int v = tid + 256 * j;
+      if (NBA % 256 == 0 || v < NBA) {
+        const int rq = v % (KR / 4), xq = v / (KR / 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ra[j][i] = p.load_a(x0 + 4 * xq, r0 + 4 * rq + i, rhi, 0);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NVB; ++j) {
+      const int v = tid + 256 * j;
+      if (NBB % 256 == 0 || v < NBB) {
+        const int rq = v % (KR / 4), yq = v / (KR / 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rb[j][i] = p.load_b(r0 + 4 * rq + i, y0 + 4 * yq, rhi, 0);
+      }
+    }
+  };
+  auto comp = [](const float4& v, int c) { return c == 0 ? v.x : (c == 1 ? v.y : (c == 2 ? v.z : v.w)); };
+  // 4x4 block (rows = 4 consecutive r, columns = 4 consecutive x|y) -> for each column one r-contiguous quad, split into NS planes
+  auto put_block = [&](const float4 (&blk)[4], __bf16* plane0, int plane_stride, int col0, int rq) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float r[4] = {comp(blk[0], c), comp(blk[1], c), comp(blk[2], c), comp(blk[3], c)};
+#pragma unroll
+      for (int k = 0; k < NS; ++k) {
+        ig_bf16x4 q;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const __bf16 t = (__bf16)r[e]; q[e] = t; r[e] -= (float)t; }
+        *reinterpret_cast<ig_bf16x4*>(plane0 + k * plane_stride + (col0 + c) * PH + 4 * rq) = q;
+      }
+    }
+  };
+  auto sstore = [&](int buf) {
+    __bf16* base = hmem + buf * STG;
+#pragma unroll
+    for (int j = 0; j < NVA; ++j) {
+      const int v = tid + 256 * j;
+      if (NBA % 256 == 0 || v < NBA) put_block(ra[j], base, ASZ, 4 * (v / (KR / 4)), v % (KR / 4));
+    }
+#pragma unroll
+    for (int j = 0; j < NVB; ++j) {
+      const int v = tid + 256 * j;
+      if (NBB % 256 == 0 || v < NBB) {
+        put_block(rb[j], base + NS * ASZ, BSZ, 4 * (v / (KR / 4)), v % (KR / 4));
+        if constexpr (P::BIAS_GRAD) if (x0 == 0) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { bsum.x += rb[j][i].x; bsum.y += rb[j][i].y; bsum.z += rb[j][i].z; bsum.w += rb[j][i].w; }
+        }
+      }
+    }
+  };
+
+  gload(rlo);
+  sstore(0);
+  __syncthreads();
+  int buf = 0;
+  for (int r0 = rlo; r0 < rhi; r0 += KR) {
+    const bool more = (r0 + KR) < rhi;
+    if (more) gload(r0 + KR);
+    const __bf16* Ab = hmem + buf * STG;
+    const __bf16* Bb = Ab + NS * ASZ;
+#pragma unroll
+    for (int g = 0; g < KR / 16; ++g) {
+      ig_bf16x8 fa[NS][TM], fb[NS][TN];
+#pragma unroll
+      for (int k = 0; k < NS; ++k) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[k][i] = *reinterpret_cast<const ig_bf16x8*>(Ab + k * ASZ + (wx * (BX / WX) + i * 32 + li) * PH + 16 * g + 8 * h);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[k][j] = *reinterpret_cast<const ig_bf16x8*>(Bb + k * BSZ + (wy * (BY / WY) + j * 32 + li) * PH + 16 * g + 8 * h);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[0][j], acc[i][j], 0, 0, 0);
+          if constexpr (NS == 3) {
+            lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2][i], fb[0][j], lo[i][j], 0, 0, 0);
+            lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[2][j], lo[i][j], 0, 0, 0);
+            lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][i], fb[1][j], lo[i][j], 0, 0, 0);
+          }
+          lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][i], fb[0][j], lo[i][j], 0, 0, 0);
+          lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[1][j], lo[i][j], 0, 0, 0);
+        }
+    }
+    if (more) sstore(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int y = y0 + wy * (BY / WY) + j * 32 + li;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
+        p.store(x0 + wx * (BX / WX) + i * 32 + row, y, acc[i][j][e] + lo[i][j][e], z, 0);
+      }
+    }
+  if constexpr (P::BIAS_GRAD) if (x0 == 0) {
+    // thread v < NBB holds the sums of columns 4*yq..4*yq+3 over its r-quads; add the KR/4 threads of a column group in rq order
+    reinterpret_cast<float4*>(bred)[tid] = bsum;
+    __syncthreads();
+    if (tid < BY) {
+      const int yq = tid >> 2, c = tid & 3;
+      float s = 0.0f;
+      for (int rq = 0; rq < KR / 4; ++rq) s += bred[(yq * (KR / 4) + rq) * 4 + c];
+      p.store_bias(y0 + tid, s, z);
+    }
+  }
+}
+
+template <class P, int NS>
+static inline void igemm_split_wgrad_launch(const P& p, int nsplit, hipStream_t stream) {
+  using T = typename P::Tile;
+  dim3 grid((p.X() + T::BX - 1) / T::BX, (p.Y() + T::BY - 1) / T::BY, nsplit);
+  hipLaunchKernelGGL((igemm_split_wgrad_kernel<P, NS>), grid, dim3(256), 0, stream, p);
+}

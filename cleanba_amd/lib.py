@@ -29,7 +29,7 @@ class Config(C.Structure):
                 ("clip_coef", C.c_float), ("ent_coef", C.c_float), ("vf_coef", C.c_float), ("max_grad_norm", C.c_float),
                 ("adam_b1", C.c_float), ("adam_b2", C.c_float), ("adam_eps", C.c_float), ("rms_decay", C.c_float),
                 ("rms_eps", C.c_float), ("actor_dense_ksplit", C.c_int32), ("forward_bf16", C.c_int32), ("grad_accum_steps", C.c_int32), ("async_batch_size", C.c_int32),
-                ("reserved", C.c_int32 * 4)]
+                ("backward_split", C.c_int32), ("reserved", C.c_int32 * 3)]
 
 
 class EnvState(C.Structure):

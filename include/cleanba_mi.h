@@ -61,7 +61,11 @@ typedef struct {
                                  recv(); a rollout is num_steps * local_num_envs/async_batch_size rows of async_batch_size samples with env
                                  ids, returns are env-id-indexed (naturecnn:467-531), advantages normalised per minibatch
                                  (naturecnn:540-541).  PPO, one actor slot.  0 = synchronous (cleanba_ppo.py). */
-  int32_t reserved[4];
+  int32_t backward_split;     /* build-only extension, default 0 = the backward GEMMs on fp32 MFMA.  2 or 3: every fp32 operand of the
+                                 backward GEMMs is split exactly into that many bf16 terms and the products are formed on bf16 MFMA with
+                                 fp32 accumulation (2: a1b1+a1b2+a2b1, product error ~2^-16; 3: six products, ~2^-22 = fp32 rounding
+                                 noise).  The forward pass, losses, returns and the optimizer are untouched.  Nature-CNN only. */
+  int32_t reserved[3];
 } cbm_config;
 
 /* Fills cfg with the reference defaults for `algo` (ppo:34-118 / impala:34-110). */

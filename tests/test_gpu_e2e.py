@@ -324,3 +324,26 @@ def test_async_batch_size_runs_match_the_oracle_engine(tmp_path, E, Ba, T, nmb, 
     d = np.abs(gpu["params"] - cpu["params"]).max()
     assert d <= 2e-5 * max(1.0, np.abs(cpu["params"]).max()), d
     np.testing.assert_allclose(gpu["stats"], cpu["stats"], rtol=5e-4, atol=5e-5)
+
+
+@pytest.mark.parametrize("split", [2, 3])
+def test_backward_split_training_run_matches_the_oracle_engine(tmp_path, split):
+    # `--backward-split` (build-only extension): whole PPO runs with the backward GEMMs on split-bf16 MFMA against the fp32 oracle engine.
+    # Sampled actions stay bit-exact because the forward pass is untouched.  Three-term splits hold the fp32 runs' bound (measured 1e-7, the same
+    # as the fp32 MFMA path); two-term splits carry a ~1e-6 relative gradient error that Adam's normalisation of small elements turns into
+    # 3e-5 after 16 steps (0.8 % of the distance the parameters moved) — bounded here at 1e-4.
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from oracle_engine import OracleEngine
+    from cleanba_amd.args import parse_args
+    from cleanba_amd.trainer import train
+    os.chdir(str(tmp_path))
+    updates = 4
+    argv = ["--local-num-envs", "4", "--num-actor-threads", "2", "--num-steps", "5", "--num-minibatches", "2", "--update-epochs", "2",
+            "--network", "nature", "--env-backend", "host", "--total-timesteps", str(updates * 4 * 2 * 5), "--log-frequency", "1000", "--concurrency"]
+    gpu = train(parse_args(argv + ["--backward-split", str(split)], "ppo"), "ppo")
+    cpu = train(parse_args(argv, "ppo"), "ppo", engine_factory=OracleEngine)
+    assert gpu["updates"] == cpu["updates"] == updates
+    d = np.abs(gpu["params"] - cpu["params"]).max()
+    assert d <= (2e-5 if split == 3 else 1e-4) * max(1.0, np.abs(cpu["params"]).max()), d
+    np.testing.assert_allclose(gpu["stats"], cpu["stats"], rtol=5e-4, atol=5e-5)

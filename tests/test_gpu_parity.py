@@ -338,3 +338,42 @@ def test_ppo_grads_at_ragged_batch_sizes(oracle):
             ref = grads_o[o:o + n]
             assert np.abs(g[o:o + n] - ref).max() <= 1e-5 * max(np.abs(ref).max(), 1e-7), (N, name)
     c.close()
+
+
+@pytest.mark.parametrize("ns", [2, 3])
+def test_backward_split_bf16_meets_the_fp32_bar(oracle, ns):
+    """cbm_config.backward_split (build-only extension): the backward GEMMs on bf16 MFMA with every fp32 operand split exactly into 2 / 3
+    bf16 terms.  The bar is the SAME as for the fp32 MFMA path — gradients within 1e-5 of the oracle per tensor, losses untouched, forward
+    logits still bit-exact — and the option must not silently be the fp32 path."""
+    out = {}
+    rng = np.random.default_rng(80)
+    N = 130
+    P = make_params(A, 81)
+    pool = make_frames(160, 82)
+    idx = rng.permutation(160)[:N].astype(np.int32)
+    actions = rng.integers(0, A, N).astype(np.int32)
+    old_lp = (-np.log(A) + 0.2 * rng.normal(size=N)).astype(np.float32)
+    adv = rng.normal(size=N).astype(np.float32)
+    tgt = rng.normal(size=N).astype(np.float32)
+    stats_o, grads_o, logits_o, _ = oracle.ppo_loss_grad(P, A, pool, idx, actions, old_lp, adv, tgt)
+    for split in (0, ns):
+        cfg = L.default_config(L.ALGO_PPO)
+        cfg.local_num_envs, cfg.num_actor_slots, cfg.num_steps = 68, 1, 8
+        cfg.backward_split = split
+        c = L.Context(cfg)
+        d = [L.DevBuf(c, x) for x in (P, pool, idx, actions, old_lp, adv, tgt)]
+        dS = L.DevBuf(c, nbytes=32, dtype=np.float32)
+        dG = L.DevBuf(c, nbytes=P.size * 4, dtype=np.float32)
+        dLg = L.DevBuf(c, nbytes=N * A * 4, dtype=np.float32, shape=(N, A))
+        L._chk(c.lib.cbm_ppo_loss_grad(c.h, L._p(d[0].ptr), L._p(d[1].ptr), L._p(d[2].ptr), N, L._p(d[3].ptr), L._p(d[4].ptr), L._p(d[5].ptr),
+                                       L._p(d[6].ptr), L._p(dS.ptr), L._p(dG.ptr), L._p(dLg.ptr), None))
+        assert (bits(dLg.download()) == bits(logits_o)).all()
+        np.testing.assert_allclose(dS.download()[:5], stats_o, rtol=1e-5, atol=1e-6)
+        g = dG.download()
+        for name, (o, shp) in oracle.nature_layout(A).items():
+            n = int(np.prod(shp))
+            ref = grads_o[o:o + n]
+            assert np.abs(g[o:o + n] - ref).max() <= 1e-5 * max(np.abs(ref).max(), 1e-7), (split, name)
+        out[split] = g
+        c.close()
+    assert not np.array_equal(out[0], out[ns])
