@@ -400,6 +400,43 @@ struct Conv2Dgrad {
   }
 };
 
+// conv2 dgrad with its four parity classes as ONE GEMM: the classes gather IDENTICAL rows of dY (A[p][(jh,jw,co)] does not depend on the
+// class), only the weights differ, so y = cls*32 + ci gives N = 128 with a [256][128] weight gather.  On fp32 MFMA this measured slower
+// than four N = 32 launches (MFMA-bound, and the big tile costs occupancy); the split-bf16 kernel is bound by tile STAGING, and here the A
+// tile is staged once for all four classes.  Used by backward_split only.
+template <class TileT>
+struct Conv2DgradMerged {
+  using Tile = TileT;
+  static constexpr bool A_RX = false, B_YR = true, BIAS_GRAD = false, BITMASK = true;
+  static constexpr int NCLS = 1;
+  const float* dypad; const float* W; float* dact1; int M; const uint32_t* mask;  // M = S*100
+  __host__ __device__ int X() const { return M; }
+  __host__ __device__ int Y() const { return 128; }
+  __device__ void r_range(int, int& lo, int& hi) const { lo = 0; hi = 256; }
+  __device__ float4 load_a(int m, int r, int, int) const {
+    m = min(m, M - 1);
+    const int s = m / 100, p = m - s * 100, ihh = p / 10, iwh = p - ihh * 10;
+    const int jh = r >> 7, rem = r & 127;
+    return *reinterpret_cast<const float4*>(dypad + ((size_t)(s * 11 + ihh + jh) * 11 + iwh) * 64 + rem);
+  }
+  __device__ float4 load_b(int r, int y, int, int) const {
+    const int cls = y >> 5, ci = y & 31;
+    const int jh = r >> 7, jw = (r >> 6) & 1, co = r & 63;
+    const int kh = (cls >> 1) + 2 * (1 - jh), kw = (cls & 1) + 2 * (1 - jw);
+    return *reinterpret_cast<const float4*>(W + ((size_t)(kh * 4 + kw) * 32 + ci) * 64 + co);
+  }
+  __device__ size_t pixel(int m, int cls) const {
+    const int s = m / 100, p = m - s * 100, ihh = p / 10, iwh = p - ihh * 10;
+    return (size_t)(s * 20 + 2 * ihh + (cls >> 1)) * 20 + 2 * iwh + (cls & 1);
+  }
+  __device__ uint32_t mask_word(int m, int y32, int) const { return mask[pixel(min(m, M - 1), y32 >> 5)]; }
+  __device__ void store_on(int m, int y, float v, bool on, int, int) const {
+    if (m >= M) return;
+    dact1[pixel(m, y >> 5) * 32 + (y & 31)] = on ? v : 0.0f;
+  }
+  __device__ void store(int m, int y, float v, int, int) const { store_on(m, y, v, true, 0, 0); }   // (BITMASK path is the one used)
+};
+
 // ---- weight gradients: C[x = k][y = co] = sum_{r = m} A[m][k] * dY[m][co], split over r into
 // partials [z][X][Y] (+ bias partial [z][Y]) reduced in ascending z (deterministic, ppo:30).
 template <class TileT>
@@ -701,6 +738,7 @@ using T256x32 = IgemmTile<256, 32, 32, 4, 1>;
 #define BR_64x64 32
 #endif
 using T128x64 = IgemmTile<128, 64, BR_128x64, 2, 2>;
+using T128x128k16 = IgemmTile<128, 128, 16, 2, 2, 2>;   // split-bf16 merged conv2 dgrad
 using T64x64 = IgemmTile<64, 64, BR_64x64, 2, 2>;
 // actor-step (small batch) tiles: half the K chunk = half the LDS, so a block still finds room on CUs mostly held by learner blocks
 using T64x64k16 = IgemmTile<64, 64, 16, 2, 2>;
@@ -849,8 +887,13 @@ void nature_backward(const NatureLayout& L, const float* P, const uint8_t* obs, 
   }
   // conv2: dgrad -> dact1, wgrad
   {
-    Conv2Dgrad<TILE_C2D> pd{ws.dact2pad, P + L.w[1], ws.act1, ws.dact1, B * 100, ws.mask1};
-    plaunch_bwd(ws, K_CONV2_DGRAD, pd, 1, st);
+    if (ws.bwd_split && IGEMM_USE_BITMASK) {
+      Conv2DgradMerged<T128x128k16> pd{ws.dact2pad, P + L.w[1], ws.dact1, B * 100, ws.mask1};
+      plaunch_bwd(ws, K_CONV2_DGRAD, pd, 1, st);
+    } else {
+      Conv2Dgrad<TILE_C2D> pd{ws.dact2pad, P + L.w[1], ws.act1, ws.dact1, B * 100, ws.mask1};
+      plaunch_bwd(ws, K_CONV2_DGRAD, pd, 1, st);
+    }
     const int M = B * 81, nz = ceil_div(M, RPS_C2);
     ConvWgrad<T128x64, 4, 4, 2, 32, 64, 20, 20, 9, 9, 1> pw{ws.act1, ws.dact2pad, wp + rg.w[3], bp + rg.b[3], M, RPS_C2};
     plaunch_bwd(ws, K_CONV2_WGRAD, pw, nz, st);
