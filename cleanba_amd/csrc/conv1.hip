@@ -152,11 +152,7 @@ __global__ __launch_bounds__(256, 2) void conv1_fwd_frames_kernel(const uint8_t*
       for (int e = 0; e < 16; ++e) {
         const int r0 = (e & 3) + 8 * (e >> 2);
         const float v = relu_(acc[t][e] + bn);
-#if defined(C1_ABL) && C1_ABL == 1
-        if (acc[t][e] == 123.456f) o[(m0 + r0) * 32] = v;
-#else
         o[(m0 + r0) * 32] = v;
-#endif
         const unsigned long long bal = __ballot(v > 0.0f);   // all 64 lanes: rows r0 (lower half) and r0 + 4 (upper half)
         // lane r0 <- the lower wave half's row, lane r0 + 4 <- the upper half's (no writelane builtin in this clang)
         asm volatile("s_nop 4\n\tv_writelane_b32 %0, %1, %2" : "+v"(word) : "s"((uint32_t)bal), "n"(r0));

@@ -300,13 +300,7 @@ struct Conv3DgradPos {
   __device__ void r_range(int, int& lo, int& hi) const { lo = 0; hi = 576; }
   __device__ int block_ctx(int x0, int) const {
     const int p = order[x0 / Tile::BX] % 81, ih = p / 9, iw = p - ih * 9;
-#if CONV3_DGRAD_POS == 2   // experiment: position-major order without the tap skipping
-    const int jh0 = 0, jh1 = 2, jw0 = 0, jw1 = 2;
-#elif CONV3_DGRAD_POS == 4   // timing experiment (wrong results): every tile multiplies 1 tap
-    const int jh0 = 0, jh1 = 0, jw0 = 0, jw1 = 0;
-#else
     const int jh0 = max(0, 2 - ih), jh1 = min(2, 8 - ih), jw0 = max(0, 2 - iw), jw1 = min(2, 8 - iw);
-#endif
     const int njw = jw1 - jw0 + 1, nt = (jh1 - jh0 + 1) * njw;
     return jh0 | (jw0 << 2) | (njw << 4) | (nt << 8);
   }
@@ -334,14 +328,8 @@ struct Conv3DgradPos {
     int s, ih, iw;
     decode(x, s, ih, iw);
     if (s >= S) return;
-#if defined(CONV3_EPI) && CONV3_EPI == 2
-    if (v == 12345.678f) dxpad[0] = v;
-#elif defined(CONV3_EPI) && CONV3_EPI == 1
-    dxpad[((size_t)(s * 11 + ih + 1) * 11 + iw + 1) * 64 + ci] = v;
-#else
     const bool on = act2[((size_t)s * 81 + ih * 9 + iw) * 64 + ci] > 0.0f;
     dxpad[((size_t)(s * 11 + ih + 1) * 11 + iw + 1) * 64 + ci] = on ? v : 0.0f;
-#endif
   }
   static constexpr bool BITMASK = true;
   const uint32_t* mask;   // act2 ReLU bits [S*81][2]
