@@ -694,10 +694,27 @@ static inline void plaunch_fwd(NatureWs& ws, int kid, const P& p, int nz, hipStr
   if (on) { hipEventRecord(pf->ev[2 * pf->n + 1], st); pf->n += 1; }
 }
 // backward GEMM launch: fp32 MFMA (default) or, with cbm_config.backward_split = 2 / 3, the split-bf16 kernel
+#ifndef DGRAD_PF2
+#define DGRAD_PF2 0x3   // bit 0 dense, 1 conv3, 2 conv2 dgrad on the two-chunk prefetch kernel (igemm_pf2_kernel): 147 -> 143, 198 -> 190, 318 -> 322 us
+#endif
 template <class P>
 static inline void plaunch_bwd(NatureWs& ws, int kid, const P& p, int nz, hipStream_t st) {
   // (three-term weight gradients measured slower than fp32 MFMA: with backward_split = 3 only the input gradients are split)
-  if (ws.bwd_split == 0 || (P::A_RX && ws.bwd_split != 2)) { plaunch(ws, kid, p, nz, st); return; }
+  if (ws.bwd_split == 0 || (P::A_RX && ws.bwd_split != 2)) {
+    if constexpr (!P::A_RX) {
+      const int bit = kid == K_DENSE_DGRAD ? 1 : (kid == K_CONV3_DGRAD ? 2 : (kid == K_CONV2_DGRAD ? 4 : 0));
+      if (DGRAD_PF2 & bit) {
+        CbmProf* pf = ws.prof;
+        const bool on = pf && pf->sel == kid && pf->n < CBM_PROF_MAX;
+        if (on) hipEventRecord(pf->ev[2 * pf->n], st);
+        igemm_pf2_launch(p, nz, st);
+        if (on) { hipEventRecord(pf->ev[2 * pf->n + 1], st); pf->n += 1; }
+        return;
+      }
+    }
+    plaunch(ws, kid, p, nz, st);
+    return;
+  }
   CbmProf* pf = ws.prof;
   const bool on = pf && pf->sel == kid && pf->n < CBM_PROF_MAX;
   if (on) hipEventRecord(pf->ev[2 * pf->n], st);

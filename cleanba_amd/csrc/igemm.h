@@ -327,6 +327,172 @@ static inline void igemm_launch(const P& p, int nsplit, hipStream_t stream) {
   hipLaunchKernelGGL(igemm_kernel<P>, grid, dim3(256), 0, stream, p);
 }
 
+// ------------------------------------------------------------------------------------------------ two-chunk prefetch variant (dgrads)
+// igemm_kernel keeps ONE K chunk in flight in registers while it multiplies the previous one.  With 16-wide chunks a wave's share of a
+// chunk is only 8-16 MFMAs (0.2-0.4 us), less than a global-load round trip under load, so the staging store at the end of an iteration
+// waits for its data.  Here two register sets alternate: the loads of chunk c+2 are issued before chunk c is multiplied and are not
+// needed until the end of the NEXT iteration.  Same math, same k-ascending chain per accumulator -> bit-identical to igemm_kernel.
+// Row-gather A, no fused bias gradient (the input-gradient problems); KSKIP and BITMASK functors supported.
+template <class P>
+__global__ __launch_bounds__(256, P::Tile::MINW) void igemm_pf2_kernel(const P p) {
+  using T = typename P::Tile;
+  constexpr int BX = T::BX, BY = T::BY, BR = T::BR, WX = T::WX, WY = T::WY;
+  constexpr bool B_YR = P::B_YR;
+  static_assert(!P::A_RX && !P::BIAS_GRAD, "two-chunk prefetch variant: dgrad-style problems");
+  constexpr int TM = BX / WX / 32, TN = BY / WY / 32;
+  constexpr int PA = BR + 1, ASZ = BX * PA, PB = BY, BSZ = BR * BY;
+  constexpr int NVA = (BX * BR / 4 + 255) / 256, NVB = (BR * BY / 4 + 255) / 256;
+  __shared__ __attribute__((aligned(16))) float smem[2 * ASZ + 2 * BSZ];
+  float* As = smem;
+  float* Bs = smem + 2 * ASZ;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, h = lane >> 5;
+  const int wx = wave / WY, wy = wave % WY;
+  const int cls = P::NCLS > 1 ? (int)(blockIdx.y % P::NCLS) : 0;
+  int bx = blockIdx.x;
+  {
+    const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = bx & 7, k = bx >> 3;
+    bx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+  }
+  const int x0 = bx * BX, y0 = (P::NCLS > 1 ? (int)(blockIdx.y / P::NCLS) : (int)blockIdx.y) * BY, z = blockIdx.z;
+  int rlo, rhi;
+  p.r_range(z, rlo, rhi);
+  constexpr bool KSKIP = igemm_kskip<P>::value;
+  int kctx = 0;
+  if constexpr (KSKIP) { kctx = p.block_ctx(x0, cls); rlo = 0; rhi = p.block_k(kctx); }
+  const int nchunk = (rhi - rlo + BR - 1) / BR;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+  auto gload = [&](int c, float4 (&ra)[NVA], float4 (&rb)[NVB]) {
+    int r0 = rlo + c * BR;
+    if constexpr (KSKIP) r0 = p.r_map(kctx, r0);
+#pragma unroll
+    for (int j = 0; j < NVA; ++j) {
+      const int v = tid + 256 * j;
+      if (BX * BR / 4 % 256 == 0 || v < BX * BR / 4) {
+        const int rq = v % (BR / 4), xl = v / (BR / 4);
+        ra[j] = p.load_a(x0 + xl, r0 + 4 * rq, rhi, cls);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NVB; ++j) {
+      const int v = tid + 256 * j;
+      if (BR * BY / 4 % 256 == 0 || v < BR * BY / 4) {
+        if (B_YR) { const int yl = v % BY, rq = v / BY; rb[j] = p.load_b(r0 + 4 * rq, y0 + yl, rhi, cls); }
+        else { const int yq = v % (BY / 4), rl = v / (BY / 4); rb[j] = p.load_b(r0 + rl, y0 + 4 * yq, rhi, cls); }
+      }
+    }
+  };
+  auto sstore = [&](int buf, const float4 (&ra)[NVA], const float4 (&rb)[NVB]) {
+    float* A_ = As + buf * ASZ;
+    float* B_ = Bs + buf * BSZ;
+#pragma unroll
+    for (int j = 0; j < NVA; ++j) {
+      const int v = tid + 256 * j;
+      if (BX * BR / 4 % 256 == 0 || v < BX * BR / 4) {
+        const int rq = v % (BR / 4), xl = v / (BR / 4);
+        float* d = A_ + xl * PA + 4 * rq;
+        d[0] = ra[j].x; d[1] = ra[j].y; d[2] = ra[j].z; d[3] = ra[j].w;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NVB; ++j) {
+      const int v = tid + 256 * j;
+      if (BR * BY / 4 % 256 == 0 || v < BR * BY / 4) {
+        if (B_YR) { const int yl = v % BY, rq = v / BY; float* d = B_ + (4 * rq) * PB + yl; d[0] = rb[j].x; d[PB] = rb[j].y; d[2 * PB] = rb[j].z; d[3 * PB] = rb[j].w; }
+        else { const int yq = v % (BY / 4), rl = v / (BY / 4); *reinterpret_cast<float4*>(B_ + rl * PB + 4 * yq) = rb[j]; }
+      }
+    }
+  };
+  auto compute = [&](int buf) {
+    const float* A_ = As + buf * ASZ;
+    const float* B_ = Bs + buf * BSZ;
+    constexpr int G = (BR / 2) % 4 == 0 ? 4 : 2, NG = BR / 2 / G;
+    float fa[2][G][TM], fb[2][G][TN];
+    auto frag = [&](int g, int set) {
+#pragma unroll
+      for (int q = 0; q < G; ++q) {
+        const int rr = 2 * (g * G + q);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[set][q][i] = A_[(wx * (BX / WX) + i * 32 + li) * PA + rr + h];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[set][q][j] = B_[(rr + h) * PB + wy * (BY / WY) + j * 32 + li];
+      }
+    };
+    frag(0, 0);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      if (g + 1 < NG) frag(g + 1, (g + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < G; ++q)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g & 1][q][i], fb[g & 1][q][j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  float4 a0[NVA], b0[NVB], a1[NVA], b1[NVB];
+  gload(0, a0, b0);
+  sstore(0, a0, b0);
+  if (nchunk > 1) gload(1, a0, b0);
+  __syncthreads();
+  int buf = 0, c = 0;
+  while (true) {
+    if (c + 2 < nchunk) gload(c + 2, a1, b1);        // set 0 holds chunk c+1
+    compute(buf);
+    if (c + 1 < nchunk) sstore(buf ^ 1, a0, b0);
+    __syncthreads();
+    buf ^= 1;
+    if (++c >= nchunk) break;
+    if (c + 2 < nchunk) gload(c + 2, a0, b0);        // set 1 holds chunk c+1
+    compute(buf);
+    if (c + 1 < nchunk) sstore(buf ^ 1, a1, b1);
+    __syncthreads();
+    buf ^= 1;
+    if (++c >= nchunk) break;
+  }
+
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int y = y0 + wy * (BY / WY) + j * 32 + li;
+      if constexpr (igemm_bitmask<P>::value) {
+        const uint32_t mw = p.mask_word(x0 + wx * (BX / WX) + i * 32 + li, y0 + wy * (BY / WY) + j * 32, cls);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
+          const uint32_t w = (uint32_t)__shfl((int)mw, row, 64);
+          p.store_on(x0 + wx * (BX / WX) + i * 32 + row, y, acc[i][j][e], (w >> li) & 1u, z, cls);
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
+          p.store(x0 + wx * (BX / WX) + i * 32 + row, y, acc[i][j][e], z, cls);
+        }
+      }
+    }
+}
+
+template <class P>
+static inline void igemm_pf2_launch(const P& p, int nsplit, hipStream_t stream) {
+  using T = typename P::Tile;
+  dim3 grid((p.X() + T::BX - 1) / T::BX, ((p.Y() + T::BY - 1) / T::BY) * P::NCLS, nsplit);
+  hipLaunchKernelGGL(igemm_pf2_kernel<P>, grid, dim3(256), 0, stream, p);
+}
+
 // ------------------------------------------------------------------------------------------------ DMA-staged variant
 // Same math and the same k-ascending accumulation order as igemm_kernel (bit-identical results), but the LDS tiles are filled by
 // global_load_lds_dwordx4: the load unit writes 16 bytes per lane straight into LDS (wave-uniform base + lane*16) — no staging
@@ -642,8 +808,7 @@ __global__ __launch_bounds__(256, 2) void igemm_split_kernel(const P p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) { acc[i][j][e] = 0.0f; lo[i][j][e] = 0.0f; }
 
-  float4 ra[NVA], rb[NVB];
-  auto gload = [&](int rc) {
+  auto gload = [&](int rc, float4 (&ra)[NVA], float4 (&rb)[NVB]) {
     int r0 = rc;
     if constexpr (KSKIP) r0 = p.r_map(kctx, rc);
 #pragma unroll
@@ -673,7 +838,7 @@ __global__ __launch_bounds__(256, 2) void igemm_split_kernel(const P p) {
       for (int k = 0; k < NS; ++k) { const __bf16 t = (__bf16)r; out[k][e] = t; r -= (float)t; }
     }
   };
-  auto sstore = [&](int buf) {
+  auto sstore = [&](int buf, const float4 (&ra)[NVA], const float4 (&rb)[NVB]) {
     __bf16* base = hmem + buf * STG;
 #pragma unroll
     for (int j = 0; j < NVA; ++j) {
@@ -706,13 +871,7 @@ __global__ __launch_bounds__(256, 2) void igemm_split_kernel(const P p) {
     }
   };
 
-  gload(rlo);
-  sstore(0);
-  __syncthreads();
-  int buf = 0;
-  for (int r0 = rlo; r0 < rhi; r0 += BR) {
-    const bool more = (r0 + BR) < rhi;
-    if (more) gload(r0 + BR);
+  auto compute = [&](int buf) {
     const __bf16* Ab = hmem + buf * STG;
     const __bf16* Bb = Ab + NS * ASZ;
 #pragma unroll
@@ -739,9 +898,29 @@ __global__ __launch_bounds__(256, 2) void igemm_split_kernel(const P p) {
           lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[1][j], lo[i][j], 0, 0, 0);
         }
     }
-    if (more) sstore(buf ^ 1);
+  };
+  // two register sets alternate: the loads of chunk c+2 are issued before chunk c is multiplied (the MFMA work of a chunk is far shorter
+  // than a global-load round trip here, so one chunk of lookahead left every iteration waiting for its data)
+  const int nchunk = (rhi - rlo + BR - 1) / BR;
+  float4 a0[NVA], b0[NVB], a1[NVA], b1[NVB];
+  gload(rlo, a0, b0);
+  sstore(0, a0, b0);
+  if (nchunk > 1) gload(rlo + BR, a0, b0);
+  __syncthreads();
+  int buf = 0, c = 0;
+  while (true) {
+    if (c + 2 < nchunk) gload(rlo + (c + 2) * BR, a1, b1);
+    compute(buf);
+    if (c + 1 < nchunk) sstore(buf ^ 1, a0, b0);
     __syncthreads();
     buf ^= 1;
+    if (++c >= nchunk) break;
+    if (c + 2 < nchunk) gload(rlo + (c + 2) * BR, a0, b0);
+    compute(buf);
+    if (c + 1 < nchunk) sstore(buf ^ 1, a1, b1);
+    __syncthreads();
+    buf ^= 1;
+    if (++c >= nchunk) break;
   }
 
 #pragma unroll
