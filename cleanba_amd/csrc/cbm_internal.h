@@ -73,7 +73,8 @@ void nature_backward(const NatureLayout& L, const float* P, const uint8_t* obs, 
 void launch_conv1_fwd_frames(const uint8_t* obs, const int32_t* idx, const float* W, const float* bias, float* out, uint32_t* mask, int S,
                              hipStream_t st);
 int conv1_wgrad_frames_splits(int S);
-void launch_conv1_wgrad_frames(const uint8_t* obs, const int32_t* idx, const float* dy, float* part, float* bpart, int S, hipStream_t st);
+void launch_conv1_wgrad_frames(const uint8_t* obs, const int32_t* idx, const float* dy, float* part, float* bpart, int S, hipStream_t st,
+                               bool split = false);
 
 // ---- pointwise / scan kernels -----------------------------------------------------------
 void launch_sample(const float* logits, int B, int A, uint32_t sk0, uint32_t sk1, int32_t* actions, float* logprobs,

@@ -255,14 +255,89 @@ __global__ __launch_bounds__(256, 2) void conv1_wgrad_frames_kernel(const uint8_
   }
 }
 
+// Split-bf16 flavour (cbm_config.backward_split): pixels are integers 0..255, exact in bf16, so only dY needs splitting (two terms):
+// dW += px * dy1 + px * dy2 on v_mfma_f32_32x32x16_bf16, sixteen output positions per instruction instead of two.  Same frame-resident
+// structure, same partial layout (the reduce applies 1/255).  A frame's 400 positions are 25 groups of 16 consecutive positions; lane
+// (li, h) supplies positions 8h..8h+7 of the group for k-row li (A) / channel li (B).
+typedef __bf16 c1_bf16x8 __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(256, 2) void conv1_wgrad_frames_split_kernel(const uint8_t* obs, const int32_t* idx, const float* dy, float* part,
+                                                                          float* bpart, int S, int frames_per_block) {
+  __shared__ __attribute__((aligned(16))) unsigned char F[FR];
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int s_lo = blockIdx.x * frames_per_block, s_hi = min(S, s_lo + frames_per_block);
+  int kb[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int k = 64 * wave + 32 * t + li;
+    kb[t] = (k >> 6) * 7056 + ((k >> 3) & 7) * 84 + (k & 7);
+  }
+  f32x16 acc[2], lo[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { acc[t][e] = 0.0f; lo[t][e] = 0.0f; }
+  float bs = 0.0f;
+  for (int s = s_lo; s < s_hi; ++s) {
+    __syncthreads();  // previous frame fully consumed
+    const int f = idx ? idx[s] : s;
+    frame_to_lds(obs + (size_t)f * FR, F, wave, lane);
+    const float* g = dy + ((size_t)s * 400 + 8 * h) * 32 + li;  // position 8h of group 0, channel li
+    float bc[8], bn[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bc[j] = g[j * 32];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll 1
+    for (int grp = 0; grp < 25; ++grp) {
+      if (grp + 1 < 25) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bn[j] = g[((grp + 1) * 16 + j) * 32];
+      }
+      const int p0 = grp * 16 + 8 * h, oh0 = p0 / 20, ow0 = p0 - oh0 * 20;
+      c1_bf16x8 b1, b2, a[2];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float v = bc[j];
+        bs += v;
+        const __bf16 t1 = (__bf16)v;
+        b1[j] = t1;
+        b2[j] = (__bf16)(v - (float)t1);
+        const int off = oh0 * 336 + (ow0 + j) * 4 + (ow0 + j >= 20 ? 336 - 80 : 0);   // position p0 + j -> byte offset of its patch origin
+#pragma unroll
+        for (int t = 0; t < 2; ++t) a[t][j] = (__bf16)(float)F[kb[t] + off];
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t], b1, acc[t], 0, 0, 0);
+        lo[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t], b2, lo[t], 0, 0, 0);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) bc[j] = bn[j];
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
+      part[((size_t)blockIdx.x * 256 + 64 * wave + 32 * t + row) * 32 + li] = acc[t][e] + lo[t][e];
+    }
+  if (wave == 0) {
+    bs += __shfl_xor(bs, 32, 64);
+    if (h == 0) bpart[blockIdx.x * 32 + li] = bs;
+  }
+}
+
 int conv1_wgrad_frames_splits(int S) {
   int blocks = 1024;
   if (S < blocks) blocks = S;
   const int fpb = (S + blocks - 1) / blocks;
   return (S + fpb - 1) / fpb;
 }
-void launch_conv1_wgrad_frames(const uint8_t* obs, const int32_t* idx, const float* dy, float* part, float* bpart, int S, hipStream_t st) {
+void launch_conv1_wgrad_frames(const uint8_t* obs, const int32_t* idx, const float* dy, float* part, float* bpart, int S, hipStream_t st, bool split) {
   const int nz = conv1_wgrad_frames_splits(S);
   const int fpb = (S + nz - 1) / nz;
-  hipLaunchKernelGGL(conv1_wgrad_frames_kernel, dim3(nz), dim3(256), 0, st, obs, idx, dy, part, bpart, S, fpb);
+  if (split) hipLaunchKernelGGL(conv1_wgrad_frames_split_kernel, dim3(nz), dim3(256), 0, st, obs, idx, dy, part, bpart, S, fpb);
+  else hipLaunchKernelGGL(conv1_wgrad_frames_kernel, dim3(nz), dim3(256), 0, st, obs, idx, dy, part, bpart, S, fpb);
 }

@@ -908,7 +908,7 @@ void nature_backward(const NatureLayout& L, const float* P, const uint8_t* obs, 
   // conv1: wgrad only (frames need no gradient); frame-resident kernel, pixels as integers, 1/255 in the reduce
   {
     const int nz = conv1_wgrad_frames_splits(B);
-    plaunch_fn(ws, K_CONV1_WGRAD, st, [&] { launch_conv1_wgrad_frames(obs, idx, ws.dact1, wp + rg.w[4], bp + rg.b[4], B, st); });
+    plaunch_fn(ws, K_CONV1_WGRAD, st, [&] { launch_conv1_wgrad_frames(obs, idx, ws.dact1, wp + rg.w[4], bp + rg.b[4], B, st, ws.bwd_split == 2); });
     conv_red.add(wp + rg.w[4], nz, 256 * 32, 32, 1, grads + L.w[0], nullptr, 1.0f / 255.0f);
     conv_red.add(bp + rg.b[4], nz, 32, 32, 0, grads + L.b[0], nullptr);
     conv_red.launch(st);
