@@ -10,15 +10,17 @@
 // gradients of conv2/conv3 outputs live in zero-bordered 11x11 buffers so that both dgrads are
 // plain VALID correlations (stride-2 conv2 as 4 parity classes).
 #include "cbm_internal.h"
-// Sibling-aware tile orders (igemm.h ORDER 1/2) were measured on MI355X and are OFF: the weight-gradient GEMMs got slower with them
-// (conv3 wgrad 161 -> 201 us, conv2 wgrad 251 -> 293 us), conv2 dgrad did not move.  The redundant operand fetches of sibling tiles
-// that FETCH_SIZE reports are Infinity-Cache hits when all XCDs walk the same rows at the same time; giving each XCD its own rows
-// removes that sharing and buys nothing in HBM traffic.  Build with -DIGEMM_ORDER_1=1 -DIGEMM_ORDER_2=2 to reproduce.
+// Sibling-aware tile orders (igemm.h ORDER 1/2), measured on MI355X.  ORDER 1 (the tap tiles of a weight-gradient reduction slice on one
+// XCD) is OFF: conv3 wgrad 161 -> 201 us, conv2 wgrad 251 -> 293 us — with all XCDs walking the same rows together the re-fetches
+// FETCH_SIZE reports are Infinity-Cache hits, and private rows per XCD lose that sharing.  ORDER 2 (the four parity classes of a conv2
+// dgrad pixel tile back to back on one XCD) is ON: the kernel time does not move (320 vs 318 us) but its L2-miss traffic falls from
+// 1.56 GB to 0.13 GB per launch (rocprofv3 --pmc FETCH_SIZE, x2 corrected) — the four classes read the same dY rows, and dispatched
+// class-major they were 3000 tiles apart.
 #ifndef IGEMM_ORDER_1
 #define IGEMM_ORDER_1 0
 #endif
 #ifndef IGEMM_ORDER_2
-#define IGEMM_ORDER_2 0
+#define IGEMM_ORDER_2 2
 #endif
 #include "igemm.h"
 #include <algorithm>
