@@ -22,6 +22,9 @@
 #ifndef IGEMM_ORDER_2
 #define IGEMM_ORDER_2 2
 #endif
+#ifndef IGEMM_ORDER_MW
+#define IGEMM_ORDER_MW 0   // MatWgrad (dense / heads weight gradients)
+#endif
 #include "igemm.h"
 #include <algorithm>
 #include <vector>
@@ -489,7 +492,7 @@ struct ConvWgrad {  // dY lives in a zero-bordered [S][OH+2*PADO... = 11][11][CO
 template <class TileT, bool PRE_RELU = false>
 struct MatWgrad {
   using Tile = TileT;
-  static constexpr int ORDER = IGEMM_ORDER_1;   // sibling tiles share an XCD's L2 (igemm.h)
+  static constexpr int ORDER = IGEMM_ORDER_MW;   // sibling tiles share an XCD's L2 (igemm.h)
   static constexpr bool A_RX = true, B_YR = false, BIAS_GRAD = true;
   static constexpr int NCLS = 1;
   const float* A; const float* G; float* part; float* bpart; int M, XK, YN, ldg, rps;
