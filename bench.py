@@ -37,9 +37,8 @@ KERNELS = {
     6: ("dense_wgrad", 2.0 * MB * 3136 * 512), 7: ("conv3_dgrad", 2.0 * MB * 49 * 64 * 576), 8: ("conv3_wgrad", 2.0 * MB * 49 * 576 * 64),
     9: ("conv2_dgrad", 2.0 * MB * 81 * 64 * 512), 10: ("conv2_wgrad", 2.0 * MB * 81 * 512 * 64), 11: ("conv1_wgrad", 2.0 * MB * 400 * 256 * 32),
 }
-# flops are ALGORITHMIC (a layer's dgrad and wgrad each cost its forward flops).  The conv2 dgrad EXECUTES 2*MB*400*32*256
-# (x1.23: its four parity classes run over a 10x10 half-resolution grid whose border taps hit zero padding); the conv3 dgrad executes
-# exactly the algorithmic count since it skips the taps that fall into the zero border.
+# flops are ALGORITHMIC (a layer's dgrad and wgrad each cost its forward flops).  Both position-major dgrads (conv2, conv3) skip
+# the taps that fall into dY's zero border per tile, so they EXECUTE exactly the algorithmic count.
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 
 

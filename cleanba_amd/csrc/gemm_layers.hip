@@ -393,6 +393,61 @@ struct Conv2Dgrad {
   }
 };
 
+// conv2 dgrad, position-major (CONV2_DGRAD_POS, on: 316 -> 286 us under load, 268 with the two-chunk prefetch): an x-tile is ONE half-resolution pixel (ihh, iwh) of BX consecutive frames, so the
+// taps that fall on dY's zero border are the same for all its rows and are skipped per block (igemm.h KSKIP): ihh = 0 keeps only jh = 1,
+// ihh = 9 only jh = 0, likewise for iwh — 324 instead of 400 tap-tiles per class and frame tile.
+template <class TileT>
+struct Conv2DgradPos {
+  using Tile = TileT;
+  static constexpr int ORDER = IGEMM_ORDER_2;
+  static constexpr bool A_RX = false, B_YR = true, BIAS_GRAD = false, KSKIP = true, BITMASK = true;
+  static constexpr int NCLS = 4;
+  const float* dypad; const float* W; float* dact1; int S; const uint32_t* mask;
+  __host__ __device__ int X() const { return ((S + Tile::BX - 1) / Tile::BX) * 100 * Tile::BX; }
+  __host__ __device__ int Y() const { return 32; }
+  __device__ void r_range(int, int& lo, int& hi) const { lo = 0; hi = 256; }
+  __device__ int block_ctx(int x0, int) const {
+    const int p = (x0 / Tile::BX) % 100, ihh = p / 10, iwh = p - ihh * 10;
+    const int jh0 = ihh == 0 ? 1 : 0, jh1 = ihh == 9 ? 0 : 1, jw0 = iwh == 0 ? 1 : 0, jw1 = iwh == 9 ? 0 : 1;
+    const int njw = jw1 - jw0 + 1, nt = (jh1 - jh0 + 1) * njw;
+    return jh0 | (jw0 << 2) | (njw << 4) | (nt << 8);
+  }
+  __device__ int block_k(int ctx) const { return (ctx >> 8) * 64; }
+  __device__ int r_map(int ctx, int rc) const {
+    const int t = rc >> 6, njw = (ctx >> 4) & 15, q = t / njw;
+    return ((ctx & 3) + q) * 128 + (((ctx >> 2) & 3) + (t - q * njw)) * 64 + (rc & 63);
+  }
+  __device__ void decode(int x, int& s, int& ihh, int& iwh) const {
+    const int tile = x / Tile::BX, t = tile / 100, p = tile - t * 100;
+    s = t * Tile::BX + (x - tile * Tile::BX); ihh = p / 10; iwh = p - ihh * 10;
+  }
+  __device__ float4 load_a(int x, int r, int, int) const {
+    int s, ihh, iwh;
+    decode(x, s, ihh, iwh);
+    s = min(s, S - 1);
+    const int jh = r >> 7, rem = r & 127;
+    return *reinterpret_cast<const float4*>(dypad + ((size_t)(s * 11 + ihh + jh) * 11 + iwh) * 64 + rem);
+  }
+  __device__ float4 load_b(int r, int ci, int, int cls) const {
+    const int jh = r >> 7, jw = (r >> 6) & 1, co = r & 63;
+    const int kh = (cls >> 1) + 2 * (1 - jh), kw = (cls & 1) + 2 * (1 - jw);
+    return *reinterpret_cast<const float4*>(W + ((size_t)(kh * 4 + kw) * 32 + ci) * 64 + co);
+  }
+  __device__ size_t pixel(int x, int cls, bool& ok) const {
+    int s, ihh, iwh;
+    decode(x, s, ihh, iwh);
+    ok = s < S;
+    return (size_t)(min(s, S - 1) * 20 + 2 * ihh + (cls >> 1)) * 20 + 2 * iwh + (cls & 1);
+  }
+  __device__ uint32_t mask_word(int x, int, int cls) const { bool ok; return mask[pixel(x, cls, ok)]; }
+  __device__ void store_on(int x, int ci, float v, bool on, int, int cls) const {
+    bool ok;
+    const size_t px = pixel(x, cls, ok);
+    if (ok) dact1[px * 32 + ci] = on ? v : 0.0f;
+  }
+  __device__ void store(int x, int ci, float v, int, int cls) const { store_on(x, ci, v, true, 0, cls); }
+};
+
 // conv2 dgrad with its four parity classes as ONE GEMM: the classes gather IDENTICAL rows of dY (A[p][(jh,jw,co)] does not depend on the
 // class), only the weights differ, so y = cls*32 + ci gives N = 128 with a [256][128] weight gather.  On fp32 MFMA this measured slower
 // than four N = 32 launches (MFMA-bound, and the big tile costs occupancy); the split-bf16 kernel is bound by tile STAGING, and here the A
@@ -700,7 +755,8 @@ static inline void plaunch_fwd(NatureWs& ws, int kid, const P& p, int nz, hipStr
 }
 // backward GEMM launch: fp32 MFMA (default) or, with cbm_config.backward_split = 2 / 3, the split-bf16 kernel
 #ifndef DGRAD_PF2
-#define DGRAD_PF2 0x3   // bit 0 dense, 1 conv3, 2 conv2 dgrad on the two-chunk prefetch kernel (igemm_pf2_kernel): 147 -> 143, 198 -> 190, 318 -> 322 us
+#define DGRAD_PF2 0x7   // bit 0 dense, 1 conv3, 2 conv2 dgrad on the two-chunk prefetch kernel (igemm_pf2_kernel): 147 -> 143, 198 -> 190, 286 -> 268 us
+                        // (the frame-major conv2 dgrad did not profit, 318 -> 322; the position-major one with its shorter K loops does)
 #endif
 template <class P>
 static inline void plaunch_bwd(NatureWs& ws, int kid, const P& p, int nz, hipStream_t st) {
@@ -727,6 +783,9 @@ static inline void plaunch_bwd(NatureWs& ws, int kid, const P& p, int nz, hipStr
   else { if (ws.bwd_split == 2) igemm_split_launch<P, 2>(p, nz, st); else igemm_split_launch<P, 3>(p, nz, st); }
   if (on) { hipEventRecord(pf->ev[2 * pf->n + 1], st); pf->n += 1; }
 }
+#ifndef CONV2_DGRAD_POS
+#define CONV2_DGRAD_POS 1
+#endif
 #ifndef CONV3_DGRAD_POS
 #define CONV3_DGRAD_POS 1   // position-major conv3 dgrad with tap skipping
 #endif
@@ -899,6 +958,9 @@ void nature_backward(const NatureLayout& L, const float* P, const uint8_t* obs, 
   {
     if (ws.bwd_split && IGEMM_USE_BITMASK) {
       Conv2DgradMerged<T128x128k16> pd{ws.dact2pad, P + L.w[1], ws.dact1, B * 100, ws.mask1};
+      plaunch_bwd(ws, K_CONV2_DGRAD, pd, 1, st);
+    } else if (CONV2_DGRAD_POS && IGEMM_USE_BITMASK) {
+      Conv2DgradPos<TILE_C2D> pd{ws.dact2pad, P + L.w[1], ws.dact1, B, ws.mask1};
       plaunch_bwd(ws, K_CONV2_DGRAD, pd, 1, st);
     } else {
       Conv2Dgrad<TILE_C2D> pd{ws.dact2pad, P + L.w[1], ws.act1, ws.dact1, B * 100, ws.mask1};
