@@ -783,6 +783,9 @@ static inline void plaunch_bwd(NatureWs& ws, int kid, const P& p, int nz, hipStr
   else { if (ws.bwd_split == 2) igemm_split_launch<P, 2>(p, nz, st); else igemm_split_launch<P, 3>(p, nz, st); }
   if (on) { hipEventRecord(pf->ev[2 * pf->n + 1], st); pf->n += 1; }
 }
+#ifndef FWD_PF2
+#define FWD_PF2 3   // learner-size conv2 / conv3 forward on the two-chunk prefetch kernel (bit-identical to igemm_kernel)
+#endif
 #ifndef CONV2_DGRAD_POS
 #define CONV2_DGRAD_POS 1
 #endif
@@ -855,9 +858,11 @@ void nature_forward(const NatureLayout& L, const float* P, const uint8_t* obs, c
     plaunch_fwd(ws, K_CONV3_FWD, p3, 1, st);
   } else {
     ConvFwd<TILE_C2F, 4, 4, 2, 32, 64, 20, 20, 9, 9> p2{ws.act1, P + L.w[1], P + L.b[1], ws.act2, B * 81, ws.mask2};
-    plaunch_fwd(ws, K_CONV2_FWD, p2, 1, st);
+    if ((FWD_PF2 & 1) && !ws.bf16_fwd) plaunch_fn(ws, K_CONV2_FWD, st, [&] { igemm_pf2_launch(p2, 1, st); });
+    else plaunch_fwd(ws, K_CONV2_FWD, p2, 1, st);
     ConvFwd<T128x64, 3, 3, 1, 64, 64, 9, 9, 7, 7> p3{ws.act2, P + L.w[2], P + L.b[2], ws.act3, B * 49, ws.mask3};
-    plaunch_fwd(ws, K_CONV3_FWD, p3, 1, st);
+    if ((FWD_PF2 & 2) && !ws.bf16_fwd) plaunch_fn(ws, K_CONV3_FWD, st, [&] { igemm_pf2_launch(p3, 1, st); });
+    else plaunch_fwd(ws, K_CONV3_FWD, p3, 1, st);
   }
   if (dense_ksplit > 1) {
 #if ACTOR_K16

@@ -476,6 +476,17 @@ __global__ __launch_bounds__(256, P::Tile::MINW) void igemm_pf2_kernel(const P p
           const uint32_t w = (uint32_t)__shfl((int)mw, row, 64);
           p.store_on(x0 + wx * (BX / WX) + i * 32 + row, y, acc[i][j][e], (w >> li) & 1u, z, cls);
         }
+      } else if constexpr (igemm_maskout<P>::value) {
+        uint32_t word = 0;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int r0 = (e & 3) + 8 * (e >> 2);
+          const bool on = p.store_flag(x0 + wx * (BX / WX) + i * 32 + r0 + 4 * h, y, acc[i][j][e], z, cls);
+          const unsigned long long bal = __ballot(on);
+          asm volatile("s_nop 4\n\tv_writelane_b32 %0, %1, %2" : "+v"(word) : "s"((uint32_t)bal), "n"(r0));
+          asm volatile("s_nop 4\n\tv_writelane_b32 %0, %1, %2" : "+v"(word) : "s"((uint32_t)(bal >> 32)), "n"(r0 + 4));
+        }
+        if (lane < 32) p.put_mask(x0 + wx * (BX / WX) + i * 32 + lane, y0 + wy * (BY / WY) + j * 32, word);
       } else {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
