@@ -485,6 +485,59 @@ struct Conv2DgradMerged {
   __device__ void store(int m, int y, float v, int, int) const { store_on(m, y, v, true, 0, 0); }   // (BITMASK path is the one used)
 };
 
+// position-major AND class-merged conv2 dgrad: one half-resolution pixel of BX frames per x-tile, y = cls*32 + ci (N = 128), zero taps skipped
+template <class TileT>
+struct Conv2DgradMergedPos {
+  using Tile = TileT;
+  static constexpr bool A_RX = false, B_YR = true, BIAS_GRAD = false, BITMASK = true, KSKIP = true;
+  static constexpr int NCLS = 1;
+  const float* dypad; const float* W; float* dact1; int S; const uint32_t* mask;
+  __host__ __device__ int X() const { return ((S + Tile::BX - 1) / Tile::BX) * 100 * Tile::BX; }
+  __host__ __device__ int Y() const { return 128; }
+  __device__ void r_range(int, int& lo, int& hi) const { lo = 0; hi = 256; }
+  __device__ int block_ctx(int x0, int) const {
+    const int p = (x0 / Tile::BX) % 100, ihh = p / 10, iwh = p - ihh * 10;
+    const int jh0 = ihh == 0 ? 1 : 0, jh1 = ihh == 9 ? 0 : 1, jw0 = iwh == 0 ? 1 : 0, jw1 = iwh == 9 ? 0 : 1;
+    const int njw = jw1 - jw0 + 1, nt = (jh1 - jh0 + 1) * njw;
+    return jh0 | (jw0 << 2) | (njw << 4) | (nt << 8);
+  }
+  __device__ int block_k(int ctx) const { return (ctx >> 8) * 64; }
+  __device__ int r_map(int ctx, int rc) const {
+    const int t = rc >> 6, njw = (ctx >> 4) & 15, q = t / njw;
+    return ((ctx & 3) + q) * 128 + (((ctx >> 2) & 3) + (t - q * njw)) * 64 + (rc & 63);
+  }
+  __device__ void decode(int x, int& s, int& ihh, int& iwh) const {
+    const int tile = x / Tile::BX, t = tile / 100, p = tile - t * 100;
+    s = t * Tile::BX + (x - tile * Tile::BX); ihh = p / 10; iwh = p - ihh * 10;
+  }
+  __device__ float4 load_a(int x, int r, int, int) const {
+    int s, ihh, iwh;
+    decode(x, s, ihh, iwh);
+    s = min(s, S - 1);
+    const int jh = r >> 7, rem = r & 127;
+    return *reinterpret_cast<const float4*>(dypad + ((size_t)(s * 11 + ihh + jh) * 11 + iwh) * 64 + rem);
+  }
+  __device__ float4 load_b(int r, int y, int, int) const {
+    const int cls = y >> 5, ci = y & 31;
+    const int jh = r >> 7, jw = (r >> 6) & 1, co = r & 63;
+    const int kh = (cls >> 1) + 2 * (1 - jh), kw = (cls & 1) + 2 * (1 - jw);
+    return *reinterpret_cast<const float4*>(W + ((size_t)(kh * 4 + kw) * 32 + ci) * 64 + co);
+  }
+  __device__ size_t pixel(int x, int cls, bool& ok) const {
+    int s, ihh, iwh;
+    decode(x, s, ihh, iwh);
+    ok = s < S;
+    return (size_t)(min(s, S - 1) * 20 + 2 * ihh + (cls >> 1)) * 20 + 2 * iwh + (cls & 1);
+  }
+  __device__ uint32_t mask_word(int x, int y32, int) const { bool ok; return mask[pixel(x, y32 >> 5, ok)]; }
+  __device__ void store_on(int x, int y, float v, bool on, int, int) const {
+    bool ok;
+    const size_t px = pixel(x, y >> 5, ok);
+    if (ok) dact1[px * 32 + (y & 31)] = on ? v : 0.0f;
+  }
+  __device__ void store(int x, int y, float v, int, int) const { store_on(x, y, v, true, 0, 0); }
+};
+
 // ---- weight gradients: C[x = k][y = co] = sum_{r = m} A[m][k] * dY[m][co], split over r into
 // partials [z][X][Y] (+ bias partial [z][Y]) reduced in ascending z (deterministic, ppo:30).
 template <class TileT>
@@ -786,6 +839,13 @@ static inline void plaunch_bwd(NatureWs& ws, int kid, const P& p, int nz, hipStr
 #ifndef FWD_PF2
 #define FWD_PF2 3   // learner-size conv2 / conv3 forward on the two-chunk prefetch kernel (bit-identical to igemm_kernel)
 #endif
+#ifndef CONV2_SPLIT_POS
+#define CONV2_SPLIT_POS 1
+#endif
+#ifndef CONV2_FP32_MERGED_POS
+#define CONV2_FP32_MERGED_POS 1           // fp32 MFMA: the merged position-major form (N = 128, one dY tile for the four classes): 268 -> 246 us
+#define CONV2_FP32_MERGED_TILE T128x128k16
+#endif
 #ifndef CONV2_DGRAD_POS
 #define CONV2_DGRAD_POS 1
 #endif
@@ -962,7 +1022,14 @@ void nature_backward(const NatureLayout& L, const float* P, const uint8_t* obs, 
   // conv2: dgrad -> dact1, wgrad
   {
     if (ws.bwd_split && IGEMM_USE_BITMASK) {
+#if CONV2_SPLIT_POS
+      Conv2DgradMergedPos<T128x128k16> pd{ws.dact2pad, P + L.w[1], ws.dact1, B, ws.mask1};
+#else
       Conv2DgradMerged<T128x128k16> pd{ws.dact2pad, P + L.w[1], ws.dact1, B * 100, ws.mask1};
+#endif
+      plaunch_bwd(ws, K_CONV2_DGRAD, pd, 1, st);
+    } else if (CONV2_FP32_MERGED_POS && IGEMM_USE_BITMASK) {
+      Conv2DgradMergedPos<CONV2_FP32_MERGED_TILE> pd{ws.dact2pad, P + L.w[1], ws.dact1, B, ws.mask1};
       plaunch_bwd(ws, K_CONV2_DGRAD, pd, 1, st);
     } else if (CONV2_DGRAD_POS && IGEMM_USE_BITMASK) {
       Conv2DgradPos<TILE_C2D> pd{ws.dact2pad, P + L.w[1], ws.dact1, B, ws.mask1};
