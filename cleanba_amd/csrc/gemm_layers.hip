@@ -212,17 +212,36 @@ static void launch_heads_fwd(const float* hid, const float* Wa, const float* ba,
 }
 
 // ------------------------------------------------------------------------------------------ backward
-// heads dgrad: dhid[m][k] = (sum_j dzv[m][j] * Wac[k][j]) * (hid > 0), j over A logits + value
-__global__ __launch_bounds__(256) void heads_dgrad_kernel(const float* dzv, const float* Wa, const float* Wc, const float* hid,
-                                                          int B, int A, int HD, float* dhid) {
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= (size_t)B * HD) return;
-  const int m = (int)(i / HD), k = (int)(i % HD);
-  const float* d = dzv + (size_t)m * 32;
-  float s = 0.0f;
-  for (int a = 0; a < A; ++a) s = fmaf(d[a], Wa[k * A + a], s);
-  s = fmaf(d[A], Wc[k], s);
-  dhid[i] = hid[i] > 0.0f ? s : 0.0f;
+// heads dgrad: dhid[m][k] = (sum_j dzv[m][j] * Wac[k][j]) * (hid > 0), j over A logits + value.
+// One thread per hidden unit k keeps its A+1 weights in registers (one pass over Wa / Wc per block of HG_FR frames instead of A strided loads
+// per output) and walks HG_FR frames whose dzv rows sit in LDS (broadcast reads); hid / dhid accesses are coalesced along k.
+#define HG_FR 4
+template <int HD>
+__global__ __launch_bounds__(HD) void heads_dgrad_kernel(const float* dzv, const float* Wa, const float* Wc, const float* hid, int B, int A, float* dhid) {
+  __shared__ float ds[HG_FR][32];
+  const int k = threadIdx.x, m0 = blockIdx.x * HG_FR;
+  for (int i = k; i < HG_FR * 32; i += HD) { const int f = m0 + i / 32; ds[i / 32][i % 32] = f < B ? dzv[(size_t)f * 32 + i % 32] : 0.0f; }
+  float w[28];
+#pragma unroll
+  for (int a = 0; a < 28; ++a) w[a] = a < A ? Wa[k * A + a] : 0.0f;
+  __syncthreads();
+  const float wc = Wc[k];
+#pragma unroll 4
+  for (int f = 0; f < HG_FR; ++f) {
+    const int m = m0 + f;
+    if (m >= B) break;
+    float s = 0.0f;
+#pragma unroll
+    for (int a = 0; a < 28; ++a) if (a < A) s = fmaf(ds[f][a], w[a], s);
+    s = fmaf(ds[f][A], wc, s);
+    const size_t i = (size_t)m * HD + k;
+    dhid[i] = hid[i] > 0.0f ? s : 0.0f;
+  }
+}
+static void launch_heads_dgrad(const float* dzv, const float* Wa, const float* Wc, const float* hid, int B, int A, int HD, float* dhid, hipStream_t st) {
+  const int nb = (B + HG_FR - 1) / HG_FR;
+  if (HD == 512) hipLaunchKernelGGL(heads_dgrad_kernel<512>, dim3(nb), dim3(512), 0, st, dzv, Wa, Wc, hid, B, A, dhid);
+  else hipLaunchKernelGGL(heads_dgrad_kernel<256>, dim3(nb), dim3(256), 0, st, dzv, Wa, Wc, hid, B, A, dhid);
 }
 
 // dense dgrad: dact3[m][j] = sum_n dhid[m][n] * Wd[j][n]; stored masked into the zero-bordered
@@ -974,8 +993,7 @@ void nature_backward(const NatureLayout& L, const float* P, const uint8_t* obs, 
   float* const bp = ws.bias_part;
   RedBatch tail_red(A), conv_red(A);
   // heads: dgrad (VALU) and wgrad (MFMA, Y = A+1 padded to 32)
-  hipLaunchKernelGGL(heads_dgrad_kernel, dim3(ceil_div(B * 512, 256)), dim3(256), 0, st, ws.dzv, P + L.w[4], P + L.w[5], ws.hid, B, A, 512,
-                     ws.dhid);
+  launch_heads_dgrad(ws.dzv, P + L.w[4], P + L.w[5], ws.hid, B, A, 512, ws.dhid, st);
   {
     const int nz = ceil_div(B, RPS_HEADS);
     MatWgrad<T128x32> p{ws.hid, ws.dzv, wp + rg.w[0], bp + rg.b[0], B, 512, 32, 32, RPS_HEADS};
