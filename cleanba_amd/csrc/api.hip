@@ -201,7 +201,7 @@ static int ctx_create_impl(const cbm_config* cfg, cbm_ctx** out, cbm_ctx** parti
   if (c->accum > 1) { if (dalloc(&c->gacc, P)) return -1; hipMemset(c->gacc, 0, P * 4); }
   if (c->asyncB && dalloc(&c->advn, T1 * B)) return -1;
   if (dalloc(&c->adv, T1 * B) || dalloc(&c->target, T1 * B) || dalloc(&c->next_value, B) || dalloc(&c->stats_dev, (size_t)c->stat_rows * 8) ||
-      dalloc(&c->loss_partials, (size_t)4 * (lmax / 256 + 2) + 3 * B) || dalloc(&c->norm_partials, CBM_NORM_PARTS) ||
+      dalloc(&c->loss_partials, (size_t)4 * (lmax / 8 + 2) + 3 * B) || dalloc(&c->norm_partials, CBM_NORM_PARTS) ||
       dalloc(&c->perm, T1 * B) || dalloc(&c->perm_tmp, T1 * B) || dalloc(&c->ckeys, 2 * T1 * B)) return -1;
   if (!is_ppo(c)) {  // static minibatch index table: contiguous env-column chunks, all T+1 rows (impala:623-634)
     const int Bm = c->Bdev / c->nmicro;

@@ -264,69 +264,80 @@ void launch_permutation(const uint32_t key_in[2], int n, int32_t* perm, int32_t*
 
 // ------------------------------------------------------------------------------------------
 // PPO loss head ppo:516-577: per-sample statistics + analytic dL/dlogits, dL/dvalue into dzv[N][32].
+// 32 lanes per sample, one per action: the exponentials run in parallel, the three softmax sums are taken in ascending action order by a
+// shuffle walk (the same order, hence the same bits, as a serial loop and as the oracle), and every lane writes its own dzv column
+// (one 128-byte row per sample).  Eight samples per block; the block adds its samples' statistics in sample order.
 __global__ __launch_bounds__(256) void ppo_loss_kernel(const float* logits, const float* value, int N, int A, const int32_t* idx,
                                                         const int32_t* actions, const float* old_logprob, const float* adv,
                                                         const float* target, float clip_coef, float ent_coef, float vf_coef,
                                                         float* dzv, float* partials) {
-  __shared__ float red[4][4];
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  float s_pg = 0.0f, s_v = 0.0f, s_ent = 0.0f, s_kl = 0.0f;
-  if (i < N) {
-    const int n = idx ? idx[i] : i;
-    const float* z = logits + (size_t)i * A;
-    const int a = actions[n];
-    const float invN = 1.0f / (float)N;
-    float mx = z[0];
-    for (int j = 1; j < A; ++j) mx = z[j] > mx ? z[j] : mx;
-    float se = 0.0f;
-    for (int j = 0; j < A; ++j) se += cbm_expf(z[j] - mx);
-    const float lse_shift = cbm_logf(se);
-    const float newlp = (z[a] - mx) - lse_shift;
-    const float lse = lse_shift + mx;
-    float mx2 = -INFINITY;
-    for (int j = 0; j < A; ++j) { float zn = z[j] - lse; if (zn < -FLT_MAX) zn = -FLT_MAX; mx2 = zn > mx2 ? zn : mx2; }
-    float s2 = 0.0f;
-    for (int j = 0; j < A; ++j) { float zn = z[j] - lse; if (zn < -FLT_MAX) zn = -FLT_MAX; s2 += cbm_expf(zn - mx2); }
-    float ent = 0.0f;
-    for (int j = 0; j < A; ++j) { float zn = z[j] - lse; if (zn < -FLT_MAX) zn = -FLT_MAX; ent += zn * (cbm_expf(zn - mx2) / s2); }
-    ent = -ent;
-    const float logratio = newlp - old_logprob[n];
-    const float ratio = cbm_expf(logratio);
-    const float ad = adv[n];
-    const float lo = 1.0f - clip_coef, hi = 1.0f + clip_coef;
-    const float rc = ratio < lo ? lo : (ratio > hi ? hi : ratio);
-    const float pg1 = -ad * ratio, pg2 = -ad * rc;
-    const float pg = pg1 > pg2 ? pg1 : pg2;
-    const float dv = value[i] - target[n];
-    s_pg = pg; s_v = dv * dv; s_ent = ent; s_kl = (ratio - 1.0f) - logratio;
-    const float w1 = pg1 > pg2 ? 1.0f : (pg1 == pg2 ? 0.5f : 0.0f);
-    const float dclip = (ratio > lo && ratio < hi) ? 1.0f : ((ratio == lo || ratio == hi) ? 0.5f : 0.0f);
-    const float dpg_dratio = w1 * (-ad) + (1.0f - w1) * (-ad) * dclip;
-    const float c_lp = dpg_dratio * ratio * invN;
-    float* d = dzv + (size_t)i * 32;
-    for (int j = 0; j < A; ++j) {
-      float zn = z[j] - lse; if (zn < -FLT_MAX) zn = -FLT_MAX;
-      const float pj = cbm_expf(zn - mx2) / s2;
-      d[j] = c_lp * ((j == a ? 1.0f : 0.0f) - pj) + ent_coef * invN * pj * (zn + ent);
-    }
-    d[A] = vf_coef * dv * invN;
-    for (int j = A + 1; j < 32; ++j) d[j] = 0.0f;
+  __shared__ float red[8][4];
+  const int g = threadIdx.x >> 5, j = threadIdx.x & 31;
+  const int i = blockIdx.x * 8 + g;
+  const bool live = i < N;
+  const int ii = live ? i : N - 1;
+  const int n = idx ? idx[ii] : ii;
+  const int a = actions[n];
+  const float invN = 1.0f / (float)N;
+  const bool act = j < A;
+  const float zj = logits[(size_t)ii * A + (act ? j : A - 1)];
+  float mx = act ? zj : -INFINITY;
+  for (int o = 16; o > 0; o >>= 1) { const float t = __shfl_xor(mx, o, 32); mx = t > mx ? t : mx; }
+  const float ej = act ? cbm_expf(zj - mx) : 0.0f;
+  float se = 0.0f;
+  for (int q = 0; q < A; ++q) se += __shfl(ej, q, 32);
+  const float lse_shift = cbm_logf(se);
+  const float za = __shfl(zj, a, 32);
+  const float newlp = (za - mx) - lse_shift;
+  const float lse = lse_shift + mx;
+  float zn = zj - lse;
+  if (zn < -FLT_MAX) zn = -FLT_MAX;
+  float mx2 = act ? zn : -INFINITY;
+  for (int o = 16; o > 0; o >>= 1) { const float t = __shfl_xor(mx2, o, 32); mx2 = t > mx2 ? t : mx2; }
+  const float e2 = act ? cbm_expf(zn - mx2) : 0.0f;
+  float s2 = 0.0f;
+  for (int q = 0; q < A; ++q) s2 += __shfl(e2, q, 32);
+  const float pj = e2 / s2;
+  const float tj = act ? zn * pj : 0.0f;
+  float ent = 0.0f;
+  for (int q = 0; q < A; ++q) ent += __shfl(tj, q, 32);
+  ent = -ent;
+  const float logratio = newlp - old_logprob[n];
+  const float ratio = cbm_expf(logratio);
+  const float ad = adv[n];
+  const float lo = 1.0f - clip_coef, hi = 1.0f + clip_coef;
+  const float rc = ratio < lo ? lo : (ratio > hi ? hi : ratio);
+  const float pg1 = -ad * ratio, pg2 = -ad * rc;
+  const float pg = pg1 > pg2 ? pg1 : pg2;
+  const float dv = value[ii] - target[n];
+  const float w1 = pg1 > pg2 ? 1.0f : (pg1 == pg2 ? 0.5f : 0.0f);
+  const float dclip = (ratio > lo && ratio < hi) ? 1.0f : ((ratio == lo || ratio == hi) ? 0.5f : 0.0f);
+  const float dpg_dratio = w1 * (-ad) + (1.0f - w1) * (-ad) * dclip;
+  const float c_lp = dpg_dratio * ratio * invN;
+  if (live) {
+    float d = 0.0f;
+    if (act) d = c_lp * ((j == a ? 1.0f : 0.0f) - pj) + ent_coef * invN * pj * (zn + ent);
+    else if (j == A) d = vf_coef * dv * invN;
+    dzv[(size_t)i * 32 + j] = d;
   }
-  // block partial sums, fixed order
-  float vals[4] = {s_pg, s_v, s_ent, s_kl};
-  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-  for (int q = 0; q < 4; ++q) {
-    float v = vals[q];
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    if (l == 0) red[w][q] = v;
+  if (j == 0) {
+    red[g][0] = live ? pg : 0.0f; red[g][1] = live ? dv * dv : 0.0f; red[g][2] = live ? ent : 0.0f;
+    red[g][3] = live ? (ratio - 1.0f) - logratio : 0.0f;
   }
   __syncthreads();
-  if (threadIdx.x < 4) partials[blockIdx.x * 4 + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+  if (threadIdx.x < 4) {
+    float v = 0.0f;
+    for (int q = 0; q < 8; ++q) v += red[q][threadIdx.x];
+    partials[blockIdx.x * 4 + threadIdx.x] = v;
+  }
 }
+// sum of the block partials: 64 lanes take strided subsets in ascending order, then a fixed shuffle tree
 __global__ void ppo_stats_kernel(const float* partials, int nblk, int N, float ent_coef, float vf_coef, float* stats5) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const int l = threadIdx.x;
   float s[4] = {0, 0, 0, 0};
-  for (int b = 0; b < nblk; ++b) for (int q = 0; q < 4; ++q) s[q] += partials[b * 4 + q];
+  for (int b = l; b < nblk; b += 64) for (int q = 0; q < 4; ++q) s[q] += partials[b * 4 + q];
+  for (int q = 0; q < 4; ++q) for (int o = 32; o > 0; o >>= 1) s[q] += __shfl_down(s[q], o, 64);
+  if (l != 0) return;
   const float n = (float)N;
   const float pg = s[0] / n, v = 0.5f * (s[1] / n), e = s[2] / n, kl = s[3] / n;
   stats5[0] = pg - ent_coef * e + v * vf_coef;
@@ -335,7 +346,7 @@ __global__ void ppo_stats_kernel(const float* partials, int nblk, int N, float e
 void launch_ppo_loss(const float* logits, const float* value, int N, int A, const int32_t* idx, const int32_t* actions,
                      const float* old_logprob, const float* adv, const float* target, float clip_coef, float ent_coef, float vf_coef,
                      float* dzv, float* partials, float* stats5, hipStream_t st) {
-  const int nblk = ceil_div(N, 256);
+  const int nblk = ceil_div(N, 8);
   hipLaunchKernelGGL(ppo_loss_kernel, dim3(nblk), dim3(256), 0, st, logits, value, N, A, idx, actions, old_logprob, adv, target, clip_coef,
                      ent_coef, vf_coef, dzv, partials);
   hipLaunchKernelGGL(ppo_stats_kernel, dim3(1), dim3(64), 0, st, partials, nblk, N, ent_coef, vf_coef, stats5);
