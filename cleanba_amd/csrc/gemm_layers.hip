@@ -679,27 +679,36 @@ struct RedJob { const float* part; float* gw; float* gw2; int nz, XY, Ycols, mod
 #define RED_MAX_JOBS 6
 struct RedJobs { RedJob j[RED_MAX_JOBS]; int n, A; };
 __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const RedJobs jobs) {
-  __shared__ float red[256];
+  // four consecutive outputs per thread (16-byte loads; every XY is a multiple of 32), same z order per output as the scalar form
+  __shared__ float4 red[256];
   int q = 0;
 #pragma unroll
   for (int k = 1; k < RED_MAX_JOBS; ++k) if (k < jobs.n && (int)blockIdx.x >= jobs.j[k].block0) q = k;
   const RedJob& J = jobs.j[q];
   const int zg = J.zg, ow = 256 / zg, nz = J.nz, XY = J.XY;
   const int o = threadIdx.x % ow, g = threadIdx.x / ow;
-  const int i = ((int)blockIdx.x - J.block0) * ow + o;
-  float s = 0.0f;
+  const int i = (((int)blockIdx.x - J.block0) * ow + o) * 4;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   if (i < XY)
-    for (int z = g; z < nz; z += zg) s += J.part[(size_t)z * XY + i];
+    for (int z = g; z < nz; z += zg) {
+      const float4 v = *reinterpret_cast<const float4*>(J.part + (size_t)z * XY + i);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
   red[threadIdx.x] = s;
   __syncthreads();
   if (g != 0 || i >= XY) return;
-  for (int r = 1; r < zg; ++r) s += red[r * ow + o];
-  s *= J.scale;
-  const int x = i / J.Ycols, y = i - x * J.Ycols, A = jobs.A;
-  if (J.mode == 0) J.gw[i] = s;
-  else if (J.mode == 1) { const int c = x >> 6, kh = (x >> 3) & 7, kw = x & 7; J.gw[((kh * 8 + kw) * 4 + c) * 32 + y] = s; }
-  else if (J.mode == 2) { if (y < A) J.gw[x * A + y] = s; else if (y == A) J.gw2[x] = s; }
-  else { if (y < A) J.gw[y] = s; else if (y == A) J.gw2[0] = s; }
+  for (int r = 1; r < zg; ++r) { const float4 v = red[r * ow + o]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+  const float out[4] = {s.x * J.scale, s.y * J.scale, s.z * J.scale, s.w * J.scale};
+  const int A = jobs.A;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int ii = i + c, x = ii / J.Ycols, y = ii - x * J.Ycols;
+    const float v = out[c];
+    if (J.mode == 0) J.gw[ii] = v;
+    else if (J.mode == 1) { const int cc = x >> 6, kh = (x >> 3) & 7, kw = x & 7; J.gw[((kh * 8 + kw) * 4 + cc) * 32 + y] = v; }
+    else if (J.mode == 2) { if (y < A) J.gw[x * A + y] = v; else if (y == A) J.gw2[x] = v; }
+    else { if (y < A) J.gw[y] = v; else if (y == A) J.gw2[0] = v; }
+  }
 }
 struct RedBatch {
   RedJobs jobs;
@@ -708,7 +717,7 @@ struct RedBatch {
   void add(const float* part, int nz, int XY, int Ycols, int mode, float* gw, float* gw2, float scale = 1.0f) {
     const int zg = nz >= 64 ? 16 : (nz >= 8 ? 4 : 1), ow = 256 / zg;
     jobs.j[jobs.n++] = RedJob{part, gw, gw2, nz, XY, Ycols, mode, zg, blocks, scale};
-    blocks += (XY + ow - 1) / ow;
+    blocks += (XY / 4 + ow - 1) / ow;
   }
   void launch(hipStream_t st) { hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3(blocks), dim3(256), 0, st, jobs); }
 };
