@@ -867,6 +867,9 @@ static inline void plaunch_bwd(NatureWs& ws, int kid, const P& p, int nz, hipStr
 #ifndef FWD_PF2
 #define FWD_PF2 3   // learner-size conv2 / conv3 forward on the two-chunk prefetch kernel (bit-identical to igemm_kernel)
 #endif
+#ifndef TILE_C2W
+#define TILE_C2W T64x64   // 256 vs 267 us under load for T128x64 (K chunks of 16), 274 for 64x64 with chunks of 16
+#endif
 #ifndef CONV2_SPLIT_POS
 #define CONV2_SPLIT_POS 1
 #endif
@@ -1066,8 +1069,13 @@ void nature_backward(const NatureLayout& L, const float* P, const uint8_t* obs, 
       plaunch_bwd(ws, K_CONV2_DGRAD, pd, 1, st);
     }
     const int M = B * 81, nz = ceil_div(M, RPS_C2);
-    ConvWgrad<T128x64, 4, 4, 2, 32, 64, 20, 20, 9, 9, 1> pw{ws.act1, ws.dact2pad, wp + rg.w[3], bp + rg.b[3], M, RPS_C2};
-    plaunch_bwd(ws, K_CONV2_WGRAD, pw, nz, st);
+    if (ws.bwd_split == 2) {   // the split kernel wants the bigger tile (staging-bound)
+      ConvWgrad<T128x64, 4, 4, 2, 32, 64, 20, 20, 9, 9, 1> pw{ws.act1, ws.dact2pad, wp + rg.w[3], bp + rg.b[3], M, RPS_C2};
+      plaunch_bwd(ws, K_CONV2_WGRAD, pw, nz, st);
+    } else {
+      ConvWgrad<TILE_C2W, 4, 4, 2, 32, 64, 20, 20, 9, 9, 1> pw{ws.act1, ws.dact2pad, wp + rg.w[3], bp + rg.b[3], M, RPS_C2};
+      plaunch(ws, K_CONV2_WGRAD, pw, nz, st);
+    }
     conv_red.add(wp + rg.w[3], nz, 512 * 64, 64, 0, grads + L.w[1], nullptr);
     conv_red.add(bp + rg.b[3], nz, 64, 64, 0, grads + L.b[1], nullptr);
   }
