@@ -180,7 +180,10 @@ __global__ __launch_bounds__(256, 2) void conv1_fwd_frames_kernel(const uint8_t*
 
 void launch_conv1_fwd_frames(const uint8_t* obs, const int32_t* idx, const float* W, const float* bias, float* out, uint32_t* mask, int S,
                              hipStream_t st) {
-  int blocks = 512;
+#ifndef C1F_BLOCKS
+#define C1F_BLOCKS 512
+#endif
+  int blocks = C1F_BLOCKS;
   if (S < blocks) blocks = S;
   const int fpb = (S + blocks - 1) / blocks;
   blocks = (S + fpb - 1) / fpb;
@@ -330,7 +333,10 @@ __global__ __launch_bounds__(256, 2) void conv1_wgrad_frames_split_kernel(const 
 }
 
 int conv1_wgrad_frames_splits(int S) {
-  int blocks = 1024;
+#ifndef C1W_BLOCKS
+#define C1W_BLOCKS 768   // 3840-frame minibatch: 5 frames per block; 225 vs 233 us for 1024 blocks (and 25 MB of partials instead of 31)
+#endif
+  int blocks = C1W_BLOCKS;
   if (S < blocks) blocks = S;
   const int fpb = (S + blocks - 1) / blocks;
   return (S + fpb - 1) / fpb;

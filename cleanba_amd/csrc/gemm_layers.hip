@@ -731,7 +731,13 @@ static int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static int round_up(int a, int b) { return ceil_div(a, b) * b; }
 
 // rows of the reduction handled by one split block (multiples of BR = 32)
-static const int RPS_C1 = 1600, RPS_C2 = 1280, RPS_C3 = 1664, RPS_HEADS = 128;
+#ifndef RPS_C2_V
+#define RPS_C2_V 1280
+#endif
+#ifndef RPS_C3_V
+#define RPS_C3_V 1664
+#endif
+static const int RPS_C1 = 1600, RPS_C2 = RPS_C2_V, RPS_C3 = RPS_C3_V, RPS_HEADS = 128;
 #ifndef DENSE_WGRAD_NZ
 #define DENSE_WGRAD_NZ 2
 #endif
