@@ -873,6 +873,10 @@ static inline void plaunch_bwd(NatureWs& ws, int kid, const P& p, int nz, hipStr
 #ifndef FWD_PF2
 #define FWD_PF2 3   // learner-size conv2 / conv3 forward on the two-chunk prefetch kernel (bit-identical to igemm_kernel)
 #endif
+#ifndef DENSE_FWD_PF2
+#define DENSE_FWD_PF2 0
+#define DENSE_FWD_TILE T64x64
+#endif
 #ifndef TILE_C2W
 #define TILE_C2W T64x64   // 256 vs 267 us under load for T128x64 (K chunks of 16), 274 for 64x64 with chunks of 16
 #endif
@@ -971,8 +975,9 @@ void nature_forward(const NatureLayout& L, const float* P, const uint8_t* obs, c
     hipLaunchKernelGGL(dense_reduce_kernel, dim3(ceil_div(B * 512, 256)), dim3(256), 0, st, ws.dense_part, P + L.b[3], ws.hid, B, 512,
                        dense_ksplit);
   } else {
-    DenseFwd<T64x64, false> pd{ws.act3, P + L.w[3], P + L.b[3], ws.hid, B, 3136, 512, 3136};
-    plaunch_fwd(ws, K_DENSE_FWD, pd, 1, st);
+    DenseFwd<DENSE_FWD_TILE, false> pd{ws.act3, P + L.w[3], P + L.b[3], ws.hid, B, 3136, 512, 3136};
+    if (DENSE_FWD_PF2 && !ws.bf16_fwd && B >= 1024) plaunch_fn(ws, K_DENSE_FWD, st, [&] { igemm_pf2_launch(pd, 1, st); });
+    else plaunch_fwd(ws, K_DENSE_FWD, pd, 1, st);
   }
   launch_heads_fwd(ws.hid, P + L.w[4], P + L.b[4], P + L.w[5], P + L.b[5], B, L.A, 512, ws.logits, ws.value, st);
 }
