@@ -377,3 +377,34 @@ def test_backward_split_bf16_meets_the_fp32_bar(oracle, ns):
         out[split] = g
         c.close()
     assert not np.array_equal(out[0], out[ns])
+
+
+def test_backward_split_impala_grads(oracle):
+    """The split-bf16 backward under the IMPALA loss (same backward kernels, V-trace loss head): gradients within 1e-5 of the oracle per tensor."""
+    rng = np.random.default_rng(90)
+    T1, Bm = 9, 15          # 135 frames: a full 128-frame tile plus a sliver
+    N = T1 * Bm
+    P = make_params(A, 91)
+    obs = make_frames(N, 92)
+    mu = rng.normal(0, 0.3, size=(T1, Bm, A)).astype(np.float32)
+    actions = rng.integers(0, A, (T1, Bm)).astype(np.int32)
+    rewards = (rng.random((T1, Bm)) < 0.3).astype(np.float32)
+    dones = (rng.random((T1, Bm)) < 0.2).astype(np.uint8)
+    first = (rng.random((T1, Bm)) < 0.2).astype(np.uint8)
+    stats_o, grads_o = oracle.impala_loss_grad(P, A, obs, None, T1, Bm, mu, actions, rewards, dones, first)
+    cfg = L.default_config(L.ALGO_IMPALA)
+    cfg.local_num_envs, cfg.num_actor_slots, cfg.num_steps = 60, 1, T1 - 1
+    cfg.backward_split = 2
+    c = L.Context(cfg)
+    d = [L.DevBuf(c, x) for x in (P, obs, mu, actions, rewards, dones, first)]
+    dS = L.DevBuf(c, nbytes=32, dtype=np.float32)
+    dG = L.DevBuf(c, nbytes=P.size * 4, dtype=np.float32)
+    L._chk(c.lib.cbm_impala_loss_grad(c.h, L._p(d[0].ptr), L._p(d[1].ptr), None, T1, Bm, L._p(d[2].ptr), L._p(d[3].ptr), L._p(d[4].ptr), L._p(d[5].ptr),
+                                      L._p(d[6].ptr), L._p(dS.ptr), L._p(dG.ptr)))
+    np.testing.assert_allclose(dS.download()[:4], stats_o, rtol=1e-5, atol=1e-5)
+    g = dG.download()
+    for name, (o, shp) in oracle.nature_layout(A).items():
+        n = int(np.prod(shp))
+        ref = grads_o[o:o + n]
+        assert np.abs(g[o:o + n] - ref).max() <= 1e-5 * max(np.abs(ref).max(), 1e-7), name
+    c.close()
