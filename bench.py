@@ -1,21 +1,26 @@
 #!/usr/bin/env python
 """bench.py — env-steps/sec of the rollout+update hot path (BASELINE.json metric) on N MI355X.
 
-Workload (BASELINE.json configs[1]): PPO a0-l0, Nature-CNN fp32, local_num_envs=120, num_steps=128,
-num_actor_threads=1, 4 epochs x 4 minibatches, A=18, synthetic Breakout-shaped frames from the device env
-(frames are rendered into the HBM ring by the env kernel: inputs are resident in HBM, no PCIe in the timed
-region).  One "step" = one full update cycle = one 128x120 rollout (actor forward + Gumbel sampling + env
-step per env-step) + one learner update (GAE, adv-norm, 16 x (minibatch fwd+bwd, [all-reduce], Adam)).
-With N>1 every rank runs its own 120 envs and learner (the reference's a0_l0_dN topology, README.md:103-108)
-and gradients are all-reduced per minibatch over RCCL: weak scaling.
+Workload (BASELINE.json configs[1]): PPO a0-l0, Nature-CNN fp32, local_num_envs=120, num_steps=128, num_actor_threads=1,
+4 epochs x 4 minibatches, A=18, synthetic Breakout-shaped frames from the device env (frames are rendered into the HBM ring by the env
+kernel: inputs are resident in HBM, no PCIe in the timed region).  One "step" = one full update cycle = one 128x120 rollout (actor forward +
+Gumbel sampling + env step per env-step) + one learner update (GAE, adv-norm, 16 x (minibatch fwd+bwd, [all-reduce], Adam)).
 
-The actor rollout k+1 is enqueued on its own HIP stream while update k runs (--concurrency semantics,
-ppo:287-304); a single host thread drives both through the C ABI, so nothing but the two device
-synchronisations brackets the timed region.
+  python bench.py --gpus N                      N ranks of the reference's a0_l0_dN topology (README.md:103-108): every rank runs its own
+                                                120 envs and learner, gradients are all-reduced per minibatch over RCCL (csrc/comm.hip): weak
+                                                scaling.  Without torchrun's variables the script launches its N ranks itself.
+  python bench.py --gpus 4 --topology a0-l1,2,3               BASELINE configs[3]: 1 actor GPU + 3 learner GPUs (README.md:62)
+  python bench.py --gpus 8 --topology "2x(a0-l1,2,3)" --env-id Atari57Mix-v5     configs[4]: two such groups (benchmark.sh:80)
+  torchrun --nproc-per-node N bench.py --gpus N ...           the driver's form; RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* are honoured
+
+The actor rollout k+1 is enqueued on its own HIP stream while update k runs (--concurrency semantics, ppo:287-304); a single host thread
+drives both through the C ABI, so nothing but the two device synchronisations brackets the timed region.
 """
 import argparse
 import json
 import os
+import re
+import subprocess
 import sys
 import time
 
@@ -40,85 +45,88 @@ KERNELS = {
 # flops are ALGORITHMIC (a layer's dgrad and wgrad each cost its forward flops).  Both position-major dgrads (conv2, conv3) skip
 # the taps that fall into dY's zero border per tile, so they EXECUTE exactly the algorithmic count.
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+HBM_PEAK_GBPS = 8000.0         # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+ALG_FLOPS_PER_ENV_STEP = 243.2e6   # SURVEY §8d (PPO, Nature-CNN, A=18): rollout forward + 4 epochs x (forward + backward)
+ALG_BYTES_PER_ENV_STEP = 345.8e3
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/pmc_traffic.py)
 
 
-def cpu_baseline(params, n_frames=768):
-    """The CPU restatement (oracle/, 'port') timed on a bounded sample of the same per-env-step work:
-    t_fwd (actor forward+sampling) and t_fb (learner forward+loss+backward) per frame on n_frames
-    Breakout-shaped frames; env-steps/s = 1 / (t_fwd*(1+1/T) + EPOCHS*t_fb)."""
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+# --------------------------------------------------------------------------------------------- CPU baseline (same harness)
+def cpu_baseline(n_envs=8, n_steps=16, updates=3):
+    """The CPU restatement (oracle/, kind "port") driven by the SAME host program as the GPU run — cleanba_amd.trainer.train with the
+    oracle-backed engine (tests/oracle_engine.py) in place of the HIP library: same actor thread, same ring hand-off, same counters — on a
+    bounded sample of the workload: Nature-CNN PPO, 4 epochs x 4 minibatches, A=18, host synthetic env, `n_envs` envs x `n_steps` steps per
+    rollout (the full 120 x 128 rollout would take ~2 minutes per update on these cores), `updates` updates, env-steps/s = the MEDIAN over
+    updates of local_batch_size / (time between consecutive update completions).  Two rows: the oracle's OpenMP over frames on all cores it
+    can use, and one intra-op thread per role like the reference pins XLA-CPU (ppo:28)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle
-    cores = min(os.cpu_count() or 1, 32, n_frames // 6)  # OpenMP over frames: more threads than frames/6 only adds reduction cost
-    oracle.set_threads(cores)
-    st, obs = L.synth_env_reset_host(1, n_frames)
-    rng = np.random.default_rng(0)
-    for _ in range(4):
-        L.synth_env_step_host(1, st, obs, rng.integers(0, A, n_frames).astype(np.int32))
-    t0 = time.time()
-    logits, value = oracle.nature_forward(params, A, obs, ksplit=14)
-    actions, lp, _ = oracle.sample_actions(logits, prng.prng_key(1))
-    t_fwd = (time.time() - t0) / n_frames
-    adv = rng.normal(size=n_frames).astype(np.float32)
-    t0 = time.time()
-    oracle.ppo_loss_grad(params, A, obs, None, actions, lp, adv, value + adv)
-    t_fb = (time.time() - t0) / n_frames
-    sps = 1.0 / (t_fwd * (1.0 + 1.0 / T) + EPOCHS * t_fb)
-    # SURVEY section 8d row (A), "reference-faithful threading": the reference pins XLA-CPU to one intra-op thread per computation
-    # (ppo:28), i.e. one busy core for the actor thread and one for the learner, running concurrently -> the slower of the two bounds it
-    oracle.set_threads(1)
-    n1 = 24
-    t0 = time.time()
-    lg1, v1 = oracle.nature_forward(params, A, obs[:n1], ksplit=14)
-    a1, lp1, _ = oracle.sample_actions(lg1, prng.prng_key(1))
-    t_fwd1 = (time.time() - t0) / n1
-    t0 = time.time()
-    oracle.ppo_loss_grad(params, A, obs[:n1], None, a1, lp1, adv[:n1], v1 + adv[:n1])
-    t_fb1 = (time.time() - t0) / n1
-    sps_ref_threads = 1.0 / max(t_fwd1 * (1.0 + 1.0 / T), EPOCHS * t_fb1)
-    return {"value": round(sps, 2), "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "reference_threading": {"value": round(sps_ref_threads, 2), "cores": 2,
-                                    "note": f"one thread per role like the reference (ppo:28): actor {t_fwd1 * 1e3:.1f} ms/frame and learner "
-                                            f"{t_fb1 * 1e3:.1f} ms/frame on one core each, overlapped; {n1}-frame sample"},
-            "sample": f"{n_frames} synthetic frames: oracle actor forward+sampling ({t_fwd * 1e3:.2f} ms/frame) and PPO "
-                      f"forward+loss+backward ({t_fb * 1e3:.2f} ms/frame) with OpenMP over frames; per-env-step cost = "
-                      f"t_fwd*(1+1/{T}) + {EPOCHS}*t_fb (Adam/GAE/shuffle excluded: <1%)"}
+    from oracle_engine import OracleEngine
+    from cleanba_amd.args import parse_args
+    from cleanba_amd.trainer import train
+
+    def run(threads):
+        oracle.set_threads(threads)
+        stamps = []
+        argv = ["--local-num-envs", str(n_envs), "--num-actor-threads", "1", "--num-steps", str(n_steps), "--env-backend", "host", "--network", "nature",
+                "--total-timesteps", str((updates + 1) * n_envs * n_steps), "--log-frequency", "100000", "--concurrency"]
+        cwd = os.getcwd()
+        os.chdir(os.environ.get("TMPDIR", "/tmp"))
+        try:
+            with open(os.devnull, "w") as dn:
+                so = sys.stdout
+                sys.stdout = dn
+                try:
+                    train(parse_args(argv, "ppo"), "ppo", engine_factory=OracleEngine, on_update=lambda v, s, e: stamps.append(time.perf_counter()))
+                finally:
+                    sys.stdout = so
+        finally:
+            os.chdir(cwd)
+        dts = np.diff(np.array(stamps))          # the first update's completion is the start mark (warm-up: page-in, thread start)
+        return float(n_envs * n_steps / np.median(dts)), [round(float(x), 3) for x in dts]
+
+    ncpu = os.cpu_count() or 1
+    cores = max(1, min(ncpu, 32, (n_envs * n_steps // NMB) // 6))   # OpenMP over frames: more threads than frames/6 only adds reduction cost
+    sps, dts = run(cores)
+    sps1, dts1 = run(1)
+    return {"value": round(sps, 2), "unit": "env-steps/s", "cores": cores + 1, "kind": "port", "estimate": False,
+            "reference_threading": {"value": round(sps1, 2), "cores": 2,
+                                    "note": "one intra-op thread per role like the reference pins XLA-CPU (ppo:28): one actor thread + one learner thread"},
+            "sample": f"same harness as the GPU run (cleanba_amd.trainer.train, actor thread + learner thread, --concurrency) on the oracle engine: "
+                      f"PPO Nature-CNN fp32, {n_envs} envs x {n_steps} steps per rollout, 4 epochs x 4 minibatches, host synthetic env; median of "
+                      f"{updates} update intervals {dts} s with {cores} OpenMP threads in the learner (+1 actor thread) on {ncpu} host cores; "
+                      f"single-thread intervals {dts1} s.  A timing of the C restatement, not of JAX."}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--prof-kernel", type=int, default=9, help="igemm kernel id timed with HIP events for the roofline line")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--bwd-split", type=int, default=0, choices=[0, 2, 3],
-                    help="build-only extension (NOT the headline): backward GEMMs on split-bf16 MFMA, see cbm_config.backward_split")
-    a = ap.parse_args()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    import torch
-    dist = None
-    force_dist = os.environ.get("CBM_FORCE_DIST") == "1"  # exercise the N>1 code path (split form + all-reduce) on one GPU
-    if world > 1 or force_dist:
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                init_method=f"tcp://{os.environ.get('MASTER_ADDR', '127.0.0.1')}:{os.environ.get('MASTER_PORT', '29500')}")
+# --------------------------------------------------------------------------------------------- data-parallel bench (a0_l0_dN)
+def run_dp(a, world, rank, local_rank):
+    from cleanba_amd.trainer import HipEngine
+    from cleanba_amd import topology
     cfg = L.default_config(L.ALGO_PPO)
-    cfg.device = local_rank
+    cfg.device = int(os.environ.get("CBM_FORCE_DEVICE", local_rank))
     cfg.local_num_envs, cfg.num_actor_slots, cfg.num_steps, cfg.num_actions = E, 1, T, A
     cfg.backward_split = a.bwd_split
-    from cleanba_amd.trainer import HipEngine
     ctx = HipEngine(cfg)
+    rdv = None
+    if world > 1:
+        rdv = topology.Rendezvous(world, rank, os.environ.get("MASTER_ADDR", "127.0.0.1"), os.environ.get("MASTER_PORT", "29500"))
+    if world > 1 or ctx.wants_comm_at_world_one():
+        topology.setup_learner_comm(ctx, rdv, list(range(world)), rank)      # RCCL communicator over all ranks (pmap's device list, ppo:656-660)
+    comm = ctx.comm_size() > 0
     key = prng.prng_key(1)
     key, nk, ak, ck = prng.split(key, 4)
     params = M.init_nature_params(A, nk, ak, ck)
     ctx.set_params(params)
     ctx.actor_set_key(0, key)
-    ctx.actor_env_reset_device(0, 1 + rank)  # env seed = seed + process_index + thread id (ppo:238)
+    ctx.actor_env_reset_device(0, 1 + rank, a.env_id.startswith("Atari57"))  # env seed = seed + process_index + thread id (ppo:238)
     lkey = key.copy()
-    from cleanba_amd.trainer import GradAllReducer
-    allreduce = GradAllReducer(ctx, world, dist_module=dist, active=dist is not None)   # tail of the gradient overlaps the conv backward
     n_opt = EPOCHS * NMB
     total_updates = a.warmup + a.steps
     opt_count = 0
@@ -128,82 +136,246 @@ def main():
         ctx.actor_rollout_device(0, T)
         ctx.actor_commit(0)
 
-    def update(v):
+    def update():
         nonlocal lkey, opt_count
         ctx.learner_wait()
         lrs = [M.linear_schedule(opt_count + i, 2.5e-4, n_opt, max(total_updates, 1)) for i in range(n_opt)]
         bcs = [M.adam_bias_corrections(opt_count + i + 1) for i in range(n_opt)]
-        if dist is None:
-            lkey, _ = ctx.learner_update(lkey, lrs, [b[0] for b in bcs], [b[1] for b in bcs], want_stats=False)
-        else:
-            lkey = ctx.learner_prepare(lkey)
-            i = 0
-            for e in range(EPOCHS):
-                lkey = ctx.learner_epoch_begin(lkey)
-                for mb in range(NMB):
-                    ctx.learner_minibatch_grad(e, mb)
-                    grad_div = allreduce()
-                    ctx.learner_optimizer_step(float(lrs[i]), float(bcs[i][0]), float(bcs[i][1]), grad_div)
-                    i += 1
-            ctx.learner_finish(n_opt, want_stats=False)
+        # one C call per update; with a communicator it all-reduces every minibatch's gradient (tail under the conv backward) itself
+        lkey, _ = ctx.learner_update(lkey, lrs, [b[0] for b in bcs], [b[1] for b in bcs], want_stats=False)
         opt_count += n_opt
 
     def barrier():
         ctx.sync()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
+        if comm:
+            ctx.comm_barrier()
             ctx.sync()
 
     rollout()  # rollout 1 (params v0)
-    for v in range(1, a.warmup + 1):
+    for _ in range(a.warmup):
         rollout()  # rollout v+1 overlaps update v
-        update(v)
+        update()
     barrier()
-    if a.prof_kernel >= 0:
+    if a.prof_kernel != -1:
         ctx.profile_select(a.prof_kernel)
+    if comm:
+        ctx.comm_profile(True)
     t0 = time.perf_counter()
-    for v in range(a.warmup + 1, total_updates + 1):
+    for _ in range(a.steps):
         rollout()
-        update(v)
+        update()
     barrier()
     dt = time.perf_counter() - t0
-    if dist is not None:
-        tmax = torch.tensor([dt], device=f"cuda:{local_rank}")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-    prof_ms, prof_n = ctx.profile_read() if a.prof_kernel >= 0 else (0.0, 0)
-    _, stats = None, None
+    dt_local = dt
+    if comm:
+        dt = float(ctx.comm_allreduce_f64([dt], "max")[0])
     env_steps = a.steps * T * E * world
     sps = env_steps / dt
 
+    line = None
     if rank == 0:
-        kname, kflops = KERNELS.get(a.prof_kernel, ("none", 0.0))
-        roof = None
-        if prof_n > 0:
-            avg_s = prof_ms / prof_n / 1e3
-            ach = kflops / avg_s / 1e12
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
-            if os.path.exists(tpath):
-                traffic = json.load(open(tpath)).get(str(a.prof_kernel), {}).get("traffic_bytes")
-            roof = {"bound": "mfma", "kernel": kname, "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "launches": prof_n, "avg_us": round(avg_s * 1e6, 1),
-                    "flops_per_launch": kflops}
         line = {"metric": "env-steps/sec (whole node), Breakout-v5 84x84x4, num_envs=120", "value": round(sps, 1), "unit": "env-steps/s",
                 "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
                 "scaling": "weak", "vs_baseline": None,
                 "dtype": "f32" if not a.bwd_split else f"f32 forward / split-bf16 x{a.bwd_split} backward GEMMs (extension, not the headline)", "data": "synthetic",
                 "config": {"workload": "PPO a0-l0-d%d: Nature-CNN fp32, local_num_envs=120, rollout_len=128, 4 epochs x 4 minibatches, A=18, "
-                                       "device synthetic Breakout-shaped env, concurrency on" % world,
+                                       "device synthetic %s env, concurrency on" % (world, "Atari-57-mix" if a.env_id.startswith("Atari57") else "Breakout-shaped"),
                            "global_batch": T * E * world, "parallelism": f"dp{world}"},
-                "roofline": roof}
-        if world == 1 and not a.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(params)
-        _emit(json.dumps(line))
+                "per_gpu": {"value": round(sps / world, 1), "rank0_local_ms_per_step": round(dt_local / a.steps * 1e3, 3)},
+                "roofline": roofline(ctx, a, dt)}
+        if comm:
+            tail_ms, exposed_ms, n = ctx.comm_profile_read()
+            P = ctx.P
+            line["allreduce"] = {"backend": "rccl", "ranks": world, "bytes_per_minibatch": int(P * 4), "minibatches": n,
+                                 "tail_bytes": int((P - ctx.grad_tail_offset()) * 4),
+                                 "tail_allreduce_us_avg": round(tail_ms / max(n, 1) * 1e3, 1),
+                                 "exposed_us_avg": round(exposed_ms / max(n, 1) * 1e3, 1),
+                                 "note": "tail (dense + heads) runs on the communication stream under the conv backward; exposed = end of the "
+                                         "backward pass -> optimizer may start on the learner stream (head all-reduce + whatever of the tail was not hidden)"}
     ctx.close()
-    if dist is not None:
-        dist.destroy_process_group()
+    return line, params
+
+
+def roofline(ctx, a, dt):
+    """Per-kernel HIP-event times of the timed region (events bracket every learner-stream launch of ids 0..11).  The `roofline` object is
+    the kernel with the LARGEST measured time share; `kernels` lists all twelve; `whole_step` prices the whole step's algorithmic flops."""
+    if a.prof_kernel == -1:
+        return None
+    traffic_tab = json.load(open(TRAFFIC_FILE)) if os.path.exists(TRAFFIC_FILE) else {}
+    if a.prof_kernel == -2:
+        ms, cnt = ctx.profile_read_all(12)
+    else:
+        tot, n = ctx.profile_read()
+        ms, cnt = np.zeros(12), np.zeros(12, np.int32)
+        ms[a.prof_kernel], cnt[a.prof_kernel] = tot, n
+    rows = {}
+    for k, (name, flops) in KERNELS.items():
+        if cnt[k] == 0:
+            continue
+        avg_s = ms[k] / cnt[k] / 1e3
+        tf = flops / avg_s / 1e12
+        tr = traffic_tab.get(str(k), {}).get("traffic_bytes")
+        rows[k] = {"kernel": name, "avg_us": round(avg_s * 1e6, 1), "launches": int(cnt[k]), "achieved": round(tf, 2),
+                   "frac": round(tf / FP32_MFMA_PEAK_TFLOPS, 4), "time_share": round(ms[k] / 1e3 / dt, 4), "flops_per_launch": flops,
+                   "traffic": tr, "hbm_gbps": None if tr is None else round(tr / avg_s / 1e9, 1),
+                   "hbm_frac": None if tr is None else round(tr / avg_s / 1e9 / HBM_PEAK_GBPS, 4)}
+    if not rows:
+        return None
+    dom = max(rows, key=lambda k: rows[k]["time_share"])
+    r = rows[dom]
+    whole_tf = ALG_FLOPS_PER_ENV_STEP * (a.steps * T * E) / dt / 1e12
+    out = {"bound": "mfma", "kernel": r["kernel"], "achieved": r["achieved"], "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": r["frac"],
+           "traffic": r["traffic"], "hbm_gbps": r["hbm_gbps"], "hbm_frac": r["hbm_frac"], "launches": r["launches"], "avg_us": r["avg_us"],
+           "flops_per_launch": r["flops_per_launch"], "time_share": r["time_share"],
+           "selection": "largest measured time share of the timed region (HIP events around every learner-stream launch of kernel ids 0-11)",
+           "min_frac": min(v["frac"] for k, v in rows.items() if k != 4),   # (id 4, the 32-wide heads wgrad, is 0.2 % of the flops)
+           "whole_step": {"achieved": round(whole_tf, 2), "frac": round(whole_tf / FP32_MFMA_PEAK_TFLOPS, 4),
+                          "algorithmic_hbm_gbps": round(ALG_BYTES_PER_ENV_STEP * (a.steps * T * E) / dt / 1e9, 1),
+                          "note": "243.2 MFLOP and 345.8 KB per env-step (SURVEY 8d) x env-steps / wall time, this GPU"},
+           "kernels": [rows[k] for k in sorted(rows)]}
+    return out
+
+
+def host_env_value(a, params):
+    """Secondary value: the SAME workload through the envpool-shaped host API — numpy frames over PCIe into cbm_actor_step_host, per-step
+    action D2H like the reference (ppo:317) — with the host twin of the synthetic env, `threads` actor threads.  Not the headline."""
+    from cleanba_amd.args import parse_args
+    from cleanba_amd.trainer import train
+    out = {}
+    for threads in (1, 2):
+        stamps = []
+        n_up = 4
+        argv = ["--local-num-envs", str(E // threads), "--num-actor-threads", str(threads), "--num-steps", str(T), "--env-backend", "host",
+                "--network", "nature", "--total-timesteps", str((n_up + 2) * E * T), "--log-frequency", "100000", "--concurrency"]
+        cwd = os.getcwd()
+        os.chdir(os.environ.get("TMPDIR", "/tmp"))
+        try:
+            so = sys.stdout
+            sys.stdout = open(os.devnull, "w")
+            try:
+                train(parse_args(argv, "ppo"), "ppo", on_update=lambda v, s, e: (e.sync(), stamps.append(time.perf_counter())))
+            finally:
+                sys.stdout = so
+        finally:
+            os.chdir(cwd)
+        dts = np.diff(np.array(stamps))[1:]     # skip the first two updates (pipeline fill)
+        out[f"actor_threads_{threads}"] = round(float(E * T / np.median(dts)), 1)
+    out["unit"] = "env-steps/s"
+    out["note"] = ("envpool step API path: host synthetic env (std::thread pool like envpool's), 3.39 MB H2D + 480 B D2H and one stream "
+                   "sync per 120-env step (ppo:317); total envs = 120 split over the actor threads; median update interval")
+    return out
+
+
+# --------------------------------------------------------------------------------------------- split-topology bench
+def parse_topology(spec):
+    """'a0-l1,2,3' -> (groups=1, [0], [1,2,3]);  '2x(a0-l1,2,3)' -> (2, [0], [1,2,3]);  'a0,1-l2,3' -> (1, [0,1], [2,3])."""
+    m = re.fullmatch(r"(?:(\d+)x\()?a([\d,]+)-l([\d,]+)\)?", spec.replace(" ", ""))
+    if not m:
+        raise SystemExit(f"--topology {spec!r}: expected dp | a<ids>-l<ids> | <G>x(a<ids>-l<ids>), e.g. a0-l1,2,3 or 2x(a0-l1,2,3)")
+    return int(m.group(1) or 1), [int(x) for x in m.group(2).split(",")], [int(x) for x in m.group(3).split(",")]
+
+
+def run_topology(a, world, rank):
+    """BASELINE configs[3]/[4] through the product trainer (cleanba_amd.trainer.train): one process per role, the actor writes shards into
+    the learners' rings (HIP IPC peer writes), gradients are all-reduced over every learner of every group (RCCL).  Timed on learner 0 of
+    group 0 between the completions of update `warmup` and update `warmup + steps` (device-synchronised), max over the learner ranks."""
+    from cleanba_amd.args import parse_args
+    from cleanba_amd.trainer import train
+    from cleanba_amd import topology
+    groups, aids, lids = parse_topology(a.topology)
+    G = len(aids) + len(lids)
+    if world != groups * G:
+        raise SystemExit(f"--topology {a.topology} needs {groups * G} role processes, got world size {world}")
+    argv = ["--local-num-envs", str(E), "--num-actor-threads", str(a.actor_threads), "--num-steps", str(T), "--env-backend", "device", "--network", "nature",
+            "--env-id", a.env_id, "--total-timesteps", str((a.warmup + a.steps) * E * T * a.actor_threads * len(aids) * groups),
+            "--log-frequency", "100000", "--concurrency", "--distributed", "--actor-device-ids"] + [str(i) for i in aids] + \
+           ["--learner-device-ids"] + [str(i) for i in lids]
+    args = parse_args(argv, "ppo")
+    lay = topology.Layout(args, world, rank)
+    os.environ["LOCAL_RANK"] = str(lay.device_id)
+    marks = {}
+
+    def on_update(v, stats, engine):
+        if v == a.warmup or v == a.warmup + a.steps:
+            engine.sync()
+            marks[v] = time.perf_counter()
+
+    cwd = os.getcwd()
+    os.chdir(os.environ.get("TMPDIR", "/tmp"))
+    so = sys.stdout
+    sys.stdout = sys.stderr
+    try:
+        res = train(args, "ppo", on_update=on_update)
+    finally:
+        sys.stdout = so
+        os.chdir(cwd)
+    if lay.is_actor or lay.group != 0 or lay.learner_index != 0:
+        return None
+    dt = marks[a.warmup + a.steps] - marks[a.warmup]
+    env_steps = a.steps * E * T * a.actor_threads * len(aids) * groups
+    return {"metric": "env-steps/sec (whole node), Breakout-v5 84x84x4, num_envs=120", "value": round(env_steps / dt, 1), "unit": "env-steps/s",
+            "n_gpus": len(set(aids + lids)) * groups, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "strong" if groups == 1 else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"PPO {a.topology}: Nature-CNN fp32, local_num_envs=120 x {a.actor_threads} actor thread(s) per actor GPU, rollout_len=128, "
+                                   f"4 epochs x 4 minibatches, A=18, device synthetic env ({a.env_id}), concurrency on; {groups} group(s) of "
+                                   f"{len(aids)} actor + {len(lids)} learner role processes",
+                       "global_batch": E * T * a.actor_threads * len(aids) * groups, "parallelism": f"{groups}x(actor{len(aids)}+dp{len(lids)})"},
+            "roofline": None, "role_processes": world, "timed_on": "learner 0 of group 0 (update completions, device-synchronised)",
+            "updates": int(res["updates"])}
+
+
+# --------------------------------------------------------------------------------------------- launcher
+def self_launch(n, argv):
+    """`python bench.py --gpus N` without torchrun: start the N rank processes here (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*), pass rank 0's
+    stdout through, wait for all, return the worst exit code."""
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    codes = [p.wait() for p in procs]
+    return max(abs(c) for c in codes)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--topology", default="dp", help="dp (a0_l0_dN, the default) | a0-l1,2,3 | 2x(a0-l1,2,3) | a0-l0,1 ...: one process per role")
+    ap.add_argument("--env-id", default="Breakout-v5", help="Breakout-v5 | Atari57Mix-v5 (BASELINE configs[4])")
+    ap.add_argument("--actor-threads", type=int, default=1, help="actor threads per actor GPU in the split topologies")
+    ap.add_argument("--prof-kernel", type=int, default=-2, help="-2: HIP events around every GEMM launch (ids 0-11, default); k: only kernel k; -1: off")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-env", action="store_true", help="skip the secondary envpool-API measurement")
+    ap.add_argument("--bwd-split", type=int, default=0, choices=[0, 2, 3],
+                    help="build-only extension (NOT the headline): backward GEMMs on split-bf16 MFMA, see cbm_config.backward_split")
+    a = ap.parse_args()
+    if a.topology != "dp":
+        groups, aids, lids = parse_topology(a.topology)
+        want_world = groups * (len(aids) + len(lids))
+    else:
+        want_world = a.gpus
+    if "WORLD_SIZE" not in os.environ and want_world > 1:
+        sys.exit(self_launch(want_world, sys.argv[1:]))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.topology == "dp" and world != a.gpus and rank == 0:
+        print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: running the {world} ranks that were launched", file=sys.stderr)
+    if a.topology != "dp":
+        line = run_topology(a, world, rank)
+        if line is not None:
+            _emit(json.dumps(line))
+        return
+    line, params = run_dp(a, world, rank, local_rank)
+    if rank == 0:
+        if world == 1 and not a.no_host_env:
+            line["host_env"] = host_env_value(a, params)
+        if world == 1 and not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        _emit(json.dumps(line))
 
 
 _REAL_STDOUT = None
@@ -219,7 +391,7 @@ def _emit(text):
 
 def _quiet_stdout():
     """Everything else that writes to fd 1 — RCCL's start-up banner (C stdio, flushed at exit, i.e. AFTER the result line), library warnings,
-    the other ranks under torchrun — is sent to stderr, so stdout carries exactly one line: rank 0's JSON."""
+    the other ranks under torchrun — is sent to stderr, so stdout carries exactly one line: the result JSON."""
     global _REAL_STDOUT
     sys.stdout.flush()
     _REAL_STDOUT = os.dup(1)

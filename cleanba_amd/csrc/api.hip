@@ -10,7 +10,7 @@
 //   - parameters are published by the learner into a 3-deep versioned buffer; an actor rollout
 //     `u` reads version max(0,u-2) with --concurrency (the `update != 2` skew, ppo:287-304) or
 //     u-1 without.
-#include "cbm_internal.h"
+#include "cbm_ctx.h"
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
@@ -27,58 +27,7 @@ void cbm_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* cbm_last_error(void) { return g_err; }
-extern "C" const char* cbm_build_info(void) { return "cleanba-mi gfx950 f32-mfma abi=1 built " __DATE__ " " __TIME__; }
-
-#define MAX_SLOTS 16
-#define MAX_RING 4
-#define NPV 3
-
-struct RingEntry {
-  uint8_t* obs = nullptr;
-  int32_t* actions = nullptr;
-  float *logprobs = nullptr, *values = nullptr, *rewards = nullptr, *logits = nullptr;
-  uint8_t *dones = nullptr, *firststeps = nullptr;
-  int32_t* env_ids = nullptr;   // async rollouts: which env each sample of a row belongs to (naturecnn:355,367)
-  hipEvent_t ready[MAX_SLOTS];
-  hipEvent_t consumed;
-};
-struct Slot {
-  hipStream_t stream = nullptr;
-  NatureWs ws;
-  uint32_t key[2] = {0, 0};
-  int t = 0, rollout = 0, ring = 0, pver = 0;
-  cbm_env_state* env_state = nullptr;
-  uint32_t env_seed = 0;
-  bool env_inited = false;
-  float* stats_dev = nullptr;
-};
-struct cbm_ctx {
-  cbm_config cfg;
-  NatureLayout L;
-  int E, S, Bdev, T, T1, A, MB, nmb, epochs;
-  int asyncB = 0, NE = 0;   // legacy --async-batch-size: rows of asyncB samples drawn from NE envs (0 = synchronous)
-  int64_t P;
-  float *params = nullptr, *grads = nullptr, *opt_m = nullptr, *opt_v = nullptr;
-  float* actor_params[NPV] = {nullptr, nullptr, nullptr};
-  hipEvent_t params_ready[NPV];
-  RingEntry ring[MAX_RING];
-  Slot slots[MAX_SLOTS];
-  hipStream_t lstream = nullptr;
-  NatureWs lws;
-  float* advn = nullptr;     // per-minibatch normalised advantages (async mode, naturecnn:540-541)
-  float *adv = nullptr, *target = nullptr, *next_value = nullptr, *stats_dev = nullptr, *loss_partials = nullptr, *norm_partials = nullptr;
-  int32_t *perm = nullptr, *perm_tmp = nullptr, *impala_idx = nullptr;
-  float* gacc = nullptr;   // MultiSteps running mean (grad_accum_steps > 1)
-  int accum = 1, nmicro = 0;
-  uint64_t* ckeys = nullptr;
-  std::mutex mu;
-  std::condition_variable cv;
-  int committed[MAX_SLOTS];
-  int updates_done = 0;
-  int stat_rows = 0;
-  CbmProf prof;
-  hipEvent_t tail_ev = nullptr, ext_ev = nullptr;   // gradient-tail hand-off to an external communication stream
-};
+extern "C" const char* cbm_build_info(void) { return "cleanba-mi gfx950 f32-mfma abi=2 built " __DATE__ " " __TIME__; }
 
 static bool is_ppo(const cbm_ctx* c) { return c->cfg.algo == CBM_ALGO_PPO; }
 
@@ -196,7 +145,12 @@ static int ctx_create_impl(const cbm_config* cfg, cbm_ctx** out, cbm_ctx** parti
   c->lws.bwd_split = cfg->backward_split;
   CBM_HIP(hipEventCreateWithFlags(&c->tail_ev, hipEventDisableTiming));
   CBM_HIP(hipEventCreateWithFlags(&c->ext_ev, hipEventDisableTiming));
+  CBM_HIP(hipEventCreateWithFlags(&c->bwd_ev, hipEventDisableTiming));
   c->lws.tail_ev = c->tail_ev;
+  CBM_HIP(hipStreamCreateWithFlags(&c->cstream, hipStreamNonBlocking));
+  CBM_HIP(hipStreamCreateWithFlags(&c->iostream, hipStreamNonBlocking));
+  if (dalloc(&c->comm_scratch, CBM_COMM_SCRATCH)) return -1;
+  { const char* ov = getenv("CBM_ALLREDUCE_OVERLAP"); c->comm_overlap = !(ov && !strcmp(ov, "0")); }
   c->stat_rows = c->epochs * c->nmicro;
   if (c->accum > 1) { if (dalloc(&c->gacc, P)) return -1; hipMemset(c->gacc, 0, P * 4); }
   if (c->asyncB && dalloc(&c->advn, T1 * B)) return -1;
@@ -252,6 +206,12 @@ extern "C" int cbm_ctx_destroy(cbm_ctx* c) {
   nature_ws_free(c->lws);
   if (c->tail_ev) hipEventDestroy(c->tail_ev);
   if (c->ext_ev) hipEventDestroy(c->ext_ev);
+  if (c->bwd_ev) hipEventDestroy(c->bwd_ev);
+  cbm_comm_destroy_all(c);
+  if (c->comm_prof_created) for (int i = 0; i < 4 * CBM_COMM_PROF_MAX; ++i) hipEventDestroy(c->comm_prof_ev[i]);
+  if (c->comm_scratch) hipFree(c->comm_scratch);
+  if (c->cstream) hipStreamDestroy(c->cstream);
+  if (c->iostream) hipStreamDestroy(c->iostream);
   hipStreamDestroy(c->lstream);
   delete c;
   return 0;
@@ -290,6 +250,8 @@ extern "C" int cbm_buffer(cbm_ctx* c, const char* name, int32_t ri, void** p, in
       {"params", c->params, (size_t)c->P * 4}, {"grads", c->grads, (size_t)c->P * 4}, {"opt_m", c->opt_m, (size_t)c->P * 4},
       {"opt_v", c->opt_v, (size_t)c->P * 4}, {"actor_params", c->actor_params[c->slots[0].pver % NPV], (size_t)c->P * 4},
       {"actor_params_latest", c->actor_params[c->updates_done % NPV], (size_t)c->P * 4},
+      {"actor_params_v0", c->actor_params[0], (size_t)c->P * 4}, {"actor_params_v1", c->actor_params[1], (size_t)c->P * 4},
+      {"actor_params_v2", c->actor_params[2], (size_t)c->P * 4},
       {"adv", c->adv, TB * 4}, {"target", c->target, TB * 4}, {"perm", c->perm, TB * 4}, {"next_value", c->next_value, (size_t)c->Bdev * 4},
       {"stats", c->stats_dev, (size_t)c->stat_rows * 8 * 4}, {"obs", R.obs, TB * CBM_FRAME}, {"actions", R.actions, TB * 4},
       {"logprobs", R.logprobs, TB * 4}, {"values", R.values, TB * 4}, {"rewards", R.rewards, TB * 4}, {"logits", R.logits, TB * c->A * 4},
@@ -345,7 +307,8 @@ extern "C" int cbm_actor_begin_rollout(cbm_ctx* c, int32_t s, int32_t concurrenc
   const int need_free = u - depth;  // ring entry reused: its previous rollout must be consumed
   {
     std::unique_lock<std::mutex> lk(c->mu);
-    c->cv.wait(lk, [&] { return c->updates_done >= need && c->updates_done >= need_free; });
+    c->cv.wait(lk, [&] { return c->aborted || (c->updates_done >= need && c->updates_done >= need_free); });
+    if (c->aborted) { cbm_set_error("context aborted"); return -4; }
   }
   const int ri = (u - 1) % depth;
   if (need > 0) CBM_HIP(hipStreamWaitEvent(sl.stream, c->params_ready[need % NPV], 0));
@@ -522,7 +485,8 @@ extern "C" int cbm_ingest_begin(cbm_ctx* c, int32_t s, int32_t* ring_index) {
   const int depth = c->cfg.ring_depth;
   {
     std::unique_lock<std::mutex> lk(c->mu);
-    c->cv.wait(lk, [&] { return c->updates_done >= u - depth; });
+    c->cv.wait(lk, [&] { return c->aborted || c->updates_done >= u - depth; });
+    if (c->aborted) { cbm_set_error("context aborted"); return -4; }
   }
   sl.ring = (u - 1) % depth;
   if (u > depth) CBM_HIP(hipStreamWaitEvent(sl.stream, c->ring[sl.ring].consumed, 0));
@@ -556,6 +520,14 @@ extern "C" int cbm_params_publish_external(cbm_ctx* c, const float* dev_params, 
   c->cv.notify_all();
   return 0;
 }
+extern "C" int cbm_ctx_abort(cbm_ctx* c) {
+  {
+    std::lock_guard<std::mutex> lk(c->mu);
+    c->aborted = true;
+  }
+  c->cv.notify_all();
+  return 0;
+}
 extern "C" void* cbm_actor_stream(cbm_ctx* c, int32_t s) { return (void*)c->slots[s].stream; }
 extern "C" int cbm_actor_ring_index(cbm_ctx* c, int32_t s) { return c->slots[s].ring; }
 
@@ -565,7 +537,8 @@ extern "C" int cbm_learner_wait(cbm_ctx* c) {
   const int v = c->updates_done + 1;
   {
     std::unique_lock<std::mutex> lk(c->mu);
-    c->cv.wait(lk, [&] { for (int s = 0; s < c->S; ++s) if (c->committed[s] < v) return false; return true; });
+    c->cv.wait(lk, [&] { if (c->aborted) return true; for (int s = 0; s < c->S; ++s) if (c->committed[s] < v) return false; return true; });
+    if (c->aborted) { cbm_set_error("context aborted"); return -4; }
   }
   RingEntry& R = c->ring[(v - 1) % c->cfg.ring_depth];
   for (int s = 0; s < c->S; ++s) CBM_HIP(hipStreamWaitEvent(c->lstream, R.ready[s], 0));
@@ -585,7 +558,10 @@ extern "C" int cbm_learner_prepare(cbm_ctx* c, uint32_t key[2]) {
     return 0;
   }
   // compute_gae ppo:543-560: bootstrap value with the LEARNER's params on next_obs (row T)
+  CbmProf* const pf = c->lws.prof;
+  c->lws.prof = nullptr;   // the per-kernel timers are for the minibatch-size launches, not for this 1-row bootstrap pass
   nature_forward(c->L, c->params, R.obs + (size_t)T * B * CBM_FRAME, nullptr, B, c->cfg.actor_dense_ksplit, c->lws, c->lstream);
+  c->lws.prof = pf;
   CBM_HIP(hipMemcpyAsync(c->next_value, c->lws.value, (size_t)B * 4, hipMemcpyDeviceToDevice, c->lstream));
   launch_gae(R.rewards, R.values, R.dones, c->next_value, R.dones + (size_t)T * B, T, B, c->cfg.gamma, c->cfg.gae_lambda, c->adv, c->target, c->lstream);
   if (c->cfg.norm_adv) launch_advnorm(c->adv, T, B, c->nmb, c->lstream);
@@ -635,18 +611,6 @@ extern "C" int cbm_learner_minibatch_grad(cbm_ctx* c, int32_t epoch, int32_t mb)
 // bytes (Nature) / 91 % (ResNet) — is final while the conv dgrad / wgrad kernels are still to run.  A data-parallel host all-reduces that
 // tail on its own communication stream as soon as the event fires, the small head after the backward pass, and joins the streams.
 extern "C" int64_t cbm_learner_grad_tail_offset(cbm_ctx* c) { return c->L.w[3]; }
-extern "C" int cbm_learner_stream_wait_tail(cbm_ctx* c, void* stream) {   // call after cbm_learner_minibatch_grad
-  CBM_HIP(hipSetDevice(c->cfg.device));
-  CBM_HIP(hipStreamWaitEvent((hipStream_t)stream, c->tail_ev, 0));
-  return 0;
-}
-extern "C" int cbm_learner_wait_stream(cbm_ctx* c, void* stream) {        // learner stream waits for everything enqueued on `stream` so far
-  CBM_HIP(hipSetDevice(c->cfg.device));
-  CBM_HIP(hipEventRecord(c->ext_ev, (hipStream_t)stream));
-  CBM_HIP(hipStreamWaitEvent(c->lstream, c->ext_ev, 0));
-  return 0;
-}
-
 // optax.MultiSteps (0.1.4): acc <- (g - acc)/(mini_step+1) + acc; the k-th micro-batch hands the mean to the inner optimizer and clears acc
 extern "C" int cbm_learner_accumulate(cbm_ctx* c, int32_t mini_step, float grad_div) {
   CBM_HIP(hipSetDevice(c->cfg.device));
@@ -675,10 +639,12 @@ extern "C" int cbm_learner_finish(cbm_ctx* c, float* stats_out) {
   CBM_HIP(hipEventRecord(R.consumed, c->lstream));
   if (stats_out) {
     const int w = is_ppo(c) ? 5 : 4;
+    if (cbm_learner_allreduce_stats_impl(c)) return -1;   // pmean over the learners (ppo:649-653); no-op without a communicator
+    const float inv = c->comms[CBM_COMM_LEARNERS].nranks ? 1.0f / (float)c->comms[CBM_COMM_LEARNERS].nranks : 1.0f;
     std::vector<float> h((size_t)c->stat_rows * 8);
     CBM_HIP(hipMemcpyAsync(h.data(), c->stats_dev, h.size() * 4, hipMemcpyDeviceToHost, c->lstream));
     CBM_HIP(hipStreamSynchronize(c->lstream));
-    for (int r = 0; r < c->stat_rows; ++r) for (int q = 0; q < w; ++q) stats_out[r * w + q] = h[(size_t)r * 8 + q];
+    for (int r = 0; r < c->stat_rows; ++r) for (int q = 0; q < w; ++q) stats_out[r * w + q] = h[(size_t)r * 8 + q] * inv;
   }
   {
     std::lock_guard<std::mutex> lk(c->mu);
@@ -697,11 +663,14 @@ extern "C" int cbm_learner_update(cbm_ctx* c, uint32_t key[2], const float* lrs,
     if (is_ppo(c)) learner_epoch_perm(c, key);
     for (int mb = 0; mb < c->nmicro; ++mb) {
       if (cbm_learner_minibatch_grad(c, e, mb)) return -1;
+      float grad_div = 1.0f;
+      if (cbm_learner_allreduce_grads_impl(c, &grad_div)) return -1;   // pmean over the learner GPUs (ppo:628); nothing on one GPU
       if (c->accum > 1) {
-        if (cbm_learner_accumulate(c, mb % c->accum, 1.0f)) return -1;
+        if (cbm_learner_accumulate(c, mb % c->accum, grad_div)) return -1;
         if (mb % c->accum != c->accum - 1) continue;
+        grad_div = 1.0f;
       }
-      if (cbm_learner_optimizer_step(c, lrs[step], bc1 ? bc1[step] : 1.0f, bc2 ? bc2[step] : 1.0f, 1.0f)) return -1;
+      if (cbm_learner_optimizer_step(c, lrs[step], bc1 ? bc1[step] : 1.0f, bc2 ? bc2[step] : 1.0f, grad_div)) return -1;
       ++step;
     }
   }
@@ -724,7 +693,7 @@ extern "C" int cbm_profile_select(cbm_ctx* c, int32_t kernel_id) {
   }
   c->prof.sel = kernel_id;
   c->prof.n = 0;
-  c->lws.prof = kernel_id >= 0 ? &c->prof : nullptr;
+  c->lws.prof = (kernel_id >= 0 || kernel_id == CBM_PROF_ALL) ? &c->prof : nullptr;
   return 0;
 }
 extern "C" int cbm_profile_read(cbm_ctx* c, double* total_ms, int32_t* count) {
@@ -738,6 +707,20 @@ extern "C" int cbm_profile_read(cbm_ctx* c, double* total_ms, int32_t* count) {
   }
   if (total_ms) *total_ms = tot;
   if (count) *count = c->prof.n;
+  c->prof.n = 0;
+  return 0;
+}
+
+extern "C" int cbm_profile_read_all(cbm_ctx* c, double* total_ms, int32_t* count, int32_t n_ids) {
+  CBM_HIP(hipSetDevice(c->cfg.device));
+  CBM_HIP(hipStreamSynchronize(c->lstream));
+  for (int k = 0; k < n_ids; ++k) { total_ms[k] = 0.0; count[k] = 0; }
+  for (int i = 0; i < c->prof.n; ++i) {
+    float ms = 0.0f;
+    CBM_HIP(hipEventElapsedTime(&ms, c->prof.ev[2 * i], c->prof.ev[2 * i + 1]));
+    const int k = c->prof.kid[i];
+    if (k >= 0 && k < n_ids) { total_ms[k] += ms; count[k] += 1; }
+  }
   c->prof.n = 0;
   return 0;
 }

@@ -1,0 +1,80 @@
+// cbm_ctx.h — the context object behind the opaque cbm_ctx handle (shared by api.hip and comm.hip).
+#pragma once
+#include "cbm_internal.h"
+#include <mutex>
+#include <condition_variable>
+#include <atomic>
+
+#define MAX_SLOTS 16
+#define MAX_RING 4
+#define NPV 3
+#define CBM_COMM_SCRATCH 16
+#define CBM_COMM_PROF_MAX 1024
+
+struct CbmComm {
+  void* comm = nullptr;   // ncclComm_t
+  int nranks = 0, rank = -1;
+  bool loopback = false;  // self-test: nranks identical ranks, all-reduce(SUM) = scale by nranks
+};
+
+struct RingEntry {
+  uint8_t* obs = nullptr;
+  int32_t* actions = nullptr;
+  float *logprobs = nullptr, *values = nullptr, *rewards = nullptr, *logits = nullptr;
+  uint8_t *dones = nullptr, *firststeps = nullptr;
+  int32_t* env_ids = nullptr;   // async rollouts: which env each sample of a row belongs to (naturecnn:355,367)
+  hipEvent_t ready[MAX_SLOTS];
+  hipEvent_t consumed;
+};
+struct Slot {
+  hipStream_t stream = nullptr;
+  NatureWs ws;
+  uint32_t key[2] = {0, 0};
+  int t = 0, rollout = 0, ring = 0, pver = 0;
+  cbm_env_state* env_state = nullptr;
+  uint32_t env_seed = 0;
+  bool env_inited = false;
+  float* stats_dev = nullptr;
+};
+struct cbm_ctx {
+  cbm_config cfg;
+  NatureLayout L;
+  int E, S, Bdev, T, T1, A, MB, nmb, epochs;
+  int asyncB = 0, NE = 0;   // legacy --async-batch-size: rows of asyncB samples drawn from NE envs (0 = synchronous)
+  int64_t P;
+  float *params = nullptr, *grads = nullptr, *opt_m = nullptr, *opt_v = nullptr;
+  float* actor_params[NPV] = {nullptr, nullptr, nullptr};
+  hipEvent_t params_ready[NPV];
+  RingEntry ring[MAX_RING];
+  Slot slots[MAX_SLOTS];
+  hipStream_t lstream = nullptr;
+  NatureWs lws;
+  float* advn = nullptr;     // per-minibatch normalised advantages (async mode, naturecnn:540-541)
+  float *adv = nullptr, *target = nullptr, *next_value = nullptr, *stats_dev = nullptr, *loss_partials = nullptr, *norm_partials = nullptr;
+  int32_t *perm = nullptr, *perm_tmp = nullptr, *impala_idx = nullptr;
+  float* gacc = nullptr;   // MultiSteps running mean (grad_accum_steps > 1)
+  int accum = 1, nmicro = 0;
+  uint64_t* ckeys = nullptr;
+  std::mutex mu;
+  std::condition_variable cv;
+  int committed[MAX_SLOTS];
+  int updates_done = 0;
+  int stat_rows = 0;
+  CbmProf prof;
+  hipEvent_t tail_ev = nullptr, ext_ev = nullptr;   // gradient-tail hand-off to the communication stream
+  // ---- comm.hip: RCCL communicators, the communication stream of the gradient all-reduce, the io stream of shard / parameter peer writes
+  CbmComm comms[CBM_COMM_SLOTS];
+  hipStream_t cstream = nullptr, iostream = nullptr;
+  hipEvent_t bwd_ev = nullptr;
+  std::mutex io_mu;
+  double* comm_scratch = nullptr;
+  bool comm_overlap = true;
+  bool comm_prof_on = false, comm_prof_created = false;
+  int comm_prof_n = 0;
+  hipEvent_t comm_prof_ev[4 * CBM_COMM_PROF_MAX];
+  bool aborted = false;   // cbm_ctx_abort: every blocking wait returns an error from now on
+};
+int cbm_learner_allreduce_grads_impl(cbm_ctx* c, float* grad_div);
+int cbm_learner_allreduce_stats_impl(cbm_ctx* c);
+int cbm_comm_destroy_all(cbm_ctx* c);
+

@@ -809,10 +809,10 @@ void nature_ws_free(NatureWs& ws) {
 template <class P>
 static inline void plaunch(NatureWs& ws, int kid, const P& p, int nz, hipStream_t st) {
   CbmProf* pf = ws.prof;
-  const bool on = pf && pf->sel == kid && pf->n < CBM_PROF_MAX;
+  const bool on = pf && (pf->sel == kid || pf->sel == CBM_PROF_ALL) && pf->n < CBM_PROF_MAX;
   if (on) hipEventRecord(pf->ev[2 * pf->n], st);
   igemm_launch(p, nz, st);
-  if (on) { hipEventRecord(pf->ev[2 * pf->n + 1], st); pf->n += 1; }
+  if (on) { hipEventRecord(pf->ev[2 * pf->n + 1], st); pf->kid[pf->n] = (int8_t)kid; pf->n += 1; }
 }
 // forward GEMMs: fp32 chain (default) or the bf16-MFMA variant when the context was created with forward_bf16
 #ifndef IGEMM_USE_DMA
@@ -824,10 +824,10 @@ static inline void plaunch_fwd(NatureWs& ws, int kid, const P& p, int nz, hipStr
     if constexpr (P::DMA_OK) {
       if (IGEMM_USE_DMA && p.X() >= 1024) {   // learner-size grids: tiles staged by the load unit (igemm_dma_kernel), same bits
         CbmProf* pf = ws.prof;
-        const bool on = pf && pf->sel == kid && pf->n < CBM_PROF_MAX;
+        const bool on = pf && (pf->sel == kid || pf->sel == CBM_PROF_ALL) && pf->n < CBM_PROF_MAX;
         if (on) hipEventRecord(pf->ev[2 * pf->n], st);
         igemm_dma_launch(p, nz, st);
-        if (on) { hipEventRecord(pf->ev[2 * pf->n + 1], st); pf->n += 1; }
+        if (on) { hipEventRecord(pf->ev[2 * pf->n + 1], st); pf->kid[pf->n] = (int8_t)kid; pf->n += 1; }
         return;
       }
     }
@@ -835,10 +835,10 @@ static inline void plaunch_fwd(NatureWs& ws, int kid, const P& p, int nz, hipStr
     return;
   }
   CbmProf* pf = ws.prof;
-  const bool on = pf && pf->sel == kid && pf->n < CBM_PROF_MAX;
+  const bool on = pf && (pf->sel == kid || pf->sel == CBM_PROF_ALL) && pf->n < CBM_PROF_MAX;
   if (on) hipEventRecord(pf->ev[2 * pf->n], st);
   igemm_bf16_launch(p, nz, st);
-  if (on) { hipEventRecord(pf->ev[2 * pf->n + 1], st); pf->n += 1; }
+  if (on) { hipEventRecord(pf->ev[2 * pf->n + 1], st); pf->kid[pf->n] = (int8_t)kid; pf->n += 1; }
 }
 // backward GEMM launch: fp32 MFMA (default) or, with cbm_config.backward_split = 2 / 3, the split-bf16 kernel
 #ifndef DGRAD_PF2
@@ -853,10 +853,10 @@ static inline void plaunch_bwd(NatureWs& ws, int kid, const P& p, int nz, hipStr
       const int bit = kid == K_DENSE_DGRAD ? 1 : (kid == K_CONV3_DGRAD ? 2 : (kid == K_CONV2_DGRAD ? 4 : 0));
       if (DGRAD_PF2 & bit) {
         CbmProf* pf = ws.prof;
-        const bool on = pf && pf->sel == kid && pf->n < CBM_PROF_MAX;
+        const bool on = pf && (pf->sel == kid || pf->sel == CBM_PROF_ALL) && pf->n < CBM_PROF_MAX;
         if (on) hipEventRecord(pf->ev[2 * pf->n], st);
         igemm_pf2_launch(p, nz, st);
-        if (on) { hipEventRecord(pf->ev[2 * pf->n + 1], st); pf->n += 1; }
+        if (on) { hipEventRecord(pf->ev[2 * pf->n + 1], st); pf->kid[pf->n] = (int8_t)kid; pf->n += 1; }
         return;
       }
     }
@@ -864,11 +864,11 @@ static inline void plaunch_bwd(NatureWs& ws, int kid, const P& p, int nz, hipStr
     return;
   }
   CbmProf* pf = ws.prof;
-  const bool on = pf && pf->sel == kid && pf->n < CBM_PROF_MAX;
+  const bool on = pf && (pf->sel == kid || pf->sel == CBM_PROF_ALL) && pf->n < CBM_PROF_MAX;
   if (on) hipEventRecord(pf->ev[2 * pf->n], st);
   if constexpr (P::A_RX) igemm_split_wgrad_launch<P, 2>(p, nz, st);
   else { if (ws.bwd_split == 2) igemm_split_launch<P, 2>(p, nz, st); else igemm_split_launch<P, 3>(p, nz, st); }
-  if (on) { hipEventRecord(pf->ev[2 * pf->n + 1], st); pf->n += 1; }
+  if (on) { hipEventRecord(pf->ev[2 * pf->n + 1], st); pf->kid[pf->n] = (int8_t)kid; pf->n += 1; }
 }
 #ifndef FWD_PF2
 #define FWD_PF2 3   // learner-size conv2 / conv3 forward on the two-chunk prefetch kernel (bit-identical to igemm_kernel)
@@ -896,10 +896,10 @@ static inline void plaunch_bwd(NatureWs& ws, int kid, const P& p, int nz, hipStr
 template <class F>
 static inline void plaunch_fn(NatureWs& ws, int kid, hipStream_t st, F&& launch) {
   CbmProf* pf = ws.prof;
-  const bool on = pf && pf->sel == kid && pf->n < CBM_PROF_MAX;
+  const bool on = pf && (pf->sel == kid || pf->sel == CBM_PROF_ALL) && pf->n < CBM_PROF_MAX;
   if (on) hipEventRecord(pf->ev[2 * pf->n], st);
   launch();
-  if (on) { hipEventRecord(pf->ev[2 * pf->n + 1], st); pf->n += 1; }
+  if (on) { hipEventRecord(pf->ev[2 * pf->n + 1], st); pf->kid[pf->n] = (int8_t)kid; pf->n += 1; }
 }
 using T128x32 = IgemmTile<128, 32, 32, 4, 1>;
 using T128x32k16 = IgemmTile<128, 32, 16, 4, 1>;

@@ -1,8 +1,8 @@
 """Process fan-out for split actor/learner topologies, so that the reference's own command lines work unchanged.
 
 The reference runs `--actor-device-ids 0 --learner-device-ids 1 2 3` inside ONE JAX process (README.md:62) and scales out with one such
-process per group (`--distributed` + the SLURM variables, README.md:71-72).  Here every GPU is its own process (cleanba_amd.topology), so
-the entry points call `maybe_fan_out`: a process that was asked for a split topology and is not already a per-GPU worker spawns its group's
+process per group (`--distributed` + the SLURM variables, README.md:71-72).  Here every ROLE is its own process (cleanba_amd.topology), so
+the entry points call `maybe_fan_out`: a process that was asked for a split topology and is not already a role worker spawns its group's
 G = len(actor ids) + len(learner ids) workers — RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* in torchrun's convention, LOCAL_RANK = the GPU
 index from the id lists (relative to HIP_/CUDA_VISIBLE_DEVICES, like the reference) — and waits for them.  With `--distributed` the parent's
 SLURM task index selects the group: global rank = SLURM_PROCID * G + position, world = SLURM_NTASKS * G.
@@ -16,6 +16,7 @@ from . import topology
 
 def plan(args, environ):
     """Environment dicts of the workers this process must spawn, or None when it is a worker itself / no split was requested."""
+    topology.validate(args)      # unsupported id lists fail here, before anything is spawned
     if not topology.is_split(args):
         return None
     if "RANK" in environ and "WORLD_SIZE" in environ:      # started by torchrun or by the fan-out below
@@ -47,7 +48,7 @@ def maybe_fan_out(args, module, argv):
         return None
     cmd = [sys.executable, "-m", module] + list(sys.argv[1:] if argv is None else argv)
     if "--distributed" not in cmd:
-        cmd.append("--distributed")          # the workers always rendezvous (torch.distributed)
+        cmd.append("--distributed")          # the workers always rendezvous (cleanba_amd.topology.Rendezvous)
     procs = [subprocess.Popen(cmd, env=e) for e in envs]
     codes = [p.wait() for p in procs]
     return max(abs(c) for c in codes)

@@ -51,8 +51,20 @@ SYMBOLS = [
     "cbm_impala_loss_grad", "cbm_adam_step", "cbm_rmsprop_step", "cbm_synth_env_reset_host", "cbm_synth_env_reset_host_games", "cbm_synth_env_step_host", "cbm_actor_env_reset_device_games",
     "cbm_actor_env_reset_device", "cbm_profile_select", "cbm_profile_read", "cbm_ingest_begin", "cbm_ingest_commit",
     "cbm_params_publish_external", "cbm_actor_stream", "cbm_actor_ring_index", "cbm_actor_step_async", "cbm_gae_async", "cbm_mb_advnorm",
-    "cbm_synth_env_step_host_ids", "cbm_learner_grad_tail_offset", "cbm_learner_stream_wait_tail", "cbm_learner_wait_stream", "cbm_vtrace",
+    "cbm_synth_env_step_host_ids", "cbm_learner_grad_tail_offset", "cbm_vtrace", "cbm_comm_init_loopback",
+    "cbm_comm_load", "cbm_comm_unique_id", "cbm_comm_init", "cbm_comm_size", "cbm_comm_allreduce_f64", "cbm_comm_barrier",
+    "cbm_learner_allreduce_grads", "cbm_comm_profile", "cbm_comm_profile_read", "cbm_ipc_export", "cbm_ipc_open", "cbm_ipc_close",
+    "cbm_actor_ship_shard", "cbm_io_sync", "cbm_params_push", "cbm_params_mark_published", "cbm_ctx_abort", "cbm_profile_read_all",
 ]
+
+COMM_LEARNERS, COMM_WORLD = 0, 1
+COMM_ID_BYTES, IPC_HANDLE_BYTES = 128, 64
+RING_FIELDS = ("obs", "actions", "logprobs", "values", "rewards", "dones", "firststeps", "logits")
+
+
+class PeerRing(C.Structure):
+    """cbm_peer_ring: device pointers of one ring entry of the destination context (None = field not shipped)."""
+    _fields_ = [(f, C.c_void_p) for f in RING_FIELDS]
 
 _lib = None
 
@@ -64,11 +76,15 @@ def build(force=False):
     return SO_PATH
 
 
+_TORCH_RCCL = None   # torch's bundled librccl.so (bound by cbm_comm_load so the process holds ONE HIP runtime and ONE RCCL)
+
+
 def _share_hip_runtime_with_torch():
     """PyTorch-ROCm wheels bundle their own libamdhip64.so / libhsa-runtime64.so (torch/lib, DT_NEEDED without the .7 suffix), which the
     loader does not unify with /opt/rocm's copy when OUR library is loaded first: the process then holds two HIP runtimes and torch finds
     "No HIP GPUs".  The distributed paths share streams and buffers with torch (RCCL all-reduce, shard sends), so bind to torch's runtime
     up front — by path, without importing torch.  CBM_SYSTEM_HIP=1 keeps /opt/rocm's runtime (torch-free deployments)."""
+    global _TORCH_RCCL
     if os.environ.get("CBM_SYSTEM_HIP") == "1":
         return
     import importlib.util
@@ -77,6 +93,8 @@ def _share_hip_runtime_with_torch():
         p = os.path.join(loc, "lib", "libamdhip64.so")
         if os.path.exists(p):
             C.CDLL(p, mode=C.RTLD_GLOBAL)
+            r = os.path.join(loc, "lib", "librccl.so")
+            _TORCH_RCCL = r if os.path.exists(r) else None
             return
 
 
@@ -97,6 +115,7 @@ def load():
     lib.cbm_learner_stream.argtypes = [C.c_void_p]
     lib.cbm_actor_stream.restype = C.c_void_p
     lib.cbm_actor_stream.argtypes = [C.c_void_p, C.c_int32]
+    lib.cbm_comm_load.argtypes = [C.c_char_p]
     _lib = lib
     return lib
 
@@ -272,6 +291,11 @@ class Context:
         _chk(self.lib.cbm_profile_read(self.h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    def profile_read_all(self, n_ids=12):
+        ms, n = np.zeros(n_ids, np.float64), np.zeros(n_ids, np.int32)
+        _chk(self.lib.cbm_profile_read_all(self.h, _p(ms), _p(n), int(n_ids)))
+        return ms, n
+
     # ---- split topologies
     def ingest_begin(self, slot):
         r = C.c_int32()
@@ -289,6 +313,73 @@ class Context:
 
     def actor_ring_index(self, slot):
         return int(self.lib.cbm_actor_ring_index(self.h, int(slot)))
+
+    def abort(self):
+        """Every blocking wait of this context fails from now on (a host thread died: do not hang the others)."""
+        if self.h:
+            self.lib.cbm_ctx_abort(self.h)
+
+    # ---- collectives among the learner GPUs (RCCL behind the C ABI)
+    def comm_init(self, which, uid, nranks, rank):
+        if _TORCH_RCCL:
+            _chk(self.lib.cbm_comm_load(_TORCH_RCCL.encode()))
+        buf = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(bytes(uid))
+        _chk(self.lib.cbm_comm_init(self.h, int(which), buf, int(nranks), int(rank)))
+
+    def comm_init_loopback(self, nranks, which=COMM_LEARNERS):
+        _chk(self.lib.cbm_comm_init_loopback(self.h, int(which), int(nranks)))
+
+    def comm_size(self, which=COMM_LEARNERS):
+        return int(self.lib.cbm_comm_size(self.h, int(which)))
+
+    def comm_allreduce_f64(self, values, op="sum", which=COMM_LEARNERS):
+        a = np.ascontiguousarray(values, np.float64).copy()
+        _chk(self.lib.cbm_comm_allreduce_f64(self.h, int(which), _p(a), int(a.size), {"sum": 0, "max": 1, "min": 2}[op]))
+        return a
+
+    def comm_barrier(self, which=COMM_LEARNERS):
+        _chk(self.lib.cbm_comm_barrier(self.h, int(which)))
+
+    def learner_allreduce_grads(self):
+        d = C.c_float()
+        _chk(self.lib.cbm_learner_allreduce_grads(self.h, C.byref(d)))
+        return d.value
+
+    def comm_profile(self, on=True):
+        _chk(self.lib.cbm_comm_profile(self.h, int(bool(on))))
+
+    def comm_profile_read(self):
+        a, b, n = C.c_double(), C.c_double(), C.c_int32()
+        _chk(self.lib.cbm_comm_profile_read(self.h, C.byref(a), C.byref(b), C.byref(n)))
+        return a.value, b.value, n.value
+
+    # ---- peer writes (split topologies)
+    def ipc_export(self, name, ring=0):
+        h = (C.c_uint8 * IPC_HANDLE_BYTES)()
+        _chk(self.lib.cbm_ipc_export(self.h, name.encode(), int(ring), h))
+        return bytes(h)
+
+    def ipc_open(self, handle):
+        p = C.c_void_p()
+        buf = (C.c_uint8 * IPC_HANDLE_BYTES).from_buffer_copy(bytes(handle))
+        _chk(self.lib.cbm_ipc_open(self.h, buf, C.byref(p)))
+        return p.value
+
+    def ipc_close(self, ptr):
+        _chk(self.lib.cbm_ipc_close(self.h, C.c_void_p(ptr)))
+
+    def actor_ship_shard(self, slot, ring, li, n_learners, peer_ring, dst_cols, dst_col0):
+        _chk(self.lib.cbm_actor_ship_shard(self.h, int(slot), int(ring), int(li), int(n_learners), C.byref(peer_ring), int(dst_cols), int(dst_col0)))
+
+    def io_sync(self):
+        _chk(self.lib.cbm_io_sync(self.h))
+
+    def params_push(self, peer_versions):
+        arr = (C.c_void_p * 3)(*[C.c_void_p(p) for p in peer_versions])
+        _chk(self.lib.cbm_params_push(self.h, arr))
+
+    def params_mark_published(self):
+        _chk(self.lib.cbm_params_mark_published(self.h))
 
     # ---- learner
     def learner_wait(self):
@@ -319,12 +410,6 @@ class Context:
 
     def grad_tail_offset(self):
         return int(self.lib.cbm_learner_grad_tail_offset(self.h))
-
-    def learner_stream_wait_tail(self, stream_handle):
-        _chk(self.lib.cbm_learner_stream_wait_tail(self.h, C.c_void_p(int(stream_handle))))
-
-    def learner_wait_stream(self, stream_handle):
-        _chk(self.lib.cbm_learner_wait_stream(self.h, C.c_void_p(int(stream_handle))))
 
     def learner_accumulate(self, mini_step, grad_div=1.0):
         _chk(self.lib.cbm_learner_accumulate(self.h, int(mini_step), C.c_float(grad_div)))

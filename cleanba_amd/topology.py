@@ -1,149 +1,237 @@
-"""Split actor / learner topologies (`--actor-device-ids 0 --learner-device-ids 1 2 3`, README.md:62; with `--distributed`,
-several such groups, benchmark.sh:80) as one process per GPU.
+"""Split actor / learner topologies (`--actor-device-ids 0 --learner-device-ids 1 2 3`, README.md:62; `--learner-device-ids 0 1` sharing
+GPU 0 with the actor, README.md:58; two actor GPUs feeding two learner GPUs, benchmark.sh:90; several such groups with `--distributed`,
+benchmark.sh:80) as one process per ROLE: every entry of the two id lists is a process bound to that GPU (an actor and a learner may
+share one GPU).
 
 Reference semantics kept (ppo:97-100, 358-363, 435-439, 587, 628, 721-725):
-  * each actor slot's [T+1, E] rollout is cut along the env axis into L contiguous shards; learner l receives columns
-    [l*E/L, (l+1)*E/L) of every slot and hstacks them slot-major;
+  * each actor thread's [T+1, E] rollout is cut along the env axis into L contiguous shards; learner l receives columns
+    [l*E/L, (l+1)*E/L) of every (actor device, thread) and hstacks them device-thread-major;
   * GAE / adv-norm / shuffle / minibatching are local to the shard; gradients are averaged over ALL learner ranks of ALL
-    groups once per minibatch (one flat all-reduce);
-  * learner 0 of each group sends the new parameters to its actor after every update.
-What replaces `jax.device_put_sharded` / `device_put`: point-to-point sends of the shard (RCCL over xGMI on GPUs, gloo in
-the CPU tests) straight from / into the HBM rings, ordered on the actor slot's stream.
+    groups once per minibatch;
+  * learner 0 of each group hands the new parameters to its actors after every update.
+What replaces `jax.device_put_sharded` / `device_put`: the actor WRITES each shard straight into the learner's HBM ring through a HIP IPC
+mapping (one strided 2-D copy per field on a side stream — xGMI peer writes, no staging), learner 0 writes parameters straight into the
+actors' version buffers the same way, and only "it has landed" travels as a host message (cleanba_amd.topology.Rendezvous, a TCP
+key-value store) — the points where the reference blocks on queue.put / queue.get.
 
-Rank layout: group g occupies ranks [g*G, (g+1)*G), G = len(actor_device_ids) + len(learner_device_ids); inside a group
-the first len(actor_device_ids) ranks are actors, the rest learners, and local rank == position in that list.
+Rank layout: group g occupies ranks [g*G, (g+1)*G), G = len(actor_device_ids) + len(learner_device_ids); inside a group the actor
+roles come first, then the learners, and LOCAL_RANK == the GPU id from the list.
 """
+import datetime
+import pickle
 import queue
 import threading
-
-import numpy as np
+import time
 
 PPO_FIELDS = ("obs", "actions", "logprobs", "values", "rewards", "dones")
 IMPALA_FIELDS = ("obs", "actions", "logits", "rewards", "dones", "firststeps")
 
 
 def is_split(args):
-    return sorted(args.actor_device_ids) != sorted(args.learner_device_ids)
+    """One process does everything only for the a0-l0 shape; every other pair of id lists is a set of role processes."""
+    return not (len(args.actor_device_ids) == 1 and list(args.actor_device_ids) == list(args.learner_device_ids))
+
+
+def validate(args):
+    """Fail before any worker is spawned, with the supported shapes spelled out."""
+    a, l = list(args.actor_device_ids), list(args.learner_device_ids)
+    if not a or not l or len(set(a)) != len(a) or len(set(l)) != len(l) or min(a + l) < 0:
+        raise SystemExit(f"--actor-device-ids {a} / --learner-device-ids {l}: each list needs distinct, non-negative GPU ids")
+    if args.local_num_envs % len(l):
+        raise SystemExit("local_num_envs must be divisible by len(learner_device_ids) (ppo:412)")
+    if getattr(args, "async_batch_size", 0) and is_split(args):
+        raise SystemExit("--async-batch-size runs a0-l0 only (naturecnn:105)")
 
 
 class Layout:
     def __init__(self, args, world_size, rank):
+        validate(args)
         self.na, self.nl = len(args.actor_device_ids), len(args.learner_device_ids)
-        assert self.na == 1, "one actor device per group (the reference's published topologies: a0-l1, a0-l1,2, a0-l1,2,3)"
-        assert not set(args.actor_device_ids) & set(args.learner_device_ids), "split topology needs disjoint device lists"
         self.G = self.na + self.nl
-        assert world_size % self.G == 0, f"world_size {world_size} must be a multiple of {self.G} (actor + learner GPUs per group)"
+        if world_size % self.G:
+            raise SystemExit(f"world_size {world_size} must be a multiple of {self.G} (actor + learner roles per group)")
         self.groups = world_size // self.G
         self.group, self.pos = rank // self.G, rank % self.G
         self.is_actor = self.pos < self.na
+        self.actor_index = self.pos if self.is_actor else -1
         self.learner_index = self.pos - self.na
         base = self.group * self.G
-        self.actor_rank = base
+        self.actor_ranks = [base + i for i in range(self.na)]
         self.learner_ranks = [base + self.na + i for i in range(self.nl)]
         self.all_learner_ranks = [g * self.G + self.na + i for g in range(self.groups) for i in range(self.nl)]
         self.device_id = (list(args.actor_device_ids) + list(args.learner_device_ids))[self.pos]
+        self.threads = args.num_actor_threads
+        self.ports = self.na * self.threads          # ingest ports of a learner = (actor device, thread) pairs, device-major (ppo:668-686)
+        self.shard_envs = args.local_num_envs // self.nl
 
 
-class Groups:
-    """Process groups of a split run.  Every rank builds them in the same order (torch.distributed requirement).  Rollout shards and
-    parameters travel on DIFFERENT communicators: with `--concurrency` the actor is sending rollout u+1 while learner 0 is sending
-    parameters u the other way, and two in-flight point-to-point kernels on one RCCL communicator would deadlock."""
+class Rendezvous:
+    """Host control plane of a multi-process run: torch's TCPStore (a C++ key-value server on rank 0; no process group, no GPU).  Carries
+    the RCCL unique id, the IPC handles and the 'landed' notifications.  `get` polls so that a failed peer (which posts 'abort') or a
+    vanished server ends the wait instead of hanging it."""
 
-    def __init__(self, dist, lay):
-        self.learners = dist.new_group(ranks=lay.all_learner_ranks)
-        self.data, self.params = {}, {}
-        for g in range(lay.groups):
-            a = g * lay.G
-            for li in range(lay.nl):
-                self.data[(g, li)] = dist.new_group(ranks=[a, a + lay.na + li])
-            self.params[g] = dist.new_group(ranks=[a, a + lay.na])
+    def __init__(self, world, rank, addr, port, timeout_s=1800.0):
+        from torch.distributed import TCPStore
+        self.world, self.rank, self.timeout_s = world, rank, timeout_s
+        self.store = TCPStore(addr, int(port), world, rank == 0, timeout=datetime.timedelta(seconds=timeout_s), wait_for_workers=False)
+
+    def put(self, key, value=b"1"):
+        self.store.set(key, value)
+
+    def get(self, key, take=False):
+        """Blocks until `key` exists.  Polls with non-blocking checks (50 us backing off to 1 ms) instead of a blocking wait, so that a failed
+        peer's 'abort' key or a vanished server ends the wait, and the 'landed' notifications of the split path cost well under a millisecond."""
+        t0 = time.time()
+        nap, since_abort_check = 5e-5, 0.0
+        while not self.store.check([key]):
+            time.sleep(nap)
+            since_abort_check += nap
+            nap = min(nap * 1.5, 1e-3)
+            if since_abort_check >= 1.0:
+                since_abort_check = 0.0
+                if self.store.check(["abort"]):
+                    raise RuntimeError(f"rank {self.rank}: a peer aborted while this rank waited for '{key}'")
+                if time.time() - t0 > self.timeout_s:
+                    raise TimeoutError(f"rank {self.rank}: '{key}' did not arrive within {self.timeout_s} s")
+        v = self.store.get(key)
+        if take:
+            self.store.delete_key(key)
+        return v
+
+    def abort(self):
+        try:
+            self.store.set("abort", b"1")
+        except Exception:  # noqa: BLE001
+            pass
+
+    def barrier(self, tag):
+        n = self.store.add(f"barrier/{tag}", 1)
+        if n == self.world:
+            self.put(f"barrier/{tag}/go")
+        self.get(f"barrier/{tag}/go")
+        # rank 0 hosts the store: it may only leave (and possibly exit) once every other rank has finished talking to it
+        if self.rank != 0:
+            self.store.add(f"barrier/{tag}/ack", 1)
+        else:
+            t0 = time.time()
+            while self.store.add(f"barrier/{tag}/ack", 0) < self.world - 1:
+                time.sleep(1e-3)
+                if time.time() - t0 > 60.0:
+                    break   # a peer died after the barrier: nothing left to protect
+
+    def share(self, key, make, owner_rank):
+        """The owner computes a value once, everybody receives it."""
+        if self.rank == owner_rank:
+            v = make()
+            self.put(key, v)
+            return v
+        return self.get(key)
+
+
+def setup_learner_comm(engine, rdv, ranks, rank, tag="learners"):
+    """The communicator of the gradient / statistics all-reduce over `ranks` (pmap's device list, ppo:435-439,656-660)."""
+    if len(ranks) < 2 and not engine.wants_comm_at_world_one():
+        return
+    uid = rdv.share(f"comm/{tag}/uid", engine.comm_unique_id, ranks[0]) if len(ranks) > 1 else engine.comm_unique_id()
+    engine.comm_init(uid, len(ranks), ranks.index(rank))
 
 
 class ActorShipper:
-    """Sends every committed rollout of every slot to the group's learners, in (update, slot) order, on the engine's io stream so that
-    the slot's own stream keeps stepping the next rollout while the shards are in flight."""
+    """Actor role: writes every committed rollout of every local thread into the group's learners, in (update, thread) order, on the engine's
+    io stream — the thread's own stream keeps stepping the next rollout meanwhile — and posts 'landed' once the copies are complete."""
 
-    def __init__(self, engine, layout, groups, args, algo, dist, num_rollouts):
-        self.engine, self.lay, self.groups, self.args, self.dist, self.n = engine, layout, groups, args, dist, num_rollouts
+    def __init__(self, engine, layout, rdv, args, algo, num_rollouts):
+        self.engine, self.lay, self.rdv, self.n = engine, layout, rdv, num_rollouts
         self.fields = PPO_FIELDS if algo == "ppo" else IMPALA_FIELDS
-        self.slots = args.num_actor_threads * len(args.actor_device_ids)
-        self.q = [queue.Queue() for _ in range(self.slots)]
+        self.q = [queue.Queue() for _ in range(layout.threads)]
         self.thread = threading.Thread(target=self._run, daemon=True)
         self.error = None
+        g = layout.group
+        # map every learner's ring (ppo:358-363's device_put_sharded targets)
+        self.peer = [engine.open_peer_ring(pickle.loads(rdv.get(f"g{g}/ring/{li}"))) for li in range(layout.nl)]
 
     def on_commit(self, slot, update, ring_index):
-        """Called by the slot's rollout thread right after cbm_actor_commit: the fence marks the end of this rollout's writes."""
-        self.q[slot].put((update, ring_index, self.engine.actor_fence(slot)))
+        """Called by the thread's rollout loop right after cbm_actor_commit (the commit event orders the copies after the rollout)."""
+        self.q[slot].put((update, ring_index))
 
     def _run(self):
         try:
-            E, L = self.args.local_num_envs, self.lay.nl
-            El = E // L
+            lay = self.lay
+            cols = lay.ports * lay.shard_envs
             for u in range(1, self.n + 1):
-                for s in range(self.slots):
-                    upd, ring, fence = self.q[s].get()
+                for s in range(lay.threads):
+                    upd, ring = self.q[s].get()
                     assert upd == u
-                    t = self.engine.ring_tensors(ring)
-                    with self.engine.io_context():
-                        self.engine.io_wait(fence)
-                        for li, dst in enumerate(self.lay.learner_ranks):
-                            lo = s * E + li * El
-                            for f in self.fields:
-                                self.dist.send(t[f][:, lo:lo + El].contiguous(), dst=dst, group=self.groups.data[(self.lay.group, li)])
-                        self.engine.io_sync()
+                    port = lay.actor_index * lay.threads + s
+                    for li in range(lay.nl):
+                        self.engine.actor_ship_shard(s, ring, li, lay.nl, self.peer[li][ring], cols, port * lay.shard_envs)
+                    self.engine.io_sync()
+                    for li in range(lay.nl):
+                        self.rdv.put(f"g{lay.group}/shard/{li}/{u}/{port}", str(ring).encode())
         except BaseException as e:  # noqa: BLE001
             self.error = e
+            self.rdv.abort()
+            self.engine.abort()
             raise
 
 
 class ParamReceiver:
-    """Actor side of ppo:721-725: a new parameter version arrives from learner 0 after every update."""
+    """Actor role, ppo:721-725: learner 0 has written a new parameter version into this actor's version buffer."""
 
-    def __init__(self, engine, layout, groups, dist, num_updates):
-        self.engine, self.lay, self.groups, self.dist, self.n = engine, layout, groups, dist, num_updates
+    def __init__(self, engine, layout, rdv, num_updates):
+        self.engine, self.lay, self.rdv, self.n = engine, layout, rdv, num_updates
         self.thread = threading.Thread(target=self._run, daemon=True)
         self.error = None
+        rdv.put(f"g{layout.group}/aparams/{layout.actor_index}", pickle.dumps(engine.export_actor_params()))
 
     def _run(self):
         try:
-            with self.engine.io_context():
-                buf = self.engine.params_staging_tensor()
-                for _ in range(self.n):
-                    self.dist.recv(buf, src=self.lay.learner_ranks[0], group=self.groups.params[self.lay.group])
-                    self.engine.io_sync()
-                    self.engine.params_publish_external_tensor(buf)
+            for v in range(1, self.n + 1):
+                self.rdv.get(f"g{self.lay.group}/params/{self.lay.actor_index}/{v}", take=True)
+                self.engine.params_mark_published()
         except BaseException as e:  # noqa: BLE001
             self.error = e
+            self.rdv.abort()
+            self.engine.abort()
             raise
 
 
 class LearnerReceiver:
-    """Learner side of ppo:358-363 (device_put_sharded): fills one ring entry per slot with this learner's column shard, running ahead
-    of the update loop by up to ring_depth rollouts (cbm_ingest_begin blocks when the ring is full)."""
+    """Learner role: one ring entry per rollout, one ingest port per (actor device, thread); an entry is handed to the update loop when
+    every port's shard has landed.  Runs ahead of the update loop by up to ring_depth rollouts (cbm_ingest_begin blocks on a full ring)."""
 
-    def __init__(self, engine, layout, groups, args, algo, dist, num_rollouts):
-        self.engine, self.lay, self.groups, self.args, self.dist, self.n = engine, layout, groups, args, dist, num_rollouts
+    def __init__(self, engine, layout, rdv, args, algo, num_rollouts):
+        self.engine, self.lay, self.rdv, self.n = engine, layout, rdv, num_rollouts
         self.fields = PPO_FIELDS if algo == "ppo" else IMPALA_FIELDS
-        self.slots = args.num_actor_threads * len(args.actor_device_ids)
         self.thread = threading.Thread(target=self._run, daemon=True)
         self.error = None
+        rdv.put(f"g{layout.group}/ring/{layout.learner_index}", pickle.dumps(engine.export_ring(self.fields)))
 
     def _run(self):
         try:
-            El = self.args.local_num_envs // self.lay.nl
-            grp = self.groups.data[(self.lay.group, self.lay.learner_index)]
-            for _ in range(self.n):
-                for s in range(self.slots):
-                    ring = self.engine.ingest_begin(s)
-                    t = self.engine.ring_tensors(ring)
-                    with self.engine.io_context():
-                        for f in self.fields:
-                            dst = t[f][:, s * El:(s + 1) * El]
-                            tmp = dst.contiguous()
-                            self.dist.recv(tmp, src=self.lay.actor_rank, group=grp)
-                            dst.copy_(tmp)
-                        self.engine.io_sync()
-                    self.engine.ingest_commit(s)
+            lay = self.lay
+            for u in range(1, self.n + 1):
+                for port in range(lay.ports):
+                    ring = self.engine.ingest_begin(port)
+                    got = int(self.rdv.get(f"g{lay.group}/shard/{lay.learner_index}/{u}/{port}", take=True))
+                    assert got == ring, f"actor wrote ring entry {got}, learner expected {ring}"
+                    self.engine.ingest_commit(port)
         except BaseException as e:  # noqa: BLE001
             self.error = e
+            self.rdv.abort()
+            self.engine.abort()
             raise
+
+
+class ParamSender:
+    """Learner 0: after every update, write the parameters into every actor of the group and tell it (ppo:721-725)."""
+
+    def __init__(self, engine, layout, rdv):
+        self.engine, self.lay, self.rdv = engine, layout, rdv
+        g = layout.group
+        self.peers = [engine.open_peer_params(pickle.loads(rdv.get(f"g{g}/aparams/{ai}"))) for ai in range(layout.na)]
+
+    def __call__(self, version):
+        for ai, peer in enumerate(self.peers):
+            self.engine.params_push(peer)
+            self.rdv.put(f"g{self.lay.group}/params/{ai}/{version}")

@@ -5,7 +5,7 @@ driving the HIP library through its C ABI (cleanba_amd.lib.Context).
 What stays the same as the reference: CLI flags, thread topology (one host thread per actor slot, learner on
 the main thread), step order, storage fields, `global_step` accounting (ppo:311), the `SPS:` print (ppo:383),
 scalar names, policy-version skew with --concurrency (ppo:287-304), per-minibatch gradient
-all-reduce across learner processes (pmean, ppo:628) — here RCCL through torch.distributed.
+all-reduce across learner processes (pmean, ppo:628) — here RCCL behind the C ABI (csrc/comm.hip), rendezvous over a TCP store.
 What is different by design: rollout data never leaves HBM (ring slots instead of Queue payloads), and with
 `--env-backend device` the env itself steps on the GPU so a whole rollout is enqueued without host syncs.
 """
@@ -73,14 +73,18 @@ def make_config(args, algo):
     return cfg
 
 
-def rollout(key, args, algo, engine, writer, device_thread_id, world_size, process_index, stop_event, errors, on_commit=None):
-    """One actor slot.  Mirrors rollout() ppo:226-406 / impala:268-446."""
+def rollout(key, args, algo, engine, writer, slot, world_size, process_index, stop_event, errors, on_commit=None, device_thread_id=None):
+    """One actor thread.  Mirrors rollout() ppo:226-406 / impala:268-446.  `slot` is the thread's slot in this process's context,
+    `device_thread_id` its index among ALL actor threads of the group (d_idx * num_actor_threads + thread_id, ppo:680), which seeds its envs."""
     try:
-        _rollout(key, args, algo, engine, writer, device_thread_id, world_size, process_index, stop_event, on_commit)
+        _rollout(key, args, algo, engine, writer, slot, world_size, process_index, stop_event, on_commit,
+                 slot if device_thread_id is None else device_thread_id)
     except Exception as e:  # surface thread failures in the learner loop instead of hanging it
-        errors.append(e)
-        stop_event.set()
-        raise
+        if not stop_event.is_set():   # (after the stop the aborted context makes the blocked begin_rollout fail on purpose)
+            errors.append(e)
+            stop_event.set()
+            engine.abort()            # the learner blocked in cbm_learner_wait returns with an error instead of waiting forever
+            raise
 
 
 def _rollout_async(key, args, engine, writer, slot, world_size, process_index, stop_event):
@@ -153,12 +157,12 @@ def _rollout_async(key, args, engine, writer, slot, world_size, process_index, s
                 writer.add_scalar(tag, val, global_step)
 
 
-def _rollout(key, args, algo, engine, writer, slot, world_size, process_index, stop_event, on_commit=None):
+def _rollout(key, args, algo, engine, writer, slot, world_size, process_index, stop_event, on_commit=None, device_thread_id=0):
     if getattr(args, "async_batch_size", 0):
         return _rollout_async(key, args, engine, writer, slot, world_size, process_index, stop_event)
     len_actor_device_ids = len(args.actor_device_ids)
     E = args.local_num_envs
-    env_seed = args.seed + (0 if args.same_env_seed_all_ranks else process_index) + slot  # ppo:238
+    env_seed = args.seed + (0 if args.same_env_seed_all_ranks else process_index) + device_thread_id  # ppo:238
     device_env = args.env_backend == "device"
     engine.actor_set_key(slot, key)
     if device_env:
@@ -271,48 +275,6 @@ def _rollout(key, args, algo, engine, writer, slot, world_size, process_index, s
                                                        (time.time() - update_time_start)), global_step)
 
 
-class GradAllReducer:
-    """pmean(grads) over all learner processes (ppo:628) = all-reduce(SUM) of the library's flat gradient buffer, divided by the world
-    size inside the optimizer kernel.  RCCL via torch.distributed on the HIP engine, gloo on CPU in tests.
-
-    On the HIP engine the all-reduce is split in two so that most of it hides under the backward pass: the gradient is produced from the
-    back, and the tail [grad_tail_offset, P) — dense layer + heads, 95 % of the bytes — is final long before the conv kernels are done.
-    `cbm_learner_minibatch_grad` only enqueues work, so by the time this is called the GPU is still inside the backward pass: the tail is
-    all-reduced on a communication stream that waits for the library's tail event, the small head on the learner stream after the
-    backward pass, and the learner stream joins the communication stream before the optimizer step.  `overlap=False` (or an engine without
-    the hooks) gives the single flat all-reduce."""
-
-    def __init__(self, engine, world_size, group=None, dist_module=None, overlap=None, active=None):
-        self.engine, self.world, self.group = engine, world_size, group
-        self.active = world_size > 1 if active is None else bool(active)   # active=True at world 1: exercise the path on one GPU
-        self.tensor = engine.grads_tensor() if self.active else None
-        self.dist = dist_module
-        want = os.environ.get("CBM_ALLREDUCE_OVERLAP", "1") != "0" if overlap is None else overlap
-        self.overlap = bool(want and self.active and hasattr(engine, "learner_stream_wait_tail"))
-        if self.overlap:
-            import torch
-            self.comm = torch.cuda.Stream(device=self.tensor.device)
-            self.tail = engine.grad_tail_offset()
-
-    def __call__(self):
-        if self.active:
-            dist = self.dist
-            if dist is None:
-                import torch.distributed as dist
-            if self.overlap:
-                import torch
-                with torch.cuda.stream(self.comm):
-                    self.engine.learner_stream_wait_tail(self.comm.cuda_stream)
-                    dist.all_reduce(self.tensor[self.tail:], op=dist.ReduceOp.SUM, group=self.group)
-                with self.engine.stream_context():
-                    dist.all_reduce(self.tensor[:self.tail], op=dist.ReduceOp.SUM, group=self.group)
-                self.engine.learner_wait_stream(self.comm.cuda_stream)
-            else:
-                with self.engine.stream_context():
-                    dist.all_reduce(self.tensor, op=dist.ReduceOp.SUM, group=self.group)
-        return float(self.world)  # grad_div: the mean is taken inside the optimizer kernel
-
-
 def schedules(args, algo, opt_count, n_steps):
     """lr / bias corrections for optimizer steps opt_count .. opt_count+n_steps-1 (inject_hyperparams count)."""
     spu = args.num_minibatches * (args.update_epochs if algo == "ppo" else 1)
@@ -326,16 +288,17 @@ def schedules(args, algo, opt_count, n_steps):
     return np.array(lrs, np.float32), np.array(b1s, np.float32), np.array(b2s, np.float32)
 
 
-def train(args, algo="ppo", engine_factory=None, on_update=None, rendezvous=None, dist_module=None):
+def train(args, algo="ppo", engine_factory=None, on_update=None, rendezvous=None):
     """The `__main__` block of cleanba_ppo.py / cleanba_impala.py (ppo:409-771).  `rendezvous` = (world, rank, local_rank, addr, port)
-    and `dist_module` override the process environment / torch.distributed (used by the single-GPU loopback test of the split path)."""
+    overrides the process environment (tests); `on_update(version, stats, engine)` runs on the learner thread after every update (bench)."""
     world_size, rank, local_rank, master_addr, master_port = rendezvous or (distributed_env() if args.distributed else (1, 0, 0, None, None))
     from . import topology
+    topology.validate(args)
     lay = None
-    if topology.is_split(args):  # actor GPU(s) and learner GPUs are different processes (README.md:62, benchmark.sh:80)
+    if topology.is_split(args):  # actor and learner roles are different processes (README.md:58,62, benchmark.sh:80,90)
         if not args.distributed or world_size < 2:
-            raise SystemExit("split topologies (--actor-device-ids != --learner-device-ids) run one process per GPU: launch with "
-                             "torchrun / the SLURM variables and pass --distributed")
+            raise SystemExit("split topologies (--actor-device-ids != --learner-device-ids) run one process per role: launch through the "
+                             "entry points (which fan out), torchrun or the SLURM variables, and pass --distributed")
         lay = topology.Layout(args, world_size, rank)
         n_proc, proc_index = lay.groups, lay.group   # the reference's world_size counts actor+learner groups (ppo:425-430)
     else:
@@ -343,15 +306,15 @@ def train(args, algo="ppo", engine_factory=None, on_update=None, rendezvous=None
     if getattr(args, "async_batch_size", 0) and algo != "ppo":
         raise SystemExit("--async-batch-size belongs to the PPO script (cleanba_impala.py already drives envpool through recv/send)")
     finalize(args, n_proc, proc_index)
-    if args.distributed and world_size > 1 and dist_module is None:
-        import torch.distributed as dist
-        if not dist.is_initialized():
-            import torch
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
-            if backend == "nccl":
-                torch.cuda.set_device(local_rank)
-            dist.init_process_group(backend, init_method=f"tcp://{master_addr}:{master_port}", rank=rank, world_size=world_size)
-    run_name = f"{args.env_id}__{args.exp_name}__{args.seed}__{uuid.uuid4()}"
+    rdv = topology.Rendezvous(world_size, rank, master_addr, master_port) if world_size > 1 else None
+    synthetic = args.env_backend != "envpool"
+    run_name = f"{args.env_id}{'-synthetic' if synthetic else ''}__{args.exp_name}__{args.seed}__{uuid.uuid4()}"
+    if rdv is not None:
+        run_name = rdv.share("run_name", lambda: run_name.encode(), 0).decode()
+    if synthetic and rank == 0:
+        print(f"NOTE: --env-backend {args.env_backend} steps the built-in synthetic Atari-shaped env (84x84x4 uint8 frames, {args.num_actions} "
+              f"actions), not ALE '{args.env_id}': returns are not comparable with the reference's {args.env_id} curves (the run name carries "
+              "'-synthetic').  Use --env-backend envpool where envpool is installed.")
     if args.track and rank == 0:   # ppo:447-458 — same wandb.init call when wandb is importable; never a silent no-op
         try:
             import wandb
@@ -359,8 +322,15 @@ def train(args, algo="ppo", engine_factory=None, on_update=None, rendezvous=None
                        monitor_gym=True, save_code=True)
         except ImportError:
             print("--track: wandb is not installed here; scalars are written to TensorBoard event files under runs/ only")
-    writer = JsonlWriter(f"runs/{run_name}") if rank == 0 else SimpleNamespace(add_scalar=lambda *a: None, add_text=lambda *a: None, close=lambda: None)
-    writer.add_text("hyperparameters", "|param|value|\n|-|-|\n%s" % ("\n".join([f"|{k}|{v}|" for k, v in vars(args).items()])))
+    null_writer = SimpleNamespace(add_scalar=lambda *a: None, add_text=lambda *a: None, close=lambda: None)
+    if rank == 0:
+        writer = JsonlWriter(f"runs/{run_name}")
+    elif lay is not None and lay.group == 0 and not lay.is_actor and lay.learner_index == 0:
+        writer = JsonlWriter(f"runs/{run_name}/learner")   # the loss scalars of a split run come from learner 0 (rank 0 is an actor)
+    else:
+        writer = null_writer
+    writer.add_text("hyperparameters", "|param|value|\n|-|-|\n%s" % ("\n".join([f"|{k}|{v}|" for k, v in vars(args).items()] +
+                                                                            [f"|synthetic_env|{synthetic}|"])))
 
     # seeding (ppo:465-470): identical model / learner keys in every process, env seeds differ by process index
     key = prng.prng_key(args.seed)
@@ -368,15 +338,46 @@ def train(args, algo="ppo", engine_factory=None, on_update=None, rendezvous=None
     learner_key = key.copy()
 
     cfg = make_config(args, algo)
-    if lay is not None and not lay.is_actor:   # learner-only context: its slots are ingest ports for E/L env columns each
-        cfg.local_num_envs = args.local_num_envs // lay.nl
-    engine = engine_factory(cfg) if engine_factory else HipEngine(cfg)
-    params = M.init_params(args.network, args.num_actions, network_key, actor_key, critic_key)
-    engine.set_params(params)
     if lay is not None:
-        return _train_split(args, algo, engine, lay, writer, key, rank, run_name, dist_module)
-    allreduce = GradAllReducer(engine, world_size)
+        if engine_factory is None:
+            cfg.device = lay.device_id
+    if os.environ.get("CBM_FORCE_DEVICE"):   # testing aid: every role on this GPU (the split path between processes on a one-GPU box)
+        cfg.device = int(os.environ["CBM_FORCE_DEVICE"])
+    if lay is not None:
+        if lay.is_actor:
+            cfg.num_actor_slots = lay.threads            # this actor GPU's own threads
+        else:                                            # learner role: its slots are ingest ports for E/L env columns each
+            cfg.local_num_envs, cfg.num_actor_slots = lay.shard_envs, lay.ports
+    engine = engine_factory(cfg) if engine_factory else HipEngine(cfg)
+    try:
+        params = M.init_params(args.network, args.num_actions, network_key, actor_key, critic_key)
+        engine.set_params(params)
+        if lay is not None:
+            return _train_split(args, algo, engine, lay, rdv, writer, key, rank, run_name, on_update)
+        return _train_single(args, algo, engine, rdv, writer, key, learner_key, world_size, rank, run_name, on_update, engine_factory)
+    except BaseException:
+        if rdv is not None:
+            rdv.abort()
+        engine.abort()
+        raise
 
+
+def log_losses(writer, algo, stats, global_step):
+    """losses/* are the means over epochs x minibatches (ppo:651-655 / impala:636-639 take .mean() of the per-step values)."""
+    m = np.asarray(stats, np.float64).mean(axis=0)
+    writer.add_scalar("losses/value_loss", float(m[2]), global_step)
+    writer.add_scalar("losses/policy_loss", float(m[1]), global_step)
+    writer.add_scalar("losses/entropy", float(m[3]), global_step)
+    if algo == "ppo":
+        writer.add_scalar("losses/approx_kl", float(m[4]), global_step)
+    writer.add_scalar("losses/loss", float(m[0]), global_step)
+
+
+def _train_single(args, algo, engine, rdv, writer, key, learner_key, world_size, rank, run_name, on_update, engine_factory):
+    """a0-l0 (x world_size processes with --distributed: the reference's a0_l0_dN, README.md:103-108)."""
+    from . import topology
+    if rdv is not None or engine.wants_comm_at_world_one():
+        topology.setup_learner_comm(engine, rdv, list(range(world_size)), rank)
     dummy_writer = SimpleNamespace(add_scalar=lambda x, y, z: None)
     stop_event, errors, threads = threading.Event(), [], []
     n_slots = args.num_actor_threads * len(args.actor_device_ids)
@@ -390,67 +391,44 @@ def train(args, algo="ppo", engine_factory=None, on_update=None, rendezvous=None
     learner_policy_version = 0
     opt_count = 0
     n_opt = args.num_minibatches * (args.update_epochs if algo == "ppo" else 1)
-    epochs = args.update_epochs if algo == "ppo" else 1
     start = time.time()
     last_stats = None
     while True:
         learner_policy_version += 1
         t0 = time.time()
-        engine.learner_wait()  # every actor slot's rollout (ppo:697-711)
-        if errors:
-            raise errors[0]
+        try:
+            engine.learner_wait()  # every actor slot's rollout (ppo:697-711)
+        except Exception:
+            if errors:
+                raise errors[0]
+            raise
         rollout_queue_get_time.append(time.time() - t0)
         training_time_start = time.time()
         lrs, bc1, bc2 = schedules(args, algo, opt_count, n_opt)
         want_stats = learner_policy_version % args.log_frequency == 0 or learner_policy_version >= args.num_updates
-        if world_size == 1:
-            learner_key, stats = engine.learner_update(learner_key, lrs, bc1, bc2, want_stats)
-        else:
-            learner_key = engine.learner_prepare(learner_key)
-            i = 0
-            for e in range(epochs):
-                learner_key = engine.learner_epoch_begin(learner_key)
-                k = args.gradient_accumulation_steps
-                for mb in range(args.num_minibatches * k):
-                    engine.learner_minibatch_grad(e, mb)
-                    grad_div = allreduce()
-                    if k > 1:   # optax.MultiSteps: running mean of the (already pmean-ed) micro-batch gradients, step on every k-th
-                        engine.learner_accumulate(mb % k, grad_div)
-                        if mb % k != k - 1:
-                            continue
-                        grad_div = 1.0
-                    engine.learner_optimizer_step(float(lrs[i]), float(bc1[i]), float(bc2[i]), grad_div)
-                    i += 1
-            stats = engine.learner_finish(n_opt, want_stats)
+        # one call per update on one GPU and on N: with a learner communicator the library all-reduces every minibatch's gradient
+        # (pmean, ppo:628) and the requested loss statistics (ppo:649-653) itself
+        learner_key, stats = engine.learner_update(learner_key, lrs, bc1, bc2, want_stats)
         opt_count += n_opt
         if stats is not None:
             last_stats = stats
         global_step = learner_policy_version * args.local_batch_size * world_size
         if on_update:
-            on_update(learner_policy_version, stats)
+            on_update(learner_policy_version, stats, engine)
         if learner_policy_version % args.log_frequency == 0 and stats is not None:
             writer.add_scalar("stats/rollout_queue_get_time", np.mean(rollout_queue_get_time), global_step)
             writer.add_scalar("stats/training_time", time.time() - training_time_start, global_step)
             print(global_step, f"learner_policy_version={learner_policy_version}, training time: {time.time() - training_time_start}s")
             writer.add_scalar("charts/learning_rate", float(lrs[-1]), global_step)
-            if algo == "ppo":
-                writer.add_scalar("losses/value_loss", float(stats[-1, 2]), global_step)
-                writer.add_scalar("losses/policy_loss", float(stats[-1, 1]), global_step)
-                writer.add_scalar("losses/entropy", float(stats[-1, 3]), global_step)
-                writer.add_scalar("losses/approx_kl", float(stats[-1, 4]), global_step)
-                writer.add_scalar("losses/loss", float(stats[-1, 0]), global_step)
-            else:
-                writer.add_scalar("losses/value_loss", float(stats[-1, 2]), global_step)
-                writer.add_scalar("losses/policy_loss", float(stats[-1, 1]), global_step)
-                writer.add_scalar("losses/entropy", float(stats[-1, 3]), global_step)
-                writer.add_scalar("losses/loss", float(stats[-1, 0]), global_step)
+            log_losses(writer, algo, stats, global_step)
         if learner_policy_version >= args.num_updates:
             break
     engine.sync()
     elapsed = time.time() - start
     stop_event.set()
+    engine.abort()   # actor threads blocked on a ring entry / parameter version that will never come return now
     for th in threads:
-        th.join(timeout=30)
+        th.join()
     result = {"updates": learner_policy_version, "global_step": learner_policy_version * args.local_batch_size * world_size,
               "elapsed_s": elapsed, "stats": last_stats, "params": engine.get_params(), "run_name": run_name}
     if args.save_model and rank == 0:
@@ -473,7 +451,7 @@ def train(args, algo="ppo", engine_factory=None, on_update=None, rendezvous=None
             if args.upload_model:   # ppo:785-799
                 try:
                     from cleanrl_utils.huggingface import push_to_hub
-                    repo_name = f"{args.env_id}-{args.exp_name}-seed{args.seed}"
+                    repo_name = f"{args.env_id}{'-synthetic' if args.env_backend != 'envpool' else ''}-{args.exp_name}-seed{args.seed}"
                     push_to_hub(args, rets, f"{args.hf_entity}/{repo_name}" if args.hf_entity else repo_name, "PPO" if algo == "ppo" else "IMPALA",
                                 f"runs/{run_name}", f"videos/{run_name}-eval", extra_dependencies=["cleanba_amd"])
                 except ImportError:
@@ -483,26 +461,22 @@ def train(args, algo="ppo", engine_factory=None, on_update=None, rendezvous=None
     return result
 
 
-def _train_split(args, algo, engine, lay, writer, key, rank, run_name, dist_module=None):
-    """One process of an actor/learner-split run (cleanba_amd.topology).  Actor ranks run the rollout threads and ship shards;
-    learner ranks ingest shards, all-reduce gradients over every learner rank of every group, and learner 0 returns params."""
-    if dist_module is None:
-        import torch.distributed as dist
-    else:
-        dist = dist_module
+def _train_split(args, algo, engine, lay, rdv, writer, key, rank, run_name, on_update=None):
+    """One role process of an actor/learner-split run (cleanba_amd.topology).  Actor roles run the rollout threads and write shards into
+    the learners' rings; learner roles ingest them, all-reduce gradients over every learner of every group, and learner 0 writes the
+    parameters back into its group's actors."""
     from . import topology
-    groups = topology.Groups(dist, lay)
     n_opt = args.num_minibatches * (args.update_epochs if algo == "ppo" else 1)
-    epochs = args.update_epochs if algo == "ppo" else 1
     start = time.time()
     if lay.is_actor:
-        shipper = topology.ActorShipper(engine, lay, groups, args, algo, dist, args.num_updates)
-        receiver = topology.ParamReceiver(engine, lay, groups, dist, args.num_updates)
+        receiver = topology.ParamReceiver(engine, lay, rdv, args.num_updates)     # publishes this actor's parameter-buffer handles
+        shipper = topology.ActorShipper(engine, lay, rdv, args, algo, args.num_updates)   # maps the learners' rings
         stop_event, errors, threads = threading.Event(), [], []
         dummy_writer = SimpleNamespace(add_scalar=lambda x, y, z: None)
-        for slot in range(args.num_actor_threads * len(args.actor_device_ids)):
+        for slot in range(lay.threads):
             th = threading.Thread(target=rollout, args=(key.copy(), args, algo, engine, writer if slot == 0 else dummy_writer, slot, lay.groups,
-                                                        lay.group, stop_event, errors, shipper.on_commit), daemon=True)
+                                                        lay.group, stop_event, errors, shipper.on_commit, lay.actor_index * lay.threads + slot),
+                                  daemon=True)
             th.start()
             threads.append(th)
         shipper.thread.start()
@@ -513,120 +487,91 @@ def _train_split(args, algo, engine, lay, writer, key, rank, run_name, dist_modu
         if errors or shipper.error or receiver.error:
             raise (errors + [shipper.error, receiver.error])[0] or RuntimeError("actor failed")
         elapsed = time.time() - start
-        for th in threads:   # like the reference's actors, each slot runs one rollout past the last update before it sees the stop
-            th.join(timeout=60)
+        engine.abort()   # like the reference's actors, each thread is one rollout past the last update; release it
+        for th in threads:
+            th.join()
         engine.sync()
         result = {"updates": args.num_updates, "elapsed_s": elapsed, "stats": None, "params": engine.get_actor_params(),
-                  "run_name": run_name, "role": "actor"}
+                  "run_name": run_name, "role": "actor" if lay.na == 1 else f"actor{lay.actor_index}"}
+        rdv.barrier("done")   # keep this actor's buffers mapped until every peer has stopped writing into them
         writer.close()
         engine.close()
         return result
-    allreduce = GradAllReducer(engine, len(lay.all_learner_ranks), groups.learners)
-    ingest = topology.LearnerReceiver(engine, lay, groups, args, algo, dist, args.num_updates)
+    ingest = topology.LearnerReceiver(engine, lay, rdv, args, algo, args.num_updates)   # publishes this learner's ring handles
+    send_params = topology.ParamSender(engine, lay, rdv) if lay.learner_index == 0 else None
+    topology.setup_learner_comm(engine, rdv, lay.all_learner_ranks, rank)
     ingest.thread.start()
     learner_key = key.copy()
     opt_count, stats = 0, None
     for version in range(1, args.num_updates + 1):
-        engine.learner_wait()
+        try:
+            engine.learner_wait()
+        except Exception:
+            if ingest.error:
+                raise ingest.error
+            raise
+        t0 = time.time()
         lrs, bc1, bc2 = schedules(args, algo, opt_count, n_opt)
-        learner_key = engine.learner_prepare(learner_key)
-        i = 0
-        for e in range(epochs):
-            learner_key = engine.learner_epoch_begin(learner_key)
-            k = args.gradient_accumulation_steps
-            for mb in range(args.num_minibatches * k):
-                engine.learner_minibatch_grad(e, mb)
-                grad_div = allreduce()
-                if k > 1:
-                    engine.learner_accumulate(mb % k, grad_div)
-                    if mb % k != k - 1:
-                        continue
-                    grad_div = 1.0
-                engine.learner_optimizer_step(float(lrs[i]), float(bc1[i]), float(bc2[i]), grad_div)
-                i += 1
-        stats = engine.learner_finish(n_opt, True)
+        learner_key, stats = engine.learner_update(learner_key, lrs, bc1, bc2, True)
         opt_count += n_opt
-        if lay.learner_index == 0:
-            with engine.stream_context():
-                dist.send(engine.params_tensor(), dst=lay.actor_rank, group=groups.params[lay.group])
+        if send_params is not None:
+            send_params(version)
+        if on_update:
+            on_update(version, stats, engine)
         if version % args.log_frequency == 0 and lay.learner_index == 0:
-            print(version * args.local_batch_size * lay.groups, f"learner_policy_version={version}")
+            global_step = version * args.local_batch_size * lay.groups
+            print(global_step, f"learner_policy_version={version}, training time: {time.time() - t0}s")
+            writer.add_scalar("stats/training_time", time.time() - t0, global_step)
+            writer.add_scalar("charts/learning_rate", float(lrs[-1]), global_step)
+            log_losses(writer, algo, stats, global_step)
     engine.sync()
-    ingest.thread.join(timeout=60)
+    ingest.thread.join()
     if ingest.error:
         raise ingest.error
     result = {"updates": args.num_updates, "elapsed_s": time.time() - start, "stats": stats, "params": engine.get_params(), "run_name": run_name,
               "role": f"learner{lay.learner_index}"}
+    rdv.barrier("done")
     writer.close()
     engine.close()
     return result
 
 
 class HipEngine(L.Context):
-    """The product engine: cleanba_amd.lib.Context + the torch.distributed plumbing for the grad all-reduce."""
+    """The product engine: cleanba_amd.lib.Context plus the handle plumbing of the multi-process paths (no torch tensors, no CPU fallback)."""
 
-    def __init__(self, cfg):
-        super().__init__(cfg)
-        self._tls = threading.local()
+    def wants_comm_at_world_one(self):
+        """CBM_FORCE_DIST=1: build a real one-rank RCCL communicator so the all-reduce path runs on a single GPU (tests, bench)."""
+        return os.environ.get("CBM_FORCE_DIST") == "1"
 
-    def grads_tensor(self):
-        import torch
-        ptr, nbytes = self.buffer("grads")
+    def comm_unique_id(self):
+        if L._TORCH_RCCL:
+            L._chk(self.lib.cbm_comm_load(L._TORCH_RCCL.encode()))
+        buf = (L.C.c_uint8 * L.COMM_ID_BYTES)()
+        L._chk(self.lib.cbm_comm_unique_id(buf))
+        return bytes(buf)
 
-        class _CAI:  # __cuda_array_interface__ view of the library-owned buffer (no copy)
-            __cuda_array_interface__ = {"shape": (nbytes // 4,), "typestr": "<f4", "data": (ptr, False), "version": 2, "strides": None}
-        return torch.as_tensor(_CAI(), device=f"cuda:{self.cfg.device}")
+    def comm_init(self, uid, nranks, rank, which=L.COMM_LEARNERS):
+        super().comm_init(which, uid, nranks, rank)
 
-    def stream_context(self):
-        import torch
-        return torch.cuda.stream(torch.cuda.ExternalStream(self.learner_stream(), device=f"cuda:{self.cfg.device}"))
+    # ---- split topologies: IPC handles of the ring fields / the versioned actor parameter buffers, and their mappings
+    def export_ring(self, fields):
+        return {"cols": self.cfg.local_num_envs * self.cfg.num_actor_slots,
+                "entries": [{f: self.ipc_export(f, r) for f in fields} for r in range(self.cfg.ring_depth)]}
 
-    # ---- split topologies (cleanba_amd.topology): zero-copy torch views of the library-owned ring / parameter buffers
-    def _view(self, name, ring, dtype, shape):
-        import torch
-        ptr, _ = self.buffer(name, ring)
-        typestr = {"u8": "|u1", "i32": "<i4", "f32": "<f4"}[dtype]
+    def open_peer_ring(self, desc):
+        out = []
+        for entry in desc["entries"]:
+            pr = L.PeerRing()
+            for f, h in entry.items():
+                setattr(pr, f, self.ipc_open(h))
+            out.append(pr)
+        return out
 
-        class _CAI:
-            __cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (ptr, False), "version": 2, "strides": None}
-        return torch.as_tensor(_CAI(), device=f"cuda:{self.cfg.device}")
+    def export_actor_params(self):
+        return [self.ipc_export(f"actor_params_v{i}") for i in range(3)]
 
-    def ring_tensors(self, ring):
-        c = self.cfg
-        T1, B, A = c.num_steps + 1, c.local_num_envs * c.num_actor_slots, c.num_actions
-        return {"obs": self._view("obs", ring, "u8", (T1, B, L.FRAME)), "actions": self._view("actions", ring, "i32", (T1, B)),
-                "logprobs": self._view("logprobs", ring, "f32", (T1, B)), "values": self._view("values", ring, "f32", (T1, B)),
-                "rewards": self._view("rewards", ring, "f32", (T1, B)), "dones": self._view("dones", ring, "u8", (T1, B)),
-                "firststeps": self._view("firststeps", ring, "u8", (T1, B)), "logits": self._view("logits", ring, "f32", (T1, B, A))}
-
-    def actor_fence(self, slot):
-        import torch
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.ExternalStream(self.actor_stream(slot), device=f"cuda:{self.cfg.device}"))
-        return ev
-
-    def io_context(self):
-        """A per-thread side stream for shard / parameter transfers (never the actor or learner compute streams)."""
-        import torch
-        if not hasattr(self._tls, "stream"):
-            self._tls.stream = torch.cuda.Stream(device=f"cuda:{self.cfg.device}")
-        return torch.cuda.stream(self._tls.stream)
-
-    def io_wait(self, fence):
-        self._tls.stream.wait_event(fence)
-
-    def io_sync(self):
-        self._tls.stream.synchronize()
-
-    def params_tensor(self):
-        return self._view("params", 0, "f32", (self.P,))
-
-    def params_staging_tensor(self):
-        import torch
-        return torch.empty(self.P, dtype=torch.float32, device=f"cuda:{self.cfg.device}")
-
-    def params_publish_external_tensor(self, t):
-        self.params_publish_external(t.data_ptr())
+    def open_peer_params(self, handles):
+        return [self.ipc_open(h) for h in handles]
 
     def get_actor_params(self):
         return self.read("actor_params_latest", np.float32)

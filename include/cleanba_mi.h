@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CBM_ABI_VERSION 1
+#define CBM_ABI_VERSION 2
 
 typedef struct cbm_ctx cbm_ctx;
 
@@ -86,7 +86,8 @@ int cbm_actor_params_get(cbm_ctx* ctx, float* host_params, int64_t n);      /* a
 
 /* ---- named device buffers (for tests, all-reduce plumbing, checkpointing).
  * names: "params", "actor_params", "actor_params_latest", "grads", "opt_m", "opt_v", "adv", "target", "perm",
- *        "obs", "actions", "logprobs", "values", "rewards", "dones", "env_ids", "logits", "stats" ...   */
+ *        "obs", "actions", "logprobs", "values", "rewards", "dones", "env_ids", "logits", "stats",
+ *        "actor_params_v0" .. "actor_params_v2" (the versioned actor copies) ...   */
 int cbm_buffer(cbm_ctx* ctx, const char* name, int32_t ring_index, void** dev_ptr, int64_t* nbytes);
 int cbm_copy_to_host(cbm_ctx* ctx, void* host_dst, const void* dev_src, int64_t nbytes);
 int cbm_copy_to_device(cbm_ctx* ctx, void* dev_dst, const void* host_src, int64_t nbytes);
@@ -133,6 +134,52 @@ int cbm_params_publish_external(cbm_ctx* ctx, const float* dev_params, int64_t n
 void* cbm_actor_stream(cbm_ctx* ctx, int32_t slot);                       /* hipStream_t of an actor slot (ordering of shard sends) */
 int cbm_actor_ring_index(cbm_ctx* ctx, int32_t slot);                     /* ring entry of the slot's current / last rollout */
 
+/* ---- collectives among the learner GPUs: RCCL over xGMI behind the C ABI.  Replaces jax.pmap(axis_name="local_devices",
+ * devices=global_learner_decices) + jax.lax.pmean (ppo:628,649-660 / impala:621,636-645).  librccl is bound at run time (dlopen); the host
+ * carries the 128-byte unique id from the rank that made it to the others (any transport: a file, a TCP store, MPI ...). */
+#define CBM_COMM_SLOTS 2
+#define CBM_COMM_LEARNERS 0        /* every learner rank of every actor-learner group: gradients + loss statistics */
+#define CBM_COMM_WORLD 1           /* spare slot (job-wide barriers when actors take part) */
+#define CBM_COMM_ID_BYTES 128
+int cbm_comm_load(const char* librccl_path);                 /* optional: which librccl to bind (NULL = $CBM_RCCL_PATH, then the loader's) */
+int cbm_comm_unique_id(uint8_t id[CBM_COMM_ID_BYTES]);
+int cbm_comm_init(cbm_ctx* ctx, int32_t which, const uint8_t id[CBM_COMM_ID_BYTES], int32_t nranks, int32_t rank);
+/* Self-test communicator: behaves like `nranks` ranks holding IDENTICAL data (all-reduce(SUM) = multiply by nranks, on the same streams and
+ * behind the same events as the RCCL path), so stream-ordering bugs of the overlapped all-reduce show up as changed bits on one GPU. */
+int cbm_comm_init_loopback(cbm_ctx* ctx, int32_t which, int32_t nranks);
+int cbm_comm_size(cbm_ctx* ctx, int32_t which);              /* ranks of an initialised communicator, 0 otherwise */
+int cbm_comm_allreduce_f64(cbm_ctx* ctx, int32_t which, double* host_inout, int32_t n, int32_t op);   /* op: 0 sum, 1 max, 2 min; blocking */
+int cbm_comm_barrier(cbm_ctx* ctx, int32_t which);
+/* pmean of the flat gradient after cbm_learner_minibatch_grad (ppo:628): all-reduce(SUM) over CBM_COMM_LEARNERS on the library's
+ * communication stream — the dense + heads tail under the conv backward, the head after it — and the learner stream joins.
+ * *grad_div = rank count, to be passed to cbm_learner_optimizer_step / cbm_learner_accumulate.  Without a communicator: no work,
+ * *grad_div = 1.  cbm_learner_update does exactly this internally, so a data-parallel host makes the same single call as a one-GPU host;
+ * cbm_learner_finish all-reduces the loss statistics (pmean, ppo:649-653) when stats are requested (every rank must then request them). */
+int cbm_learner_allreduce_grads(cbm_ctx* ctx, float* grad_div);
+int cbm_comm_profile(cbm_ctx* ctx, int32_t on);              /* HIP-event timing of every gradient all-reduce from now on */
+int cbm_comm_profile_read(cbm_ctx* ctx, double* tail_ms, double* exposed_ms, int32_t* count);   /* totals: tail all-reduce; backward end -> optimizer may start */
+
+/* ---- peer writes for split topologies: the actor writes rollout shards straight into the learners' rings, learner 0 writes parameters
+ * straight into the actor's version buffers (HIP IPC mappings, strided copies on a side stream).  Replaces jax.device_put_sharded
+ * (ppo:358-363) and jax.device_put(params, actor device) (ppo:721-725) between processes. */
+#define CBM_IPC_HANDLE_BYTES 64
+typedef struct {   /* device pointers of ONE ring entry of the destination context (mapped with cbm_ipc_open, or cbm_buffer of a local ctx); NULL = skip */
+  void *obs, *actions, *logprobs, *values, *rewards, *dones, *firststeps, *logits;
+} cbm_peer_ring;
+int cbm_ipc_export(cbm_ctx* ctx, const char* name, int32_t ring_index, uint8_t handle[CBM_IPC_HANDLE_BYTES]);   /* any cbm_buffer name */
+int cbm_ipc_open(cbm_ctx* ctx, const uint8_t handle[CBM_IPC_HANDLE_BYTES], void** dev_ptr);
+int cbm_ipc_close(cbm_ctx* ctx, void* dev_ptr);
+/* Enqueues, on the io stream and after the commit of `slot`'s rollout in ring entry `ring_index`, the copy of learner `li`'s column shard
+ * (columns [slot*E + li*E/L, +E/L) of every [T+1][B] field) into columns [dst_col0, +E/L) of `dst`, whose rows have dst_cols columns. */
+int cbm_actor_ship_shard(cbm_ctx* ctx, int32_t slot, int32_t ring_index, int32_t li, int32_t n_learners, const cbm_peer_ring* dst,
+                         int32_t dst_cols, int32_t dst_col0);
+int cbm_io_sync(cbm_ctx* ctx);                                /* everything enqueued on the io stream has landed */
+int cbm_params_push(cbm_ctx* ctx, void* const peer_versions[3]);   /* learner 0: current parameters -> the actor's version buffer; blocking */
+int cbm_params_mark_published(cbm_ctx* ctx);                  /* actor: the next parameter version has landed in its buffer */
+/* Makes every blocking wait of the context (cbm_actor_begin_rollout, cbm_ingest_begin, cbm_learner_wait) return an error from now on:
+ * the host calls it when one of its threads has failed, so the others do not hang on a queue that will never be fed. */
+int cbm_ctx_abort(cbm_ctx* ctx);
+
 /* ---- learner side: replaces multi_device_update (ppo:579-660 / impala:599-645).
  * cbm_learner_wait blocks until every slot has committed rollout #update (ppo:697-711). */
 int cbm_learner_wait(cbm_ctx* ctx);
@@ -148,14 +195,7 @@ int cbm_learner_update(cbm_ctx* ctx, uint32_t key[2], const float* lrs, const fl
 int cbm_learner_prepare(cbm_ctx* ctx, uint32_t key[2]);
 int cbm_learner_epoch_begin(cbm_ctx* ctx, uint32_t key[2]);   /* key,subkey = split(key); perm = permutation(subkey) ppo:599-606 */
 int cbm_learner_minibatch_grad(cbm_ctx* ctx, int32_t epoch, int32_t minibatch);
-/* Overlap of the gradient all-reduce with the backward pass (pmean, ppo:628): the flat gradient is produced from the back; once the dense
- * layer's weight gradient exists, the tail [cbm_learner_grad_tail_offset, P) — dense + heads, 95 % of the bytes — is final.  After
- * cbm_learner_minibatch_grad (which only enqueues work), cbm_learner_stream_wait_tail makes the caller's communication stream wait for
- * that point so the tail's all-reduce runs under the conv backward; the head [0, offset) is all-reduced on the learner stream as before;
- * cbm_learner_wait_stream then makes the learner stream wait for the communication stream before the optimizer step. */
-int64_t cbm_learner_grad_tail_offset(cbm_ctx* ctx);
-int cbm_learner_stream_wait_tail(cbm_ctx* ctx, void* hip_stream);
-int cbm_learner_wait_stream(cbm_ctx* ctx, void* hip_stream);
+int64_t cbm_learner_grad_tail_offset(cbm_ctx* ctx);   /* first element of the dense + heads tail of the flat gradient (all-reduced under the conv backward) */
 /* gradient accumulation (grad_accum_steps = k > 1), split form: after each micro-batch's all-reduce call cbm_learner_accumulate with
  * mini_step = micro_batch % k; it folds "grads"/grad_div into the running mean and, on mini_step == k-1, leaves that mean in "grads" for
  * cbm_learner_optimizer_step(..., grad_div = 1). */
@@ -195,8 +235,11 @@ int cbm_rmsprop_step(cbm_ctx* ctx, float* p, const float* g, float* nu, int64_t 
 
 /* ---- per-kernel HIP-event timing for bench.py's roofline line: brackets every learner-stream launch of
  * the selected implicit-GEMM kernel (ids in DESIGN.md §kernels; -1 = off). */
+#define CBM_PROFILE_ALL (-2)   /* every launch of every id */
+#define CBM_PROFILE_IDS 12
 int cbm_profile_select(cbm_ctx* ctx, int32_t kernel_id);
 int cbm_profile_read(cbm_ctx* ctx, double* total_ms, int32_t* count);
+int cbm_profile_read_all(cbm_ctx* ctx, double* total_ms, int32_t* count, int32_t n_ids);   /* per-id totals after cbm_profile_select(CBM_PROFILE_ALL) */
 
 /* ---- synthetic Atari-shaped environment (stands in for envpool.make, ppo:128-139) ------- */
 typedef struct {

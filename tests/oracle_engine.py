@@ -4,14 +4,57 @@ Test infrastructure only (lives under tests/, imports oracle/): it lets the host
 cleanba_amd.trainer — actor threads, ring/sequence hand-off, policy-version skew, per-minibatch gradient
 all-reduce across processes — run on a CPU box with the gloo backend, where the HIP library cannot create a
 context.  It mirrors csrc/api.hip's orchestration (row layout [T+1][B], ring depth, params versions)."""
-import contextlib
 import threading
+from multiprocessing import shared_memory
 
 import numpy as np
 
 import oracle
 
 FRAME = 4 * 84 * 84
+
+
+class _Shm:
+    """numpy arrays in named shared memory: the CPU stand-in for device buffers another process maps through a HIP IPC handle."""
+
+    def __init__(self):
+        self.owned, self.mapped = [], []
+
+    def alloc(self, dtype, *shape):
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        m = shared_memory.SharedMemory(create=True, size=max(n, 8))
+        self.owned.append(m)
+        a = np.ndarray(shape, dtype, buffer=m.buf)
+        a[...] = 0
+        return a, (m.name, tuple(shape), np.dtype(dtype).str)
+
+    def open(self, handle):
+        name, shape, dt = handle
+        m = shared_memory.SharedMemory(name=name)
+        try:   # Python 3.10 registers ATTACHED segments with this process's resource tracker too, which then unlinks the owner's segment
+            from multiprocessing import resource_tracker
+            resource_tracker.unregister(m._name, "shared_memory")
+        except Exception:  # noqa: BLE001
+            pass
+        self.mapped.append(m)
+        return np.ndarray(shape, np.dtype(dt), buffer=m.buf)
+
+    def close(self):
+        for m in self.mapped:
+            try:
+                m.close()
+            except BufferError:
+                pass
+        for m in self.owned:
+            try:
+                m.close()
+            except BufferError:
+                pass
+            try:
+                m.unlink()
+            except FileNotFoundError:
+                pass
+        self.owned, self.mapped = [], []
 
 
 class OracleEngine:
@@ -32,17 +75,28 @@ class OracleEngine:
         self.epochs = cfg.update_epochs if self.ppo else 1
         self.depth = cfg.ring_depth
         self.P = oracle.nature_param_count(self.A)
-        z = lambda dt, *shape: np.zeros(shape, dt)
-        self.ring = [dict(obs=z(np.uint8, self.T1, self.B, 4, 84, 84), actions=z(np.int32, self.T1, self.B), logprobs=z(np.float32, self.T1, self.B),
-                          values=z(np.float32, self.T1, self.B), rewards=z(np.float32, self.T1, self.B), logits=z(np.float32, self.T1, self.B, self.A),
-                          dones=z(np.uint8, self.T1, self.B), firststeps=z(np.uint8, self.T1, self.B), env_ids=z(np.int32, self.T1, self.B))
-                     for _ in range(self.depth)]
+        self.shm = _Shm()
+        self.ring, self.ring_handles = [], []
+        spec = dict(obs=(np.uint8, self.T1, self.B, 4, 84, 84), actions=(np.int32, self.T1, self.B), logprobs=(np.float32, self.T1, self.B),
+                    values=(np.float32, self.T1, self.B), rewards=(np.float32, self.T1, self.B), logits=(np.float32, self.T1, self.B, self.A),
+                    dones=(np.uint8, self.T1, self.B), firststeps=(np.uint8, self.T1, self.B), env_ids=(np.int32, self.T1, self.B))
+        for _ in range(self.depth):
+            arrs, hs = {}, {}
+            for k, sp in spec.items():
+                arrs[k], hs[k] = self.shm.alloc(*sp)
+            self.ring.append(arrs)
+            self.ring_handles.append(hs)
+        self.apv, self.apv_handles = [], []          # the three versioned actor parameter buffers (version v lives in v % 3)
+        for _ in range(3):
+            a, h = self.shm.alloc(np.float32, self.P)
+            self.apv.append(a)
+            self.apv_handles.append(h)
+        self.group, self.nranks, self.aborted = None, 1, False
         self.params = np.zeros(self.P, np.float32)
         self.grads = np.zeros(self.P, np.float32)
         self.m = np.zeros(self.P, np.float32)
         self.v = np.zeros(self.P, np.float32)
         self.gacc = np.zeros(self.P, np.float32)
-        self.actor_params = {0: self.params.copy()}
         self.keys = [np.zeros(2, np.uint32) for _ in range(self.S)]
         self.slot = [dict(t=0, rollout=0, ring=0, pver=0) for _ in range(self.S)]
         self.committed = [0] * self.S
@@ -54,7 +108,8 @@ class OracleEngine:
     # ---- params
     def set_params(self, p):
         self.params = np.ascontiguousarray(p, np.float32).copy()
-        self.actor_params = {0: self.params.copy()}
+        for a in self.apv:
+            a[:] = self.params
         self.m[:] = 0
         self.v[:] = 0
 
@@ -65,14 +120,50 @@ class OracleEngine:
         pass
 
     def close(self):
-        pass
+        self.ring, self.apv = [], []
+        self.shm.close()
 
-    def grads_tensor(self):
+    def abort(self):
+        with self.cv:
+            self.aborted = True
+            self.cv.notify_all()
+
+    def _wait(self, pred):
+        with self.cv:
+            self.cv.wait_for(lambda: self.aborted or pred())
+            if self.aborted:
+                raise RuntimeError("context aborted")
+
+    # ---- the learner communicator: gloo over a private TCP store stands in for RCCL (same call order as HipEngine)
+    def wants_comm_at_world_one(self):
+        return False
+
+    def comm_unique_id(self):
+        import socket
+        from torch.distributed import TCPStore
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        self._comm_store = TCPStore("127.0.0.1", port, -1, True, wait_for_workers=False)
+        return f"127.0.0.1:{port}".encode()
+
+    def comm_init(self, uid, nranks, rank):
+        import datetime
+        import torch.distributed as dist
+        from torch.distributed import TCPStore
+        host, port = uid.decode().split(":")
+        store = getattr(self, "_comm_store", None) or TCPStore(host, int(port), -1, False)
+        dist.init_process_group("gloo", store=store, rank=rank, world_size=nranks, timeout=datetime.timedelta(seconds=600))
+        self.group, self.nranks = dist, nranks
+
+    def _allreduce(self, arr):
+        """pmean's SUM half; the caller divides (like grad_div in the HIP optimizer kernel)."""
+        if self.group is None:
+            return 1.0
         import torch
-        return torch.from_numpy(self.grads)
-
-    def stream_context(self):
-        return contextlib.nullcontext()
+        t = torch.from_numpy(arr)
+        self.group.all_reduce(t, op=self.group.ReduceOp.SUM)
+        return float(self.nranks)
 
     # ---- actor
     def actor_set_key(self, s, key):
@@ -86,8 +177,7 @@ class OracleEngine:
         sl["rollout"] += 1
         u = sl["rollout"]
         need = (u - 2 if u >= 2 else 0) if concurrency else u - 1
-        with self.cv:
-            self.cv.wait_for(lambda: self.updates_done >= need and self.updates_done >= u - self.depth)
+        self._wait(lambda: self.updates_done >= need and self.updates_done >= u - self.depth)
         sl["pver"], sl["ring"], sl["t"] = need, (u - 1) % self.depth, 0
         if u >= 2 and not self.ppo:
             prev, cur = self.ring[(u - 2) % self.depth], self.ring[sl["ring"]]
@@ -106,7 +196,7 @@ class OracleEngine:
             R["firststeps"][t, c] = firststep
         if reward_with_obs is not None:
             R["rewards"][t, c] = reward_with_obs
-        logits, value = oracle.nature_forward(self.actor_params[sl["pver"]], self.A, R["obs"][t, c], ksplit=self.cfg.actor_dense_ksplit)
+        logits, value = oracle.nature_forward(self.apv[sl["pver"] % 3].copy(), self.A, R["obs"][t, c], ksplit=self.cfg.actor_dense_ksplit)
         a, lp, self.keys[s] = oracle.sample_actions(logits, self.keys[s])
         R["actions"][t, c] = a
         if self.ppo:
@@ -124,7 +214,7 @@ class OracleEngine:
         R, t = self.ring[sl["ring"]], sl["t"]
         assert t < self.T, "rollout overrun"
         R["obs"][t], R["rewards"][t], R["dones"][t], R["env_ids"][t] = obs, reward, done, env_id
-        logits, value = oracle.nature_forward(self.actor_params[sl["pver"]], self.A, R["obs"][t], ksplit=self.cfg.actor_dense_ksplit)
+        logits, value = oracle.nature_forward(self.apv[sl["pver"] % 3].copy(), self.A, R["obs"][t], ksplit=self.cfg.actor_dense_ksplit)
         a, lp, self.keys[s] = oracle.sample_actions(logits, self.keys[s])
         R["actions"][t], R["logprobs"][t], R["values"][t] = a, lp, value
         sl["t"] += 1
@@ -154,31 +244,42 @@ class OracleEngine:
     def actor_ring_index(self, s):
         return self.slot[s]["ring"]
 
-    def ring_tensors(self, ring):
-        import torch
+    def export_ring(self, fields):
+        return {"cols": self.B, "entries": [{f: self.ring_handles[r][f] for f in fields} for r in range(self.depth)]}
+
+    def open_peer_ring(self, desc):
+        return [{f: self.shm.open(h) for f, h in entry.items()} for entry in desc["entries"]]
+
+    def actor_ship_shard(self, slot, ring, li, n_learners, peer_ring, dst_cols, dst_col0):
+        El = self.E // n_learners
+        c0 = slot * self.E + li * El
         R = self.ring[ring]
-        out = {k: torch.from_numpy(v) for k, v in R.items() if k != "obs"}
-        out["obs"] = torch.from_numpy(R["obs"].reshape(self.T1, self.B, FRAME))
-        return out
-
-    def actor_fence(self, slot):
-        return None
-
-    def io_context(self):
-        return contextlib.nullcontext()
-
-    def io_wait(self, fence):
-        pass
+        for f, dst in peer_ring.items():
+            assert dst.shape[1] == dst_cols
+            dst[:, dst_col0:dst_col0 + El] = R[f][:, c0:c0 + El]
 
     def io_sync(self):
         pass
+
+    def export_actor_params(self):
+        return list(self.apv_handles)
+
+    def open_peer_params(self, handles):
+        return [self.shm.open(h) for h in handles]
+
+    def params_push(self, peer_versions):
+        peer_versions[self.updates_done % 3][:] = self.params
+
+    def params_mark_published(self):
+        with self.cv:
+            self.updates_done += 1
+            self.cv.notify_all()
 
     def ingest_begin(self, s):
         sl = self.slot[s]
         sl["rollout"] += 1
         u = sl["rollout"]
-        with self.cv:
-            self.cv.wait_for(lambda: self.updates_done >= u - self.depth)
+        self._wait(lambda: self.updates_done >= u - self.depth)
         sl["ring"] = (u - 1) % self.depth
         return sl["ring"]
 
@@ -187,24 +288,8 @@ class OracleEngine:
             self.committed[s] = self.slot[s]["rollout"]
             self.cv.notify_all()
 
-    def params_tensor(self):
-        import torch
-        return torch.from_numpy(self.params)
-
-    def params_staging_tensor(self):
-        import torch
-        return torch.empty(self.P, dtype=torch.float32)
-
-    def params_publish_external_tensor(self, t):
-        v = self.updates_done + 1
-        with self.cv:
-            self.actor_params[v] = t.numpy().copy()
-            self.actor_params.pop(v - 3, None)
-            self.updates_done = v
-            self.cv.notify_all()
-
     def get_actor_params(self):
-        return self.actor_params[max(self.actor_params)].copy()
+        return self.apv[self.updates_done % 3].copy()
 
     # ---- learner
     def _cur(self):
@@ -212,8 +297,7 @@ class OracleEngine:
 
     def learner_wait(self):
         v = self.updates_done + 1
-        with self.cv:
-            self.cv.wait_for(lambda: all(c >= v for c in self.committed))
+        self._wait(lambda: all(c >= v for c in self.committed))
 
     def learner_prepare(self, key):
         if self.asyncB:
@@ -280,12 +364,14 @@ class OracleEngine:
 
     def learner_finish(self, n_rows, want_stats=True):
         v = self.updates_done + 1
+        stats = np.array(self.stats, np.float32) if want_stats else None
+        if want_stats and self.group is not None:      # pmean of the loss statistics over the learners (ppo:649-653)
+            stats = stats / np.float32(self._allreduce(stats))
         with self.cv:
-            self.actor_params[v] = self.params.copy()
-            self.actor_params.pop(v - 3, None)
+            self.apv[v % 3][:] = self.params
             self.updates_done = v
             self.cv.notify_all()
-        return np.array(self.stats, np.float32) if want_stats else None
+        return stats
 
     def learner_update(self, key, lrs, bc1, bc2, want_stats=True):
         key = self.learner_prepare(key)
@@ -294,10 +380,12 @@ class OracleEngine:
             key = self.learner_epoch_begin(key)
             for mb in range(self.nmicro):
                 self.learner_minibatch_grad(e, mb)
+                div = self._allreduce(self.grads)          # pmean(grads) over the learner communicator (ppo:628)
                 if self.accum > 1:
-                    self.learner_accumulate(mb % self.accum)
+                    self.learner_accumulate(mb % self.accum, div)
                     if mb % self.accum != self.accum - 1:
                         continue
-                self.learner_optimizer_step(float(lrs[i]), float(bc1[i]), float(bc2[i]))
+                    div = 1.0
+                self.learner_optimizer_step(float(lrs[i]), float(bc1[i]), float(bc2[i]), div)
                 i += 1
         return key, self.learner_finish(len(lrs), want_stats)

@@ -86,7 +86,7 @@ def test_cli_and_schedules():
     assert a.local_batch_size == 120 * 128 and a.batch_size == 2 * 120 * 128 and a.num_updates == 50000000 // (2 * 120 * 128)
     b = parse_args(["--no-concurrency"], "impala")
     assert b.concurrency is False and b.num_steps == 20 and abs(b.learning_rate - 6e-4) < 1e-12
-    with pytest.raises(AssertionError):
+    with pytest.raises((AssertionError, SystemExit)):
         finalize(parse_args(["--local-num-envs", "10", "--learner-device-ids", "0", "1", "2"], "ppo"))
     # linear_schedule ppo:475-479: constant within an update, decays by 1/num_updates per update
     lr0 = M.linear_schedule(0, 2.5e-4, 16, 100)
@@ -134,9 +134,9 @@ def _run_split(world, nl, tmp, tag, algo="ppo"):
         outs.append(out)
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "split_worker.py"), str(r), str(world), str(port), out, algo, str(nl)],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
-    for p in procs:
-        o, _ = p.communicate(timeout=600)
-        assert p.returncode == 0, o.decode()[-3000:]
+    logs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    for p, o in zip(procs, logs):
+        assert p.returncode == 0, "\n".join(ln for ln in "\n=====\n".join(logs).split("\n") if "resource_tracker" not in ln and "warnings.warn" not in ln)[-6000:]
     return [np.load(o) for o in outs]
 
 
@@ -176,6 +176,36 @@ def test_split_topology_two_groups(tmp_path):
     assert np.array_equal(a0["params"], l0["params"]) and np.array_equal(a1["params"], l1["params"])
 
 
+def test_split_topology_learner_shares_the_actor_gpu(tmp_path):
+    # README.md:58 `--actor-device-ids 0 --learner-device-ids 0 1` (a0_l01): the actor role and learner 0 are two processes on GPU 0
+    a, l0, l1 = _run_split(3, "0:0,1", str(tmp_path), "a0l01")
+    assert str(a["role"]) == "actor" and np.isfinite(l0["params"]).all()
+    assert np.array_equal(l0["params"], l1["params"]) and np.array_equal(a["params"], l0["params"])
+    # the id lists only place the roles: the same shapes on disjoint GPUs (a0-l1,2) give the same numbers
+    _, m0, _ = _run_split(3, 2, str(tmp_path), "a0l12ref")
+    assert np.array_equal(m0["params"], l0["params"])
+
+
+def test_split_topology_two_actor_gpus_two_learner_gpus(tmp_path):
+    # benchmark.sh:90 `--actor-device-ids 0 1 --learner-device-ids 2 3`: every learner hstacks its shard of BOTH actor GPUs' threads
+    a0, a1, l0, l1 = _run_split(4, "0,1:2,3", str(tmp_path), "a01l23")
+    assert str(a0["role"]) == "actor0" and str(a1["role"]) == "actor1" and str(l1["role"]) == "learner1"
+    assert np.isfinite(l0["params"]).all() and int(l0["updates"]) == 3
+    assert np.array_equal(l0["params"], l1["params"])
+    assert np.array_equal(a0["params"], l0["params"]) and np.array_equal(a1["params"], l0["params"])
+
+
+def test_unsupported_device_lists_fail_before_spawning():
+    from cleanba_amd.args import parse_args
+    from cleanba_amd import topology
+    with pytest.raises(SystemExit, match="distinct"):
+        topology.validate(parse_args(["--actor-device-ids", "0", "0"], "ppo"))
+    with pytest.raises(SystemExit, match="divisible"):
+        topology.validate(parse_args(["--local-num-envs", "10", "--learner-device-ids", "0", "1", "2"], "ppo"))
+    assert not topology.is_split(parse_args([], "ppo"))
+    assert topology.is_split(parse_args(["--actor-device-ids", "0", "1", "--learner-device-ids", "0", "1"], "ppo"))   # never "doubled slots on one GPU"
+
+
 @pytest.mark.parametrize("algo", ["ppo", "impala"])
 def test_gradient_accumulation_data_parallel(tmp_path, algo, monkeypatch):
     # optax.MultiSteps(every_k=2) (ppo:492-500): 2 minibatches x 2 micro-batches; the running mean is taken after the all-reduce,
@@ -193,7 +223,7 @@ def test_split_fan_out_plan_follows_the_reference_recipes():
     # README.md:62 (`--actor-device-ids 0 --learner-device-ids 1 2 3`, one command) and README.md:71-72 (two SLURM tasks of 4 GPUs)
     from cleanba_amd.args import parse_args
     from cleanba_amd.launch import plan
-    a = parse_args(["--actor-device-ids", "0", "--learner-device-ids", "1", "2", "3"], "ppo")
+    a = parse_args(["--actor-device-ids", "0", "--learner-device-ids", "1", "2", "3", "--local-num-envs", "60"], "ppo")
     envs = plan(a, {"PATH": "x"})
     assert [(e["RANK"], e["WORLD_SIZE"], e["LOCAL_RANK"]) for e in envs] == [("0", "4", "0"), ("1", "4", "1"), ("2", "4", "2"), ("3", "4", "3")]
     assert len({e["MASTER_PORT"] for e in envs}) == 1 and envs[0]["MASTER_ADDR"] == "127.0.0.1"
