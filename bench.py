@@ -59,7 +59,7 @@ def _free_port():
 
 
 # --------------------------------------------------------------------------------------------- CPU baseline (same harness)
-def cpu_baseline(n_envs=8, n_steps=16, updates=3):
+def cpu_baseline(n_envs=16, n_steps=32, updates=3):
     """The CPU restatement (oracle/, kind "port") driven by the SAME host program as the GPU run — cleanba_amd.trainer.train with the
     oracle-backed engine (tests/oracle_engine.py) in place of the HIP library: same actor thread, same ring hand-off, same counters — on a
     bounded sample of the workload: Nature-CNN PPO, 4 epochs x 4 minibatches, A=18, host synthetic env, `n_envs` envs x `n_steps` steps per
@@ -326,14 +326,14 @@ def run_topology(a, world, rank):
 
 # --------------------------------------------------------------------------------------------- launcher
 def self_launch(n, argv):
-    """`python bench.py --gpus N` without torchrun: start the N rank processes here (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*), pass rank 0's
-    stdout through, wait for all, return the worst exit code."""
+    """`python bench.py --gpus N` without torchrun: start the N rank processes here (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*) on this
+    process's ORIGINAL stdout (exactly one of them emits the result line), wait for all, return the worst exit code."""
     port = _free_port()
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=_REAL_STDOUT if _REAL_STDOUT is not None else None))
     codes = [p.wait() for p in procs]
     return max(abs(c) for c in codes)
 
