@@ -78,6 +78,12 @@ int conv1_wgrad_frames_splits(int S);
 void launch_conv1_wgrad_frames(const uint8_t* obs, const int32_t* idx, const float* dy, float* part, float* bpart, int S, hipStream_t st,
                                bool split = false);
 
+// frame-resident conv2 / conv3 weight gradients (wgrad_frames.hip): partials part[z][(kh,kw,ci)][co], bpart[z][co]
+int conv2_wgrad_frames_splits(int S);
+void launch_conv2_wgrad_frames(const float* act1, const float* dypad, float* part, float* bpart, int S, hipStream_t st);
+int conv3_wgrad_frames_splits(int S);
+void launch_conv3_wgrad_frames(const float* act2, const float* dypad, float* part, float* bpart, int S, hipStream_t st);
+
 // ---- pointwise / scan kernels -----------------------------------------------------------
 void launch_sample(const float* logits, int B, int A, uint32_t sk0, uint32_t sk1, int32_t* actions, float* logprobs,
                    const float* value_in, float* value_out, float* logits_out, hipStream_t st);

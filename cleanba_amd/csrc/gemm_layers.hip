@@ -750,7 +750,7 @@ struct WgRegions {
   explicit WgRegions(int B) {
     nz[0] = ceil_div(B, RPS_HEADS);
     nz[1] = std::max(dense_wgrad_splits(B), 4);   // room for the split-bf16 mode's 4 splits
-    nz[2] = ceil_div(B * 49, RPS_C3); nz[3] = ceil_div(B * 81, RPS_C2);
+    nz[2] = std::max(ceil_div(B * 49, RPS_C3), conv3_wgrad_frames_splits(B)); nz[3] = std::max(ceil_div(B * 81, RPS_C2), conv2_wgrad_frames_splits(B));
     nz[4] = std::max(ceil_div(B * 400, RPS_C1), conv1_wgrad_frames_splits(B));
     const size_t wsz[5] = {512 * 32, 3136 * 512, 576 * 64, 512 * 64, 256 * 32}, bsz[5] = {32, 512, 64, 64, 32};
     size_t ow = 0, ob = 0;
@@ -889,6 +889,9 @@ static inline void plaunch_bwd(NatureWs& ws, int kid, const P& p, int nz, hipStr
 #endif
 #ifndef CONV2_DGRAD_POS
 #define CONV2_DGRAD_POS 1
+#endif
+#ifndef CONV_WGRAD_FRAMES
+#define CONV_WGRAD_FRAMES 1   // conv2 / conv3 weight gradients by the frame-resident kernels of wgrad_frames.hip (0: im2col igemm)
 #endif
 #ifndef CONV3_DGRAD_POS
 #define CONV3_DGRAD_POS 1   // position-major conv3 dgrad with tap skipping
@@ -1052,11 +1055,16 @@ void nature_backward(const NatureLayout& L, const float* P, const uint8_t* obs, 
     Conv3Dgrad<T128x64> pd{ws.dact3pad, P + L.w[2], ws.act2, ws.dact2pad, B * 81};
 #endif
     plaunch_bwd(ws, K_CONV3_DGRAD, pd, 1, st);
+    // frame-resident kernel (wgrad_frames.hip): the whole 576x64 gradient in the block's accumulators, act2 / dY frames copied once into LDS
+    // (fp32 MFMA also in split mode: the split weight-gradient kernel measured slower than the im2col fp32 one already)
+#if CONV_WGRAD_FRAMES
+    const int nz = conv3_wgrad_frames_splits(B);
+    plaunch_fn(ws, K_CONV3_WGRAD, st, [&] { launch_conv3_wgrad_frames(ws.act2, ws.dact3pad, wp + rg.w[2], bp + rg.b[2], B, st); });
+#else
     const int M = B * 49, nz = ceil_div(M, RPS_C3);
-    // (fp32 MFMA also in split mode: the split weight-gradient kernel is bound by staging VALU work — im2col address math + conversions —
-    //  and measured 214 us against 162 us here; it pays for the dense layer, 126 vs 159 us, and conv2, 191 vs 252 us)
     ConvWgrad<TILE_C3W, 3, 3, 1, 64, 64, 9, 9, 7, 7, 2> pw{ws.act2, ws.dact3pad, wp + rg.w[2], bp + rg.b[2], M, RPS_C3};
     plaunch(ws, K_CONV3_WGRAD, pw, nz, st);
+#endif
     conv_red.add(wp + rg.w[2], nz, 576 * 64, 64, 0, grads + L.w[2], nullptr);
     conv_red.add(bp + rg.b[2], nz, 64, 64, 0, grads + L.b[2], nullptr);
   }
@@ -1079,8 +1087,12 @@ void nature_backward(const NatureLayout& L, const float* P, const uint8_t* obs, 
       Conv2Dgrad<TILE_C2D> pd{ws.dact2pad, P + L.w[1], ws.act1, ws.dact1, B * 100, ws.mask1};
       plaunch_bwd(ws, K_CONV2_DGRAD, pd, 1, st);
     }
-    const int M = B * 81, nz = ceil_div(M, RPS_C2);
-    if (ws.bwd_split == 2) {   // the split kernel wants the bigger tile (staging-bound)
+    const int M = B * 81;
+    int nz = ceil_div(M, RPS_C2);
+    if (CONV_WGRAD_FRAMES && ws.bwd_split != 2) {
+      nz = conv2_wgrad_frames_splits(B);
+      plaunch_fn(ws, K_CONV2_WGRAD, st, [&] { launch_conv2_wgrad_frames(ws.act1, ws.dact2pad, wp + rg.w[3], bp + rg.b[3], B, st); });
+    } else if (ws.bwd_split == 2) {   // the split kernel wants the bigger tile (staging-bound)
       ConvWgrad<T128x64, 4, 4, 2, 32, 64, 20, 20, 9, 9, 1> pw{ws.act1, ws.dact2pad, wp + rg.w[3], bp + rg.b[3], M, RPS_C2};
       plaunch_bwd(ws, K_CONV2_WGRAD, pw, nz, st);
     } else {

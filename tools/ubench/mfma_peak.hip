@@ -38,6 +38,11 @@ void run(const char* name, int blocks, int iters) {
   hipFree(out);
 }
 int main() {
+  run<4, false>("4acc reg 1blk/CU long", 256, 4000);
+  run<8, false>("8acc reg 1blk/CU long", 256, 2000);
+  run<8, false>("8acc reg 2blk/CU long", 512, 2000);
+  run<8, true>("8acc lds 2blk/CU long", 512, 2000);
+  run<4, true>("4acc lds 4blk/CU long", 1024, 2000);
   run<1, false>("1acc reg", 256, 2000);
   run<1, false>("1acc reg 2blk/CU", 512, 1000);
   run<1, false>("1acc reg 4blk/CU", 1024, 500);
