@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256, 2) void conv3_wgrad_frames_kernel(const float*
 }
 
 #ifndef C3W_BLOCKS
-#define C3W_BLOCKS 512
+#define C3W_BLOCKS 256   // one block per CU (two fit): 146 -> 127 us and half the partials of 512
 #endif
 int conv3_wgrad_frames_splits(int S) {
   int blocks = C3W_BLOCKS;
