@@ -25,6 +25,9 @@
 #ifndef IGEMM_ORDER_MW
 #define IGEMM_ORDER_MW 0   // MatWgrad (dense / heads weight gradients)
 #endif
+#ifndef IGEMM_ROWPTR
+#define IGEMM_ROWPTR 1   // row / chunk split gather addresses in igemm_pf2_kernel (igemm.h): bit 0 conv3 dgrad, 1 conv fwd, 2 conv2 dgrad
+#endif
 #include "igemm.h"
 #include <algorithm>
 #include <vector>
@@ -113,6 +116,18 @@ struct ConvFwd {
     return *reinterpret_cast<const float4*>(in + ((size_t)(s * IH + oh * ST + kh) * IW + ow * ST) * CI + rem);
   }
   __device__ float4 load_b(int r, int y, int, int) const { return *reinterpret_cast<const float4*>(W + (size_t)r * CO + y); }
+  // row / chunk split of the same addresses (igemm.h ROWPTR): a chunk never leaves one kernel row (KW*CI is a multiple of the K chunk)
+  static constexpr bool ROWPTR = (IGEMM_ROWPTR & 2) && (KW * CI) % TileT::BR == 0;   // measured: conv3 fwd neutral, conv2 fwd (64x64x32 tile) spills
+  __device__ const float* a_origin() const { return in; }
+  __device__ const float* b_origin() const { return W; }
+  __device__ uint32_t a_off(int m, int rl, int) const {
+    m = min(m, M - 1);
+    const int s = m / (OH * OW), p = m - s * (OH * OW), oh = p / OW, ow = p - oh * OW;
+    return (uint32_t)(((s * IH + oh * ST) * IW + ow * ST) * CI + rl);
+  }
+  __device__ uint32_t a_chunk(int r0) const { const int kh = r0 / (KW * CI); return (uint32_t)(kh * IW * CI + (r0 - kh * (KW * CI))); }
+  __device__ uint32_t b_off(int rl, int y, int) const { return (uint32_t)(rl * CO + y); }
+  __device__ uint32_t b_chunk(int r0) const { return (uint32_t)(r0 * CO); }
   // DMA-staged variant (igemm_dma_kernel): plain addresses, nothing to zero-fill in a VALID conv.  Measured slower for the convs
   // (conv3 148 -> 194 us: the 16-byte-stride A fragments cost more than the saved staging), faster for the dense layer (155 -> 136 us).
   static constexpr bool DMA_OK = false;
@@ -348,6 +363,21 @@ struct Conv3DgradPos {
     const int jh = r / 192, rem = r - jh * 192, jw = rem >> 6, co = rem & 63;
     return *reinterpret_cast<const float4*>(W + ((size_t)((2 - jh) * 3 + (2 - jw)) * 64 + ci) * 64 + co);
   }
+  static constexpr bool ROWPTR = (IGEMM_ROWPTR & 1) && 64 % TileT::BR == 0;   // a chunk stays inside one 64-wide tap; 189 -> 168 us
+  __device__ const float* a_origin() const { return dypad; }
+  __device__ const float* b_origin() const { return W; }
+  __device__ uint32_t a_off(int x, int rl, int) const {
+    int s, ih, iw;
+    decode(x, s, ih, iw);
+    s = min(s, S - 1);
+    return (uint32_t)(((s * 11 + ih) * 11 + iw) * 64 + rl);
+  }
+  __device__ uint32_t a_chunk(int r0) const { const int jh = r0 / 192; return (uint32_t)(jh * 11 * 64 + (r0 - jh * 192)); }
+  __device__ uint32_t b_off(int rl, int ci, int) const { return (uint32_t)(ci * 64 + rl); }
+  __device__ uint32_t b_chunk(int r0) const {
+    const int jh = r0 / 192, rem = r0 - jh * 192, jw = rem >> 6;
+    return (uint32_t)(((2 - jh) * 3 + (2 - jw)) * 4096 + (rem & 63));
+  }
   __device__ void store(int x, int ci, float v, int, int) const {
     int s, ih, iw;
     decode(x, s, ih, iw);
@@ -541,6 +571,24 @@ struct Conv2DgradMergedPos {
     const int jh = r >> 7, jw = (r >> 6) & 1, co = r & 63;
     const int kh = (cls >> 1) + 2 * (1 - jh), kw = (cls & 1) + 2 * (1 - jw);
     return *reinterpret_cast<const float4*>(W + ((size_t)(kh * 4 + kw) * 32 + ci) * 64 + co);
+  }
+  static constexpr bool ROWPTR = (IGEMM_ROWPTR & 4) && 64 % TileT::BR == 0;   // measured neutral (245 -> 250 us): off
+  __device__ const float* a_origin() const { return dypad; }
+  __device__ const float* b_origin() const { return W; }
+  __device__ uint32_t a_off(int x, int rl, int) const {
+    int s, ihh, iwh;
+    decode(x, s, ihh, iwh);
+    s = min(s, S - 1);
+    return (uint32_t)(((s * 11 + ihh) * 11 + iwh) * 64 + rl);
+  }
+  __device__ uint32_t a_chunk(int r0) const { return (uint32_t)((r0 >> 7) * 11 * 64 + (r0 & 127)); }
+  __device__ uint32_t b_off(int rl, int y, int) const {
+    const int cls = y >> 5, ci = y & 31;
+    return (uint32_t)((((cls >> 1) * 4 + (cls & 1)) * 32 + ci) * 64 + rl);
+  }
+  __device__ uint32_t b_chunk(int r0) const {
+    const int jh = r0 >> 7, jw = (r0 >> 6) & 1;
+    return (uint32_t)((8 * (1 - jh) + 2 * (1 - jw)) * 2048 + (r0 & 63));
   }
   __device__ size_t pixel(int x, int cls, bool& ok) const {
     int s, ihh, iwh;

@@ -48,6 +48,16 @@ template <class P, class = void>
 struct igemm_maskout { static constexpr bool value = false; };
 template <class P>
 struct igemm_maskout<P, decltype((void)P::MASKOUT)> { static constexpr bool value = P::MASKOUT; };
+// Functors with ROWPTR = true split their gather addresses into a per-thread ROW part, computed once before the K loop, and a per-chunk
+// part that is the same for the whole wave (scalar): element (x, r0 + rl) of A lives at a_origin() + a_off(x, rl, cls) + a_chunk(r0),
+// element (r0 + rl, y) of B at b_origin() + b_off(rl, y, cls) + b_chunk(r0) (float offsets, 32-bit), valid while a chunk stays inside one
+// contiguous run of the reduction index (one kernel row / one tap).  The generic load_a / load_b recompute frame / pixel / tap
+// decompositions — integer divisions, clamps, 64-bit address math — for every 16-byte load of every chunk: 4-8 VALU instructions per
+// MFMA in the conv kernels (rocprofv3 SQ_INSTS_VALU); with the split the K loop adds one scalar offset per load.
+template <class P, class = void>
+struct igemm_rowptr { static constexpr bool value = false; };
+template <class P>
+struct igemm_rowptr<P, decltype((void)P::ROWPTR)> { static constexpr bool value = P::ROWPTR; };
 #ifndef IGEMM_MIN_WAVES
 #define IGEMM_MIN_WAVES 4
 #endif
@@ -370,9 +380,34 @@ __global__ __launch_bounds__(256, P::Tile::MINW) void igemm_pf2_kernel(const P p
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
+  constexpr bool RP = igemm_rowptr<P>::value;
+  uint32_t arow[NVA], brow[NVB];
+  if constexpr (RP) {
+#pragma unroll
+    for (int j = 0; j < NVA; ++j) {
+      const int v = tid + 256 * j, rq = v % (BR / 4), xl = v / (BR / 4);
+      arow[j] = p.a_off(x0 + xl, 4 * rq, cls);
+    }
+#pragma unroll
+    for (int j = 0; j < NVB; ++j) {
+      const int v = tid + 256 * j;
+      if (B_YR) { const int yl = v % BY, rq = v / BY; brow[j] = p.b_off(4 * rq, y0 + yl, cls); }
+      else { const int yq = v % (BY / 4), rl = v / (BY / 4); brow[j] = p.b_off(rl, y0 + 4 * yq, cls); }
+    }
+  }
   auto gload = [&](int c, float4 (&ra)[NVA], float4 (&rb)[NVB]) {
     int r0 = rlo + c * BR;
     if constexpr (KSKIP) r0 = p.r_map(kctx, r0);
+    if constexpr (RP) {
+      const uint32_t ao = p.a_chunk(r0), bo = p.b_chunk(r0);   // wave-uniform
+#pragma unroll
+      for (int j = 0; j < NVA; ++j)
+        if (BX * BR / 4 % 256 == 0 || tid + 256 * j < BX * BR / 4) ra[j] = *reinterpret_cast<const float4*>(p.a_origin() + (arow[j] + ao));
+#pragma unroll
+      for (int j = 0; j < NVB; ++j)
+        if (BR * BY / 4 % 256 == 0 || tid + 256 * j < BR * BY / 4) rb[j] = *reinterpret_cast<const float4*>(p.b_origin() + (brow[j] + bo));
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < NVA; ++j) {
       const int v = tid + 256 * j;

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""profiles/r01_pmc_summary_vN.md from four rocprofv3 --pmc passes over tools/microbench.py (see the header it prints).
+"""profiles/rNN_pmc_summary.md from four rocprofv3 --pmc passes over tools/microbench.py (see the header it prints).
 usage: pmc_report.py <sq.db> <lds.db> <fetch.db> <write.db>"""
 import sqlite3
 import sys
@@ -24,7 +24,7 @@ fe, _ = load(sys.argv[3])
 wr, _ = load(sys.argv[4])
 print("rocprofv3 --pmc <set> --kernel-trace -- python tools/microbench.py 3 --plain   (MI355X; four separate passes: {SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES "
       "SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU}, {SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS "
-      "SQ_INSTS_VMEM_RD}, {FETCH_SIZE}, {WRITE_SIZE}; learner kernels of one 3840-frame PPO minibatch, isolated; final round-1 build)\n")
+      "SQ_INSTS_VMEM_RD}, {FETCH_SIZE}, {WRITE_SIZE}; learner kernels of one 3840-frame PPO minibatch, isolated)\n")
 print("MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (duration x 2.4 GHz x 1024 SIMDs); wait share = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES; LDS conflict share = SQ_LDS_BANK_CONFLICT / "
       "SQ_LDS_IDX_ACTIVE; fetch = 2 x FETCH_SIZE KiB (gfx950 correction, L2 misses incl. Infinity-Cache hits).\n")
 print("| kernel | us | MfmaUtil | wave wait share | LDS conflict share | VALU insts per MFMA-busy cycle x64 | fetch MB | write MB |")

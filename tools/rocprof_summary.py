@@ -7,10 +7,10 @@ import sys
 
 def short(name):
     name = re.sub(r"\(.*$", "", name)
-    m = re.match(r"void igemm_kernel<(\w+)<IgemmTile<(\d+), (\d+), (\d+), (\d+), (\d+)>(.*)", name)
+    m = re.match(r"void (igemm\w*)_kernel<(\w+)<IgemmTile<(\d+), (\d+), (\d+), (\d+), (\d+)(?:, \d+)?>(.*)", name)
     if m:
-        extra = re.sub(r"[<> ]", "", m.group(7))[:28]
-        return f"igemm<{m.group(1)} {m.group(2)}x{m.group(3)}x{m.group(4)} {extra}>"
+        extra = re.sub(r"[<> ]", "", m.group(8))[:24]
+        return f"{m.group(1)}<{m.group(2)} {m.group(3)}x{m.group(4)}x{m.group(5)} {extra}>"
     return name[:70]
 
 
