@@ -119,6 +119,27 @@ def expf(x):
     return float(lib().cbo_expf(C.c_float(x)))
 
 
+def logf_v(x):
+    x = _f32(x)
+    y = np.empty_like(x)
+    lib().cbo_logf_v(_p(x), _p(y), C.c_int64(x.size))
+    return y
+
+
+def expf_v(x):
+    x = _f32(x)
+    y = np.empty_like(x)
+    lib().cbo_expf_v(_p(x), _p(y), C.c_int64(x.size))
+    return y
+
+
+def bits_to_uniform_v(bits):
+    b = np.ascontiguousarray(bits, np.uint32)
+    y = np.empty(b.shape, np.float32)
+    lib().cbo_bits_to_uniform_v(_p(b), _p(y), C.c_int64(b.size))
+    return y
+
+
 def u8_unit(x):
     return float(lib().cbo_u8_unit(C.c_uint32(int(x))))
 

@@ -728,6 +728,10 @@ EXPORT void cbo_impala_loss_grad(const float* P, int A, const uint8_t* obs, cons
 EXPORT float cbo_logf(float x) { return cbm_logf(x); }
 EXPORT float cbo_expf(float x) { return cbm_expf(x); }
 EXPORT float cbo_u8_unit(uint32_t x) { return cbm_u8_unit(x); }
+/* vectorised forms (tests sweep the whole 2^23-point domain of jax.random.uniform) */
+EXPORT void cbo_logf_v(const float* x, float* y, int64_t n) { for (int64_t i = 0; i < n; ++i) y[i] = cbm_logf(x[i]); }
+EXPORT void cbo_expf_v(const float* x, float* y, int64_t n) { for (int64_t i = 0; i < n; ++i) y[i] = cbm_expf(x[i]); }
+EXPORT void cbo_bits_to_uniform_v(const uint32_t* b, float* y, int64_t n) { for (int64_t i = 0; i < n; ++i) y[i] = cbm_bits_to_uniform(b[i]); }
 
 /* ============================================================ IMPALA-ResNet torso  (ppo:149-189)
  * Network(channels=(16,32,32), hiddens=(256,)): 3 x ConvSequence [Conv3x3 SAME -> max_pool(3,3) stride 2 SAME ->
