@@ -73,7 +73,11 @@ class Rendezvous:
     def __init__(self, world, rank, addr, port, timeout_s=1800.0):
         from torch.distributed import TCPStore
         self.world, self.rank, self.timeout_s = world, rank, timeout_s
-        self.store = TCPStore(addr, int(port), world, rank == 0, timeout=datetime.timedelta(seconds=timeout_s), wait_for_workers=False)
+        # rank 0 hosts the server — unless torchrun's agent already does on this port (TORCHELASTIC_USE_AGENT_STORE: TCPStore then joins
+        # that one); every key carries a prefix so the job's keys never meet the launcher's
+        from torch.distributed import PrefixStore
+        self.store = PrefixStore("cbm", TCPStore(addr, int(port), world, rank == 0, timeout=datetime.timedelta(seconds=timeout_s),
+                                                 wait_for_workers=False))
 
     def put(self, key, value=b"1"):
         self.store.set(key, value)
