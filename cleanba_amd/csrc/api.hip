@@ -5,7 +5,7 @@
 //   - rollouts live in an HBM ring of `ring_depth` entries; every field is [T+1][B_dev] (t-major,
 //     env columns of slot s at [s*E,(s+1)*E)), exactly the hstack/flatten order of ppo:587,601.
 //   - producer (actor slot) and consumer (learner) exchange only sequence numbers on the host
-//     (committed[s], updates_done) and HIP events on the device (ready / consumed / params_ready);
+//     (committed[s], updates_done: lock-free atomics, sleepers on a futex word) and HIP events on the device (ready / consumed / params_ready);
 //     the GPU never waits for the host and the host never copies rollout data.
 //   - parameters are published by the learner into a 3-deep versioned buffer; an actor rollout
 //     `u` reads version max(0,u-2) with --concurrency (the `update != 2` skew, ppo:287-304) or
@@ -305,10 +305,8 @@ extern "C" int cbm_actor_begin_rollout(cbm_ctx* c, int32_t s, int32_t concurrenc
   const int need = concurrency ? (u >= 2 ? u - 2 : 0) : u - 1;
   const int depth = c->cfg.ring_depth;
   const int need_free = u - depth;  // ring entry reused: its previous rollout must be consumed
-  {
-    std::unique_lock<std::mutex> lk(c->mu);
-    c->cv.wait(lk, [&] { return c->aborted || (c->updates_done >= need && c->updates_done >= need_free); });
-    if (c->aborted) { cbm_set_error("context aborted"); return -4; }
+  if (!cbm_wait(c, [&] { const int d = c->updates_done.load(std::memory_order_acquire); return d >= need && d >= need_free; })) {
+    cbm_set_error("context aborted"); return -4;
   }
   const int ri = (u - 1) % depth;
   if (need > 0) CBM_HIP(hipStreamWaitEvent(sl.stream, c->params_ready[need % NPV], 0));
@@ -453,11 +451,7 @@ extern "C" int cbm_actor_commit(cbm_ctx* c, int32_t s, const uint8_t* next_obs, 
     CBM_HIP(hipStreamSynchronize(sl.stream));  // host buffers may be reused by the caller
   }
   CBM_HIP(hipEventRecord(R.ready[s], sl.stream));
-  {
-    std::lock_guard<std::mutex> lk(c->mu);
-    c->committed[s] = sl.rollout;
-  }
-  c->cv.notify_all();
+  cbm_publish(c, c->committed[s], sl.rollout);
   return 0;
 }
 
@@ -483,11 +477,7 @@ extern "C" int cbm_ingest_begin(cbm_ctx* c, int32_t s, int32_t* ring_index) {
   CBM_HIP(hipSetDevice(c->cfg.device));
   const int u = ++sl.rollout;
   const int depth = c->cfg.ring_depth;
-  {
-    std::unique_lock<std::mutex> lk(c->mu);
-    c->cv.wait(lk, [&] { return c->aborted || c->updates_done >= u - depth; });
-    if (c->aborted) { cbm_set_error("context aborted"); return -4; }
-  }
+  if (!cbm_wait(c, [&] { return c->updates_done.load(std::memory_order_acquire) >= u - depth; })) { cbm_set_error("context aborted"); return -4; }
   sl.ring = (u - 1) % depth;
   if (u > depth) CBM_HIP(hipStreamWaitEvent(sl.stream, c->ring[sl.ring].consumed, 0));
   CBM_HIP(hipStreamSynchronize(sl.stream));  // the entry is free on the device too: the caller may overwrite it from any stream
@@ -499,11 +489,7 @@ extern "C" int cbm_ingest_commit(cbm_ctx* c, int32_t s) {
   CBM_HIP(hipSetDevice(c->cfg.device));
   // contract: the caller's shard copies into the entry have COMPLETED (it synchronised the stream it issued them on)
   CBM_HIP(hipEventRecord(c->ring[sl.ring].ready[s], sl.stream));
-  {
-    std::lock_guard<std::mutex> lk(c->mu);
-    c->committed[s] = sl.rollout;
-  }
-  c->cv.notify_all();
+  cbm_publish(c, c->committed[s], sl.rollout);
   return 0;
 }
 extern "C" int cbm_params_publish_external(cbm_ctx* c, const float* dev_params, int64_t n) {
@@ -513,19 +499,13 @@ extern "C" int cbm_params_publish_external(cbm_ctx* c, const float* dev_params, 
   CBM_HIP(hipMemcpyAsync(c->actor_params[v % NPV], dev_params, (size_t)n * 4, hipMemcpyDeviceToDevice, c->lstream));
   CBM_HIP(hipEventRecord(c->params_ready[v % NPV], c->lstream));
   CBM_HIP(hipStreamSynchronize(c->lstream));  // the source buffer may be reused by the caller
-  {
-    std::lock_guard<std::mutex> lk(c->mu);
-    c->updates_done = v;
-  }
-  c->cv.notify_all();
+  cbm_publish(c, c->updates_done, v);
   return 0;
 }
 extern "C" int cbm_ctx_abort(cbm_ctx* c) {
-  {
-    std::lock_guard<std::mutex> lk(c->mu);
-    c->aborted = true;
-  }
-  c->cv.notify_all();
+  c->aborted.store(true, std::memory_order_release);
+  c->epoch.fetch_add(1, std::memory_order_release);
+  c->epoch.notify_all();
   return 0;
 }
 extern "C" void* cbm_actor_stream(cbm_ctx* c, int32_t s) { return (void*)c->slots[s].stream; }
@@ -535,10 +515,8 @@ extern "C" int cbm_actor_ring_index(cbm_ctx* c, int32_t s) { return c->slots[s].
 extern "C" int cbm_learner_wait(cbm_ctx* c) {
   CBM_HIP(hipSetDevice(c->cfg.device));
   const int v = c->updates_done + 1;
-  {
-    std::unique_lock<std::mutex> lk(c->mu);
-    c->cv.wait(lk, [&] { if (c->aborted) return true; for (int s = 0; s < c->S; ++s) if (c->committed[s] < v) return false; return true; });
-    if (c->aborted) { cbm_set_error("context aborted"); return -4; }
+  if (!cbm_wait(c, [&] { for (int s = 0; s < c->S; ++s) if (c->committed[s].load(std::memory_order_acquire) < v) return false; return true; })) {
+    cbm_set_error("context aborted"); return -4;
   }
   RingEntry& R = c->ring[(v - 1) % c->cfg.ring_depth];
   for (int s = 0; s < c->S; ++s) CBM_HIP(hipStreamWaitEvent(c->lstream, R.ready[s], 0));
@@ -646,11 +624,7 @@ extern "C" int cbm_learner_finish(cbm_ctx* c, float* stats_out) {
     CBM_HIP(hipStreamSynchronize(c->lstream));
     for (int r = 0; r < c->stat_rows; ++r) for (int q = 0; q < w; ++q) stats_out[r * w + q] = h[(size_t)r * 8 + q] * inv;
   }
-  {
-    std::lock_guard<std::mutex> lk(c->mu);
-    c->updates_done = v;
-  }
-  c->cv.notify_all();
+  cbm_publish(c, c->updates_done, v);
   return 0;
 }
 

@@ -55,10 +55,11 @@ struct cbm_ctx {
   float* gacc = nullptr;   // MultiSteps running mean (grad_accum_steps > 1)
   int accum = 1, nmicro = 0;
   uint64_t* ckeys = nullptr;
-  std::mutex mu;
-  std::condition_variable cv;
-  int committed[MAX_SLOTS];
-  int updates_done = 0;
+  // Lock-free hand-off (replaces the two Queue(maxsize=1) per actor thread, ppo:662-686): sequence numbers are atomics, a waiter sleeps on
+  // the `epoch` word (futex via std::atomic::wait) and every publisher bumps it after its store — no mutex on either side.
+  std::atomic<int> committed[MAX_SLOTS];
+  std::atomic<int> updates_done{0};
+  std::atomic<uint32_t> epoch{0};
   int stat_rows = 0;
   CbmProf prof;
   hipEvent_t tail_ev = nullptr, ext_ev = nullptr;   // gradient-tail hand-off to the communication stream
@@ -72,8 +73,24 @@ struct cbm_ctx {
   bool comm_prof_on = false, comm_prof_created = false;
   int comm_prof_n = 0;
   hipEvent_t comm_prof_ev[4 * CBM_COMM_PROF_MAX];
-  bool aborted = false;   // cbm_ctx_abort: every blocking wait returns an error from now on
+  std::atomic<bool> aborted{false};   // cbm_ctx_abort: every blocking wait returns an error from now on
 };
+// publish: store the sequence number (release), then wake the sleepers
+static inline void cbm_publish(cbm_ctx* c, std::atomic<int>& var, int value) {
+  var.store(value, std::memory_order_release);
+  c->epoch.fetch_add(1, std::memory_order_release);
+  c->epoch.notify_all();
+}
+// wait until pred() or abort; returns false on abort.  The epoch is read BEFORE the predicate, so a publish between the two wakes us.
+template <class Pred>
+static inline bool cbm_wait(cbm_ctx* c, Pred pred) {
+  for (;;) {
+    const uint32_t e = c->epoch.load(std::memory_order_acquire);
+    if (c->aborted.load(std::memory_order_acquire)) return false;
+    if (pred()) return true;
+    c->epoch.wait(e, std::memory_order_acquire);
+  }
+}
 int cbm_learner_allreduce_grads_impl(cbm_ctx* c, float* grad_div);
 int cbm_learner_allreduce_stats_impl(cbm_ctx* c);
 int cbm_comm_destroy_all(cbm_ctx* c);

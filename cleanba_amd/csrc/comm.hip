@@ -314,10 +314,6 @@ extern "C" int cbm_params_mark_published(cbm_ctx* c) {
   CBM_HIP(hipSetDevice(c->cfg.device));
   const int v = c->updates_done + 1;
   CBM_HIP(hipEventRecord(c->params_ready[v % NPV], c->lstream));   // the learner stream of an actor-only context is idle: completes at once
-  {
-    std::lock_guard<std::mutex> lk(c->mu);
-    c->updates_done = v;
-  }
-  c->cv.notify_all();
+  cbm_publish(c, c->updates_done, v);
   return 0;
 }

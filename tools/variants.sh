@@ -3,7 +3,7 @@
 # usage: tools/variants.sh name1 "-DFOO=1 -DBAR=2" name2 "-DBAZ" ...      then on the GPU box: tools/variants_run.sh name1 name2 ...
 set -e
 cd "$(dirname "$0")/../cleanba_amd/csrc"
-F="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-math-errno -Wno-unused-function -Wno-unused-result -Wno-unused-value -Wno-pass-failed"
+F="-O3 -std=c++20 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-math-errno -Wno-unused-function -Wno-unused-result -Wno-unused-value -Wno-pass-failed"
 while [ $# -ge 2 ]; do
   name=$1; defs=$2; shift; shift
   d=/tmp/abl_$name; mkdir -p $d
