@@ -991,7 +991,10 @@ void nature_forward(const NatureLayout& L, const float* P, const uint8_t* obs, c
                     NatureWs& ws, hipStream_t st) {
   if (L.kind == CBM_NET_IMPALA_RESNET) { resnet_forward(L, P, obs, idx, B, dense_ksplit, ws, st); return; }
   const bool small = B <= 512;
-  if (small) {
+#ifndef C1_FRAMES_MIN
+#define C1_FRAMES_MIN 513   // batches from this size on run conv1 on the frame-resident kernel (actor steps: the igemm gather)
+#endif
+  if (B < C1_FRAMES_MIN) {
 #if ACTOR_K16
     Conv1Fwd<T128x32k16> p{obs, idx, P + L.w[0], P + L.b[0], ws.act1, B * 400, ws.mask1};
 #else
