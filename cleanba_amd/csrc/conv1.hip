@@ -44,6 +44,9 @@ static __device__ __forceinline__ void frame_to_lds_rolled(const uint8_t* frame,
 }
 
 // ------------------------------------------------------------------------------------------ forward
+#ifndef C1F_ABL
+#define C1F_ABL 0   // timing builds: 1 no epilogue stores / masks, 2 no frame copies after the first, 4 byte -> float without the /255 math
+#endif
 // LDS: W1 as [k=(c,kh,kw)][32] f32 (32 KB) + one frame of bytes (28,224 B) = 60,992 B -> two blocks per CU, i.e. two
 // waves per SIMD whose conversion chains and MFMAs interleave.  A frame is 400 positions = 12.5 tiles of 32: wave
 // (w + f) % 4 takes tiles {first, first+4, first+8, (12)}; the rotation evens out who owns the 13th half tile.
@@ -121,7 +124,7 @@ __global__ __launch_bounds__(256, 2) void conv1_fwd_frames_kernel(const uint8_t*
 #pragma unroll
         for (int t = 0; t < MAXT; ++t) {
           const uint32_t w32 = (j < 2 ? px[t].x : px[t].y) >> (8 * h + 16 * (j & 1));  // pixel kw = 2j + h
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(cbm_u8_unit(w32 & 255u), wv[j], acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32((C1F_ABL & 4) ? (float)(w32 & 255u) : cbm_u8_unit(w32 & 255u), wv[j], acc[t], 0, 0, 0);
         }
       }
       if (four) {   // tail tile: kw = 4*st + g4
@@ -145,13 +148,24 @@ __global__ __launch_bounds__(256, 2) void conv1_fwd_frames_kernel(const uint8_t*
       __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();  // every wave is done reading this frame's bytes
-    if (s + 1 < s_hi) {
+    if (s + 1 < s_hi && !(C1F_ABL & 2)) {
       const int f = idx ? idx[s + 1] : s + 1;
       frame_to_lds(obs + (size_t)f * FR, F, wave, lane);  // lands while the epilogue stores drain
     }
     // epilogue: out[s][pos][n] = relu(acc + bias); the ReLU mask of each output pixel's 32 channels is a ballot word — lane r of the
     // lower half collects the word of tile row r, one coalesced 128-byte store per tile (read by the conv2 dgrad epilogue)
     float* o = out + (size_t)s * 400 * 32 + li;
+    if (C1F_ABL & 1) {   // timing build: one store per lane keeps the accumulators alive
+      float sum = tacc[0] + tacc[1] + tacc[2] + tacc[3];
+#pragma unroll
+      for (int t = 0; t < MAXT; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sum += acc[t][e];
+      o[(first * 32 + 4 * h) * 32] = sum;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      continue;
+    }
 #pragma unroll
     for (int t = 0; t < MAXT; ++t) {
       const int m0 = (first + 4 * t) * 32 + 4 * h;

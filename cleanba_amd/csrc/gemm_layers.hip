@@ -984,6 +984,9 @@ using T64x64k16 = IgemmTile<64, 64, 16, 2, 2>;
 #ifndef TILE_DD
 #define TILE_DD T128x128k16   // 143 -> 138 us
 #endif
+#ifndef TILE_C3F
+#define TILE_C3F T128x64      // (256x64 tiles, 2x2 accumulators per wave: 167 -> 163 us, conv2 fwd 218 -> 270: not taken)
+#endif
 
 #include "resnet_layers.inc"
 
@@ -1018,7 +1021,7 @@ void nature_forward(const NatureLayout& L, const float* P, const uint8_t* obs, c
     ConvFwd<TILE_C2F, 4, 4, 2, 32, 64, 20, 20, 9, 9> p2{ws.act1, P + L.w[1], P + L.b[1], ws.act2, B * 81, ws.mask2};
     if ((FWD_PF2 & 1) && !ws.bf16_fwd) plaunch_fn(ws, K_CONV2_FWD, st, [&] { igemm_pf2_launch(p2, 1, st); });
     else plaunch_fwd(ws, K_CONV2_FWD, p2, 1, st);
-    ConvFwd<T128x64, 3, 3, 1, 64, 64, 9, 9, 7, 7> p3{ws.act2, P + L.w[2], P + L.b[2], ws.act3, B * 49, ws.mask3};
+    ConvFwd<TILE_C3F, 3, 3, 1, 64, 64, 9, 9, 7, 7> p3{ws.act2, P + L.w[2], P + L.b[2], ws.act3, B * 49, ws.mask3};
     if ((FWD_PF2 & 2) && !ws.bf16_fwd) plaunch_fn(ws, K_CONV3_FWD, st, [&] { igemm_pf2_launch(p3, 1, st); });
     else plaunch_fwd(ws, K_CONV3_FWD, p3, 1, st);
   }
