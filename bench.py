@@ -13,8 +13,9 @@ Gumbel sampling + env step per env-step) + one learner update (GAE, adv-norm, 16
   python bench.py --gpus 8 --topology "2x(a0-l1,2,3)" --env-id Atari57Mix-v5     configs[4]: two such groups (benchmark.sh:80)
   torchrun --nproc-per-node N bench.py --gpus N ...           the driver's form; RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* are honoured
 
-The actor rollout k+1 is enqueued on its own HIP stream while update k runs (--concurrency semantics, ppo:287-304); a single host thread
-drives both through the C ABI, so nothing but the two device synchronisations brackets the timed region.
+The actor rollout k+1 is enqueued on its own HIP stream while update k runs (--concurrency semantics, ppo:287-304); the host is the
+trainer's: one thread per actor slot enqueues rollouts, the main thread drives the learner, both through the C ABI, and nothing but the two
+device synchronisations brackets the timed region.
 """
 import argparse
 import json
@@ -151,19 +152,43 @@ def run_dp(a, world, rank, local_rank):
             ctx.comm_barrier()
             ctx.sync()
 
-    rollout()  # rollout 1 (params v0)
+    # Host structure = the trainer's (cleanba_amd.trainer): one host thread per actor slot enqueues rollouts, the main thread drives the learner;
+    # cbm_actor_begin_rollout blocks the actor thread until its ring entry is free and the parameter version it needs exists (ppo:287-304).
+    # Timed region: K rollouts + K updates, exactly as many of each as a single-threaded "rollout(); update()" loop would enqueue.
+    import threading
+    go, failed, committed = threading.Event(), [], [0]
+
+    def actor_thread():
+        try:
+            for _ in range(a.warmup + 1):      # rollouts 1 .. W+1 (rollout v+1 overlaps update v)
+                rollout()
+                committed[0] += 1
+            go.wait()
+            for _ in range(a.steps):           # rollouts W+2 .. W+K+1, inside the timed region
+                rollout()
+        except BaseException as e:  # noqa: BLE001
+            failed.append(e)
+            ctx.abort()
+            raise
+
+    th = threading.Thread(target=actor_thread, daemon=True)
+    th.start()
     for _ in range(a.warmup):
-        rollout()  # rollout v+1 overlaps update v
         update()
+    while th.is_alive() and not failed and committed[0] < a.warmup + 1:
+        time.sleep(1e-4)                       # rollout W+1 has been enqueued; barrier() below waits for it on the device
     barrier()
     if a.prof_kernel != -1:
         ctx.profile_select(a.prof_kernel)
     if comm:
         ctx.comm_profile(True)
     t0 = time.perf_counter()
+    go.set()
     for _ in range(a.steps):
-        rollout()
         update()
+    th.join()
+    if failed:
+        raise failed[0]
     barrier()
     dt = time.perf_counter() - t0
     dt_local = dt

@@ -1,7 +1,7 @@
 """Where does the PPO step time go: learner alone, actor alone, both pipelined (bench.py's loop)."""
 import sys, time
 import numpy as np
-sys.path.insert(0, "/root/repo")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import cleanba_amd.lib as L
 import cleanba_amd.model as M
 import cleanba_amd.prng as prng
