@@ -18,6 +18,7 @@ Rank layout: group g occupies ranks [g*G, (g+1)*G), G = len(actor_device_ids) + 
 roles come first, then the learners, and LOCAL_RANK == the GPU id from the list.
 """
 import datetime
+import os
 import pickle
 import queue
 import threading
@@ -135,6 +136,12 @@ class Rendezvous:
 def setup_learner_comm(engine, rdv, ranks, rank, tag="learners"):
     """The communicator of the gradient / statistics all-reduce over `ranks` (pmap's device list, ppo:435-439,656-660)."""
     if len(ranks) < 2 and not engine.wants_comm_at_world_one():
+        return
+    if os.environ.get("CBM_COMM_LOOPBACK") == "1" and hasattr(engine, "comm_init_loopback"):
+        # testing aid: the self-test communicator (SUM over identical ranks) instead of RCCL, so the multi-process plumbing — launcher,
+        # rendezvous, one result line — can run with several ranks on a ONE-GPU box, where RCCL refuses two ranks per device
+        rdv.barrier(f"comm/{tag}") if rdv is not None else None
+        engine.comm_init_loopback(len(ranks))
         return
     uid = rdv.share(f"comm/{tag}/uid", engine.comm_unique_id, ranks[0]) if len(ranks) > 1 else engine.comm_unique_id()
     engine.comm_init(uid, len(ranks), ranks.index(rank))
