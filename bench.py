@@ -211,7 +211,8 @@ def run_dp(a, world, rank, local_rank):
         if comm:
             tail_ms, exposed_ms, n = ctx.comm_profile_read()
             P = ctx.P
-            line["allreduce"] = {"backend": "rccl", "ranks": world, "bytes_per_minibatch": int(P * 4), "minibatches": n,
+            line["allreduce"] = {"backend": "loopback self-test communicator (CBM_COMM_LOOPBACK, not RCCL)" if os.environ.get("CBM_COMM_LOOPBACK") == "1" else "rccl",
+                                 "ranks": world, "bytes_per_minibatch": int(P * 4), "minibatches": n,
                                  "tail_bytes": int((P - ctx.grad_tail_offset()) * 4),
                                  "tail_allreduce_us_avg": round(tail_ms / max(n, 1) * 1e3, 1),
                                  "exposed_us_avg": round(exposed_ms / max(n, 1) * 1e3, 1),
