@@ -7,9 +7,9 @@
 // copied ONCE, coalesced (16-B loads), into LDS as bytes, and the MFMA A fragments are produced straight from
 // those bytes (ds_read_u8 + exact /255) at the moment they are consumed; HBM sees each frame byte once per pass.
 //
-//   forward : block = persistent over pairs of frames (800 positions = 25 tiles of 32); each wave owns 6-7 M-tiles
-//             and walks k = (c,kh,kw) ascending with all its tiles in flight (one B fragment feeds 7 MFMAs).
-//             Same fmaf chain as the oracle -> bit-exact.
+//   forward : block = persistent over frames, one frame of bytes in LDS at a time (400 positions = 12 tiles of 32 + a 16-row tail tile on
+//             v_mfma_f32_16x16x4_f32); each wave owns 3 tiles and walks k = (c,kh,kw) ascending with all of them in flight (one B
+//             fragment feeds 3 MFMAs).  Same fmaf chain as the oracle -> bit-exact.
 //   wgrad   : block = persistent over a contiguous sample range; wave w owns k-tiles {2w, 2w+1} of dW[256][32];
 //             dY rows are read straight from HBM/L2 (256 B per wave-load), frames from LDS.  Pixels enter as exact
 //             integers and the 1/255 is applied once in the partial reduce (gradients carry a 1e-5 bar, not bits).
@@ -34,15 +34,6 @@ static __device__ __forceinline__ void frame_to_lds(const uint8_t* frame, unsign
     if (v0 + lane < FR / 16) glds16(frame + (size_t)(v0 + lane) * 16, dst + (size_t)v0 * 16);
   }
 }
-// rolled flavour for the register-heavy kernels (unrolled, hipcc keeps every round's 64-bit lane address live across the K loop)
-static __device__ __forceinline__ void frame_to_lds_rolled(const uint8_t* frame, unsigned char* dst, int wave, int lane) {
-#pragma unroll 1
-  for (int j = 0; j < 7; ++j) {
-    const int v0 = (wave + 4 * j) * 64;
-    if (v0 + lane < FR / 16) glds16(frame + (unsigned)(v0 + lane) * 16u, dst + (unsigned)v0 * 16u);
-  }
-}
-
 // ------------------------------------------------------------------------------------------ forward
 #ifndef C1F_ABL
 #define C1F_ABL 0   // timing builds: 1 no epilogue stores / masks, 2 no frame copies after the first, 4 byte -> float without the /255 math
@@ -200,152 +191,10 @@ __global__ __launch_bounds__(256, 2) void conv1_fwd_frames_kernel(const uint8_t*
   }
 }
 
-// ------------------------------------------------------------------------------------------ forward, pairs of frames, double-buffered
-// The single-frame kernel above runs two blocks per CU, and every block alternates "copy a frame" / "multiply it" in lock step with all the
-// others: HBM idles during the MFMA phases and the MFMAs during the copy bursts (0.46-0.52 of peak under load).  Here ONE block per CU keeps
-// two stages of two frames in LDS (W1 32 KB + 4 x 28,224 B = 145,664 B): the load unit copies the next pair while the waves multiply this
-// one.  A pair is 800 positions = 25 tiles of 32: every wave owns 6 whole tiles (wave + 4k) and one 16x16 quarter of tile 24
-// (v_mfma_f32_16x16x4_f32, four consecutive kw per instruction — still the oracle's k-ascending chain), i.e. 6.25 tile-equivalents each.
-#define C1P_T 6
-__global__ __launch_bounds__(256, 1) void conv1_fwd_pairs_kernel(const uint8_t* obs, const int32_t* idx, const float* W, const float* bias,
-                                                                 float* out, uint32_t* mask, int S, int frames_per_block) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem_raw[256 * 32 * 4 + 4 * FR];
-  float* Wl = reinterpret_cast<float*>(smem_raw);            // [256][32]
-  unsigned char* F0 = smem_raw + 256 * 32 * 4;               // [stage][frame of the pair][28224]
-  const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, h = lane >> 5;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  for (int i = tid; i < 256 * 32 / 4; i += 256) {   // weights: HWIO [kh][kw][c][n] -> k = (c,kh,kw) rows
-    const int k = i >> 3, n4 = (i & 7) * 4;
-    const int c = k >> 6, kh = (k >> 3) & 7, kw = k & 7;
-    *reinterpret_cast<float4*>(Wl + k * 32 + n4) = *reinterpret_cast<const float4*>(W + ((kh * 8 + kw) * 4 + c) * 32 + n4);
-  }
-  const int s_lo = blockIdx.x * frames_per_block, s_hi = min(S, s_lo + frames_per_block);
-  const float bn = bias[li];
-  typedef float f32x4_t __attribute__((ext_vector_type(4)));
-  const int r16 = lane & 15, g4 = lane >> 4;   // 16x16x4 MFMA roles: position / column r16, k = 4*step + g4
-  const int ph = wave >> 1, tj = wave & 1;     // this wave's quarter of tile 24: positions 768 + 16*ph .., columns 16*tj ..
-  const float bt = bias[16 * tj + r16];
-  auto stage = [&](int buf, int s0) __attribute__((always_inline)) {
-#pragma unroll
-    for (int f = 0; f < 2; ++f)
-      if (s0 + f < s_hi) {
-        const int fr = idx ? idx[s0 + f] : s0 + f;
-        frame_to_lds_rolled(obs + (size_t)fr * FR, F0 + (size_t)(buf * 2 + f) * FR, wave, lane);
-      }
-  };
-  // byte offset (within a stage) of the patch origin of position m of the pair
-  auto origin = [](int m) { const int f = m >= 400, q = m - 400 * f, oh = q / 20, ow = q - oh * 20; return f * FR + oh * 4 * 84 + ow * 4; };
-  int base[C1P_T];
-#pragma unroll
-  for (int t = 0; t < C1P_T; ++t) base[t] = origin((wave + 4 * t) * 32 + li);
-  const int tbase = origin(768 + 16 * ph + r16);
-  if (s_lo < s_hi) stage(0, s_lo);
-  int it = 0;
-  for (int s0 = s_lo; s0 < s_hi; s0 += 2, ++it) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();   // this pair has landed (every wave's pieces) and every wave is done with the other stage
-    if (s0 + 2 < s_hi) stage((it + 1) & 1, s0 + 2);
-    const unsigned char* F = F0 + (size_t)(it & 1) * 2 * FR;
-    const int nvalid = s0 + 1 < s_hi ? 800 : 400;   // an odd tail: the second frame's rows are computed on stale bytes and dropped
-    f32x16 acc[C1P_T];
-#pragma unroll
-    for (int t = 0; t < C1P_T; ++t)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[t][e] = 0.0f;
-    f32x4_t tacc = {0.f, 0.f, 0.f, 0.f};
-    uint2 pxa[C1P_T + 1], pxb[C1P_T + 1];   // [C1P_T] = the quarter tile's 8 bytes
-    float wa[6], wb[6];                     // [4..5] = the quarter tile's B values of the two k-steps
-    auto fetch = [&](int ckh, uint2(&px)[C1P_T + 1], float(&wv)[6]) __attribute__((always_inline)) {
-      const int koff = (ckh >> 3) * 7056 + (ckh & 7) * 84;
-#pragma unroll
-      for (int t = 0; t < C1P_T; ++t) {
-        const unsigned char* q = F + base[t] + koff;  // 4-byte aligned
-        px[t] = make_uint2(*reinterpret_cast<const uint32_t*>(q), *reinterpret_cast<const uint32_t*>(q + 4));
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) wv[j] = Wl[(ckh * 8 + 2 * j + h) * 32 + li];
-      const unsigned char* q = F + tbase + koff;
-      px[C1P_T] = make_uint2(*reinterpret_cast<const uint32_t*>(q), *reinterpret_cast<const uint32_t*>(q + 4));
-#pragma unroll
-      for (int st = 0; st < 2; ++st) wv[4 + st] = Wl[(ckh * 8 + 4 * st + g4) * 32 + 16 * tj + r16];
-    };
-    auto fma_row = [&](const uint2(&px)[C1P_T + 1], const float(&wv)[6]) __attribute__((always_inline)) {
-      // kw-pair outer / tile inner: consecutive MFMAs hit different accumulators; each accumulator still sees its k-pairs ascending
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-#pragma unroll
-        for (int t = 0; t < C1P_T; ++t) {
-          const uint32_t w32 = (j < 2 ? px[t].x : px[t].y) >> (8 * h + 16 * (j & 1));  // pixel kw = 2j + h
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(cbm_u8_unit(w32 & 255u), wv[j], acc[t], 0, 0, 0);
-        }
-      }
-#pragma unroll
-      for (int st = 0; st < 2; ++st) {   // quarter tile: kw = 4*st + g4
-        const float a = cbm_u8_unit(((st == 0 ? px[C1P_T].x : px[C1P_T].y) >> (8 * g4)) & 255u);
-        tacc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wv[4 + st], tacc, 0, 0, 0);
-      }
-    };
-    fetch(0, pxa, wa);
-#pragma unroll 1
-    for (int ckh = 0; ckh < 32; ckh += 2) {
-      fetch(ckh + 1, pxb, wb);
-      __builtin_amdgcn_sched_barrier(0);
-      fma_row(pxa, wa);
-      __builtin_amdgcn_sched_barrier(0);
-      if (ckh + 2 < 32) fetch(ckh + 2, pxa, wa);
-      __builtin_amdgcn_sched_barrier(0);
-      fma_row(pxb, wb);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    // epilogue: out[s0*400 + m][n] = relu(acc + bias) (the pair's two frames are consecutive output rows); ReLU mask words by ballot
-    float* o = out + (size_t)s0 * 400 * 32 + li;
-#pragma unroll
-    for (int t = 0; t < C1P_T; ++t) {
-      const int m0 = (wave + 4 * t) * 32;
-      uint32_t word = 0;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int r0 = (e & 3) + 8 * (e >> 2);
-        const float v = relu_(acc[t][e] + bn);
-        if (m0 + r0 + 4 * h < nvalid) o[(size_t)(m0 + r0 + 4 * h) * 32] = v;
-        const unsigned long long bal = __ballot(v > 0.0f);   // all 64 lanes: rows r0 (lower half) and r0 + 4 (upper half)
-        asm volatile("s_nop 4\n\tv_writelane_b32 %0, %1, %2" : "+v"(word) : "s"((uint32_t)bal), "n"(r0));
-        asm volatile("s_nop 4\n\tv_writelane_b32 %0, %1, %2" : "+v"(word) : "s"((uint32_t)(bal >> 32)), "n"(r0 + 4));
-      }
-      if (mask && lane < 32 && m0 + lane < nvalid) mask[(size_t)s0 * 400 + m0 + lane] = word;
-    }
-    {   // quarter of tile 24: lane (g4, r16) holds rows 768 + 16*ph + 4*g4 + i, column 16*tj + r16; 16 mask bits per row -> half a word
-      uint32_t word = 0;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float v = relu_(tacc[i] + bt);
-        if (nvalid == 800) out[((size_t)s0 * 400 + 768 + 16 * ph + 4 * g4 + i) * 32 + 16 * tj + r16] = v;
-        const unsigned long long bal = __ballot(v > 0.0f);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) asm volatile("s_nop 4\n\tv_writelane_b32 %0, %1, %2" : "+v"(word) : "s"((uint32_t)((bal >> (16 * g)) & 0xFFFFull)), "n"(4 * g + i));
-      }
-      if (mask && lane < 16 && nvalid == 800) reinterpret_cast<uint16_t*>(mask + (size_t)s0 * 400 + 768 + 16 * ph + lane)[tj] = (uint16_t)word;
-    }
-  }
-}
-
-#ifndef C1F_PAIRS
-#define C1F_PAIRS 0
-#endif
 void launch_conv1_fwd_frames(const uint8_t* obs, const int32_t* idx, const float* W, const float* bias, float* out, uint32_t* mask, int S,
                              hipStream_t st) {
 #ifndef C1F_BLOCKS
 #define C1F_BLOCKS 512
-#endif
-#if C1F_PAIRS
-  {
-    int blocks = 256;                                   // one persistent block per CU
-    int fpb = (S + blocks - 1) / blocks;
-    fpb += fpb & 1;                                     // whole pairs per block
-    blocks = (S + fpb - 1) / fpb;
-    hipLaunchKernelGGL(conv1_fwd_pairs_kernel, dim3(blocks), dim3(256), 0, st, obs, idx, W, bias, out, mask, S, fpb);
-    return;
-  }
 #endif
   int blocks = C1F_BLOCKS;
   if (S < blocks) blocks = S;
