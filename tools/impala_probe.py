@@ -1,0 +1,42 @@
+"""IMPALA (BASELINE configs[2] shape: a0-l0, E=120, T=128, Nature-CNN, optional bf16 forward): pipelined step time and rollout / update alone."""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import cleanba_amd.lib as L
+import cleanba_amd.model as M
+import cleanba_amd.prng as prng
+E, T, A = 120, int(os.environ.get("T", "128")), 18
+cfg = L.default_config(L.ALGO_IMPALA)
+cfg.local_num_envs, cfg.num_actor_slots, cfg.num_steps, cfg.num_actions = E, 1, T, A
+cfg.forward_bf16 = int(os.environ.get("BF16", "0"))
+ctx = L.Context(cfg)
+key = prng.prng_key(1)
+key, nk, ak, ck = prng.split(key, 4)
+ctx.set_params(M.init_nature_params(A, nk, ak, ck))
+ctx.actor_set_key(0, key)
+ctx.actor_env_reset_device(0, 1)
+lkey = key.copy()
+lrs = np.full(4, 6e-4, np.float32)
+first = [True]
+
+def rollout():
+    ctx.actor_begin_rollout(0, True); ctx.actor_rollout_device(0, T + 1 if first[0] else T); first[0] = False; ctx.actor_commit(0)
+
+def update():
+    global lkey
+    ctx.learner_wait()
+    lkey, _ = ctx.learner_update(lkey, lrs, lrs, lrs, want_stats=False)
+
+rollout()
+for _ in range(2): rollout(); update()
+ctx.sync(); t0 = time.perf_counter()
+N = 8
+for _ in range(N): rollout(); update()
+ctx.sync(); dt = (time.perf_counter() - t0) / N
+print(f"IMPALA E={E} T={T} bf16={cfg.forward_bf16}: pipelined {dt*1e3:.2f} ms/step = {E*T/dt/1e3:.1f} k env-steps/s")
+tr = tu = 0.0
+for _ in range(4):
+    ctx.sync(); t0 = time.perf_counter(); rollout(); ctx.sync(); tr += time.perf_counter() - t0
+    t0 = time.perf_counter(); update(); ctx.sync(); tu += time.perf_counter() - t0
+print(f"  rollout alone {tr/4*1e3:.2f} ms   update alone {tu/4*1e3:.2f} ms")
+ctx.close()
