@@ -994,6 +994,27 @@ void nature_forward(const NatureLayout& L, const float* P, const uint8_t* obs, c
                     NatureWs& ws, hipStream_t st) {
   if (L.kind == CBM_NET_IMPALA_RESNET) { resnet_forward(L, P, obs, idx, B, dense_ksplit, ws, st); return; }
   const bool small = B <= 512;
+#ifndef ACTOR_S16
+#define ACTOR_S16 1   // actor-size forward passes (no ReLU masks wanted) on the 16x16x4 small-batch kernel (igemm.h igemm_s16_kernel), same bits
+#endif
+  if (ACTOR_S16 && small && !ws.mask1 && !ws.bf16_fwd && !ws.prof) {
+    Conv1Fwd<T64x64k16> p1{obs, idx, P + L.w[0], P + L.b[0], ws.act1, B * 400, nullptr};
+    igemm_s16_launch<32, 32, 64>(p1, 1, st);
+    ConvFwd<T64x64k16, 4, 4, 2, 32, 64, 20, 20, 9, 9> p2{ws.act1, P + L.w[1], P + L.b[1], ws.act2, B * 81, nullptr};
+    igemm_s16_launch<32, 32, 64>(p2, 1, st);
+    ConvFwd<T64x64k16, 3, 3, 1, 64, 64, 9, 9, 7, 7> p3{ws.act2, P + L.w[2], P + L.b[2], ws.act3, B * 49, nullptr};
+    igemm_s16_launch<32, 32, 64>(p3, 1, st);
+    if (dense_ksplit > 1) {
+      DenseFwd<T64x64k16, true> pd{ws.act3, P + L.w[3], P + L.b[3], ws.dense_part, B, 3136, 512, 3136 / dense_ksplit};
+      igemm_s16_launch<32, 32, 32>(pd, dense_ksplit, st);
+      hipLaunchKernelGGL(dense_reduce_kernel, dim3(ceil_div(B * 512, 256)), dim3(256), 0, st, ws.dense_part, P + L.b[3], ws.hid, B, 512, dense_ksplit);
+    } else {
+      DenseFwd<T64x64k16, false> pd{ws.act3, P + L.w[3], P + L.b[3], ws.hid, B, 3136, 512, 3136};
+      igemm_s16_launch<32, 32, 64>(pd, 1, st);
+    }
+    launch_heads_fwd(ws.hid, P + L.w[4], P + L.b[4], P + L.w[5], P + L.b[5], B, L.A, 512, ws.logits, ws.value, st);
+    return;
+  }
 #ifndef C1_FRAMES_MIN
 #define C1_FRAMES_MIN 513   // batches from this size on run conv1 on the frame-resident kernel (actor steps: the igemm gather)
 #endif

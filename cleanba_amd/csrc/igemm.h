@@ -539,6 +539,117 @@ static inline void igemm_pf2_launch(const P& p, int nsplit, hipStream_t stream) 
   hipLaunchKernelGGL(igemm_pf2_kernel<P>, grid, dim3(256), 0, stream, p);
 }
 
+// ------------------------------------------------------------------------------------------------ small-batch variant (actor steps)
+// An actor step runs the network on 120 frames: 0.4-0.8 GFLOP per layer, a few microseconds of the chip.  On 64x64 tiles of
+// v_mfma_f32_32x32x2_f32 that work lands on 90-375 blocks whose waves each own ONE accumulator and walk K in 16-wide chunks: 256-288
+// MFMAs of 64 cycles back to back (6.8-7.7 us of one SIMD's matrix pipe) plus a barrier and an LDS round trip per chunk — 18-24 us per
+// layer, eight launches per env-step, and the step time of the whole trainer grows by ~0.43 us for every microsecond of rollout.
+// Here the same problems run on v_mfma_f32_16x16x4_f32 (k = 4 per instruction, 32 cycles): a wave owns a 16x16 output tile, so the same
+// flops spread over 4x the waves (all 1024 SIMDs get work) and a wave's pipe time is K/4 x 32 cycles = 1.7-1.9 us; K chunks are 32-64
+// wide (8-9 barriers per block instead of 32-36) with two chunks of loads in flight.  The instruction multiplies k = 4s .. 4s+3 in
+// ascending order into the accumulator, steps ascend, chunks ascend: the SAME k-ascending fmaf chain as igemm_kernel -> identical bits
+// (tests/test_gpu_parity.py::test_forward_bit_exact runs both).  Row-gather A / row-major B problems (the forward GEMMs), plain
+// p.store epilogue (no ReLU-mask emission: actor workspaces have no masks).
+//   LDS: A[x][r] pitch BR+4 and B[r][y] pitch BY+16 floats: both fragment reads (lane = (g4, r16): A[r16][4s+g4], B[4s+g4][r16]) are
+//   conflict-free and both tiles are filled with 16-byte stores.
+typedef float f32x4_mfma __attribute__((ext_vector_type(4)));
+template <class P, int BX, int BY, int BR>
+__global__ __launch_bounds__(256) void igemm_s16_kernel(const P p) {
+  static_assert(BX % 16 == 0 && BY % 16 == 0 && BR % 32 == 0 && (BX / 16) * (BY / 16) % 4 == 0, "tile shape");
+  static_assert(!P::A_RX && !P::B_YR && !P::BIAS_GRAD && P::NCLS == 1, "forward-style problems");
+  constexpr int NT16 = (BX / 16) * (BY / 16) / 4;          // 16x16 tiles per wave
+  constexpr int PA = BR + 4, PB = BY + 16, ASZ = BX * PA, BSZ = BR * PB;
+  constexpr int NVA = (BX * BR / 4 + 255) / 256, NVB = (BR * BY / 4 + 255) / 256;
+  __shared__ __attribute__((aligned(16))) float smem[2 * ASZ + 2 * BSZ];
+  float* As = smem;
+  float* Bs = smem + 2 * ASZ;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r16 = lane & 15, g4 = lane >> 4;
+  const int x0 = blockIdx.x * BX, y0 = blockIdx.y * BY, z = blockIdx.z;
+  int rlo, rhi;
+  p.r_range(z, rlo, rhi);
+  const int nchunk = (rhi - rlo + BR - 1) / BR;
+  // this wave's tiles: tile index q = wave * NT16 + i over the (BX/16) x (BY/16) grid, y fastest
+  f32x4_mfma acc[NT16];
+#pragma unroll
+  for (int i = 0; i < NT16; ++i) acc[i] = f32x4_mfma{0.0f, 0.0f, 0.0f, 0.0f};
+
+  auto gload = [&](int c, float4 (&ra)[NVA], float4 (&rb)[NVB]) {
+    const int r0 = rlo + c * BR;
+#pragma unroll
+    for (int j = 0; j < NVA; ++j) {
+      const int v = tid + 256 * j;
+      if (BX * BR / 4 % 256 == 0 || v < BX * BR / 4) { const int rq = v % (BR / 4), xl = v / (BR / 4); ra[j] = p.load_a(x0 + xl, r0 + 4 * rq, rhi, 0); }
+    }
+#pragma unroll
+    for (int j = 0; j < NVB; ++j) {
+      const int v = tid + 256 * j;
+      if (BR * BY / 4 % 256 == 0 || v < BR * BY / 4) { const int yq = v % (BY / 4), rl = v / (BY / 4); rb[j] = p.load_b(r0 + rl, y0 + 4 * yq, rhi, 0); }
+    }
+  };
+  auto sstore = [&](int buf, const float4 (&ra)[NVA], const float4 (&rb)[NVB]) {
+    float* A_ = As + buf * ASZ;
+    float* B_ = Bs + buf * BSZ;
+#pragma unroll
+    for (int j = 0; j < NVA; ++j) {
+      const int v = tid + 256 * j;
+      if (BX * BR / 4 % 256 == 0 || v < BX * BR / 4) { const int rq = v % (BR / 4), xl = v / (BR / 4); *reinterpret_cast<float4*>(A_ + xl * PA + 4 * rq) = ra[j]; }
+    }
+#pragma unroll
+    for (int j = 0; j < NVB; ++j) {
+      const int v = tid + 256 * j;
+      if (BR * BY / 4 % 256 == 0 || v < BR * BY / 4) { const int yq = v % (BY / 4), rl = v / (BY / 4); *reinterpret_cast<float4*>(B_ + rl * PB + 4 * yq) = rb[j]; }
+    }
+  };
+  auto compute = [&](int buf) {
+    const float* A_ = As + buf * ASZ;
+    const float* B_ = Bs + buf * BSZ;
+#pragma unroll
+    for (int st = 0; st < BR / 4; ++st) {
+#pragma unroll
+      for (int i = 0; i < NT16; ++i) {
+        const int q = wave * NT16 + i, tx = q / (BY / 16), ty = q % (BY / 16);
+        const float a = A_[(tx * 16 + r16) * PA + 4 * st + g4];
+        const float b = B_[(4 * st + g4) * PB + ty * 16 + r16];
+        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
+      }
+    }
+  };
+
+  float4 a0[NVA], b0[NVB], a1[NVA], b1[NVB];
+  gload(0, a0, b0);
+  sstore(0, a0, b0);
+  if (nchunk > 1) gload(1, a0, b0);
+  __syncthreads();
+  int buf = 0, c = 0;
+  while (true) {
+    if (c + 2 < nchunk) gload(c + 2, a1, b1);        // set 0 holds chunk c+1
+    compute(buf);
+    if (c + 1 < nchunk) sstore(buf ^ 1, a0, b0);
+    __syncthreads();
+    buf ^= 1;
+    if (++c >= nchunk) break;
+    if (c + 2 < nchunk) gload(c + 2, a0, b0);        // set 1 holds chunk c+1
+    compute(buf);
+    if (c + 1 < nchunk) sstore(buf ^ 1, a1, b1);
+    __syncthreads();
+    buf ^= 1;
+    if (++c >= nchunk) break;
+  }
+  // D layout of the 16x16 tile: lane (g4, r16) holds rows 4*g4 + i, column r16
+#pragma unroll
+  for (int i = 0; i < NT16; ++i) {
+    const int q = wave * NT16 + i, tx = q / (BY / 16), ty = q % (BY / 16);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) p.store(x0 + tx * 16 + 4 * g4 + e, y0 + ty * 16 + r16, acc[i][e], z, 0);
+  }
+}
+template <int BX, int BY, int BR, class P>
+static inline void igemm_s16_launch(const P& p, int nsplit, hipStream_t stream) {
+  dim3 grid((p.X() + BX - 1) / BX, (p.Y() + BY - 1) / BY, nsplit);
+  hipLaunchKernelGGL((igemm_s16_kernel<P, BX, BY, BR>), grid, dim3(256), 0, stream, p);
+}
+
 // ------------------------------------------------------------------------------------------------ DMA-staged variant
 // Same math and the same k-ascending accumulation order as igemm_kernel (bit-identical results), but the LDS tiles are filled by
 // global_load_lds_dwordx4: the load unit writes 16 bytes per lane straight into LDS (wave-uniform base + lane*16) — no staging
