@@ -340,11 +340,14 @@ static void actor_infer_row(cbm_ctx* c, int s, int t) {
   Slot& sl = c->slots[s];
   RingEntry& R = c->ring[sl.ring];
   const size_t o = row_off(c, t, s);
-  nature_forward(c->L, c->actor_params[sl.pver % NPV], R.obs + o * CBM_FRAME, nullptr, c->E, c->cfg.actor_dense_ksplit, sl.ws, sl.stream);
   uint32_t n0, n1, s0, s1;  // key, subkey = jax.random.split(key)  (ppo:256)
   cbm_split_at(sl.key[0], sl.key[1], 2, 0, &n0, &n1);
   cbm_split_at(sl.key[0], sl.key[1], 2, 1, &s0, &s1);
   sl.key[0] = n0; sl.key[1] = n1;
+  const ActorSample smp = is_ppo(c) ? ActorSample{s0, s1, R.actions + o, R.logprobs + o, R.values + o, nullptr}
+                                    : ActorSample{s0, s1, R.actions + o, nullptr, nullptr, R.logits + o * c->A};
+  if (nature_forward(c->L, c->actor_params[sl.pver % NPV], R.obs + o * CBM_FRAME, nullptr, c->E, c->cfg.actor_dense_ksplit, sl.ws, sl.stream, &smp))
+    return;   // the forward pass ended in the fused reduce + heads + sampling launch
   if (is_ppo(c))
     launch_sample(sl.ws.logits, c->E, c->A, s0, s1, R.actions + o, R.logprobs + o, sl.ws.value, R.values + o, nullptr, sl.stream);
   else

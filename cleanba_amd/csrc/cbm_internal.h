@@ -64,9 +64,19 @@ struct NatureWs {
 int nature_ws_alloc(NatureWs& ws, int maxB, bool with_grad, int dense_ksplit_small, int kind = 0);
 void nature_ws_free(NatureWs& ws);
 
-// forward: obs[idx[b]] (idx may be null) -> ws.logits [B,A], ws.value [B]; activations kept in ws.
-void nature_forward(const NatureLayout& L, const float* P, const uint8_t* obs, const int32_t* idx, int B,
-                    int dense_ksplit, NatureWs& ws, hipStream_t st);
+// get_action_and_value's sampling step handed to the forward pass so that an actor step can end in ONE launch (split-K reduce of the dense
+// layer + heads + Gumbel arg-max + log-softmax): same outputs as launch_sample on ws.logits / ws.value.
+struct ActorSample {
+  uint32_t sk0, sk1;          // subkey words (jax.random.split(key)[1])
+  int32_t* actions;           // [B]
+  float* logprobs;            // [B] or null (IMPALA)
+  float* value_out;           // [B] or null
+  float* logits_out;          // [B][A] or null (PPO)
+};
+// forward: obs[idx[b]] (idx may be null) -> ws.logits [B,A], ws.value [B]; activations kept in ws.  With `sample` non-null the call MAY
+// also do the sampling (returns true then; ws.logits / ws.value / ws.hid are not written); false = the caller launches launch_sample.
+bool nature_forward(const NatureLayout& L, const float* P, const uint8_t* obs, const int32_t* idx, int B,
+                    int dense_ksplit, NatureWs& ws, hipStream_t st, const ActorSample* sample = nullptr);
 // backward from ws.dzv ([B][32]: dlogits | dvalue | 0) -> grads (flat, same layout as params).
 void nature_backward(const NatureLayout& L, const float* P, const uint8_t* obs, const int32_t* idx, int B,
                      NatureWs& ws, float* grads, hipStream_t st);

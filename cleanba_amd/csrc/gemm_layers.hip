@@ -240,6 +240,70 @@ struct HeadsFwd {
     else if (n == A) value[m] = v + bc[0];
   }
 };
+// Actor tail: heads + sampling in ONE launch.  One block per 16 frames: their hid rows go to LDS, the head weights to registers, the heads run on v_mfma_f32_16x16x4_f32 (HeadsFwd's chain: k ascending from 0, bias afterwards), logits / value stay
+// in LDS, and the sampling is sample_kernel's code (pointwise.hip: same threefry counters, same shuffle tournament, same exp-sum order).
+// Replaces the heads GEMM + sample_kernel (12.9 + 4.8 us per actor step); logits / value never reach HBM.  Bit-identical outputs.
+template <int HD>
+__global__ __launch_bounds__(256) void actor_tail_kernel(const float* hid, const float* Wa, const float* ba, const float* Wc, const float* bc, int B, int A,
+                                                         ActorSample smp) {
+  constexpr int PH = HD + 4;                       // row pitch: conflict-free A fragment reads (lane (g4, r16): hs[r16][4s + g4])
+  __shared__ __attribute__((aligned(16))) float hs[16 * PH];     // hid rows
+  __shared__ float lg[16][33];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, g4 = lane >> 4;
+  const int m0 = blockIdx.x * 16;
+  // waves 0 / 1 own output columns 0-15 / 16-31: ALL their B fragments (HD/4 floats per lane, L2-resident weights) are requested up front,
+  // together with the hid rows, so the block pays one load latency instead of one per K chunk
+  const int n = wave * 16 + r16;
+  const bool on = wave < 2 && n <= A;
+  const float* wp = n < A ? Wa + n : Wc;
+  const int wstride = n < A ? A : 1;
+  float bw[HD / 4];
+#pragma unroll
+  for (int st = 0; st < HD / 4; ++st) bw[st] = on ? wp[(size_t)(4 * st + g4) * wstride] : 0.0f;
+  for (int i = tid; i < 16 * HD / 4; i += 256) {
+    const int row = i / (HD / 4), c4 = (i % (HD / 4)) * 4;
+    *reinterpret_cast<float4*>(hs + row * PH + c4) = *reinterpret_cast<const float4*>(hid + (size_t)min(m0 + row, B - 1) * HD + c4);
+  }
+  __syncthreads();
+  if (wave < 2) {
+    f32x4_mfma acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int st = 0; st < HD / 4; ++st) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(hs[r16 * PH + 4 * st + g4], bw[st], acc, 0, 0, 0);
+    const float bias = n < A ? ba[n] : (n == A ? bc[0] : 0.0f);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) lg[4 * g4 + e][n] = acc[e] + bias;   // D layout: lane (g4, r16) holds rows 4*g4 + e, column r16
+  }
+  __syncthreads();
+  const uint32_t nn = (uint32_t)(B * A);
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {   // sampling: 32 lanes per row, 8 rows per pass
+    const int row = pass * 8 + (tid >> 5), b = m0 + row, a = tid & 31;
+    const bool live = b < B && a < A;
+    const int bb = b < B ? b : B - 1, aa = a < A ? a : A - 1;
+    const float z = lg[row][aa];
+    const float u = cbm_bits_to_uniform(cbm_random_bits_at(smp.sk0, smp.sk1, nn, (uint32_t)(bb * A + aa)));
+    float g = live ? z - cbm_logf(-cbm_logf(u)) : -INFINITY;
+    if (live && smp.logits_out) smp.logits_out[(size_t)b * A + a] = z;
+    int bi = a;
+    float bv = g, mx = live ? z : -INFINITY;
+    for (int o = 16; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(bv, o, 32);
+      const int oi = __shfl_xor(bi, o, 32);
+      const float om = __shfl_xor(mx, o, 32);
+      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+      mx = om > mx ? om : mx;
+    }
+    const float e = live ? cbm_expf(z - mx) : 0.0f;
+    const float zb = __shfl(z, bi, 32);
+    float ssum = 0.0f;
+    for (int j = 0; j < A; ++j) ssum += __shfl(e, j, 32);
+    if (b < B && a == 0) {
+      smp.actions[b] = bi;
+      if (smp.logprobs) smp.logprobs[b] = (zb - mx) - cbm_logf(ssum);
+      if (smp.value_out) smp.value_out[b] = lg[row][A];
+    }
+  }
+}
 #ifndef HEADS_S16
 #define HEADS_S16 1
 #endif
@@ -1018,9 +1082,9 @@ using T64x64k16 = IgemmTile<64, 64, 16, 2, 2>;
 
 #include "resnet_layers.inc"
 
-void nature_forward(const NatureLayout& L, const float* P, const uint8_t* obs, const int32_t* idx, int B, int dense_ksplit,
-                    NatureWs& ws, hipStream_t st) {
-  if (L.kind == CBM_NET_IMPALA_RESNET) { resnet_forward(L, P, obs, idx, B, dense_ksplit, ws, st); return; }
+bool nature_forward(const NatureLayout& L, const float* P, const uint8_t* obs, const int32_t* idx, int B, int dense_ksplit,
+                    NatureWs& ws, hipStream_t st, const ActorSample* sample) {
+  if (L.kind == CBM_NET_IMPALA_RESNET) { resnet_forward(L, P, obs, idx, B, dense_ksplit, ws, st); return false; }
   const bool small = B <= 512;
 #ifndef ACTOR_S16
 #define ACTOR_S16 1   // actor-size forward passes (no ReLU masks wanted) on the 16x16x4 small-batch kernel (igemm.h igemm_s16_kernel), same bits
@@ -1039,13 +1103,21 @@ void nature_forward(const NatureLayout& L, const float* P, const uint8_t* obs, c
     if (dense_ksplit > 1) {
       DenseFwd<T64x64k16, true> pd{ws.act3, P + L.w[3], P + L.b[3], ws.dense_part, B, 3136, 512, 3136 / dense_ksplit};
       igemm_s16_launch<32, 32, 32>(pd, dense_ksplit, st);
+#ifndef ACTOR_TAIL_FUSED
+#define ACTOR_TAIL_FUSED 1
+#endif
       hipLaunchKernelGGL(dense_reduce_kernel, dim3(ceil_div(B * 512, 256)), dim3(256), 0, st, ws.dense_part, P + L.b[3], ws.hid, B, 512, dense_ksplit);
+      if (ACTOR_TAIL_FUSED && sample && L.A + 1 <= 32) {
+        hipLaunchKernelGGL(actor_tail_kernel<512>, dim3(ceil_div(B, 16)), dim3(256), 0, st, ws.hid, P + L.w[4], P + L.b[4], P + L.w[5], P + L.b[5], B, L.A,
+                           *sample);
+        return true;
+      }
     } else {
       DenseFwd<T64x64k16, false> pd{ws.act3, P + L.w[3], P + L.b[3], ws.hid, B, 3136, 512, 3136};
       igemm_s16_launch<32, 32, 64>(pd, 1, st);
     }
     launch_heads_fwd(ws.hid, P + L.w[4], P + L.b[4], P + L.w[5], P + L.b[5], B, L.A, 512, ws.logits, ws.value, st);
-    return;
+    return false;
   }
 #ifndef C1_FRAMES_MIN
 #define C1_FRAMES_MIN 513   // batches from this size on run conv1 on the frame-resident kernel (actor steps: the igemm gather)
@@ -1093,6 +1165,7 @@ void nature_forward(const NatureLayout& L, const float* P, const uint8_t* obs, c
     else plaunch_fwd(ws, K_DENSE_FWD, pd, 1, st);
   }
   launch_heads_fwd(ws.hid, P + L.w[4], P + L.b[4], P + L.w[5], P + L.b[5], B, L.A, 512, ws.logits, ws.value, st);
+  return false;
 }
 
 // Tile order of the position-major conv3 dgrad.  igemm_kernel hands XCD k the contiguous run of x-tiles [start_k, start_k + len_k)
