@@ -189,12 +189,23 @@ __global__ __launch_bounds__(256) void env_step_kernel(uint32_t seed, int E, int
   // 4-byte granularity: 1764 words per plane
   const uint32_t* p32 = reinterpret_cast<const uint32_t*>(p);
   uint32_t* o32 = reinterpret_cast<uint32_t*>(o);
-  for (int i = threadIdx.x; i < 1764; i += 256) {
+  // the three older planes are shifted from the previous stack: all of a thread's loads are issued before its first store (the loop below
+  // used to pay one L2 round trip per iteration, seven in a row, on the critical path of every env-step)
+  uint32_t older[7][3];
+#pragma unroll
+  for (int j = 0; j < 7; ++j) {
+    const int i = threadIdx.x + 256 * j;
+    if (i < 1764 && !rs) { older[j][0] = p32[1764 + i]; older[j][1] = p32[2 * 1764 + i]; older[j][2] = p32[3 * 1764 + i]; }
+  }
+#pragma unroll
+  for (int j = 0; j < 7; ++j) {
+    const int i = threadIdx.x + 256 * j;
+    if (i >= 1764) break;
     const int y = (4 * i) / 84, x = (4 * i) % 84;
     const uint32_t nw = (uint32_t)env_pixel(&s, gm, y, x) | ((uint32_t)env_pixel(&s, gm, y, x + 1) << 8) |
                         ((uint32_t)env_pixel(&s, gm, y, x + 2) << 16) | ((uint32_t)env_pixel(&s, gm, y, x + 3) << 24);
     if (rs) { o32[i] = nw; o32[1764 + i] = nw; o32[2 * 1764 + i] = nw; }
-    else { o32[i] = p32[1764 + i]; o32[1764 + i] = p32[2 * 1764 + i]; o32[2 * 1764 + i] = p32[3 * 1764 + i]; }
+    else { o32[i] = older[j][0]; o32[1764 + i] = older[j][1]; o32[2 * 1764 + i] = older[j][2]; }
     o32[3 * 1764 + i] = nw;
   }
 }
