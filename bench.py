@@ -184,8 +184,11 @@ def run_dp(a, world, rank, local_rank):
         ctx.comm_profile(True)
     t0 = time.perf_counter()
     go.set()
-    for _ in range(a.steps):
-        update()
+    prof_steps = a.steps if a.prof_kernel == -1 else max(1, min(a.steps, a.prof_steps if a.prof_steps > 0 else (a.steps + 3) // 4))
+    for i in range(a.steps):
+        if i == prof_steps and a.prof_kernel != -1:
+            ctx.profile_select(-3)             # CBM_PROFILE_PAUSE: the event pairs cost ~6 us each (they serialise back-to-back launches),
+        update()                               # so only the first prof_steps steps of the timed region carry them
     th.join()
     if failed:
         raise failed[0]
@@ -207,7 +210,7 @@ def run_dp(a, world, rank, local_rank):
                                        "device synthetic %s env, concurrency on" % (world, "Atari-57-mix" if a.env_id.startswith("Atari57") else "Breakout-shaped"),
                            "global_batch": T * E * world, "parallelism": f"dp{world}"},
                 "per_gpu": {"value": round(sps / world, 1), "rank0_local_ms_per_step": round(dt_local / a.steps * 1e3, 3)},
-                "roofline": roofline(ctx, a, dt)}
+                "roofline": roofline(ctx, a, dt, prof_steps)}
         if comm:
             tail_ms, exposed_ms, n = ctx.comm_profile_read()
             P = ctx.P
@@ -222,7 +225,7 @@ def run_dp(a, world, rank, local_rank):
     return line, params
 
 
-def roofline(ctx, a, dt):
+def roofline(ctx, a, dt, prof_steps):
     """Per-kernel HIP-event times of the timed region (events bracket every learner-stream launch of ids 0..11).  The `roofline` object is
     the kernel with the LARGEST measured time share; `kernels` lists all twelve; `whole_step` prices the whole step's algorithmic flops."""
     if a.prof_kernel == -1:
@@ -242,7 +245,7 @@ def roofline(ctx, a, dt):
         tf = flops / avg_s / 1e12
         tr = traffic_tab.get(str(k), {}).get("traffic_bytes")
         rows[k] = {"kernel": name, "avg_us": round(avg_s * 1e6, 1), "launches": int(cnt[k]), "achieved": round(tf, 2),
-                   "frac": round(tf / FP32_MFMA_PEAK_TFLOPS, 4), "time_share": round(ms[k] / 1e3 / dt, 4), "flops_per_launch": flops,
+                   "frac": round(tf / FP32_MFMA_PEAK_TFLOPS, 4), "time_share": round(ms[k] / 1e3 / (dt * prof_steps / a.steps), 4), "flops_per_launch": flops,
                    "traffic": tr, "hbm_gbps": None if tr is None else round(tr / avg_s / 1e9, 1),
                    "hbm_frac": None if tr is None else round(tr / avg_s / 1e9 / HBM_PEAK_GBPS, 4)}
     if not rows:
@@ -253,7 +256,8 @@ def roofline(ctx, a, dt):
     out = {"bound": "mfma", "kernel": r["kernel"], "achieved": r["achieved"], "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": r["frac"],
            "traffic": r["traffic"], "hbm_gbps": r["hbm_gbps"], "hbm_frac": r["hbm_frac"], "launches": r["launches"], "avg_us": r["avg_us"],
            "flops_per_launch": r["flops_per_launch"], "time_share": r["time_share"],
-           "selection": "largest measured time share of the timed region (HIP events around every learner-stream launch of kernel ids 0-11)",
+           "selection": "largest measured time share (HIP events around every learner-stream launch of kernel ids 0-11 during the first "
+                        "%d of the %d timed steps)" % (prof_steps, a.steps), "event_steps": prof_steps,
            "min_frac": min(v["frac"] for k, v in rows.items() if k != 4),   # (id 4, the 32-wide heads wgrad, is 0.2 % of the flops)
            "whole_step": {"achieved": round(whole_tf, 2), "frac": round(whole_tf / FP32_MFMA_PEAK_TFLOPS, 4),
                           "algorithmic_hbm_gbps": round(ALG_BYTES_PER_ENV_STEP * (a.steps * T * E) / dt / 1e9, 1),
@@ -372,6 +376,7 @@ def main():
     ap.add_argument("--topology", default="dp", help="dp (a0_l0_dN, the default) | a0-l1,2,3 | 2x(a0-l1,2,3) | a0-l0,1 ...: one process per role")
     ap.add_argument("--env-id", default="Breakout-v5", help="Breakout-v5 | Atari57Mix-v5 (BASELINE configs[4])")
     ap.add_argument("--actor-threads", type=int, default=1, help="actor threads per actor GPU in the split topologies")
+    ap.add_argument("--prof-steps", type=int, default=0, help="timed steps that carry the per-launch HIP events (0: a quarter of --steps)")
     ap.add_argument("--prof-kernel", type=int, default=-2, help="-2: HIP events around every GEMM launch (ids 0-11, default); k: only kernel k; -1: off")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-env", action="store_true", help="skip the secondary envpool-API measurement")

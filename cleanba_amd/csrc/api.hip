@@ -668,6 +668,10 @@ extern "C" int cbm_profile_select(cbm_ctx* c, int32_t kernel_id) {
     for (int i = 0; i < 2 * CBM_PROF_MAX; ++i) CBM_HIP(hipEventCreate(&c->prof.ev[i]));
     c->prof.created = true;
   }
+  if (kernel_id == CBM_PROF_PAUSE) {   // stop recording, keep what was recorded for the next cbm_profile_read*
+    c->lws.prof = nullptr;
+    return 0;
+  }
   c->prof.sel = kernel_id;
   c->prof.n = 0;
   c->lws.prof = (kernel_id >= 0 || kernel_id == CBM_PROF_ALL) ? &c->prof : nullptr;

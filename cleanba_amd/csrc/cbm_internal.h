@@ -24,6 +24,7 @@ NatureLayout net_layout(int kind, int A);
 enum { K_CONV1_FWD = 0, K_CONV2_FWD, K_CONV3_FWD, K_DENSE_FWD, K_HEADS_WGRAD, K_DENSE_DGRAD, K_DENSE_WGRAD, K_CONV3_DGRAD,
        K_CONV3_WGRAD, K_CONV2_DGRAD, K_CONV2_WGRAD, K_CONV1_WGRAD, K_NUM };
 #define CBM_PROF_MAX 16384
+#define CBM_PROF_PAUSE (-3) // stop recording but keep the recorded launches readable
 #define CBM_PROF_ALL (-2)   // time every launch of every id (bench.py picks the dominant kernel by measured time)
 struct CbmProf {
   int sel = -1;

@@ -1097,12 +1097,18 @@ bool nature_forward(const NatureLayout& L, const float* P, const uint8_t* obs, c
 #endif
     igemm_s16_launch<ACTOR_C1_BX, 32, ACTOR_C1_BR>(p1, 1, st);
     ConvFwd<T64x64k16, 4, 4, 2, 32, 64, 20, 20, 9, 9> p2{ws.act1, P + L.w[1], P + L.b[1], ws.act2, B * 81, nullptr};
-    igemm_s16_launch<32, 32, 64>(p2, 1, st);
+#ifndef ACTOR_CV
+#define ACTOR_CV 32, 32, 64
+#endif
+#ifndef ACTOR_DN
+#define ACTOR_DN 32, 32, 32
+#endif
+    igemm_s16_launch<ACTOR_CV>(p2, 1, st);
     ConvFwd<T64x64k16, 3, 3, 1, 64, 64, 9, 9, 7, 7> p3{ws.act2, P + L.w[2], P + L.b[2], ws.act3, B * 49, nullptr};
-    igemm_s16_launch<32, 32, 64>(p3, 1, st);
+    igemm_s16_launch<ACTOR_CV>(p3, 1, st);
     if (dense_ksplit > 1) {
       DenseFwd<T64x64k16, true> pd{ws.act3, P + L.w[3], P + L.b[3], ws.dense_part, B, 3136, 512, 3136 / dense_ksplit};
-      igemm_s16_launch<32, 32, 32>(pd, dense_ksplit, st);
+      igemm_s16_launch<ACTOR_DN>(pd, dense_ksplit, st);
 #ifndef ACTOR_TAIL_FUSED
 #define ACTOR_TAIL_FUSED 1
 #endif

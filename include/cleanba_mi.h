@@ -236,6 +236,7 @@ int cbm_rmsprop_step(cbm_ctx* ctx, float* p, const float* g, float* nu, int64_t 
 /* ---- per-kernel HIP-event timing for bench.py's roofline line: brackets every learner-stream launch of
  * the selected implicit-GEMM kernel (ids in DESIGN.md §kernels; -1 = off). */
 #define CBM_PROFILE_ALL (-2)   /* every launch of every id */
+#define CBM_PROFILE_PAUSE (-3) /* stop recording; launches recorded so far stay readable (bench.py times a sample of the region) */
 #define CBM_PROFILE_IDS 12
 int cbm_profile_select(cbm_ctx* ctx, int32_t kernel_id);
 int cbm_profile_read(cbm_ctx* ctx, double* total_ms, int32_t* count);
