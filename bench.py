@@ -291,7 +291,7 @@ def host_env_value(a, params):
         dts = np.diff(np.array(stamps))[1:]     # skip the first two updates (pipeline fill)
         out[f"actor_threads_{threads}"] = round(float(E * T / np.median(dts)), 1)
     out["unit"] = "env-steps/s"
-    out["note"] = ("envpool step API path: host synthetic env (std::thread pool like envpool's), 3.39 MB H2D + 480 B D2H and one stream "
+    out["note"] = ("envpool step API path: host synthetic env (persistent worker pool like envpool's, fresh obs array per step), 3.39 MB H2D + 480 B D2H and one stream "
                    "sync per 120-env step (ppo:317); total envs = 120 split over the actor threads; median update interval")
     return out
 

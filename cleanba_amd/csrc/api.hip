@@ -395,6 +395,17 @@ extern "C" int cbm_actor_step_async(cbm_ctx* c, int32_t s, const uint8_t* obs, c
   sl.t += 1;
   return 0;
 }
+extern "C" int cbm_host_register(cbm_ctx* c, void* ptr, int64_t nbytes) {
+  CBM_HIP(hipSetDevice(c->cfg.device));
+  if (!ptr || nbytes <= 0) { cbm_set_error("cbm_host_register: empty buffer"); return -1; }
+  CBM_HIP(hipHostRegister(ptr, (size_t)nbytes, hipHostRegisterDefault));
+  return 0;
+}
+extern "C" int cbm_host_unregister(cbm_ctx* c, void* ptr) {
+  CBM_HIP(hipSetDevice(c->cfg.device));
+  CBM_HIP(hipHostUnregister(ptr));
+  return 0;
+}
 extern "C" int cbm_actor_record_host(cbm_ctx* c, int32_t s, const float* reward) {
   Slot& sl = c->slots[s];
   CBM_HIP(hipSetDevice(c->cfg.device));

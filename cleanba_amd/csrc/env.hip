@@ -10,6 +10,9 @@
 // clipped reward in {0,1} w.p. ~0.02, truncation at max_episode_steps (ppo:121-123,328).
 #include "cbm_internal.h"
 #include <stdlib.h>
+#include <unistd.h>
+#include <atomic>
+#include <functional>
 #include <thread>
 #include <vector>
 #include <string.h>
@@ -244,24 +247,83 @@ extern "C" int cbm_synth_env_reset_host_games(uint32_t seed, int32_t n, int32_t 
   }
   return 0;
 }
+// env_pixel for a whole 84x84 plane, painted layer by layer in reverse order of env_pixel's precedence (scenery < side walls < top bar <
+// ball < paddle; rows 17..34 belong to the bricks alone) instead of 7056 calls of the per-pixel function: ~20 us -> ~1 us per env on a host
+// core.  tests/test_env.py compares it with the device kernel (which calls env_pixel) byte for byte.
+static void host_render_plane(const cbm_env_state* s, const EnvGame& gm, uint8_t* o) {
+  memset(o, 0, 7056);
+  for (int r = gm.n_rects - 1; r >= 0; --r) {
+    const uint32_t k = gm.rect_key * 2654435761u + (uint32_t)r * 0x9E3779B9u;
+    const int ry0 = 36 + (int)(k % 32u), rx0 = 2 + (int)((k >> 5) % 64u), rh = 2 + (int)((k >> 11) % 6u), rw = 4 + (int)((k >> 14) % 14u);
+    const int x1 = rx0 + rw < 83 ? rx0 + rw : 83;
+    for (int y = ry0; y < ry0 + rh && y < 84; ++y)
+      if (x1 > rx0) memset(o + y * 84 + rx0, 90 + 20 * r, (size_t)(x1 - rx0));
+  }
+  for (int y = 12; y < 84; ++y) { o[y * 84] = 142; o[y * 84 + 83] = 142; }
+  memset(o + 10 * 84, 142, 2 * 84);
+  for (int y = s->ball_y < 0 ? 0 : s->ball_y; y < s->ball_y + 2 && y < 84; ++y)
+    for (int x = s->ball_x < 0 ? 0 : s->ball_x; x < s->ball_x + 2 && x < 84; ++x) o[y * 84 + x] = 255;
+  for (int y = 78; y < 80; ++y)
+    for (int x = s->paddle_x < 0 ? 0 : s->paddle_x; x < s->paddle_x + gm.paddle_w && x < 84; ++x) o[y * 84 + x] = 200;
+  for (int y = 17; y < 35; ++y)
+    for (int x = 0; x < 84; ++x) o[y * 84 + x] = env_pixel(s, gm, y, x);
+}
 static void host_step_one(uint32_t seed, int e, int32_t action, int32_t max_episode_steps, cbm_env_state* st, uint8_t* obs, float* reward,
-                          uint8_t* done, uint8_t* terminated, int32_t* elapsed_step) {
+                          uint8_t* done, uint8_t* terminated, int32_t* elapsed_step, const uint8_t* obs_prev = nullptr) {
   cbm_env_state s = st[e];
   const EnvGame gm = env_game(s.game);
   const EnvOut out = env_transition(&s, seed, (uint32_t)e, action, max_episode_steps);
   st[e] = s;
   *reward = out.reward; *done = out.done; *terminated = out.terminated; *elapsed_step = out.elapsed;
   uint8_t* o = obs + (size_t)e * CBM_FRAME;
-  if (!out.was_reset) memmove(o, o + 7056, 3 * 7056);
-  for (int i = 0; i < 7056; ++i) {
-    const uint8_t v = env_pixel(&s, gm, i / 84, i % 84);
-    o[3 * 7056 + i] = v;
-    if (out.was_reset) { o[i] = v; o[7056 + i] = v; o[2 * 7056 + i] = v; }
-  }
+  if (!out.was_reset) memmove(o, (obs_prev ? obs_prev + (size_t)e * CBM_FRAME : o) + 7056, 3 * 7056);
+  host_render_plane(&s, gm, o + 3 * 7056);
+  if (out.was_reset) { memcpy(o, o + 3 * 7056, 7056); memcpy(o + 7056, o + 3 * 7056, 7056); memcpy(o + 2 * 7056, o + 3 * 7056, 7056); }
 }
 // envpool steps its envs on a C++ thread pool; the twin does the same so that host-env runs are not bound by one core: the k envs of a call
 // are cut into contiguous chunks, one std::thread each (an env's trajectory depends only on its own id, seed and actions — any
 // partition gives the same bytes).  CBM_ENV_THREADS overrides the thread count (default min(8, cores), at least 8 envs per thread).
+// The workers are a persistent pool per calling thread (envpool keeps its worker threads too; spawning eight std::threads per step cost
+// ~0.4 ms of a 120-env step): the caller publishes a generation number, every worker runs its chunk and counts down, the caller runs
+// chunk 0 itself and waits for the count.  thread_local, so two actor threads stepping their own envs never share a pool.
+struct HostPool {
+  std::vector<std::thread> th;
+  std::atomic<uint32_t> gen{0};
+  std::atomic<int> left{0};
+  std::atomic<bool> stop{false};
+  std::function<void(int)> job;   // job(t) runs chunk t
+  const pid_t owner = getpid();   // a fork()ed child inherits the object but not the threads: it steps serially
+  explicit HostPool(int workers) {
+    for (int t = 1; t <= workers; ++t)
+      th.emplace_back([this, t] {
+        uint32_t seen = 0;
+        for (;;) {
+          for (int spin = 0; spin < 2000 && gen.load(std::memory_order_acquire) == seen; ++spin) __builtin_ia32_pause();
+          gen.wait(seen, std::memory_order_acquire);
+          seen = gen.load(std::memory_order_acquire);
+          if (stop.load(std::memory_order_acquire)) return;
+          job(t);
+          if (left.fetch_sub(1, std::memory_order_acq_rel) == 1) left.notify_one();
+        }
+      });
+  }
+  ~HostPool() {
+    stop.store(true, std::memory_order_release);
+    gen.fetch_add(1, std::memory_order_release);
+    gen.notify_all();
+    for (auto& x : th) x.join();
+  }
+  void run(int nt, std::function<void(int)> f) {   // nt - 1 <= th.size() worker chunks + chunk 0 on the caller
+    job = std::move(f);
+    left.store((int)th.size(), std::memory_order_release);
+    gen.fetch_add(1, std::memory_order_release);
+    gen.notify_all();
+    job(0);
+    for (int spin = 0; spin < 4000 && left.load(std::memory_order_acquire) != 0; ++spin) __builtin_ia32_pause();
+    for (int l; (l = left.load(std::memory_order_acquire)) != 0;) left.wait(l, std::memory_order_acquire);
+    (void)nt;
+  }
+};
 template <class F>
 static void host_parallel_for(int k, F body) {
   static const int max_threads = [] {
@@ -269,19 +331,27 @@ static void host_parallel_for(int k, F body) {
     int n = e ? atoi(e) : (int)std::thread::hardware_concurrency();
     return n < 1 ? 1 : (n > 8 && !e ? 8 : n);
   }();
-  int nt = k / 8 < max_threads ? k / 8 : max_threads;
+  const int nt = k / 8 < max_threads ? k / 8 : max_threads;
   if (nt <= 1) { for (int j = 0; j < k; ++j) body(j); return; }
-  std::vector<std::thread> th;
-  th.reserve(nt);
-  for (int t = 0; t < nt; ++t) {
+  thread_local HostPool pool(max_threads - 1);
+  if (pool.owner != getpid()) { for (int j = 0; j < k; ++j) body(j); return; }
+  pool.run(nt, [&](int t) {
+    if (t >= nt) return;
     const int lo = (int)((int64_t)k * t / nt), hi = (int)((int64_t)k * (t + 1) / nt);
-    th.emplace_back([=] { for (int j = lo; j < hi; ++j) body(j); });
-  }
-  for (auto& x : th) x.join();
+    for (int j = lo; j < hi; ++j) body(j);
+  });
 }
 extern "C" int cbm_synth_env_step_host(uint32_t seed, int32_t n, int32_t max_episode_steps, const int32_t* actions, cbm_env_state* st,
                                        uint8_t* obs, float* reward, uint8_t* done, uint8_t* terminated, int32_t* elapsed_step) {
   host_parallel_for(n, [=](int e) { host_step_one(seed, e, actions[e], max_episode_steps, st, obs, reward + e, done + e, terminated + e, elapsed_step + e); });
+  return 0;
+}
+extern "C" int cbm_synth_env_step_host_to(uint32_t seed, int32_t n, int32_t max_episode_steps, const int32_t* actions, cbm_env_state* st,
+                                          const uint8_t* obs_prev, uint8_t* obs_next, float* reward, uint8_t* done, uint8_t* terminated,
+                                          int32_t* elapsed_step) {
+  host_parallel_for(n, [=](int e) {
+    host_step_one(seed, e, actions[e], max_episode_steps, st, obs_next, reward + e, done + e, terminated + e, elapsed_step + e, obs_prev);
+  });
   return 0;
 }
 // envpool's send(action, env_id) for a subset: steps the k envs listed in env_ids (indices into st / obs, which hold ALL envs); the per-env

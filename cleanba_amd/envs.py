@@ -55,8 +55,9 @@ class SyntheticAtariEnv:
         return self._obs.copy()
 
     def step(self, actions):
-        r, d, term, el = L.synth_env_step_host(self.seed, self._st, self._obs, actions, self.spec.config.max_episode_steps)
-        return self._obs.copy(), r, d.astype(bool), self._info(r, term, el)
+        self._obs, r, d, term, el = L.synth_env_step_host_to(self.seed, self._st, self._obs, actions, self.spec.config.max_episode_steps)
+        self._obs.flags.writeable = False    # a fresh array per step like envpool's; the env reads it once more (next step's older planes)
+        return self._obs, r, d.astype(bool), self._info(r, term, el)
 
     # async API (impala:308,352,365).  batch_size == num_envs: every recv() returns all envs sorted by env_id (what cleanba_impala.py
     # relies on).  batch_size < num_envs (legacy --async-batch-size, naturecnn:119-133): recv() returns the batch_size envs whose step

@@ -51,10 +51,10 @@ SYMBOLS = [
     "cbm_impala_loss_grad", "cbm_adam_step", "cbm_rmsprop_step", "cbm_synth_env_reset_host", "cbm_synth_env_reset_host_games", "cbm_synth_env_step_host", "cbm_actor_env_reset_device_games",
     "cbm_actor_env_reset_device", "cbm_profile_select", "cbm_profile_read", "cbm_ingest_begin", "cbm_ingest_commit",
     "cbm_params_publish_external", "cbm_actor_stream", "cbm_actor_ring_index", "cbm_actor_step_async", "cbm_gae_async", "cbm_mb_advnorm",
-    "cbm_synth_env_step_host_ids", "cbm_learner_grad_tail_offset", "cbm_vtrace", "cbm_comm_init_loopback",
+    "cbm_synth_env_step_host_ids", "cbm_synth_env_step_host_to", "cbm_learner_grad_tail_offset", "cbm_vtrace", "cbm_comm_init_loopback",
     "cbm_comm_load", "cbm_comm_unique_id", "cbm_comm_init", "cbm_comm_size", "cbm_comm_allreduce_f64", "cbm_comm_barrier",
     "cbm_learner_allreduce_grads", "cbm_comm_profile", "cbm_comm_profile_read", "cbm_ipc_export", "cbm_ipc_open", "cbm_ipc_close",
-    "cbm_actor_ship_shard", "cbm_io_sync", "cbm_params_push", "cbm_params_mark_published", "cbm_ctx_abort", "cbm_profile_read_all",
+    "cbm_host_register", "cbm_host_unregister", "cbm_actor_ship_shard", "cbm_io_sync", "cbm_params_push", "cbm_params_mark_published", "cbm_ctx_abort", "cbm_profile_read_all",
 ]
 
 COMM_LEARNERS, COMM_WORLD = 0, 1
@@ -270,6 +270,14 @@ class Context:
         r = np.ascontiguousarray(reward, np.float32)
         _chk(self.lib.cbm_actor_record_host(self.h, int(slot), _p(r)))
 
+    def host_register(self, arr):
+        """Page-locks a numpy array the env reuses for its observations (cbm_host_register)."""
+        assert arr.flags["C_CONTIGUOUS"]
+        _chk(self.lib.cbm_host_register(self.h, _p(arr), C.c_int64(arr.nbytes)))
+
+    def host_unregister(self, arr):
+        _chk(self.lib.cbm_host_unregister(self.h, _p(arr)))
+
     def actor_rollout_device(self, slot, nsteps):
         _chk(self.lib.cbm_actor_rollout_device(self.h, int(slot), int(nsteps)))
 
@@ -442,6 +450,20 @@ def synth_env_step_host(seed, st, obs, actions, max_episode_steps=27000):
     _chk(load().cbm_synth_env_step_host(C.c_uint32(int(seed) & 0xFFFFFFFF), int(n), int(max_episode_steps), _p(actions), st,
                                         _p(obs), _p(reward), _p(done), _p(term), _p(elapsed)))
     return reward, done, term, elapsed
+
+
+def synth_env_step_host_to(seed, st, obs_prev, actions, max_episode_steps=27000):
+    """Out-of-place step: returns (obs_next, reward, done, terminated, elapsed) with obs_next a fresh array (envpool's recv() contract)."""
+    n = obs_prev.shape[0]
+    actions = np.ascontiguousarray(actions, np.int32)
+    obs_next = np.empty_like(obs_prev)
+    reward = np.zeros(n, np.float32)
+    done = np.zeros(n, np.uint8)
+    term = np.zeros(n, np.uint8)
+    elapsed = np.zeros(n, np.int32)
+    _chk(load().cbm_synth_env_step_host_to(C.c_uint32(int(seed) & 0xFFFFFFFF), int(n), int(max_episode_steps), _p(actions), st,
+                                           _p(obs_prev), _p(obs_next), _p(reward), _p(done), _p(term), _p(elapsed)))
+    return obs_next, reward, done, term, elapsed
 
 
 def synth_env_step_host_ids(seed, st, obs, env_ids, actions, max_episode_steps=27000):

@@ -116,6 +116,11 @@ int cbm_actor_step_async(cbm_ctx* ctx, int32_t slot, const uint8_t* obs, const f
 /* reward_with_obs: IMPALA stores the reward that arrived WITH obs_t (impala:372-384); NULL for PPO,
  * which instead records what envs.step returned for the action just taken (ppo:321-342): */
 int cbm_actor_record_host(cbm_ctx* ctx, int32_t slot, const float* reward);
+/* Page-lock a host buffer the env hands to cbm_actor_step_host / cbm_actor_commit again and again (envpool's recv buffers, a numpy array
+ * the host reuses): the 3.39 MB observation upload of a 120-env step (the jnp transfer inside get_action_and_value, ppo:313) then goes by
+ * DMA from the caller's pages instead of through the runtime's pageable staging.  Optional; unregister before freeing the memory. */
+int cbm_host_register(cbm_ctx* ctx, void* ptr, int64_t nbytes);
+int cbm_host_unregister(cbm_ctx* ctx, void* ptr);
 /* Device-env rollout: the built-in synthetic Atari-shaped env (cbm_synth_*) steps on the GPU, so
  * the whole T-step rollout is enqueued without host round trips.  nsteps = T (PPO) / T or T+1 (IMPALA). */
 int cbm_actor_rollout_device(cbm_ctx* ctx, int32_t slot, int32_t nsteps);
@@ -258,6 +263,11 @@ int cbm_synth_env_reset_host_games(uint32_t seed, int32_t n, int32_t atari57_mix
 int cbm_synth_env_step_host(uint32_t seed, int32_t n, int32_t max_episode_steps, const int32_t* actions,
                             cbm_env_state* st, uint8_t* obs, float* reward, uint8_t* done, uint8_t* terminated,
                             int32_t* elapsed_step);
+/* The same step out of place: reads the stacks in obs_prev, writes the new stacks to obs_next (a fresh array per step like envpool's
+ * recv() hands out, without a second pass to copy it). */
+int cbm_synth_env_step_host_to(uint32_t seed, int32_t n, int32_t max_episode_steps, const int32_t* actions, cbm_env_state* st,
+                               const uint8_t* obs_prev, uint8_t* obs_next, float* reward, uint8_t* done, uint8_t* terminated,
+                               int32_t* elapsed_step);
 /* envpool async mode, send(action, env_id) for a subset (impala:365, naturecnn:358): steps the k listed envs of the num_envs held in st / obs;
  * outputs in list order. */
 int cbm_synth_env_step_host_ids(uint32_t seed, int32_t num_envs, int32_t k, int32_t max_episode_steps, const int32_t* env_ids,
