@@ -273,26 +273,31 @@ def host_env_value(a, params):
     from cleanba_amd.trainer import train
     out = {}
     for threads in (1, 2):
-        stamps = []
-        n_up = 4
+        warm, n_up = 2, 8
+        marks = {}
+
+        def on_update(v, stats, e, marks=marks, warm=warm, last=warm + n_up):
+            if v == warm or v == last:       # two syncs per run; in between the learner thread enqueues ahead like the product run
+                e.sync()
+                marks[v] = time.perf_counter()
+
         argv = ["--local-num-envs", str(E // threads), "--num-actor-threads", str(threads), "--num-steps", str(T), "--env-backend", "host",
-                "--network", "nature", "--total-timesteps", str((n_up + 2) * E * T), "--log-frequency", "100000", "--concurrency"]
+                "--network", "nature", "--total-timesteps", str((warm + n_up) * E * T), "--log-frequency", "100000", "--concurrency"]
         cwd = os.getcwd()
         os.chdir(os.environ.get("TMPDIR", "/tmp"))
         try:
             so = sys.stdout
             sys.stdout = open(os.devnull, "w")
             try:
-                train(parse_args(argv, "ppo"), "ppo", on_update=lambda v, s, e: (e.sync(), stamps.append(time.perf_counter())))
+                train(parse_args(argv, "ppo"), "ppo", on_update=on_update)
             finally:
                 sys.stdout = so
         finally:
             os.chdir(cwd)
-        dts = np.diff(np.array(stamps))[1:]     # skip the first two updates (pipeline fill)
-        out[f"actor_threads_{threads}"] = round(float(E * T / np.median(dts)), 1)
+        out[f"actor_threads_{threads}"] = round(float(n_up * E * T / (marks[warm + n_up] - marks[warm])), 1)
     out["unit"] = "env-steps/s"
     out["note"] = ("envpool step API path: host synthetic env (persistent worker pool like envpool's, fresh obs array per step), 3.39 MB H2D + 480 B D2H and one stream "
-                   "sync per 120-env step (ppo:317); total envs = 120 split over the actor threads; median update interval")
+                   "sync per 120-env step (ppo:317); total envs = 120 split over the actor threads; 8 updates between two device syncs")
     return out
 
 

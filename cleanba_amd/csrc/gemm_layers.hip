@@ -1055,6 +1055,7 @@ using T256x32 = IgemmTile<256, 32, 32, 4, 1>;
 #endif
 using T128x64 = IgemmTile<128, 64, BR_128x64, 2, 2>;
 using T128x128k16 = IgemmTile<128, 128, 16, 2, 2, 2>;   // split-bf16 merged conv2 dgrad
+using T128x128k32 = IgemmTile<128, 128, 32, 2, 2, 2>;
 using T64x64 = IgemmTile<64, 64, BR_64x64, 2, 2>;
 // actor-step (small batch) tiles: half the K chunk = half the LDS, so a block still finds room on CUs mostly held by learner blocks
 using T64x64k16 = IgemmTile<64, 64, 16, 2, 2>;
@@ -1089,7 +1090,8 @@ bool nature_forward(const NatureLayout& L, const float* P, const uint8_t* obs, c
 #ifndef ACTOR_S16
 #define ACTOR_S16 1   // actor-size forward passes (no ReLU masks wanted) on the 16x16x4 small-batch kernel (igemm.h igemm_s16_kernel), same bits
 #endif
-  if (ACTOR_S16 && small && !ws.mask1 && !ws.bf16_fwd && !ws.prof) {
+  // (forward_bf16 too: at <= 512 frames the bf16 MFMA buys nothing over these latency-bound launches, so the actor's behaviour logits stay fp32)
+  if (ACTOR_S16 && small && !ws.mask1 && !ws.prof) {
     Conv1Fwd<T64x64k16> p1{obs, idx, P + L.w[0], P + L.b[0], ws.act1, B * 400, nullptr};
 #ifndef ACTOR_C1_BX
 #define ACTOR_C1_BX 32

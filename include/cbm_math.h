@@ -86,14 +86,16 @@ CBM_HD float cbm_bits_to_uniform(uint32_t bits) {
 }
 
 /* ------------------------------------------------------------------ pixel scale
- * x / 255.0f, correctly rounded, without a hardware divide: q = x*r, one Newton
- * residual step.  tests/test_math.py checks all 256 inputs against true division. */
+ * x / 255.0f, correctly rounded, without a hardware divide: 1/255 as a two-term float
+ * (hi = fl(1/255), lo = fl(1/255 - hi)); x*hi is exact inside the fma, so the result is
+ * fl(x*hi + fl(x*lo)) = fl(x/255) for every byte (3 instructions per pixel with the
+ * int->float conversion; the earlier multiply + Newton residual took 4).
+ * tests/test_oracle_prng.py checks all 256 inputs against true division. */
 CBM_HD float cbm_u8_unit(uint32_t x) {
-  const float r = 0.003921568859368562698364257812f; /* fl(1/255) */
+  const float hi = 0x1.010102p-8f;    /* fl(1/255) */
+  const float lo = -0x1.fdfdfep-33f;  /* fl(1/255 - hi) */
   const float xf = (float)x;
-  const float q = xf * r;
-  const float e = fmaf(-255.0f, q, xf);
-  return fmaf(e, r, q);
+  return fmaf(xf, hi, xf * lo);
 }
 
 /* ------------------------------------------------------------------ logf

@@ -54,7 +54,8 @@ typedef struct {
   float rms_decay, rms_eps;                          /* impala:534                       */
   int32_t actor_dense_ksplit;/* K segments of the 3136->512 dense when M<=128 (numerics spec) */
   int32_t forward_bf16;       /* build-only extension (BASELINE configs[2]): forward GEMMs of conv2/conv3/dense on bf16 MFMA, fp32 accumulate;
-                                 0 = the reference's fp32 everywhere.  Nature-CNN only. */
+                                 0 = the reference's fp32 everywhere.  Nature-CNN only.  Passes of <= 512 frames without a backward (the actor step, the
+                                 bootstrap row) stay on the fp32 small-batch kernels. */
   int32_t grad_accum_steps;   /* optax.MultiSteps every_k (ppo:79,492-500): each of the num_minibatches*k micro-batches feeds a running
                                  mean; the optimizer steps on every k-th.  0/1 = off. */
   int32_t async_batch_size;   /* legacy `--async-batch-size` (naturecnn:65-66): envpool returns this many of the local_num_envs envs per

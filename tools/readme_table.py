@@ -1,0 +1,58 @@
+"""Re-measures README.md's table of secondary workloads on the GPU box through the product trainer (cleanba_amd.trainer.train): device time
+between the completion of update 3 and of update 15 (two syncs per run).  usage: python tools/readme_table.py [substring filter]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cleanba_amd.args import parse_args  # noqa: E402
+from cleanba_amd.trainer import train  # noqa: E402
+
+E, T = 120, 128
+ROWS = [
+    ("PPO nature T=128", "ppo", ["--network", "nature", "--env-backend", "device"], 1, T),
+    ("PPO resnet T=128", "ppo", ["--network", "impala_resnet", "--env-backend", "device"], 1, T),
+    ("IMPALA nature T=128", "impala", ["--network", "nature", "--env-backend", "device"], 1, T),
+    ("IMPALA nature T=128 bf16 forward (configs[2])", "impala", ["--network", "nature", "--env-backend", "device", "--bf16-forward"], 1, T),
+    ("IMPALA nature T=128 two actor threads", "impala", ["--network", "nature", "--env-backend", "device"], 2, T),
+    ("IMPALA resnet T=128", "impala", ["--network", "impala_resnet", "--env-backend", "device"], 1, T),
+    ("PPO nature T=128 two actor threads (240 envs)", "ppo", ["--network", "nature", "--env-backend", "device"], 2, T),
+    ("IMPALA nature T=20 two actor threads", "impala", ["--network", "nature", "--env-backend", "device"], 2, 20),
+    ("PPO nature T=128 backward-split 2", "ppo", ["--network", "nature", "--env-backend", "device", "--backward-split", "2"], 1, T),
+    ("PPO nature host env 1 thread", "ppo", ["--network", "nature", "--env-backend", "host"], 1, T),
+    ("PPO nature Atari57 mix", "ppo", ["--network", "nature", "--env-backend", "device", "--env-id", "Atari57Mix-v5"], 1, T),
+]
+flt = sys.argv[1] if len(sys.argv) > 1 else ""
+os.chdir(os.environ.get("TMPDIR", "/tmp"))
+for name, algo, extra, threads, t in ROWS:
+    if flt not in name:
+        continue
+    warm, n_up = 3, (12 if "resnet" not in name else 6)
+    total = warm + n_up
+    marks = {}
+
+    def on_update(v, st, e, marks=marks, warm=warm, total=total):
+        if v == warm or v == total:      # two syncs per run: the learner thread keeps enqueueing ahead in between, like the product run
+            e.sync()
+            marks[v] = time.perf_counter()
+
+    argv = ["--local-num-envs", str(E), "--num-actor-threads", str(threads), "--num-steps", str(t), "--total-timesteps",
+            str(total * E * threads * t), "--log-frequency", "100000", "--concurrency"] + extra
+    so = sys.stdout
+    sys.stdout = open(os.devnull, "w")
+    try:
+        train(parse_args(argv, algo), algo, on_update=on_update)
+    except BaseException as e:  # noqa: BLE001
+        sys.stdout = so
+        print("%-50s FAILED %r" % (name, e))
+        continue
+    finally:
+        sys.stdout = so
+    if warm not in marks or total not in marks:
+        print("%-50s versions seen: %s" % (name, sorted(marks)))
+        continue
+    dt = (marks[total] - marks[warm]) / n_up
+    per = E * threads * t
+    print("%-50s %9.1f k env-steps/s   %7.2f ms per update (%d envs x %d steps)" % (name, per / dt / 1e3, dt * 1e3, E * threads, t))
