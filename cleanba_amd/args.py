@@ -120,9 +120,8 @@ def parse_args(argv=None, algo="ppo"):
 def finalize(args, world_size=1, rank=0):
     """Derived fields and the reference's assertions (ppo:411-430)."""
     n_actor_dev, n_learner = len(args.actor_device_ids), len(args.learner_device_ids)
-    if getattr(args, "network", "impala_resnet") == "impala_resnet" and (list(args.channels) != [16, 32, 32] or list(args.hiddens) != [256]):
-        # the HIP torso is specialised for the reference defaults (ppo:59-61); other widths would silently train a different net
-        raise SystemExit("--channels/--hiddens: only the reference defaults [16, 32, 32] / [256] are built into the HIP ResNet torso")
+    # --channels / --hiddens (ppo:92-95) travel in cbm_config; cbm_ctx_create rejects widths the HIP ResNet torso is not built for, with the
+    # same message for a C host as for this CLI (trainer.make_config)
     if getattr(args, "async_batch_size", 0):
         # the legacy async script (naturecnn:102-105): one actor thread on one actor device, host envs, PPO, learner on the same GPU
         if args.local_num_envs % args.async_batch_size:

@@ -48,6 +48,8 @@ extern "C" int cbm_default_config(int32_t algo, cbm_config* cfg) {
   cfg->adam_b1 = 0.9f; cfg->adam_b2 = 0.999f; cfg->adam_eps = 1e-5f;
   cfg->rms_decay = 0.99f; cfg->rms_eps = 0.01f;
   cfg->actor_dense_ksplit = 14;
+  cfg->num_channels = 3; cfg->channels[0] = 16; cfg->channels[1] = 32; cfg->channels[2] = 32;   // ppo:92
+  cfg->num_hiddens = 1; cfg->hiddens[0] = 256;                                                  // ppo:94
   if (algo == CBM_ALGO_PPO) {
     cfg->num_steps = 128; cfg->update_epochs = 4; cfg->norm_adv = 1; cfg->clip_coef = 0.1f; cfg->max_grad_norm = 0.5f;
   } else {
@@ -55,6 +57,8 @@ extern "C" int cbm_default_config(int32_t algo, cbm_config* cfg) {
   }
   return 0;
 }
+
+extern "C" int32_t cbm_config_size(void) { return (int32_t)sizeof(cbm_config); }
 
 extern "C" int64_t cbm_param_count(int32_t network, int32_t num_actions) {
   if (network != CBM_NET_NATURE && network != CBM_NET_IMPALA_RESNET) return -1;
@@ -77,6 +81,13 @@ static int ctx_create_impl(const cbm_config* cfg, cbm_ctx** out, cbm_ctx** parti
   if (cfg->algo == CBM_ALGO_IMPALA && cfg->num_steps + 1 > 2000) { cbm_set_error("IMPALA num_steps must be <= 1999 (the V-trace kernel keeps 8 floats per step in LDS)"); return -1; }
   if (cfg->backward_split != 0 && cfg->backward_split != 2 && cfg->backward_split != 3) { cbm_set_error("backward_split must be 0, 2 or 3"); return -1; }
   if (cfg->backward_split && cfg->network != CBM_NET_NATURE) { cbm_set_error("backward_split is built for the Nature-CNN torso only"); return -1; }
+  if (cfg->network == CBM_NET_IMPALA_RESNET &&
+      !(cfg->num_channels == 3 && cfg->channels[0] == 16 && cfg->channels[1] == 32 && cfg->channels[2] == 32 && cfg->num_hiddens == 1 &&
+        cfg->hiddens[0] == 256)) {
+    // the slab-convolution geometries, the dense tiles and the parameter layout are compiled for these widths (ppo:92-95 defaults)
+    cbm_set_error("--channels/--hiddens: only the reference defaults [16, 32, 32] / [256] are built into the HIP ResNet torso");
+    return -1;
+  }
   if (cfg->forward_bf16 && cfg->network != CBM_NET_NATURE) { cbm_set_error("forward_bf16 is built for the Nature-CNN torso only"); return -1; }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { cbm_set_error("no HIP device visible: libcleanba_mi needs an MI355X"); return -3; }

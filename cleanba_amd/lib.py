@@ -29,7 +29,8 @@ class Config(C.Structure):
                 ("clip_coef", C.c_float), ("ent_coef", C.c_float), ("vf_coef", C.c_float), ("max_grad_norm", C.c_float),
                 ("adam_b1", C.c_float), ("adam_b2", C.c_float), ("adam_eps", C.c_float), ("rms_decay", C.c_float),
                 ("rms_eps", C.c_float), ("actor_dense_ksplit", C.c_int32), ("forward_bf16", C.c_int32), ("grad_accum_steps", C.c_int32), ("async_batch_size", C.c_int32),
-                ("backward_split", C.c_int32), ("reserved", C.c_int32 * 3)]
+                ("backward_split", C.c_int32), ("num_channels", C.c_int32), ("channels", C.c_int32 * 4), ("num_hiddens", C.c_int32),
+                ("hiddens", C.c_int32 * 4), ("reserved", C.c_int32 * 3)]
 
 
 class EnvState(C.Structure):
@@ -41,7 +42,7 @@ class EnvState(C.Structure):
 
 # every symbol include/cleanba_mi.h declares (checked by tests/test_abi.py against the header text)
 SYMBOLS = [
-    "cbm_default_config", "cbm_ctx_create", "cbm_ctx_destroy", "cbm_last_error", "cbm_build_info", "cbm_param_count",
+    "cbm_default_config", "cbm_config_size", "cbm_ctx_create", "cbm_ctx_destroy", "cbm_last_error", "cbm_build_info", "cbm_param_count",
     "cbm_params_set", "cbm_params_get", "cbm_actor_params_get", "cbm_buffer", "cbm_copy_to_host", "cbm_copy_to_device",
     "cbm_dev_alloc", "cbm_dev_free", "cbm_learner_stream", "cbm_sync", "cbm_actor_set_key", "cbm_actor_get_key",
     "cbm_actor_begin_rollout", "cbm_actor_step_host", "cbm_actor_record_host", "cbm_actor_rollout_device",
@@ -110,6 +111,8 @@ def load():
     lib.cbm_last_error.restype = C.c_char_p
     lib.cbm_build_info.restype = C.c_char_p
     lib.cbm_param_count.restype = C.c_int64
+    if lib.cbm_config_size() != C.sizeof(Config):
+        raise CbmError(f"cbm_config is {lib.cbm_config_size()} bytes in {SO_PATH}, {C.sizeof(Config)} in cleanba_amd/lib.py: rebuild the library")
     lib.cbm_learner_grad_tail_offset.restype = C.c_int64
     lib.cbm_learner_stream.restype = C.c_void_p
     lib.cbm_learner_stream.argtypes = [C.c_void_p]

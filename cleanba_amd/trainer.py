@@ -57,6 +57,14 @@ def make_config(args, algo):
     cfg.device = args.learner_device_ids[0] if not args.distributed else int(os.environ.get("LOCAL_RANK", os.environ.get("SLURM_LOCALID", 0)))
     cfg.network = {"nature": L.NET_NATURE, "impala_resnet": L.NET_IMPALA_RESNET}[args.network]
     cfg.num_actions = args.num_actions
+    ch, hd = list(getattr(args, "channels", [16, 32, 32])), list(getattr(args, "hiddens", [256]))   # ppo:92-95; cbm_ctx_create checks them
+    if len(ch) > 4 or len(hd) > 4:
+        raise SystemExit("--channels/--hiddens: only the reference defaults [16, 32, 32] / [256] are built into the HIP ResNet torso")
+    cfg.num_channels, cfg.num_hiddens = len(ch), len(hd)
+    for i, v in enumerate(ch):
+        cfg.channels[i] = int(v)
+    for i, v in enumerate(hd):
+        cfg.hiddens[i] = int(v)
     cfg.forward_bf16 = int(bool(getattr(args, "bf16_forward", False)))
     cfg.backward_split = int(getattr(args, "backward_split", 0) or 0)
     cfg.actor_dense_ksplit = 14 if args.network == "nature" else 11  # K segments of the flatten->dense when M <= 1024 rows

@@ -66,11 +66,16 @@ typedef struct {
                                  backward GEMMs is split exactly into that many bf16 terms and the products are formed on bf16 MFMA with
                                  fp32 accumulation (2: a1b1+a1b2+a2b1, product error ~2^-16; 3: six products, ~2^-22 = fp32 rounding
                                  noise).  The forward pass, losses, returns and the optimizer are untouched.  Nature-CNN only. */
+  int32_t num_channels;       /* Network(channels, hiddens) of ppo:92-95,175-176 (`--channels`, `--hiddens`): the IMPALA-ResNet torso is built for */
+  int32_t channels[4];        /* the reference defaults channels = (16, 32, 32), hiddens = (256,); cbm_default_config fills them and          */
+  int32_t num_hiddens;        /* cbm_ctx_create REJECTS anything else ("--channels/--hiddens: only the reference defaults ...") rather than   */
+  int32_t hiddens[4];         /* silently training a different network.  Ignored for CBM_NET_NATURE (the legacy script has no such flags).    */
   int32_t reserved[3];
 } cbm_config;
 
 /* Fills cfg with the reference defaults for `algo` (ppo:34-118 / impala:34-110). */
 int cbm_default_config(int32_t algo, cbm_config* cfg);
+int32_t cbm_config_size(void);   /* sizeof(cbm_config) as the library was compiled: an FFI binding checks its own struct against it */
 
 int cbm_ctx_create(const cbm_config* cfg, cbm_ctx** out);
 int cbm_ctx_destroy(cbm_ctx* ctx);

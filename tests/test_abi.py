@@ -37,6 +37,30 @@ def test_config_struct_matches_defaults(lib):
     assert L.param_count(L.NET_NATURE, 18) == 1693875 and L.param_count(L.NET_NATURE, 4) == 1686693
 
 
+def test_channels_and_hiddens_travel_in_the_config_and_are_checked_by_the_library(lib):
+    """ppo:92-95: the C ABI carries Network(channels, hiddens); widths the HIP torso is not compiled for are refused by cbm_ctx_create (for a C
+    host exactly as for the CLI), before any device is touched."""
+    import ctypes as C
+    assert lib.cbm_config_size() == C.sizeof(L.Config)
+    cfg = L.default_config(L.ALGO_PPO)
+    assert (cfg.num_channels, list(cfg.channels)[:3], cfg.num_hiddens, cfg.hiddens[0]) == (3, [16, 32, 32], 1, 256)
+    cfg.network = L.NET_IMPALA_RESNET
+    for mutate in (lambda c: c.channels.__setitem__(2, 64), lambda c: setattr(c, "num_channels", 2), lambda c: c.hiddens.__setitem__(0, 512),
+                   lambda c: setattr(c, "num_hiddens", 2)):
+        bad = L.default_config(L.ALGO_PPO)
+        bad.network = L.NET_IMPALA_RESNET
+        mutate(bad)
+        with pytest.raises(L.CbmError, match="--channels/--hiddens: only the reference defaults"):
+            L.Context(bad)
+    from cleanba_amd.args import parse_args
+    from cleanba_amd.trainer import make_config
+    args = parse_args(["--channels", "16", "32", "64", "--hiddens", "512"], "ppo")
+    c2 = make_config(args, "ppo")
+    assert list(c2.channels)[:3] == [16, 32, 64] and c2.hiddens[0] == 512
+    with pytest.raises(L.CbmError, match="--channels/--hiddens"):
+        L.Context(c2)
+
+
 def test_no_gpu_fails_loudly(lib):
     import torch
     if torch.cuda.is_available():
