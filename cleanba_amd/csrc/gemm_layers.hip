@@ -879,7 +879,8 @@ static int round_up(int a, int b) { return ceil_div(a, b) * b; }
 #endif
 static const int RPS_C1 = 1600, RPS_C2 = RPS_C2_V, RPS_C3 = RPS_C3_V, RPS_HEADS = 128;
 #ifndef DENSE_WGRAD_NZ
-#define DENSE_WGRAD_NZ 5   // 128x128 tiles (2x2 accumulators per wave): 100 tiles x 5 reduction slices; 170 -> 143 us (64x64 tiles, 2 slices)
+#define DENSE_WGRAD_NZ 10  // 128x256 tiles (2x4 accumulators per wave): 50 tiles x 10 reduction slices, 133 -> 124 us isolated (128x128 x 5: 133; 64x64 x 2: 170;
+                           // 5 / 8 / 15 slices of the 128x256 tile: 143 / 148 / 160)
 #endif
 static int dense_wgrad_splits(int B) { return B >= 2048 ? DENSE_WGRAD_NZ : 1; }
 
@@ -1056,6 +1057,8 @@ using T256x32 = IgemmTile<256, 32, 32, 4, 1>;
 using T128x64 = IgemmTile<128, 64, BR_128x64, 2, 2>;
 using T128x128k16 = IgemmTile<128, 128, 16, 2, 2, 2>;   // split-bf16 merged conv2 dgrad
 using T128x128k32 = IgemmTile<128, 128, 32, 2, 2, 2>;
+using T128x256k16 = IgemmTile<128, 256, 16, 2, 2, 2>;   // 2x4 accumulators per wave
+using T256x128k16 = IgemmTile<256, 128, 16, 2, 2, 2>;
 using T64x64 = IgemmTile<64, 64, BR_64x64, 2, 2>;
 // actor-step (small batch) tiles: half the K chunk = half the LDS, so a block still finds room on CUs mostly held by learner blocks
 using T64x64k16 = IgemmTile<64, 64, 16, 2, 2>;
@@ -1072,7 +1075,7 @@ using T64x64k16 = IgemmTile<64, 64, 16, 2, 2>;
 #define TILE_C3W T64x64
 #endif
 #ifndef TILE_DW
-#define TILE_DW T128x128k16
+#define TILE_DW T128x256k16
 #endif
 #ifndef TILE_DD
 #define TILE_DD T128x128k16   // 143 -> 138 us
