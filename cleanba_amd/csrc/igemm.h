@@ -343,6 +343,12 @@ static inline void igemm_launch(const P& p, int nsplit, hipStream_t stream) {
 // waits for its data.  Here two register sets alternate: the loads of chunk c+2 are issued before chunk c is multiplied and are not
 // needed until the end of the NEXT iteration.  Same math, same k-ascending chain per accumulator -> bit-identical to igemm_kernel.
 // Row-gather A, no fused bias gradient (the input-gradient problems); KSKIP and BITMASK functors supported.
+#ifndef PF2_DEPTH
+#define PF2_DEPTH 2   // register sets of prefetched K chunks (2 or 3)
+#endif
+#ifndef PF2_ABL
+#define PF2_ABL 0   // timing builds: 1 no global loads after the first two chunks, 2 no staging stores, 4 no barriers in the loop, 8 no epilogue stores
+#endif
 template <class P>
 __global__ __launch_bounds__(256, P::Tile::MINW) void igemm_pf2_kernel(const P p) {
   using T = typename P::Tile;
@@ -478,26 +484,66 @@ __global__ __launch_bounds__(256, P::Tile::MINW) void igemm_pf2_kernel(const P p
   };
 
   float4 a0[NVA], b0[NVB], a1[NVA], b1[NVB];
+#if PF2_DEPTH == 3
+  // three register sets: the loads of chunk c+3 are issued before chunk c is multiplied and stored two iterations later
+  float4 a2[NVA], b2[NVB];
+  gload(0, a0, b0);
+  sstore(0, a0, b0);
+  if (nchunk > 1) gload(1, a1, b1);
+  if (nchunk > 2) gload(2, a2, b2);
+  __syncthreads();
+  int buf = 0, c = 0;
+  while (true) {
+    if (!(PF2_ABL & 1) && c + 3 < nchunk) gload(c + 3, a0, b0);
+    compute(buf);
+    if (!(PF2_ABL & 2) && c + 1 < nchunk) sstore(buf ^ 1, a1, b1);
+    if (!(PF2_ABL & 4)) __syncthreads();
+    buf ^= 1;
+    if (++c >= nchunk) break;
+    if (!(PF2_ABL & 1) && c + 3 < nchunk) gload(c + 3, a1, b1);
+    compute(buf);
+    if (!(PF2_ABL & 2) && c + 1 < nchunk) sstore(buf ^ 1, a2, b2);
+    if (!(PF2_ABL & 4)) __syncthreads();
+    buf ^= 1;
+    if (++c >= nchunk) break;
+    if (!(PF2_ABL & 1) && c + 3 < nchunk) gload(c + 3, a2, b2);
+    compute(buf);
+    if (!(PF2_ABL & 2) && c + 1 < nchunk) sstore(buf ^ 1, a0, b0);
+    if (!(PF2_ABL & 4)) __syncthreads();
+    buf ^= 1;
+    if (++c >= nchunk) break;
+  }
+#else
   gload(0, a0, b0);
   sstore(0, a0, b0);
   if (nchunk > 1) gload(1, a0, b0);
   __syncthreads();
   int buf = 0, c = 0;
   while (true) {
-    if (c + 2 < nchunk) gload(c + 2, a1, b1);        // set 0 holds chunk c+1
+    if (!(PF2_ABL & 1) && c + 2 < nchunk) gload(c + 2, a1, b1);        // set 0 holds chunk c+1
     compute(buf);
-    if (c + 1 < nchunk) sstore(buf ^ 1, a0, b0);
-    __syncthreads();
+    if (!(PF2_ABL & 2) && c + 1 < nchunk) sstore(buf ^ 1, a0, b0);
+    if (!(PF2_ABL & 4)) __syncthreads();
     buf ^= 1;
     if (++c >= nchunk) break;
-    if (c + 2 < nchunk) gload(c + 2, a0, b0);        // set 1 holds chunk c+1
+    if (!(PF2_ABL & 1) && c + 2 < nchunk) gload(c + 2, a0, b0);        // set 1 holds chunk c+1
     compute(buf);
-    if (c + 1 < nchunk) sstore(buf ^ 1, a1, b1);
-    __syncthreads();
+    if (!(PF2_ABL & 2) && c + 1 < nchunk) sstore(buf ^ 1, a1, b1);
+    if (!(PF2_ABL & 4)) __syncthreads();
     buf ^= 1;
     if (++c >= nchunk) break;
   }
 
+#endif
+
+  if (PF2_ABL & 8) {   // timing build: keep every accumulator alive, store nothing
+    float sum = 0.0f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) sum += acc[i][j][0];
+    if (sum != 12345.678f) return;
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
