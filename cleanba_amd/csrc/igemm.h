@@ -343,6 +343,9 @@ static inline void igemm_launch(const P& p, int nsplit, hipStream_t stream) {
 // waits for its data.  Here two register sets alternate: the loads of chunk c+2 are issued before chunk c is multiplied and are not
 // needed until the end of the NEXT iteration.  Same math, same k-ascending chain per accumulator -> bit-identical to igemm_kernel.
 // Row-gather A, no fused bias gradient (the input-gradient problems); KSKIP and BITMASK functors supported.
+#ifndef PF2_AMAP
+#define PF2_AMAP 0    // 1: a thread's float4 of the A tile = row (v % BX), k-quad (v / BX): conflict-free staging stores, scattered global rows
+#endif
 #ifndef PF2_DEPTH
 #define PF2_DEPTH 2   // register sets of prefetched K chunks (2 or 3)
 #endif
@@ -391,7 +394,7 @@ __global__ __launch_bounds__(256, P::Tile::MINW) void igemm_pf2_kernel(const P p
   if constexpr (RP) {
 #pragma unroll
     for (int j = 0; j < NVA; ++j) {
-      const int v = tid + 256 * j, rq = v % (BR / 4), xl = v / (BR / 4);
+      const int v = tid + 256 * j, rq = PF2_AMAP ? v / BX : v % (BR / 4), xl = PF2_AMAP ? v % BX : v / (BR / 4);
       arow[j] = p.a_off(x0 + xl, 4 * rq, cls);
     }
 #pragma unroll
@@ -418,7 +421,7 @@ __global__ __launch_bounds__(256, P::Tile::MINW) void igemm_pf2_kernel(const P p
     for (int j = 0; j < NVA; ++j) {
       const int v = tid + 256 * j;
       if (BX * BR / 4 % 256 == 0 || v < BX * BR / 4) {
-        const int rq = v % (BR / 4), xl = v / (BR / 4);
+        const int rq = PF2_AMAP ? v / BX : v % (BR / 4), xl = PF2_AMAP ? v % BX : v / (BR / 4);
         ra[j] = p.load_a(x0 + xl, r0 + 4 * rq, rhi, cls);
       }
     }
@@ -438,7 +441,7 @@ __global__ __launch_bounds__(256, P::Tile::MINW) void igemm_pf2_kernel(const P p
     for (int j = 0; j < NVA; ++j) {
       const int v = tid + 256 * j;
       if (BX * BR / 4 % 256 == 0 || v < BX * BR / 4) {
-        const int rq = v % (BR / 4), xl = v / (BR / 4);
+        const int rq = PF2_AMAP ? v / BX : v % (BR / 4), xl = PF2_AMAP ? v % BX : v / (BR / 4);
         float* d = A_ + xl * PA + 4 * rq;
         d[0] = ra[j].x; d[1] = ra[j].y; d[2] = ra[j].z; d[3] = ra[j].w;
       }
