@@ -419,6 +419,9 @@ struct Conv3Dgrad {
 // that can be non-zero are the same for all its rows (jh in [max(0,2-ih), min(2,8-ih)], same for jw: 1, 2 or 3 per axis) and the block
 // reduces over exactly those (igemm.h KSKIP): 441 instead of 729 tap-tiles per frame tile.  Tiles are ordered frame-tile-major, pixel-minor, so
 // the 81 blocks that read the same BX frames of dY run back to back on one XCD.  Rows beyond S (last frame tile) load frame S-1 and store nothing.
+#ifndef POS_UNIFORM_TILE
+#define POS_UNIFORM_TILE 0   // 1: x-tile index through readfirstlane (wave-uniform decode on the SALU): conv3 dgrad 155 -> 153 us, conv2 dgrad 234 -> 250 (the intrinsic blocks the CSE of the decode across the 64 epilogue stores)
+#endif
 template <class TileT>
 struct Conv3DgradPos {
   using Tile = TileT;
@@ -441,7 +444,8 @@ struct Conv3DgradPos {
     return ((ctx & 3) + q) * 192 + (((ctx >> 2) & 3) + (t - q * njw)) * 64 + (rc & 63);
   }
   __device__ void decode(int x, int& s, int& ih, int& iw) const {
-    const int xt = x / Tile::BX, tile = order[xt], t = tile / 81, p = tile - t * 81;
+    // every row a wave touches lies in its block's x-tile: the tile index (and the divisions / table read that decode it) is wave-uniform -> SALU
+    const int xt = POS_UNIFORM_TILE ? __builtin_amdgcn_readfirstlane(x / Tile::BX) : x / Tile::BX, tile = order[xt], t = tile / 81, p = tile - t * 81;
     s = t * Tile::BX + (x - xt * Tile::BX); ih = p / 9; iw = p - ih * 9;
   }
   __device__ float4 load_a(int x, int r, int, int) const {
@@ -559,7 +563,7 @@ struct Conv2DgradPos {
     return ((ctx & 3) + q) * 128 + (((ctx >> 2) & 3) + (t - q * njw)) * 64 + (rc & 63);
   }
   __device__ void decode(int x, int& s, int& ihh, int& iwh) const {
-    const int tile = x / Tile::BX, t = tile / 100, p = tile - t * 100;
+    const int tile = POS_UNIFORM_TILE ? __builtin_amdgcn_readfirstlane(x / Tile::BX) : x / Tile::BX, t = tile / 100, p = tile - t * 100;
     s = t * Tile::BX + (x - tile * Tile::BX); ihh = p / 10; iwh = p - ihh * 10;
   }
   __device__ float4 load_a(int x, int r, int, int) const {
@@ -648,7 +652,7 @@ struct Conv2DgradMergedPos {
     return ((ctx & 3) + q) * 128 + (((ctx >> 2) & 3) + (t - q * njw)) * 64 + (rc & 63);
   }
   __device__ void decode(int x, int& s, int& ihh, int& iwh) const {
-    const int tile = x / Tile::BX, t = tile / 100, p = tile - t * 100;
+    const int tile = POS_UNIFORM_TILE ? __builtin_amdgcn_readfirstlane(x / Tile::BX) : x / Tile::BX, t = tile / 100, p = tile - t * 100;
     s = t * Tile::BX + (x - tile * Tile::BX); ihh = p / 10; iwh = p - ihh * 10;
   }
   __device__ float4 load_a(int x, int r, int, int) const {
