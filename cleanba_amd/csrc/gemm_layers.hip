@@ -353,6 +353,9 @@ static void launch_heads_dgrad(const float* dzv, const float* Wa, const float* W
 
 // dense dgrad: dact3[m][j] = sum_n dhid[m][n] * Wd[j][n]; stored masked into the zero-bordered
 // dact3pad [S][11][11][64] (data at rows/cols 2..8).
+#ifndef EPI_ROWCTX
+#define EPI_ROWCTX 1   // dgrad epilogues through igemm.h's EpiRow (one pointer per tile and lane instead of a (frame, pixel) decode per stored value)
+#endif
 template <class TileT>
 struct DenseDgrad {
   using Tile = TileT;
@@ -382,6 +385,11 @@ struct DenseDgrad {
     if (m >= M || j >= 3136) return;
     const int pos = j >> 6, c = j & 63, hh = pos / 7, ww = pos - hh * 7;
     dact3pad[((size_t)(m * 11 + hh + 2) * 11 + ww + 2) * 64 + c] = on ? v : 0.0f;
+  }
+  static constexpr bool ROWEPI = EPI_ROWCTX;   // consecutive frames m are 121*64 floats apart in dact3pad
+  __device__ EpiRow epi_row(int m0, int j, int) const {
+    const int jj = min(j, 3135), pos = jj >> 6, c = jj & 63, hh = pos / 7, ww = pos - hh * 7;
+    return EpiRow{dact3pad + ((size_t)(m0 * 11 + hh + 2) * 11 + ww + 2) * 64 + c, j < 3136 ? M - m0 : 0, 7744u};
   }
 };
 
@@ -493,6 +501,12 @@ struct Conv3DgradPos {
     decode(x, s, ih, iw);
     if (s >= S) return;
     dxpad[((size_t)(s * 11 + ih + 1) * 11 + iw + 1) * 64 + ci] = on ? v : 0.0f;
+  }
+  static constexpr bool ROWEPI = EPI_ROWCTX;   // the rows of an x-tile are consecutive frames at one pixel: 121*64 floats apart in dact2pad
+  __device__ EpiRow epi_row(int xt0, int ci, int) const {
+    int s, ih, iw;
+    decode(xt0, s, ih, iw);
+    return EpiRow{dxpad + ((size_t)(s * 11 + ih + 1) * 11 + iw + 1) * 64 + ci, S - s, 7744u};
   }
 };
 
@@ -699,6 +713,13 @@ struct Conv2DgradMergedPos {
     if (ok) dact1[px * 32 + (y & 31)] = on ? v : 0.0f;
   }
   __device__ void store(int x, int y, float v, int, int) const { store_on(x, y, v, true, 0, 0); }
+  static constexpr bool ROWEPI = EPI_ROWCTX;   // the rows of an x-tile are consecutive frames at one half-resolution pixel: 400*32 floats apart in dact1
+  __device__ EpiRow epi_row(int xt0, int y, int) const {
+    int s, ihh, iwh;
+    decode(xt0, s, ihh, iwh);
+    const int cls = y >> 5;
+    return EpiRow{dact1 + ((size_t)(s * 20 + 2 * ihh + (cls >> 1)) * 20 + 2 * iwh + (cls & 1)) * 32 + (y & 31), S - s, 12800u};
+  }
 };
 
 // ---- weight gradients: C[x = k][y = co] = sum_{r = m} A[m][k] * dY[m][co], split over r into

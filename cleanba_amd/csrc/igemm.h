@@ -54,6 +54,15 @@ struct igemm_maskout<P, decltype((void)P::MASKOUT)> { static constexpr bool valu
 // contiguous run of the reduction index (one kernel row / one tap).  The generic load_a / load_b recompute frame / pixel / tap
 // decompositions — integer divisions, clamps, 64-bit address math — for every 16-byte load of every chunk: 4-8 VALU instructions per
 // MFMA in the conv kernels (rocprofv3 SQ_INSTS_VALU); with the split the K loop adds one scalar offset per load.
+// Optional P::ROWEPI (with BITMASK): the rows of a 32-row output tile are a constant stride apart in the destination, so the functor hands the
+// epilogue ONE pointer per (tile, lane) — EpiRow epi_row(x_tile0, y, cls) = {address of (tile row 0, column y), rows of the tile that exist (0 for a
+// lane whose column does not), row stride in floats} — instead of decoding (frame, pixel) from x for each of the 16 values a lane stores
+// (24-33 VALU instructions per stored value in the position-major dgrads, 15 % of the conv2 dgrad's time).
+struct EpiRow { float* ptr; int valid; uint32_t stride; };
+template <class P, class = void>
+struct igemm_rowepi { static constexpr bool value = false; };
+template <class P>
+struct igemm_rowepi<P, decltype((void)P::ROWEPI)> { static constexpr bool value = P::ROWEPI; };
 template <class P, class = void>
 struct igemm_rowptr { static constexpr bool value = false; };
 template <class P>
@@ -552,7 +561,20 @@ __global__ __launch_bounds__(256, P::Tile::MINW) void igemm_pf2_kernel(const P p
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int y = y0 + wy * (BY / WY) + j * 32 + li;
-      if constexpr (igemm_bitmask<P>::value) {
+      if constexpr (igemm_bitmask<P>::value && igemm_rowepi<P>::value) {
+        const uint32_t mw = p.mask_word(x0 + wx * (BX / WX) + i * 32 + li, y0 + wy * (BY / WY) + j * 32, cls);
+        const EpiRow er = p.epi_row(x0 + wx * (BX / WX) + i * 32, y, cls);
+        const uint32_t bit = 1u << li;
+        float* ph = er.ptr + (size_t)(4 * h) * er.stride;
+        const int lim = er.valid - 4 * h;          // row r0 of this half-wave exists iff r0 < lim
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int r0 = (e & 3) + 8 * (e >> 2);
+          const uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)mw, r0), w1 = (uint32_t)__builtin_amdgcn_readlane((int)mw, r0 + 4);
+          const uint32_t w = h ? w1 : w0;
+          if (r0 < lim) ph[(size_t)r0 * er.stride] = (w & bit) ? acc[i][j][e] : 0.0f;
+        }
+      } else if constexpr (igemm_bitmask<P>::value) {
         const uint32_t mw = p.mask_word(x0 + wx * (BX / WX) + i * 32 + li, y0 + wy * (BY / WY) + j * 32, cls);
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
