@@ -567,12 +567,20 @@ __global__ __launch_bounds__(256, P::Tile::MINW) void igemm_pf2_kernel(const P p
         const uint32_t bit = 1u << li;
         float* ph = er.ptr + (size_t)(4 * h) * er.stride;
         const int lim = er.valid - 4 * h;          // row r0 of this half-wave exists iff r0 < lim
+        if (__all(lim >= 28)) {                    // whole tile inside the problem (wave-uniform branch): no per-value bound test
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int r0 = (e & 3) + 8 * (e >> 2);
-          const uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)mw, r0), w1 = (uint32_t)__builtin_amdgcn_readlane((int)mw, r0 + 4);
-          const uint32_t w = h ? w1 : w0;
-          if (r0 < lim) ph[(size_t)r0 * er.stride] = (w & bit) ? acc[i][j][e] : 0.0f;
+          for (int e = 0; e < 16; ++e) {
+            const int r0 = (e & 3) + 8 * (e >> 2);
+            const uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)mw, r0), w1 = (uint32_t)__builtin_amdgcn_readlane((int)mw, r0 + 4);
+            ph[(size_t)r0 * er.stride] = ((h ? w1 : w0) & bit) ? acc[i][j][e] : 0.0f;
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int r0 = (e & 3) + 8 * (e >> 2);
+            const uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)mw, r0), w1 = (uint32_t)__builtin_amdgcn_readlane((int)mw, r0 + 4);
+            if (r0 < lim) ph[(size_t)r0 * er.stride] = ((h ? w1 : w0) & bit) ? acc[i][j][e] : 0.0f;
+          }
         }
       } else if constexpr (igemm_bitmask<P>::value) {
         const uint32_t mw = p.mask_word(x0 + wx * (BX / WX) + i * 32 + li, y0 + wy * (BY / WY) + j * 32, cls);
