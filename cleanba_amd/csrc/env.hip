@@ -346,6 +346,14 @@ extern "C" int cbm_synth_env_step_host(uint32_t seed, int32_t n, int32_t max_epi
   host_parallel_for(n, [=](int e) { host_step_one(seed, e, actions[e], max_episode_steps, st, obs, reward + e, done + e, terminated + e, elapsed_step + e); });
   return 0;
 }
+// diagnostics: one 84x84 plane of a state, painted by the per-pixel function the device kernels call (layered = 0) or by the host twin's
+// layered painter (layered = 1); tests/test_env.py compares the two over random states of every game preset
+extern "C" int cbm_synth_env_render_host(const cbm_env_state* st, int32_t layered, uint8_t* plane) {
+  const EnvGame gm = env_game(st->game);
+  if (layered) { host_render_plane(st, gm, plane); return 0; }
+  for (int i = 0; i < 7056; ++i) plane[i] = env_pixel(st, gm, i / 84, i % 84);
+  return 0;
+}
 extern "C" int cbm_synth_env_step_host_to(uint32_t seed, int32_t n, int32_t max_episode_steps, const int32_t* actions, cbm_env_state* st,
                                           const uint8_t* obs_prev, uint8_t* obs_next, float* reward, uint8_t* done, uint8_t* terminated,
                                           int32_t* elapsed_step) {

@@ -52,7 +52,7 @@ SYMBOLS = [
     "cbm_impala_loss_grad", "cbm_adam_step", "cbm_rmsprop_step", "cbm_synth_env_reset_host", "cbm_synth_env_reset_host_games", "cbm_synth_env_step_host", "cbm_actor_env_reset_device_games",
     "cbm_actor_env_reset_device", "cbm_profile_select", "cbm_profile_read", "cbm_ingest_begin", "cbm_ingest_commit",
     "cbm_params_publish_external", "cbm_actor_stream", "cbm_actor_ring_index", "cbm_actor_step_async", "cbm_gae_async", "cbm_mb_advnorm",
-    "cbm_synth_env_step_host_ids", "cbm_synth_env_step_host_to", "cbm_learner_grad_tail_offset", "cbm_vtrace", "cbm_comm_init_loopback",
+    "cbm_synth_env_step_host_ids", "cbm_synth_env_step_host_to", "cbm_synth_env_render_host", "cbm_learner_grad_tail_offset", "cbm_vtrace", "cbm_comm_init_loopback",
     "cbm_comm_load", "cbm_comm_unique_id", "cbm_comm_init", "cbm_comm_size", "cbm_comm_allreduce_f64", "cbm_comm_barrier",
     "cbm_learner_allreduce_grads", "cbm_comm_profile", "cbm_comm_profile_read", "cbm_ipc_export", "cbm_ipc_open", "cbm_ipc_close",
     "cbm_host_register", "cbm_host_unregister", "cbm_actor_ship_shard", "cbm_io_sync", "cbm_params_push", "cbm_params_mark_published", "cbm_ctx_abort", "cbm_profile_read_all",
@@ -453,6 +453,12 @@ def synth_env_step_host(seed, st, obs, actions, max_episode_steps=27000):
     _chk(load().cbm_synth_env_step_host(C.c_uint32(int(seed) & 0xFFFFFFFF), int(n), int(max_episode_steps), _p(actions), st,
                                         _p(obs), _p(reward), _p(done), _p(term), _p(elapsed)))
     return reward, done, term, elapsed
+
+
+def synth_env_render_host(state, layered):
+    plane = np.empty((84, 84), np.uint8)
+    _chk(load().cbm_synth_env_render_host(C.byref(state), int(bool(layered)), _p(plane)))
+    return plane
 
 
 def synth_env_step_host_to(seed, st, obs_prev, actions, max_episode_steps=27000):

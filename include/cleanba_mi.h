@@ -274,6 +274,9 @@ int cbm_synth_env_step_host(uint32_t seed, int32_t n, int32_t max_episode_steps,
 int cbm_synth_env_step_host_to(uint32_t seed, int32_t n, int32_t max_episode_steps, const int32_t* actions, cbm_env_state* st,
                                const uint8_t* obs_prev, uint8_t* obs_next, float* reward, uint8_t* done, uint8_t* terminated,
                                int32_t* elapsed_step);
+/* Diagnostics: paints the newest 84x84 plane of one env state, layered = 0 with the per-pixel function of the device kernels, 1 with the host
+ * twin's layered painter (the two must agree byte for byte). */
+int cbm_synth_env_render_host(const cbm_env_state* st, int32_t layered, uint8_t* plane);
 /* envpool async mode, send(action, env_id) for a subset (impala:365, naturecnn:358): steps the k listed envs of the num_envs held in st / obs;
  * outputs in list order. */
 int cbm_synth_env_step_host_ids(uint32_t seed, int32_t num_envs, int32_t k, int32_t max_episode_steps, const int32_t* env_ids,

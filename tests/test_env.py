@@ -104,3 +104,22 @@ def test_async_batches_are_the_same_trajectories_in_a_different_order():
         buf[:] = -7          # the caller may reuse its action buffer right after send()
     asy.close()
     assert len(orders) > 10   # the batches are not a fixed round-robin
+
+
+def test_layered_host_painter_equals_the_per_pixel_function_and_out_of_place_step_equals_in_place():
+    """The host twin paints a plane layer by layer and steps out of place (a fresh array per step like envpool's recv); the device kernels call
+    the per-pixel function and shift in place.  Same bytes, for every game preset, through resets."""
+    n, seed = 114, 11
+    st_a, obs_a = L.synth_env_reset_host(seed, n, atari57_mix=True)
+    st_b, obs_b = L.synth_env_reset_host(seed, n, atari57_mix=True)
+    rng = np.random.default_rng(2)
+    for t in range(400):
+        a = rng.integers(0, 18, n).astype(np.int32)
+        ra, da, ta, ea = L.synth_env_step_host(seed, st_a, obs_a, a, 200)          # in place (short episodes: many resets)
+        obs_b, rb, db, tb, eb = L.synth_env_step_host_to(seed, st_b, obs_b, a, 200)   # out of place
+        assert (obs_a == obs_b).all() and (ra == rb).all() and (da == db).all() and (ta == tb).all() and (ea == eb).all()
+        if t % 25 == 0:
+            for e in range(n):
+                slow, fast = L.synth_env_render_host(st_a[e], 0), L.synth_env_render_host(st_a[e], 1)
+                assert (slow == fast).all(), (t, e)
+                assert (fast == obs_a[e, 3]).all()

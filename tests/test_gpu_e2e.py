@@ -278,6 +278,45 @@ def test_host_env_loop_equals_device_env_loop(tmp_path, algo):
     assert np.array_equal(out["host"]["params"], out["device"]["params"])
 
 
+def test_page_locked_host_buffer_gives_the_same_actions():
+    """cbm_host_register: the env's observation buffer page-locked (DMA from the caller's pages) vs pageable (runtime staging) — same uploads,
+    same actions, same stored rows."""
+    import cleanba_amd.lib as L
+    import cleanba_amd.model as M
+    import cleanba_amd.prng as prng
+    E, T = 12, 6
+    outs = []
+    for pinned in (False, True):
+        cfg = L.default_config(L.ALGO_PPO)
+        cfg.local_num_envs, cfg.num_actor_slots, cfg.num_steps = E, 1, T
+        ctx = L.Context(cfg)
+        key = prng.prng_key(3)
+        key, nk, ak, ck = prng.split(key, 4)
+        ctx.set_params(M.init_nature_params(18, nk, ak, ck))
+        ctx.actor_set_key(0, key)
+        st, obs = L.synth_env_reset_host(7, E)
+        if pinned:
+            ctx.host_register(obs)
+        done = np.zeros(E, np.uint8)
+        ctx.actor_begin_rollout(0, False)
+        ring = ctx.actor_ring_index(0)
+        acts = []
+        for t in range(T):
+            a = ctx.actor_step_host(0, obs, done)
+            acts.append(a.copy())
+            r, d, _, _ = L.synth_env_step_host(7, st, obs, a)      # in place: the registered buffer is reused
+            ctx.actor_record_host(0, r)
+            done = d
+        ctx.actor_commit(0, obs, done)
+        ctx.sync()
+        stored = ctx.read("obs", np.uint8, ring=ring)[:T * E * 28224].copy()
+        if pinned:
+            ctx.host_unregister(obs)
+        ctx.close()
+        outs.append((np.stack(acts), stored))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+
+
 @pytest.mark.parametrize("algo,E,thr,T,nmb,epochs,accum,conc", [
     ("ppo", 2, 1, 4, 1, 1, 1, False), ("ppo", 3, 2, 5, 2, 3, 1, True), ("ppo", 4, 3, 4, 4, 2, 2, True),
     ("impala", 2, 2, 4, 2, 1, 1, False), ("impala", 6, 1, 5, 3, 1, 2, True), ("impala", 4, 3, 3, 4, 1, 1, True)])
