@@ -191,6 +191,151 @@ __global__ __launch_bounds__(256, 2) void conv1_fwd_frames_kernel(const uint8_t*
   }
 }
 
+// Plane-streamed flavour (C1F_PLANES): the byte -> x/255 conversion leaves the MFMA loop.  In conv1_fwd_frames_kernel every A fragment is
+// made from its byte at the moment it is consumed — a pixel sits in 2x2 patches, so each is converted four times, 3-4 VALU instructions per
+// MFMA, and VALU instructions take matrix-pipe issue slots on this chip.  Here a frame goes through LDS one channel plane at a
+// time AS FLOATS: the 7056 bytes of plane c are loaded to registers while plane c-1 is multiplied, converted once (1 VALU instruction per
+// MFMA) and written as two half-planes [kw parity][84][42] — lane half h of a 32x32x2 MFMA supplies k = 2j + h, i.e. always one parity — so
+// a tile's four kw-pairs of one (c,kh) patch row are 4 consecutive floats: two conflict-free ds_read_b64, no extraction, no conversion.
+// Same LDS footprint as the byte kernel (28,224 B plane + 32 KB weights, two blocks per CU), same tile ownership, same k = (c,kh,kw)
+// ascending chain per output -> the same bits.
+__global__ __launch_bounds__(256, 2) void conv1_fwd_planes_kernel(const uint8_t* obs, const int32_t* idx, const float* W, const float* bias,
+                                                                  float* out, uint32_t* mask, int S, int frames_per_block) {
+  __shared__ __attribute__((aligned(16))) float smem_f[256 * 32 + 2 * 84 * 42];
+  float* Wl = smem_f;                 // [256][32]
+  float* Pf = smem_f + 256 * 32;      // [2][84][42]
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int s_lo = blockIdx.x * frames_per_block, s_hi = min(S, s_lo + frames_per_block);
+  uint32_t pw[7];
+  auto load_plane = [&](const uint8_t* plane) __attribute__((always_inline)) {
+    const uint32_t* g = reinterpret_cast<const uint32_t*>(plane);
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      const int v = tid + 256 * j;
+      pw[j] = g[min(v, 1763)];
+    }
+  };
+  if (s_lo < s_hi) load_plane(obs + (size_t)(idx ? idx[s_lo] : s_lo) * FR);
+  for (int i = tid; i < 256 * 32 / 4; i += 256) {
+    const int k = i >> 3, n4 = (i & 7) * 4;
+    const int c = k >> 6, kh = (k >> 3) & 7, kw = k & 7;
+    *reinterpret_cast<float4*>(Wl + k * 32 + n4) = *reinterpret_cast<const float4*>(W + ((kh * 8 + kw) * 4 + c) * 32 + n4);
+  }
+  const float bn = bias[li];
+  constexpr int MAXT = 3;
+  typedef float f32x4_t __attribute__((ext_vector_type(4)));
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  const int r16 = lane & 15, g4 = lane >> 4;
+  for (int s = s_lo; s < s_hi; ++s) {
+    const int first = (wave + (s - s_lo)) & 3;
+    const bool four = first < 2;
+    const int tj = first & 1;
+    int base[MAXT];
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) {
+      const int p = min((first + 4 * t) * 32 + li, 399);
+      const int oh = p / 20, ow = p - oh * 20;
+      base[t] = h * 3528 + oh * 4 * 42 + ow * 2;
+    }
+    // tail tile (positions 384..399 = row 19, columns 4..19): lane (g4, r16) supplies kw = 4*st + g4 -> parity g4 & 1, half-plane column 2*ow + (g4 >> 1) + 2*st
+    const int tbase = (g4 & 1) * 3528 + ((384 + r16) / 20) * 4 * 42 + ((384 + r16) % 20) * 2 + (g4 >> 1);
+    f32x16 acc[MAXT];
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[t][e] = 0.0f;
+    f32x4_t tacc = {0.f, 0.f, 0.f, 0.f};
+    const uint8_t* frame = obs + (size_t)(idx ? idx[s] : s) * FR;
+#pragma unroll 1
+    for (int c = 0; c < 4; ++c) {
+      __syncthreads();                       // every wave is done with the previous plane (and, for c == 0, with the weights' staging loads)
+#pragma unroll
+      for (int j = 0; j < 7; ++j) {
+        const int v = tid + 256 * j;
+        if (v < 1764) {
+          const int y = v / 21, xw = v - y * 21;
+          const uint32_t w = pw[j];
+          f32x2_t ev = {cbm_u8_unit(w & 255u), cbm_u8_unit((w >> 16) & 255u)}, od = {cbm_u8_unit((w >> 8) & 255u), cbm_u8_unit(w >> 24)};
+          *reinterpret_cast<f32x2_t*>(Pf + y * 42 + 2 * xw) = ev;
+          *reinterpret_cast<f32x2_t*>(Pf + 3528 + y * 42 + 2 * xw) = od;
+        }
+      }
+      if (c < 3) load_plane(frame + (c + 1) * 7056);                                           // lands while this plane is multiplied
+      else if (s + 1 < s_hi) load_plane(obs + (size_t)(idx ? idx[s + 1] : s + 1) * FR);
+      __syncthreads();
+      f32x2_t aa[2][MAXT][2];
+      float ta[2][2], wv[2][6];
+      auto fetch = [&](int kh, int set) __attribute__((always_inline)) {
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t) {
+          const float* q = Pf + base[t] + kh * 42;
+          aa[set][t][0] = *reinterpret_cast<const f32x2_t*>(q);
+          aa[set][t][1] = *reinterpret_cast<const f32x2_t*>(q + 2);
+        }
+        const int krow = (c * 8 + kh) * 8;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wv[set][j] = Wl[(krow + 2 * j + h) * 32 + li];
+        if (four) {
+#pragma unroll
+          for (int st = 0; st < 2; ++st) {
+            ta[set][st] = Pf[tbase + kh * 42 + 2 * st];
+            wv[set][4 + st] = Wl[(krow + 4 * st + g4) * 32 + 16 * tj + r16];
+          }
+        }
+      };
+      auto fma_row = [&](int set) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int t = 0; t < MAXT; ++t)
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aa[set][t][j >> 1][j & 1], wv[set][j], acc[t], 0, 0, 0);
+        if (four) {
+#pragma unroll
+          for (int st = 0; st < 2; ++st) tacc = __builtin_amdgcn_mfma_f32_16x16x4f32(ta[set][st], wv[set][4 + st], tacc, 0, 0, 0);
+        }
+      };
+      fetch(0, 0);
+#pragma unroll
+      for (int kh = 0; kh < 8; ++kh) {
+        if (kh + 1 < 8) fetch(kh + 1, (kh + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        fma_row(kh & 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    float* o = out + (size_t)s * 400 * 32 + li;
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) {
+      const int m0 = (first + 4 * t) * 32 + 4 * h;
+      uint32_t word = 0;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int r0 = (e & 3) + 8 * (e >> 2);
+        const float v = relu_(acc[t][e] + bn);
+        o[(m0 + r0) * 32] = v;
+        const unsigned long long bal = __ballot(v > 0.0f);
+        asm volatile("s_nop 4\n\tv_writelane_b32 %0, %1, %2" : "+v"(word) : "s"((uint32_t)bal), "n"(r0));
+        asm volatile("s_nop 4\n\tv_writelane_b32 %0, %1, %2" : "+v"(word) : "s"((uint32_t)(bal >> 32)), "n"(r0 + 4));
+      }
+      if (mask && lane < 32) mask[(size_t)s * 400 + (first + 4 * t) * 32 + lane] = word;
+    }
+    if (four) {
+      const float bt = bias[16 * tj + r16];
+      uint32_t word = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float v = relu_(tacc[i] + bt);
+        out[((size_t)s * 400 + 384 + 4 * g4 + i) * 32 + 16 * tj + r16] = v;
+        const unsigned long long bal = __ballot(v > 0.0f);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) asm volatile("s_nop 4\n\tv_writelane_b32 %0, %1, %2" : "+v"(word) : "s"((uint32_t)((bal >> (16 * g)) & 0xFFFFull)), "n"(4 * g + i));
+      }
+      if (mask && lane < 16) reinterpret_cast<uint16_t*>(mask + (size_t)s * 400 + 384 + lane)[tj] = (uint16_t)word;
+    }
+  }
+}
+
 void launch_conv1_fwd_frames(const uint8_t* obs, const int32_t* idx, const float* W, const float* bias, float* out, uint32_t* mask, int S,
                              hipStream_t st) {
 #ifndef C1F_BLOCKS
@@ -202,7 +347,11 @@ void launch_conv1_fwd_frames(const uint8_t* obs, const int32_t* idx, const float
   if (S < blocks) blocks = S;
   const int fpb = (S + blocks - 1) / blocks;
   blocks = (S + fpb - 1) / fpb;
-  hipLaunchKernelGGL(conv1_fwd_frames_kernel, dim3(blocks), dim3(256), 0, st, obs, idx, W, bias, out, mask, S, fpb);
+#ifndef C1F_PLANES
+#define C1F_PLANES 1
+#endif
+  if (C1F_PLANES) hipLaunchKernelGGL(conv1_fwd_planes_kernel, dim3(blocks), dim3(256), 0, st, obs, idx, W, bias, out, mask, S, fpb);
+  else hipLaunchKernelGGL(conv1_fwd_frames_kernel, dim3(blocks), dim3(256), 0, st, obs, idx, W, bias, out, mask, S, fpb);
 }
 
 // ------------------------------------------------------------------------------------------ wgrad
