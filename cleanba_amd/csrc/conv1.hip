@@ -339,9 +339,10 @@ __global__ __launch_bounds__(256, 2) void conv1_fwd_planes_kernel(const uint8_t*
 void launch_conv1_fwd_frames(const uint8_t* obs, const int32_t* idx, const float* W, const float* bias, float* out, uint32_t* mask, int S,
                              hipStream_t st) {
 #ifndef C1F_BLOCKS
-#define C1F_BLOCKS 4096   // one frame per block up to 4096 frames.  512 persistent blocks (exactly two per CU) were fragile under the concurrent
+#define C1F_BLOCKS 2048   // two frames per block at 3840 frames.  512 persistent blocks (exactly two per CU) were fragile under the concurrent
                           // rollout: a CU that could not take its second block (LDS held by actor blocks) left a straggler — 375 us under load
-                          // against 286 isolated; with many short blocks the dispatcher balances: 306 us under load, 275 isolated, step -0.9 ms
+                          // against 286 isolated; with many short blocks the dispatcher balances.  Plane-streamed kernel under load / isolated:
+                          // 4096 blocks 279 / 260 us, 2048 275 / 253, 1280 283 / 276, 768 292 / 245 (the byte kernel: 308 / 282)
 #endif
   int blocks = C1F_BLOCKS;
   if (S < blocks) blocks = S;
