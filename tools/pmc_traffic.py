@@ -11,7 +11,7 @@ sys.path.insert(0, __file__.rsplit("/", 1)[0])
 from rocprof_summary import short
 
 # substrings of the shipped kernels' names -> bench.py kernel ids (first match wins)
-IDS = [("conv1_fwd_frames_kernel", 0), ("ConvFwd<IgemmTile<64, 64, 32, 2, 2, 4>, 4, 4, 2", 1), ("ConvFwd<IgemmTile<128, 64, 16, 2, 2, 4>, 3, 3, 1", 2),
+IDS = [("conv1_fwd_planes_kernel", 0), ("ConvFwd<IgemmTile<64, 64, 32, 2, 2, 4>, 4, 4, 2", 1), ("ConvFwd<IgemmTile<128, 64, 16, 2, 2, 4>, 3, 3, 1", 2),
        ("igemm_dma_kernel<DenseFwd", 3), ("MatWgrad<IgemmTile<128, 32", 4), ("DenseDgrad", 5), ("MatWgrad<IgemmTile<128, 256", 6), ("Conv3DgradPos", 7),
        ("conv3_wgrad_frames_kernel", 8), ("Conv2DgradMergedPos", 9), ("conv2_wgrad_frames_kernel", 10), ("conv1_wgrad_frames_kernel", 11)]
 
