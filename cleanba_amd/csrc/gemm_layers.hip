@@ -1084,7 +1084,9 @@ using T128x128k16 = IgemmTile<128, 128, 16, 2, 2, 2>;   // split-bf16 merged con
 using T128x128k32 = IgemmTile<128, 128, 32, 2, 2, 2>;
 using T128x256k16 = IgemmTile<128, 256, 16, 2, 2, 2>;   // 2x4 accumulators per wave
 using T256x128k16 = IgemmTile<256, 128, 16, 2, 2, 2>;
-using T256x64k16 = IgemmTile<256, 64, 16, 4, 1, 2>;     // 2x2 accumulators per wave on the N = 64 convs
+using T256x64k16 = IgemmTile<256, 64, 16, 4, 1, 2>;
+using T64x64w3 = IgemmTile<64, 64, 32, 2, 2, 3>;        // 170-VGPR budget (3 waves per SIMD)
+using T64x64w2 = IgemmTile<64, 64, 32, 2, 2, 2>;     // 2x2 accumulators per wave on the N = 64 convs
 using T64x64 = IgemmTile<64, 64, BR_64x64, 2, 2>;
 // actor-step (small batch) tiles: half the K chunk = half the LDS, so a block still finds room on CUs mostly held by learner blocks
 using T64x64k16 = IgemmTile<64, 64, 16, 2, 2>;
