@@ -304,6 +304,92 @@ __global__ __launch_bounds__(256) void actor_tail_kernel(const float* hid, const
     }
   }
 }
+// Actor tail, one block per frame (ACTOR_TAIL_ROWS): the dense layer's split-K reduction, the two heads and the sampling in ONE launch.
+// The 16-row MFMA tail above needs the reduced hidden rows in HBM first (dense_reduce_kernel, 4.9 us + a launch); folding the reduction into
+// its 8 blocks made them the bottleneck (15.8 ms rollouts).  With a block per frame the reduction is 120-way parallel again: every thread
+// sums its two hidden units over the S partial slices in slice order (dense_reduce_kernel's chain), the A + 1 head outputs are 512-long
+// k-ascending fmaf chains on A + 1 lanes (bitwise the MFMA's chain: DESIGN 3) fed from LDS, and the frame's 32 sampling lanes run
+// sample_kernel's code.  hid never reaches HBM.
+#ifndef TAIL_ABL
+#define TAIL_ABL 0   // timing builds: 1 no partial-slice loads, 2 no head chains, 4 no sampling math, 8 no weight staging
+#endif
+template <int HD>
+__global__ __launch_bounds__(256) void actor_tail_rows_kernel(const float* part, const float* bd, int S, const float* Wa, const float* ba, const float* Wc,
+                                                              const float* bc, int B, int A, ActorSample smp) {
+  __shared__ __attribute__((aligned(16))) float hsT[HD];      // hid of this frame, stored as [k % 4][k / 4]: lane group g4 of a 16x16x4 MFMA reads its k = 4*st + g4 as consecutive floats
+  __shared__ float lg[32];
+  const int tid = threadIdx.x, b = blockIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, g4 = lane >> 4;
+  const size_t MN = (size_t)B * HD;
+  // all partial slices of this thread's two hidden units are requested at once (S <= 16), then added in slice order
+  float v0[16], v1[16];
+#pragma unroll
+  for (int s = 0; s < 16; ++s) {
+    const int ss = s < S ? s : 0;
+    v0[s] = (TAIL_ABL & 1) && s ? 0.0f : part[ss * MN + (size_t)b * HD + tid];
+    v1[s] = (TAIL_ABL & 1) && s ? 0.0f : part[ss * MN + (size_t)b * HD + tid + 256];
+  }
+  // heads on v_mfma_f32_16x16x4_f32 with ONE live row (row 0 = this frame; the instruction's other 15 rows repeat it and are ignored): waves
+  // 0 / 1 own output columns 0-15 / 16-31 and take their B fragments (HD/4 floats per lane, L2-resident weights) straight into registers,
+  // requested together with the partial slices
+  const int n = wave * 16 + r16;
+  const bool on = wave < 2 && n <= A;
+  const float* wp = n < A ? Wa + n : Wc;
+  const int wstride = n < A ? A : 1;
+  float bw[HD / 4];
+  if (wave < 2) {
+#pragma unroll
+    for (int st = 0; st < HD / 4; ++st) bw[st] = on && !(TAIL_ABL & 8) ? wp[(size_t)(4 * st + g4) * wstride] : 0.0f;
+  }
+  float t0 = v0[0], t1 = v1[0];
+#pragma unroll
+  for (int s = 1; s < 16; ++s)
+    if (s < S) { t0 = t0 + v0[s]; t1 = t1 + v1[s]; }
+  hsT[(tid & 3) * (HD / 4) + (tid >> 2)] = relu(t0 + bd[tid]);                 // k = tid, tid + 256
+  hsT[(tid & 3) * (HD / 4) + ((tid + 256) >> 2)] = relu(t1 + bd[tid + 256]);
+  __syncthreads();
+  if (wave < 2) {
+    f32x4_mfma acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int q = 0; q < ((TAIL_ABL & 2) ? 1 : HD / 16); ++q) {
+      const float4 h4 = *reinterpret_cast<const float4*>(hsT + g4 * (HD / 4) + 4 * q);   // k = 4*(4q + i) + g4, i = 0..3
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(h4.x, bw[4 * q], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(h4.y, bw[4 * q + 1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(h4.z, bw[4 * q + 2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(h4.w, bw[4 * q + 3], acc, 0, 0, 0);
+    }
+    if (g4 == 0 && n <= A) lg[n] = acc[0] + (n < A ? ba[n] : bc[0]);   // D: lane (g4 = 0, r16) element 0 = row 0, column r16
+  }
+  __syncthreads();
+  if (tid < 32) {
+    const int a = tid;
+    const bool live = a < A;
+    const int aa = live ? a : A - 1;
+    const uint32_t nn = (uint32_t)(B * A);
+    const int bg = b;
+    const float z = lg[aa];
+    const float u = cbm_bits_to_uniform(cbm_random_bits_at(smp.sk0, smp.sk1, nn, (uint32_t)(bg * A + aa)));
+    float g = live ? ((TAIL_ABL & 4) ? z - u : z - cbm_logf(-cbm_logf(u))) : -INFINITY;
+    if (live && smp.logits_out) smp.logits_out[(size_t)b * A + a] = z;
+    int bi = a;
+    float bv = g, mx = live ? z : -INFINITY;
+    for (int o = 16; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(bv, o, 32);
+      const int oi = __shfl_xor(bi, o, 32);
+      const float om = __shfl_xor(mx, o, 32);
+      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+      mx = om > mx ? om : mx;
+    }
+    const float e = live ? ((TAIL_ABL & 4) ? z - mx : cbm_expf(z - mx)) : 0.0f;
+    const float zb = __shfl(z, bi, 32);
+    float ssum = 0.0f;
+    for (int j = 0; j < A; ++j) ssum += __shfl(e, j, 32);
+    if (a == 0) {
+      smp.actions[b] = bi;
+      if (smp.logprobs) smp.logprobs[b] = (zb - mx) - cbm_logf(ssum);
+      if (smp.value_out) smp.value_out[b] = lg[A];
+    }
+  }
+}
 #ifndef HEADS_S16
 #define HEADS_S16 1
 #endif
@@ -1145,6 +1231,14 @@ bool nature_forward(const NatureLayout& L, const float* P, const uint8_t* obs, c
 #ifndef ACTOR_TAIL_FUSED
 #define ACTOR_TAIL_FUSED 1
 #endif
+#ifndef ACTOR_TAIL_ROWS
+#define ACTOR_TAIL_ROWS 1
+#endif
+      if (ACTOR_TAIL_ROWS && sample && L.A + 1 <= 32 && dense_ksplit <= 16) {
+        hipLaunchKernelGGL(actor_tail_rows_kernel<512>, dim3(B), dim3(256), 0, st, ws.dense_part, P + L.b[3], dense_ksplit, P + L.w[4], P + L.b[4],
+                           P + L.w[5], P + L.b[5], B, L.A, *sample);
+        return true;
+      }
       hipLaunchKernelGGL(dense_reduce_kernel, dim3(ceil_div(B * 512, 256)), dim3(256), 0, st, ws.dense_part, P + L.b[3], ws.hid, B, 512, dense_ksplit);
       if (ACTOR_TAIL_FUSED && sample && L.A + 1 <= 32) {
         hipLaunchKernelGGL(actor_tail_kernel<512>, dim3(ceil_div(B, 16)), dim3(256), 0, st, ws.hid, P + L.w[4], P + L.b[4], P + L.w[5], P + L.b[5], B, L.A,
