@@ -347,7 +347,10 @@ extern "C" int cbm_actor_begin_rollout(cbm_ctx* c, int32_t s, int32_t concurrenc
 }
 
 // get_action_and_value on ring row t of slot s + Gumbel sampling, results stored into the row
-static void actor_infer_row(cbm_ctx* c, int s, int t) {
+// `env` (device env only): where the env's step with the sampled action reads and writes; when the forward pass ends in the per-frame tail
+// launch that launch also steps the env (returns true), otherwise the caller launches env_step_kernel.
+struct ActorEnvRows { size_t o_prev, o_next, o_reward; };
+static bool actor_infer_row(cbm_ctx* c, int s, int t, const ActorEnvRows* env = nullptr) {
   Slot& sl = c->slots[s];
   RingEntry& R = c->ring[sl.ring];
   const size_t o = row_off(c, t, s);
@@ -355,14 +358,21 @@ static void actor_infer_row(cbm_ctx* c, int s, int t) {
   cbm_split_at(sl.key[0], sl.key[1], 2, 0, &n0, &n1);
   cbm_split_at(sl.key[0], sl.key[1], 2, 1, &s0, &s1);
   sl.key[0] = n0; sl.key[1] = n1;
-  const ActorSample smp = is_ppo(c) ? ActorSample{s0, s1, R.actions + o, R.logprobs + o, R.values + o, nullptr}
-                                    : ActorSample{s0, s1, R.actions + o, nullptr, nullptr, R.logits + o * c->A};
-  if (nature_forward(c->L, c->actor_params[sl.pver % NPV], R.obs + o * CBM_FRAME, nullptr, c->E, c->cfg.actor_dense_ksplit, sl.ws, sl.stream, &smp))
-    return;   // the forward pass ended in the fused reduce + heads + sampling launch
+  ActorSample smp = is_ppo(c) ? ActorSample{s0, s1, R.actions + o, R.logprobs + o, R.values + o, nullptr}
+                              : ActorSample{s0, s1, R.actions + o, nullptr, nullptr, R.logits + o * c->A};
+  if (env) {
+    smp.env_seed = sl.env_seed; smp.env_max_steps = 27000;  // ATARI_MAX_FRAMES ppo:121-123
+    smp.env_st = sl.env_state; smp.env_obs_prev = R.obs + env->o_prev * CBM_FRAME; smp.env_obs_next = R.obs + env->o_next * CBM_FRAME;
+    smp.env_reward = R.rewards + env->o_reward; smp.env_done_next = R.dones + env->o_next; smp.env_firststep_next = R.firststeps + env->o_next;
+  }
+  const int done = nature_forward(c->L, c->actor_params[sl.pver % NPV], R.obs + o * CBM_FRAME, nullptr, c->E, c->cfg.actor_dense_ksplit, sl.ws,
+                                  sl.stream, &smp);
+  if (done) return done == 2;   // the forward pass ended in the fused reduce + heads + sampling (+ env step) launch
   if (is_ppo(c))
     launch_sample(sl.ws.logits, c->E, c->A, s0, s1, R.actions + o, R.logprobs + o, sl.ws.value, R.values + o, nullptr, sl.stream);
   else
     launch_sample(sl.ws.logits, c->E, c->A, s0, s1, R.actions + o, nullptr, nullptr, nullptr, R.logits + o * c->A, sl.stream);
+  return false;
 }
 
 extern "C" int cbm_actor_step_host(cbm_ctx* c, int32_t s, const uint8_t* obs, const uint8_t* done, const uint8_t* firststep,
@@ -437,10 +447,11 @@ extern "C" int cbm_actor_rollout_device(cbm_ctx* c, int32_t s, int32_t nsteps) {
     for (int i = 0; i < nsteps; ++i) {
       const int t = sl.t;
       if (t >= c->T) { cbm_set_error("rollout overrun"); return -1; }
-      actor_infer_row(c, s, t);
       const size_t o = row_off(c, t, s), o1 = row_off(c, t + 1, s);
-      launch_env_step(sl.env_seed, c->E, max_steps, R.actions + o, sl.env_state, R.obs + o * CBM_FRAME, R.obs + o1 * CBM_FRAME, R.rewards + o,
-                      R.dones + o1, R.firststeps + o1, sl.stream);
+      const ActorEnvRows er{o, o1, o};
+      if (!actor_infer_row(c, s, t, &er))
+        launch_env_step(sl.env_seed, c->E, max_steps, R.actions + o, sl.env_state, R.obs + o * CBM_FRAME, R.obs + o1 * CBM_FRAME, R.rewards + o,
+                        R.dones + o1, R.firststeps + o1, sl.stream);
       sl.t += 1;
     }
   } else {
@@ -453,11 +464,14 @@ extern "C" int cbm_actor_rollout_device(cbm_ctx* c, int32_t s, int32_t nsteps) {
     for (int i = 0; i < nsteps; ++i) {
       const int t = sl.t;
       if (t > c->T) { cbm_set_error("rollout overrun"); return -1; }
-      actor_infer_row(c, s, t);
       if (t < c->T) {
         const size_t o = row_off(c, t, s), o1 = row_off(c, t + 1, s);
-        launch_env_step(sl.env_seed, c->E, max_steps, R.actions + o, sl.env_state, R.obs + o * CBM_FRAME, R.obs + o1 * CBM_FRAME, R.rewards + o1,
-                        R.dones + o1, R.firststeps + o1, sl.stream);
+        const ActorEnvRows er{o, o1, o1};
+        if (!actor_infer_row(c, s, t, &er))
+          launch_env_step(sl.env_seed, c->E, max_steps, R.actions + o, sl.env_state, R.obs + o * CBM_FRAME, R.obs + o1 * CBM_FRAME, R.rewards + o1,
+                          R.dones + o1, R.firststeps + o1, sl.stream);
+      } else {
+        actor_infer_row(c, s, t);
       }
       sl.t += 1;
     }

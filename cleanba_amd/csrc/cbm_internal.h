@@ -73,10 +73,13 @@ struct ActorSample {
   float* logprobs;            // [B] or null (IMPALA)
   float* value_out;           // [B] or null
   float* logits_out;          // [B][A] or null (PPO)
+  // optional: the device env's step with the sampled action, done by the launch that sampled it (nature_forward returns 2 then)
+  uint32_t env_seed; int32_t env_max_steps; cbm_env_state* env_st; const uint8_t* env_obs_prev; uint8_t* env_obs_next; float* env_reward;
+  uint8_t* env_done_next; uint8_t* env_firststep_next;   // env_obs_next == nullptr: no env step
 };
 // forward: obs[idx[b]] (idx may be null) -> ws.logits [B,A], ws.value [B]; activations kept in ws.  With `sample` non-null the call MAY
 // also do the sampling (returns true then; ws.logits / ws.value / ws.hid are not written); false = the caller launches launch_sample.
-bool nature_forward(const NatureLayout& L, const float* P, const uint8_t* obs, const int32_t* idx, int B,
+int nature_forward(const NatureLayout& L, const float* P, const uint8_t* obs, const int32_t* idx, int B,
                     int dense_ksplit, NatureWs& ws, hipStream_t st, const ActorSample* sample = nullptr);
 // backward from ws.dzv ([B][32]: dlogits | dvalue | 0) -> grads (flat, same layout as params).
 void nature_backward(const NatureLayout& L, const float* P, const uint8_t* obs, const int32_t* idx, int B,

@@ -29,6 +29,7 @@
 #define IGEMM_ROWPTR 1   // row / chunk split gather addresses in igemm_pf2_kernel (igemm.h): bit 0 conv3 dgrad, 1 conv fwd, 2 conv2 dgrad
 #endif
 #include "igemm.h"
+#include "env_model.h"
 #include <algorithm>
 #include <vector>
 #include <type_traits>
@@ -316,10 +317,16 @@ __global__ __launch_bounds__(256) void actor_tail_kernel(const float* hid, const
 template <int HD>
 __global__ __launch_bounds__(256) void actor_tail_rows_kernel(const float* part, const float* bd, int S, const float* Wa, const float* ba, const float* Wc,
                                                               const float* bc, int B, int A, ActorSample smp) {
+  __shared__ int act_s;
   __shared__ __attribute__((aligned(16))) float hsT[HD];      // hid of this frame, stored as [k % 4][k / 4]: lane group g4 of a 16x16x4 MFMA reads its k = 4*st + g4 as consecutive floats
   __shared__ float lg[32];
   const int tid = threadIdx.x, b = blockIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, g4 = lane >> 4;
   const size_t MN = (size_t)B * HD;
+  // device env: this block also steps env b with the action it samples; the stack's older planes are requested now
+  const EnvStepArgs ea{smp.env_seed, smp.env_max_steps, smp.env_st, smp.env_obs_prev, smp.env_obs_next, smp.env_reward, smp.env_done_next,
+                       smp.env_firststep_next};
+  uint32_t older[7][3];
+  if (ea.obs_next) env_step_prefetch(ea, b, older);
   // all partial slices of this thread's two hidden units are requested at once (S <= 16), then added in slice order
   float v0[16], v1[16];
 #pragma unroll
@@ -385,9 +392,14 @@ __global__ __launch_bounds__(256) void actor_tail_rows_kernel(const float* part,
     for (int j = 0; j < A; ++j) ssum += __shfl(e, j, 32);
     if (a == 0) {
       smp.actions[b] = bi;
+      act_s = bi;
       if (smp.logprobs) smp.logprobs[b] = (zb - mx) - cbm_logf(ssum);
       if (smp.value_out) smp.value_out[b] = lg[A];
     }
+  }
+  if (ea.obs_next) {
+    __syncthreads();
+    env_step_block(ea, b, act_s, older);
   }
 }
 #ifndef HEADS_S16
@@ -1200,9 +1212,9 @@ using T64x64k16 = IgemmTile<64, 64, 16, 2, 2>;
 
 #include "resnet_layers.inc"
 
-bool nature_forward(const NatureLayout& L, const float* P, const uint8_t* obs, const int32_t* idx, int B, int dense_ksplit,
+int nature_forward(const NatureLayout& L, const float* P, const uint8_t* obs, const int32_t* idx, int B, int dense_ksplit,
                     NatureWs& ws, hipStream_t st, const ActorSample* sample) {
-  if (L.kind == CBM_NET_IMPALA_RESNET) { resnet_forward(L, P, obs, idx, B, dense_ksplit, ws, st); return false; }
+  if (L.kind == CBM_NET_IMPALA_RESNET) { resnet_forward(L, P, obs, idx, B, dense_ksplit, ws, st); return 0; }
   const bool small = B <= 512;
 #ifndef ACTOR_S16
 #define ACTOR_S16 1   // actor-size forward passes (no ReLU masks wanted) on the 16x16x4 small-batch kernel (igemm.h igemm_s16_kernel), same bits
@@ -1237,20 +1249,20 @@ bool nature_forward(const NatureLayout& L, const float* P, const uint8_t* obs, c
       if (ACTOR_TAIL_ROWS && sample && L.A + 1 <= 32 && dense_ksplit <= 16) {
         hipLaunchKernelGGL(actor_tail_rows_kernel<512>, dim3(B), dim3(256), 0, st, ws.dense_part, P + L.b[3], dense_ksplit, P + L.w[4], P + L.b[4],
                            P + L.w[5], P + L.b[5], B, L.A, *sample);
-        return true;
+        return sample->env_obs_next ? 2 : 1;
       }
       hipLaunchKernelGGL(dense_reduce_kernel, dim3(ceil_div(B * 512, 256)), dim3(256), 0, st, ws.dense_part, P + L.b[3], ws.hid, B, 512, dense_ksplit);
       if (ACTOR_TAIL_FUSED && sample && L.A + 1 <= 32) {
         hipLaunchKernelGGL(actor_tail_kernel<512>, dim3(ceil_div(B, 16)), dim3(256), 0, st, ws.hid, P + L.w[4], P + L.b[4], P + L.w[5], P + L.b[5], B, L.A,
                            *sample);
-        return true;
+        return 1;
       }
     } else {
       DenseFwd<T64x64k16, false> pd{ws.act3, P + L.w[3], P + L.b[3], ws.hid, B, 3136, 512, 3136};
       igemm_s16_launch<32, 32, 64>(pd, 1, st);
     }
     launch_heads_fwd(ws.hid, P + L.w[4], P + L.b[4], P + L.w[5], P + L.b[5], B, L.A, 512, ws.logits, ws.value, st);
-    return false;
+    return 0;
   }
 #ifndef C1_FRAMES_MIN
 #define C1_FRAMES_MIN 513   // batches from this size on run conv1 on the frame-resident kernel (actor steps: the igemm gather)
