@@ -25,6 +25,9 @@
 #ifndef IGEMM_ORDER_MW
 #define IGEMM_ORDER_MW 0   // MatWgrad (dense / heads weight gradients)
 #endif
+#ifndef S16_ROWPTR
+#define S16_ROWPTR 1   // small-batch (actor) kernels: row / chunk split gather addresses
+#endif
 #ifndef IGEMM_ROWPTR
 #define IGEMM_ROWPTR 1   // row / chunk split gather addresses in igemm_pf2_kernel (igemm.h): bit 0 conv3 dgrad, 1 conv fwd, 2 conv2 dgrad
 #endif
@@ -119,6 +122,7 @@ struct ConvFwd {
   __device__ float4 load_b(int r, int y, int, int) const { return *reinterpret_cast<const float4*>(W + (size_t)r * CO + y); }
   // row / chunk split of the same addresses (igemm.h ROWPTR): a chunk never leaves one kernel row (KW*CI is a multiple of the K chunk)
   static constexpr bool ROWPTR = (IGEMM_ROWPTR & 2) && (KW * CI) % TileT::BR == 0;   // measured: conv3 fwd neutral, conv2 fwd (64x64x32 tile) spills
+  static constexpr bool ROWPTR_S16 = S16_ROWPTR;   // small-batch kernel (K chunks of 32 / 64 never leave a kernel row either)
   __device__ const float* a_origin() const { return in; }
   __device__ const float* b_origin() const { return W; }
   __device__ uint32_t a_off(int m, int rl, int) const {
@@ -176,6 +180,13 @@ struct DenseFwd {
     return f4sel(ok, *reinterpret_cast<const float4*>(W + (size_t)min(r, K - 1) * N + min(y, N - 4)));
   }
   static constexpr bool DMA_OK = !PRE_RELU;   // needs seg % BR == 0 and N % BY == 0 (checked at the call site)
+  static constexpr bool ROWPTR_S16 = S16_ROWPTR && !PRE_RELU;   // same preconditions (whole chunks, whole column tiles)
+  __device__ const float* a_origin() const { return A; }
+  __device__ const float* b_origin() const { return W; }
+  __device__ uint32_t a_off(int m, int rl, int) const { return (uint32_t)(min(m, M - 1) * K + rl); }
+  __device__ uint32_t a_chunk(int r0) const { return (uint32_t)r0; }
+  __device__ uint32_t b_off(int rl, int y, int) const { return (uint32_t)(rl * N + y); }
+  __device__ uint32_t b_chunk(int r0) const { return (uint32_t)(r0 * N); }
   __device__ const float* a_ptr(int m, int r, int) const { return A + (size_t)min(m, M - 1) * K + r; }
   __device__ const float* b_ptr(int r, int y, int) const { return W + (size_t)r * N + y; }
   __device__ void store(int m, int n, float v, int z, int) const {

@@ -59,10 +59,17 @@ struct igemm_maskout<P, decltype((void)P::MASKOUT)> { static constexpr bool valu
 // lane whose column does not), row stride in floats} — instead of decoding (frame, pixel) from x for each of the 16 values a lane stores
 // (24-33 VALU instructions per stored value in the position-major dgrads, 15 % of the conv2 dgrad's time).
 struct EpiRow { float* ptr; int valid; uint32_t stride; };
+// 16-byte global load returned BY VALUE: `arr[j] = *reinterpret_cast<const float4*>(ptr)` is a struct copy that clang lowers to a
+// memcpy(private <- global), which pins the whole register array in scratch memory (no SROA) — what made the row-pointer paths 50 % slower
+static __device__ __forceinline__ float4 ig_ld4(const float* g) { const float4 v = *reinterpret_cast<const float4*>(g); return make_float4(v.x, v.y, v.z, v.w); }
 template <class P, class = void>
 struct igemm_rowepi { static constexpr bool value = false; };
 template <class P>
 struct igemm_rowepi<P, decltype((void)P::ROWEPI)> { static constexpr bool value = P::ROWEPI; };
+template <class P, class = void>
+struct igemm_rowptr_s16 { static constexpr bool value = false; };
+template <class P>
+struct igemm_rowptr_s16<P, decltype((void)P::ROWPTR_S16)> { static constexpr bool value = P::ROWPTR_S16; };
 template <class P, class = void>
 struct igemm_rowptr { static constexpr bool value = false; };
 template <class P>
@@ -420,26 +427,26 @@ __global__ __launch_bounds__(256, P::Tile::MINW) void igemm_pf2_kernel(const P p
       const uint32_t ao = p.a_chunk(r0), bo = p.b_chunk(r0);   // wave-uniform
 #pragma unroll
       for (int j = 0; j < NVA; ++j)
-        if (BX * BR / 4 % 256 == 0 || tid + 256 * j < BX * BR / 4) ra[j] = *reinterpret_cast<const float4*>(p.a_origin() + (arow[j] + ao));
+        if (BX * BR / 4 % 256 == 0 || tid + 256 * j < BX * BR / 4) ra[j] = ig_ld4(p.a_origin() + (arow[j] + ao));
 #pragma unroll
       for (int j = 0; j < NVB; ++j)
-        if (BR * BY / 4 % 256 == 0 || tid + 256 * j < BR * BY / 4) rb[j] = *reinterpret_cast<const float4*>(p.b_origin() + (brow[j] + bo));
-      return;
-    }
+        if (BR * BY / 4 % 256 == 0 || tid + 256 * j < BR * BY / 4) rb[j] = ig_ld4(p.b_origin() + (brow[j] + bo));
+    } else {   // (an early `return` out of the branch above keeps the register sets in scratch memory)
 #pragma unroll
-    for (int j = 0; j < NVA; ++j) {
-      const int v = tid + 256 * j;
-      if (BX * BR / 4 % 256 == 0 || v < BX * BR / 4) {
-        const int rq = PF2_AMAP ? v / BX : v % (BR / 4), xl = PF2_AMAP ? v % BX : v / (BR / 4);
-        ra[j] = p.load_a(x0 + xl, r0 + 4 * rq, rhi, cls);
+      for (int j = 0; j < NVA; ++j) {
+        const int v = tid + 256 * j;
+        if (BX * BR / 4 % 256 == 0 || v < BX * BR / 4) {
+          const int rq = PF2_AMAP ? v / BX : v % (BR / 4), xl = PF2_AMAP ? v % BX : v / (BR / 4);
+          ra[j] = p.load_a(x0 + xl, r0 + 4 * rq, rhi, cls);
+        }
       }
-    }
 #pragma unroll
-    for (int j = 0; j < NVB; ++j) {
-      const int v = tid + 256 * j;
-      if (BR * BY / 4 % 256 == 0 || v < BR * BY / 4) {
-        if (B_YR) { const int yl = v % BY, rq = v / BY; rb[j] = p.load_b(r0 + 4 * rq, y0 + yl, rhi, cls); }
-        else { const int yq = v % (BY / 4), rl = v / (BY / 4); rb[j] = p.load_b(r0 + rl, y0 + 4 * yq, rhi, cls); }
+      for (int j = 0; j < NVB; ++j) {
+        const int v = tid + 256 * j;
+        if (BR * BY / 4 % 256 == 0 || v < BR * BY / 4) {
+          if (B_YR) { const int yl = v % BY, rq = v / BY; rb[j] = p.load_b(r0 + 4 * rq, y0 + yl, rhi, cls); }
+          else { const int yq = v % (BY / 4), rl = v / (BY / 4); rb[j] = p.load_b(r0 + rl, y0 + 4 * yq, rhi, cls); }
+        }
       }
     }
   };
@@ -633,7 +640,7 @@ static inline void igemm_pf2_launch(const P& p, int nsplit, hipStream_t stream) 
 //   conflict-free and both tiles are filled with 16-byte stores.
 typedef float f32x4_mfma __attribute__((ext_vector_type(4)));
 template <class P, int BX, int BY, int BR>
-__global__ __launch_bounds__(256) void igemm_s16_kernel(const P p) {
+__global__ __launch_bounds__(256, 2) void igemm_s16_kernel(const P p) {   // (, 2): without it the register allocator aims at 8 waves per SIMD (64 VGPRs) and spills the prefetch sets to scratch — LDS caps these kernels at 3 blocks per CU anyway
   static_assert(BX % 16 == 0 && BY % 16 == 0 && BR % 32 == 0 && (BX / 16) * (BY / 16) % 4 == 0, "tile shape");
   static_assert(!P::A_RX && !P::B_YR && !P::BIAS_GRAD && P::NCLS == 1, "forward-style problems");
   constexpr int NT16 = (BX / 16) * (BY / 16) / 4;          // 16x16 tiles per wave
@@ -653,17 +660,37 @@ __global__ __launch_bounds__(256) void igemm_s16_kernel(const P p) {
 #pragma unroll
   for (int i = 0; i < NT16; ++i) acc[i] = f32x4_mfma{0.0f, 0.0f, 0.0f, 0.0f};
 
+  // P::ROWPTR_S16: the row part of every gather address is computed once per thread, the chunk part is wave-uniform (SALU) — the functor's
+  // load_a / load_b re-derive frame, pixel, tap and bounds for each 16-byte load (5-11 VALU instructions per MFMA in these short kernels)
+  constexpr bool RP = igemm_rowptr_s16<P>::value;
+  uint32_t arow[NVA], brow[NVB];
+  if constexpr (RP) {
+#pragma unroll
+    for (int j = 0; j < NVA; ++j) { const int v = tid + 256 * j, rq = v % (BR / 4), xl = v / (BR / 4); arow[j] = p.a_off(x0 + xl, 4 * rq, 0); }
+#pragma unroll
+    for (int j = 0; j < NVB; ++j) { const int v = tid + 256 * j, yq = v % (BY / 4), rl = v / (BY / 4); brow[j] = p.b_off(rl, y0 + 4 * yq, 0); }
+  }
   auto gload = [&](int c, float4 (&ra)[NVA], float4 (&rb)[NVB]) {
     const int r0 = rlo + c * BR;
+    if constexpr (RP) {
+      const uint32_t ao = p.a_chunk(r0), bo = p.b_chunk(r0);
 #pragma unroll
-    for (int j = 0; j < NVA; ++j) {
-      const int v = tid + 256 * j;
-      if (BX * BR / 4 % 256 == 0 || v < BX * BR / 4) { const int rq = v % (BR / 4), xl = v / (BR / 4); ra[j] = p.load_a(x0 + xl, r0 + 4 * rq, rhi, 0); }
-    }
+      for (int j = 0; j < NVA; ++j)
+        if (BX * BR / 4 % 256 == 0 || tid + 256 * j < BX * BR / 4) ra[j] = ig_ld4(p.a_origin() + (arow[j] + ao));
 #pragma unroll
-    for (int j = 0; j < NVB; ++j) {
-      const int v = tid + 256 * j;
-      if (BR * BY / 4 % 256 == 0 || v < BR * BY / 4) { const int yq = v % (BY / 4), rl = v / (BY / 4); rb[j] = p.load_b(r0 + rl, y0 + 4 * yq, rhi, 0); }
+      for (int j = 0; j < NVB; ++j)
+        if (BR * BY / 4 % 256 == 0 || tid + 256 * j < BR * BY / 4) rb[j] = ig_ld4(p.b_origin() + (brow[j] + bo));
+    } else {   // (an early `return` out of the branch above keeps the register sets in scratch memory: no SROA)
+#pragma unroll
+      for (int j = 0; j < NVA; ++j) {
+        const int v = tid + 256 * j;
+        if (BX * BR / 4 % 256 == 0 || v < BX * BR / 4) { const int rq = v % (BR / 4), xl = v / (BR / 4); ra[j] = p.load_a(x0 + xl, r0 + 4 * rq, rhi, 0); }
+      }
+#pragma unroll
+      for (int j = 0; j < NVB; ++j) {
+        const int v = tid + 256 * j;
+        if (BR * BY / 4 % 256 == 0 || v < BR * BY / 4) { const int yq = v % (BY / 4), rl = v / (BY / 4); rb[j] = p.load_b(r0 + rl, y0 + 4 * yq, rhi, 0); }
+      }
     }
   };
   auto sstore = [&](int buf, const float4 (&ra)[NVA], const float4 (&rb)[NVB]) {
