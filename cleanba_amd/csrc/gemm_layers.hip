@@ -87,6 +87,23 @@ struct Conv1Fwd {
     const int c = r >> 6, kh = (r >> 3) & 7, kw = r & 7;
     return *reinterpret_cast<const float4*>(W + ((kh * 8 + kw) * 4 + c) * 32 + y);
   }
+  // row / chunk split of the same addresses for the small-batch kernel (K chunks of 32 = 4 patch rows of 8 pixels, 64 = one channel plane's
+  // patch): A offsets are BYTES into obs, B offsets floats into the HWIO weights
+  static constexpr bool ROWPTR_S16 = S16_ROWPTR;
+  __device__ uint32_t a_off(int m, int rl, int) const {
+    m = min(m, M - 1);
+    const int s = m / 400, p = m - s * 400, oh = p / 20, ow = p - oh * 20;
+    const int f = idx ? idx[s] : s;
+    return (uint32_t)(f * CBM_FRAME + (oh * 4 + (rl >> 3)) * 84 + ow * 4 + (rl & 7));
+  }
+  __device__ uint32_t a_chunk(int r0) const { return (uint32_t)((r0 >> 6) * 7056 + ((r0 >> 3) & 7) * 84); }
+  __device__ uint32_t b_off(int rl, int y, int) const { return (uint32_t)((((rl >> 3) * 8 + (rl & 7)) * 4) * 32 + y); }
+  __device__ uint32_t b_chunk(int r0) const { return (uint32_t)(((((r0 >> 3) & 7) * 8) * 4 + (r0 >> 6)) * 32); }
+  __device__ float4 rp_a(uint32_t off) const {
+    const uint32_t w = *reinterpret_cast<const uint32_t*>(obs + off);
+    return make_float4(cbm_u8_unit(w & 255u), cbm_u8_unit((w >> 8) & 255u), cbm_u8_unit((w >> 16) & 255u), cbm_u8_unit(w >> 24));
+  }
+  __device__ float4 rp_b(uint32_t off) const { return ig_ld4(W + off); }
   __device__ void store(int m, int n, float v, int, int) const {
     if (m < M) {
       const float o = relu(v + bias[n]);
@@ -123,6 +140,8 @@ struct ConvFwd {
   // row / chunk split of the same addresses (igemm.h ROWPTR): a chunk never leaves one kernel row (KW*CI is a multiple of the K chunk)
   static constexpr bool ROWPTR = (IGEMM_ROWPTR & 2) && (KW * CI) % TileT::BR == 0;   // measured: conv3 fwd neutral, conv2 fwd (64x64x32 tile) spills
   static constexpr bool ROWPTR_S16 = S16_ROWPTR;   // small-batch kernel (K chunks of 32 / 64 never leave a kernel row either)
+  __device__ float4 rp_a(uint32_t off) const { return ig_ld4(in + off); }
+  __device__ float4 rp_b(uint32_t off) const { return ig_ld4(W + off); }
   __device__ const float* a_origin() const { return in; }
   __device__ const float* b_origin() const { return W; }
   __device__ uint32_t a_off(int m, int rl, int) const {
@@ -181,6 +200,8 @@ struct DenseFwd {
   }
   static constexpr bool DMA_OK = !PRE_RELU;   // needs seg % BR == 0 and N % BY == 0 (checked at the call site)
   static constexpr bool ROWPTR_S16 = S16_ROWPTR && !PRE_RELU;   // same preconditions (whole chunks, whole column tiles)
+  __device__ float4 rp_a(uint32_t off) const { return ig_ld4(A + off); }
+  __device__ float4 rp_b(uint32_t off) const { return ig_ld4(W + off); }
   __device__ const float* a_origin() const { return A; }
   __device__ const float* b_origin() const { return W; }
   __device__ uint32_t a_off(int m, int rl, int) const { return (uint32_t)(min(m, M - 1) * K + rl); }

@@ -676,10 +676,10 @@ __global__ __launch_bounds__(256, 2) void igemm_s16_kernel(const P p) {   // (, 
       const uint32_t ao = p.a_chunk(r0), bo = p.b_chunk(r0);
 #pragma unroll
       for (int j = 0; j < NVA; ++j)
-        if (BX * BR / 4 % 256 == 0 || tid + 256 * j < BX * BR / 4) ra[j] = ig_ld4(p.a_origin() + (arow[j] + ao));
+        if (BX * BR / 4 % 256 == 0 || tid + 256 * j < BX * BR / 4) ra[j] = p.rp_a(arow[j] + ao);
 #pragma unroll
       for (int j = 0; j < NVB; ++j)
-        if (BR * BY / 4 % 256 == 0 || tid + 256 * j < BR * BY / 4) rb[j] = ig_ld4(p.b_origin() + (brow[j] + bo));
+        if (BR * BY / 4 % 256 == 0 || tid + 256 * j < BR * BY / 4) rb[j] = p.rp_b(brow[j] + bo);
     } else {   // (an early `return` out of the branch above keeps the register sets in scratch memory: no SROA)
 #pragma unroll
       for (int j = 0; j < NVA; ++j) {
