@@ -359,6 +359,9 @@ static inline void igemm_launch(const P& p, int nsplit, hipStream_t stream) {
 // waits for its data.  Here two register sets alternate: the loads of chunk c+2 are issued before chunk c is multiplied and are not
 // needed until the end of the NEXT iteration.  Same math, same k-ascending chain per accumulator -> bit-identical to igemm_kernel.
 // Row-gather A, no fused bias gradient (the input-gradient problems); KSKIP and BITMASK functors supported.
+#ifndef PF2_ADEINT
+#define PF2_ADEINT 0   // measured: 16-byte A fragment reads from a parity-de-interleaved tile are 2-11 % SLOWER than the four 4-byte reads (conv2 fwd 197 -> 208, conv3 fwd 145 -> 161 us)
+#endif
 #ifndef PF2_AMAP
 #define PF2_AMAP 0    // 1: a thread's float4 of the A tile = row (v % BX), k-quad (v / BX): conflict-free staging stores, scattered global rows
 #endif
@@ -375,7 +378,10 @@ __global__ __launch_bounds__(256, P::Tile::MINW) void igemm_pf2_kernel(const P p
   constexpr bool B_YR = P::B_YR;
   static_assert(!P::A_RX && !P::BIAS_GRAD, "two-chunk prefetch variant: dgrad-style problems");
   constexpr int TM = BX / WX / 32, TN = BY / WY / 32;
-  constexpr int PA = BR + 1, ASZ = BX * PA, PB = BY, BSZ = BR * BY;
+  // A tile: PF2_ADEINT stores a row's K chunk de-interleaved — the BR/2 even k, then the BR/2 odd k, pitch BR + 4 — because lane half h of a
+  // 32x32x2 MFMA supplies k = 2s + h: its operands of four consecutive steps are then 16 contiguous bytes (ONE conflict-free ds_read_b128
+  // instead of four ds_read_b32), and a staged float4 is two 8-byte stores instead of four conflicting 4-byte ones into an odd pitch
+  constexpr int PA = PF2_ADEINT ? BR + 4 : BR + 1, ASZ = BX * PA, PB = BY, BSZ = BR * BY;
   constexpr int NVA = (BX * BR / 4 + 255) / 256, NVB = (BR * BY / 4 + 255) / 256;
   __shared__ __attribute__((aligned(16))) float smem[2 * ASZ + 2 * BSZ];
   float* As = smem;
@@ -458,8 +464,13 @@ __global__ __launch_bounds__(256, P::Tile::MINW) void igemm_pf2_kernel(const P p
       const int v = tid + 256 * j;
       if (BX * BR / 4 % 256 == 0 || v < BX * BR / 4) {
         const int rq = PF2_AMAP ? v / BX : v % (BR / 4), xl = PF2_AMAP ? v % BX : v / (BR / 4);
-        float* d = A_ + xl * PA + 4 * rq;
-        d[0] = ra[j].x; d[1] = ra[j].y; d[2] = ra[j].z; d[3] = ra[j].w;
+        if constexpr (PF2_ADEINT) {
+          float* d = A_ + xl * PA + 2 * rq;
+          d[0] = ra[j].x; d[1] = ra[j].z; d[BR / 2] = ra[j].y; d[BR / 2 + 1] = ra[j].w;
+        } else {
+          float* d = A_ + xl * PA + 4 * rq;
+          d[0] = ra[j].x; d[1] = ra[j].y; d[2] = ra[j].z; d[3] = ra[j].w;
+        }
       }
     }
 #pragma unroll
@@ -477,13 +488,28 @@ __global__ __launch_bounds__(256, P::Tile::MINW) void igemm_pf2_kernel(const P p
     constexpr int G = (BR / 2) % 4 == 0 ? 4 : 2, NG = BR / 2 / G;
     float fa[2][G][TM], fb[2][G][TN];
     auto frag = [&](int g, int set) {
+      if constexpr (PF2_ADEINT && G == 4) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          typedef float ig_f4 __attribute__((ext_vector_type(4)));   // (a native vector: a HIP float4 copy here would become a memcpy into scratch)
+          const ig_f4 v = *reinterpret_cast<const ig_f4*>(A_ + (wx * (BX / WX) + i * 32 + li) * PA + h * (BR / 2) + 4 * g);
+          fa[set][0][i] = v[0]; fa[set][1][i] = v[1]; fa[set][2][i] = v[2]; fa[set][3][i] = v[3];
+        }
+#pragma unroll
+        for (int q = 0; q < G; ++q) {
+          const int rr = 2 * (g * G + q);
+#pragma unroll
+          for (int j = 0; j < TN; ++j) fb[set][q][j] = B_[(rr + h) * PB + wy * (BY / WY) + j * 32 + li];
+        }
+      } else {
 #pragma unroll
       for (int q = 0; q < G; ++q) {
         const int rr = 2 * (g * G + q);
 #pragma unroll
-        for (int i = 0; i < TM; ++i) fa[set][q][i] = A_[(wx * (BX / WX) + i * 32 + li) * PA + rr + h];
+        for (int i = 0; i < TM; ++i) fa[set][q][i] = PF2_ADEINT ? A_[(wx * (BX / WX) + i * 32 + li) * PA + h * (BR / 2) + (rr >> 1)] : A_[(wx * (BX / WX) + i * 32 + li) * PA + rr + h];
 #pragma unroll
         for (int j = 0; j < TN; ++j) fb[set][q][j] = B_[(rr + h) * PB + wy * (BY / WY) + j * 32 + li];
+      }
       }
     };
     frag(0, 0);
