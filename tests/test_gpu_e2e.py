@@ -100,6 +100,62 @@ def test_ppo_rollout_and_update_match_oracle(oracle):
     ctx.close()
 
 
+@pytest.mark.parametrize("A2,E", [(4, 5), (6, 3), (17, 7), (27, 2)])
+def test_other_action_counts_match_oracle(oracle, A2, E):
+    """num_actions other than 18 (envpool games with smaller action sets, ppo:135 full_action_space=False) and odd env counts: the per-frame
+    actor tail (heads on one live MFMA row, A + 1 <= 32 columns over two waves), the fused env step and one learner update against the oracle."""
+    T = 6
+    cfg = L.default_config(L.ALGO_PPO)
+    cfg.local_num_envs, cfg.num_actor_slots, cfg.num_steps, cfg.num_actions = E, 1, T, A2
+    cfg.num_minibatches, cfg.update_epochs = 1, 1
+    ctx = L.Context(cfg)
+    key = prng.prng_key(9)
+    key, nk, ak, ck = prng.split(key, 4)
+    params = M.init_nature_params(A2, nk, ak, ck)
+    ctx.set_params(params)
+    ctx.actor_set_key(0, key)
+    ctx.actor_env_reset_device(0, 3)
+    ctx.actor_begin_rollout(0, False)
+    ctx.actor_rollout_device(0, T)
+    ctx.actor_commit(0)
+    ctx.learner_wait()
+    obs = ctx.read("obs", np.uint8).reshape(T + 1, E, 4, 84, 84)
+    actions = ctx.read("actions", np.int32).reshape(T + 1, E)[:T]
+    logprobs = ctx.read("logprobs", np.float32).reshape(T + 1, E)[:T]
+    values = ctx.read("values", np.float32).reshape(T + 1, E)[:T]
+    rewards = ctx.read("rewards", np.float32).reshape(T + 1, E)[:T]
+    dones = ctx.read("dones", np.uint8).reshape(T + 1, E)
+    st, o = L.synth_env_reset_host(3, E)
+    k = key.copy()
+    for t in range(T):
+        assert (o == obs[t]).all(), f"frames differ at t={t}"
+        logits, value = oracle.nature_forward(params, A2, o, ksplit=cfg.actor_dense_ksplit)
+        a, lp, k = oracle.sample_actions(logits, k)
+        assert (a == actions[t]).all() and a.max() < A2, f"sampled actions differ at t={t}"
+        assert (bits(lp) == bits(logprobs[t])).all() and (bits(value) == bits(values[t])).all()
+        r, d, _, _ = L.synth_env_step_host(3, st, o, a)
+        assert (r == rewards[t]).all() and (d == dones[t + 1]).all()
+    assert (o == obs[T]).all()
+    lkey = prng.prng_key(5)
+    lrs, bc1, bc2 = _sched(1, 2.5e-4)
+    key_after, stats = ctx.learner_update(lkey, lrs, bc1, bc2)
+    p_gpu = ctx.get_params()
+    _, nv = oracle.nature_forward(params, A2, obs[T], ksplit=cfg.actor_dense_ksplit)
+    adv, tgt = oracle.gae(rewards, values, dones[:T], nv, dones[T])
+    adv = oracle.advnorm(adv, 1)
+    N = T * E
+    ks = oracle.split(lkey.copy(), 2)
+    perm = oracle.permutation(ks[1], N)
+    p = params.copy(); m = np.zeros_like(p); v = np.zeros_like(p)
+    st5, g, _, _ = oracle.ppo_loss_grad(p, A2, obs[:T].reshape(N, 4, 84, 84), perm, actions.reshape(N)[perm], logprobs.reshape(N)[perm],
+                                        adv.reshape(N)[perm], tgt.reshape(N)[perm])
+    oracle.adam_step(p, g, m, v, 0.5, float(lrs[0]), bc1=float(bc1[0]), bc2=float(bc2[0]))
+    assert (key_after == ks[0]).all()
+    np.testing.assert_allclose(stats[0], st5, rtol=2e-4, atol=2e-5)
+    assert np.abs(p_gpu - p).max() <= 1e-5 * np.abs(p).max()
+    ctx.close()
+
+
 def test_impala_rollouts_and_update_match_oracle(oracle):
     E, T = 8, 6
     cfg = L.default_config(L.ALGO_IMPALA)
