@@ -184,7 +184,7 @@ def run_dp(a, world, rank, local_rank):
         ctx.comm_profile(True)
     t0 = time.perf_counter()
     go.set()
-    prof_steps = a.steps if a.prof_kernel == -1 else max(1, min(a.steps, a.prof_steps if a.prof_steps > 0 else (a.steps + 3) // 4))
+    prof_steps = a.steps if a.prof_kernel == -1 else max(1, min(a.steps, a.prof_steps if a.prof_steps > 0 else (a.steps + 7) // 8))
     for i in range(a.steps):
         if i == prof_steps and a.prof_kernel != -1:
             ctx.profile_select(-3)             # CBM_PROFILE_PAUSE: the event pairs cost ~6 us each (they serialise back-to-back launches),
@@ -381,7 +381,7 @@ def main():
     ap.add_argument("--topology", default="dp", help="dp (a0_l0_dN, the default) | a0-l1,2,3 | 2x(a0-l1,2,3) | a0-l0,1 ...: one process per role")
     ap.add_argument("--env-id", default="Breakout-v5", help="Breakout-v5 | Atari57Mix-v5 (BASELINE configs[4])")
     ap.add_argument("--actor-threads", type=int, default=1, help="actor threads per actor GPU in the split topologies")
-    ap.add_argument("--prof-steps", type=int, default=0, help="timed steps that carry the per-launch HIP events (0: a quarter of --steps)")
+    ap.add_argument("--prof-steps", type=int, default=0, help="timed steps that carry the per-launch HIP events (0: an eighth of --steps)")
     ap.add_argument("--prof-kernel", type=int, default=-2, help="-2: HIP events around every GEMM launch (ids 0-11, default); k: only kernel k; -1: off")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-env", action="store_true", help="skip the secondary envpool-API measurement")
