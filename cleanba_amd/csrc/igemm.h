@@ -359,6 +359,9 @@ static inline void igemm_launch(const P& p, int nsplit, hipStream_t stream) {
 // waits for its data.  Here two register sets alternate: the loads of chunk c+2 are issued before chunk c is multiplied and are not
 // needed until the end of the NEXT iteration.  Same math, same k-ascending chain per accumulator -> bit-identical to igemm_kernel.
 // Row-gather A, no fused bias gradient (the input-gradient problems); KSKIP and BITMASK functors supported.
+#ifndef PF2_MASKT
+#define PF2_MASKT 0   // dgrad epilogues: ReLU-mask words bit-transposed once per tile (five ds_bpermute stages): measured 2-5 % slower than two v_readlane per value
+#endif
 #ifndef PF2_ADEINT
 #define PF2_ADEINT 0   // measured: 16-byte A fragment reads from a parity-de-interleaved tile are 2-11 % SLOWER than the four 4-byte reads (conv2 fwd 197 -> 208, conv3 fwd 145 -> 161 us)
 #endif
@@ -597,9 +600,36 @@ __global__ __launch_bounds__(256, P::Tile::MINW) void igemm_pf2_kernel(const P p
       if constexpr (igemm_bitmask<P>::value && igemm_rowepi<P>::value) {
         const uint32_t mw = p.mask_word(x0 + wx * (BX / WX) + i * 32 + li, y0 + wy * (BY / WY) + j * 32, cls);
         const EpiRow er = p.epi_row(x0 + wx * (BX / WX) + i * 32, y, cls);
-        const uint32_t bit = 1u << li;
         float* ph = er.ptr + (size_t)(4 * h) * er.stride;
         const int lim = er.valid - 4 * h;          // row r0 of this half-wave exists iff r0 < lim
+#if PF2_MASKT
+        // 32x32 bit transpose across the 32 lanes of each half (lane r holds the mask word of tile row r; afterwards lane c holds column c's
+        // 32 row bits): five exchange stages once per tile, then a stored value costs a bit-field extract and an AND
+        uint32_t tw = mw;
+#pragma unroll
+        for (int sft = 16; sft > 0; sft >>= 1) {
+          const uint32_t km = sft == 16 ? 0x0000FFFFu : sft == 8 ? 0x00FF00FFu : sft == 4 ? 0x0F0F0F0Fu : sft == 2 ? 0x33333333u : 0x55555555u;
+          const uint32_t pw = (uint32_t)__shfl_xor((int)tw, sft, 32);
+          tw = (li & sft) ? ((tw & ~km) | ((pw & ~km) >> sft)) : ((tw & km) | ((pw & km) << sft));
+        }
+        const uint32_t trow = tw >> (4 * h);       // bit r0 = ReLU bit of (tile row r0 + 4h, this lane's column)
+        if (__all(lim >= 28)) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int r0 = (e & 3) + 8 * (e >> 2);
+            const uint32_t keep = (uint32_t)(-(int32_t)((trow >> r0) & 1u));
+            ph[(size_t)r0 * er.stride] = __uint_as_float(__float_as_uint(acc[i][j][e]) & keep);
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int r0 = (e & 3) + 8 * (e >> 2);
+            const uint32_t keep = (uint32_t)(-(int32_t)((trow >> r0) & 1u));
+            if (r0 < lim) ph[(size_t)r0 * er.stride] = __uint_as_float(__float_as_uint(acc[i][j][e]) & keep);
+          }
+        }
+#else
+        const uint32_t bit = 1u << li;
         if (__all(lim >= 28)) {                    // whole tile inside the problem (wave-uniform branch): no per-value bound test
 #pragma unroll
           for (int e = 0; e < 16; ++e) {
@@ -615,6 +645,7 @@ __global__ __launch_bounds__(256, P::Tile::MINW) void igemm_pf2_kernel(const P p
             if (r0 < lim) ph[(size_t)r0 * er.stride] = ((h ? w1 : w0) & bit) ? acc[i][j][e] : 0.0f;
           }
         }
+#endif
       } else if constexpr (igemm_bitmask<P>::value) {
         const uint32_t mw = p.mask_word(x0 + wx * (BX / WX) + i * 32 + li, y0 + wy * (BY / WY) + j * 32, cls);
 #pragma unroll
