@@ -606,12 +606,19 @@ extern "C" int cbm_learner_minibatch_grad(cbm_ctx* c, int32_t epoch, int32_t mb)
   float* stats = c->stats_dev + (size_t)(epoch * c->nmicro + mb) * 8;
   if (is_ppo(c)) {
     const int32_t* idx = c->perm + (size_t)mb * c->MB;
+    c->lws.skip_heads = ppo_heads_fusable(c->L);
     nature_forward(c->L, c->params, R.obs, idx, c->MB, learner_ksplit(c), c->lws, c->lstream);
     const float* adv = c->adv;
     if (c->asyncB && c->cfg.norm_adv) { launch_mb_advnorm(c->adv, idx, c->MB, c->advn, c->lstream); adv = c->advn; }
-    launch_ppo_loss(c->lws.logits, c->lws.value, c->MB, c->A, idx, R.actions, R.logprobs, adv, c->target, c->cfg.clip_coef, c->cfg.ent_coef,
-                    c->cfg.vf_coef, c->lws.dzv, c->loss_partials, stats, c->lstream);
+    if (c->lws.skip_heads) {   // heads forward + loss + heads dgrad in one launch (set around this forward / backward pair only)
+      launch_ppo_heads_fused(c->L, c->params, c->lws, c->MB, idx, R.actions, R.logprobs, adv, c->target, c->cfg.clip_coef, c->cfg.ent_coef, c->cfg.vf_coef,
+                             c->loss_partials, stats, c->lstream);
+    } else {
+      launch_ppo_loss(c->lws.logits, c->lws.value, c->MB, c->A, idx, R.actions, R.logprobs, adv, c->target, c->cfg.clip_coef, c->cfg.ent_coef,
+                      c->cfg.vf_coef, c->lws.dzv, c->loss_partials, stats, c->lstream);
+    }
     nature_backward(c->L, c->params, R.obs, idx, c->MB, c->lws, c->grads, c->lstream);
+    c->lws.skip_heads = false;
   } else {
     const int Bm = c->Bdev / c->nmicro;
     const int32_t* idx = c->impala_idx + (size_t)mb * c->MB;
@@ -817,10 +824,16 @@ extern "C" int cbm_ppo_loss_grad(cbm_ctx* c, const float* params, const uint8_t*
                                  float* value_out) {
   CBM_HIP(hipSetDevice(c->cfg.device));
   if (check_B(c, N)) return -1;
+  c->lws.skip_heads = ppo_heads_fusable(c->L);
   nature_forward(c->L, params, obs, idx, N, 1, c->lws, c->lstream);
-  launch_ppo_loss(c->lws.logits, c->lws.value, N, c->A, nullptr, actions, old_logprob, adv, target, c->cfg.clip_coef, c->cfg.ent_coef,
-                  c->cfg.vf_coef, c->lws.dzv, c->loss_partials, stats5, c->lstream);
+  if (c->lws.skip_heads)
+    launch_ppo_heads_fused(c->L, params, c->lws, N, nullptr, actions, old_logprob, adv, target, c->cfg.clip_coef, c->cfg.ent_coef, c->cfg.vf_coef,
+                           c->loss_partials, stats5, c->lstream);
+  else
+    launch_ppo_loss(c->lws.logits, c->lws.value, N, c->A, nullptr, actions, old_logprob, adv, target, c->cfg.clip_coef, c->cfg.ent_coef,
+                    c->cfg.vf_coef, c->lws.dzv, c->loss_partials, stats5, c->lstream);
   if (grads) nature_backward(c->L, params, obs, idx, N, c->lws, grads, c->lstream);
+  c->lws.skip_heads = false;
   if (logits_out) CBM_HIP(hipMemcpyAsync(logits_out, c->lws.logits, (size_t)N * c->A * 4, hipMemcpyDeviceToDevice, c->lstream));
   if (value_out) CBM_HIP(hipMemcpyAsync(value_out, c->lws.value, (size_t)N * 4, hipMemcpyDeviceToDevice, c->lstream));
   CBM_HIP(hipStreamSynchronize(c->lstream));

@@ -42,6 +42,7 @@ struct NatureWs {
   hipEvent_t tail_ev = nullptr;   // when set: recorded by the backward pass once the gradients of dense + heads (the flat tail [w[3], total)) are final
   int bwd_split = 0;       // cbm_config.backward_split: 0 fp32 MFMA, 2 / 3 split-bf16 backward GEMMs (igemm_split_kernel)
   bool bf16_fwd = false;   // cbm_config.forward_bf16: conv2/conv3/dense forward on bf16 MFMA (Nature-CNN)
+  bool skip_heads = false; // set around a forward / backward pair whose heads forward, PPO loss and heads dgrad run as launch_ppo_heads_fused
   float *act1 = nullptr, *act2 = nullptr, *act3 = nullptr, *hid = nullptr;
   float *logits = nullptr, *value = nullptr;
   float* dense_part = nullptr;  // [ksplit][maxB][512] when maxB is small
@@ -115,6 +116,14 @@ void launch_permutation(const uint32_t key[2], int n, int32_t* perm, int32_t* tm
 void launch_ppo_loss(const float* logits, const float* value, int N, int A, const int32_t* idx, const int32_t* actions,
                      const float* old_logprob, const float* adv, const float* target, float clip_coef, float ent_coef,
                      float vf_coef, float* dzv, float* partials, float* stats5, hipStream_t st);
+// the block partials of ppo_loss_kernel / the fused heads kernel -> the five statistics of ppo:649-653
+void launch_ppo_stats(const float* partials, int nblk, int N, float ent_coef, float vf_coef, float* stats5, hipStream_t st);
+// heads forward + PPO loss + heads input gradient of a minibatch in one launch (gemm_layers.hip): hid [B][HD] -> logits / value (ws), dzv [B][32],
+// dhid [B][HD], the five statistics.  Same logits bits as launch_heads_fwd, same loss arithmetic as launch_ppo_loss.
+bool ppo_heads_fusable(const NatureLayout& L);
+void launch_ppo_heads_fused(const NatureLayout& L, const float* P, NatureWs& ws, int B, const int32_t* idx, const int32_t* actions,
+                            const float* old_logprob, const float* adv, const float* target, float clip_coef, float ent_coef, float vf_coef,
+                            float* partials, float* stats5, hipStream_t st);
 void launch_impala_loss(const float* logits, const float* value, const float* mu_logits, const int32_t* actions,
                         const float* rewards, const uint8_t* dones, const uint8_t* firststeps, int T1, int Bm, int A,
                         int col0, int ld, float gamma, float vf_coef, float ent_coef, float* dzv, float* partials,

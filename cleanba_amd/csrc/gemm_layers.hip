@@ -33,6 +33,7 @@
 #endif
 #include "igemm.h"
 #include "env_model.h"
+#include "ppo_loss.h"
 #include <algorithm>
 #include <vector>
 #include <type_traits>
@@ -475,6 +476,122 @@ __global__ __launch_bounds__(HD) void heads_dgrad_kernel(const float* dzv, const
     dhid[i] = hid[i] > 0.0f ? s : 0.0f;
   }
 }
+// ---- heads forward + PPO loss + heads input gradient, one launch (PPO learner minibatches) ------------------------------------------------
+// The three were separate launches of 16 + 8 + 14 us for a few MFLOP: hid [B][HD] read twice, logits / dzv round-tripped through HBM.  One block
+// per 16 samples: (A) hid rows -> LDS, head weights straight from L2 into the registers of waves 0 / 1 (HeadsFwd's k-ascending MFMA chain: the
+// same logits bits); (B) logits / value -> LDS; (C) the loss head of ppo_loss.h on 32 lanes per sample, dzv -> LDS + HBM (the heads weight
+// gradient reads it), block partial of the four statistics; (D) dhid[m][k] = (sum_j dzv[m][j] Wac[k][j]) * (hid > 0) as 16x16x4 MFMAs over
+// j (5 steps for A = 18), eight 16-column tiles per wave, the weight fragments requested before the loss math.
+#ifndef HF_ABL
+#define HF_ABL 0   // timing builds: 1 no dgrad phase, 2 no loss math, 4 short heads chain, 8 no dgrad weight loads
+#endif
+template <int HD>
+__global__ __launch_bounds__(256) void ppo_heads_fused_kernel(const float* hid, const float* Wa, const float* ba, const float* Wc, const float* bc, int B, int A,
+                                                              const int32_t* idx, const int32_t* actions, const float* old_logprob, const float* adv,
+                                                              const float* target, float clip_coef, float ent_coef, float vf_coef, float* logits_out,
+                                                              float* value_out, float* dzv, float* dhid, float* partials) {
+  constexpr int PH = HD + 4, NT = HD / 64;         // NT: 16-column dhid tiles per wave
+  __shared__ __attribute__((aligned(16))) float hs[16 * PH];    // hid rows
+  __shared__ __attribute__((aligned(16))) float wl[HD * 31];    // [HD][A] actor weights as they lie in memory (A + 1 <= 32)
+  __shared__ float wc[HD];                                      // critic weights
+  __shared__ float lg[16][33];
+  __shared__ float dz[16][36];
+  __shared__ float red[16][4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, g4 = lane >> 4;
+  const int m0 = blockIdx.x * 16;
+  // (A) hid rows and both weight matrices -> LDS.  (Head weights held in registers, as in the actor tail, did not survive here: with the
+  // dgrad fragments also live the compiler sank the loads next to their MFMAs — 128 L2 round trips in the chain, 21 us.)
+  for (int i = tid; i < 16 * HD / 4; i += 256) {
+    const int row = i / (HD / 4), c4 = (i % (HD / 4)) * 4;
+    *reinterpret_cast<float4*>(hs + row * PH + c4) = *reinterpret_cast<const float4*>(hid + (size_t)min(m0 + row, B - 1) * HD + c4);
+  }
+  for (int i = tid; i < HD * A / 4; i += 256) reinterpret_cast<float4*>(wl)[i] = reinterpret_cast<const float4*>(Wa)[i];
+  for (int i = tid; i < HD; i += 256) wc[i] = Wc[i];
+  __shared__ int s_act[16];
+  __shared__ float s_olp[16], s_adv[16], s_tgt[16];
+  if (tid < 16) {   // the samples' scalars (a gather through idx: two dependent round trips) are fetched under the staging, not inside the loss phase
+    const int ii = min(m0 + tid, B - 1), n = idx ? idx[ii] : ii;
+    s_act[tid] = actions[n]; s_olp[tid] = old_logprob[n]; s_adv[tid] = adv[n]; s_tgt[tid] = target[n];
+  }
+  __syncthreads();
+  {
+    const int n = wave * 16 + r16;
+    if (wave < 2) {
+      const float* wp = n < A ? wl + n : wc;
+      const int wstride = n < A ? A : 1;
+      const bool on = n <= A;
+      f32x4_mfma acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll 16
+      for (int st = 0; st < ((HF_ABL & 4) ? 4 : HD / 4); ++st) {
+        const float bv = on ? wp[(4 * st + g4) * wstride] : 0.0f;
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(hs[r16 * PH + 4 * st + g4], bv, acc, 0, 0, 0);
+      }
+      const float bias = n < A ? ba[n] : (n == A ? bc[0] : 0.0f);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) lg[4 * g4 + e][n] = acc[e] + bias;
+    }
+  }
+  const int nst = (A + 4) / 4;                      // j runs over A logits + the value column
+  __syncthreads();
+  const float invN = 1.0f / (float)B;
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const int row = pass * 8 + (tid >> 5), i = m0 + row, j = tid & 31;
+    const bool live = i < B;
+    const float zj = lg[row][j < A ? j : A - 1], val = lg[row][A];
+    PpoSampleStats ss;
+    ss.pg = ss.dv2 = ss.ent = ss.kl = 0.0f;
+    const float d = (HF_ABL & 2) ? zj * s_adv[row] : ppo_loss_lane(zj, j, A, s_act[row], val, s_olp[row], s_adv[row], s_tgt[row], clip_coef, ent_coef, vf_coef, invN, ss);
+    dz[row][j] = live ? d : 0.0f;
+    if (live) {
+      dzv[(size_t)i * 32 + j] = d;
+      if (j < A) logits_out[(size_t)i * A + j] = zj;
+      else if (j == A) value_out[i] = val;
+    }
+    if (j == 0) { red[row][0] = live ? ss.pg : 0.0f; red[row][1] = live ? ss.dv2 : 0.0f; red[row][2] = live ? ss.ent : 0.0f; red[row][3] = live ? ss.kl : 0.0f; }
+  }
+  __syncthreads();
+  if (tid < 4) {
+    float v = 0.0f;
+    for (int q = 0; q < 16; ++q) v += red[q][tid];
+    partials[blockIdx.x * 4 + tid] = v;
+  }
+  if (!(HF_ABL & 1))
+#pragma unroll
+  for (int ti = 0; ti < NT; ++ti) {
+    const int k = (wave * NT + ti) * 16 + r16;
+    f32x4_mfma acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int st = 0; st < 8; ++st)
+      if (st < nst) {
+        const int jc = 4 * st + g4;
+        const float bv = (HF_ABL & 8) ? 0.0f : (jc < A ? wl[k * A + jc] : (jc == A ? wc[k] : 0.0f));
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(dz[r16][jc], bv, acc, 0, 0, 0);
+      }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int row = 4 * g4 + e, m = m0 + row;
+      if (m < B) dhid[(size_t)m * HD + k] = hs[row * PH + k] > 0.0f ? acc[e] : 0.0f;
+    }
+  }
+}
+#ifndef PPO_HEADS_FUSED
+#define PPO_HEADS_FUSED 1
+#endif
+bool ppo_heads_fusable(const NatureLayout& L) { return PPO_HEADS_FUSED && L.A + 1 <= 32 && (L.hid == 512 || L.hid == 256); }
+void launch_ppo_heads_fused(const NatureLayout& L, const float* P, NatureWs& ws, int B, const int32_t* idx, const int32_t* actions,
+                            const float* old_logprob, const float* adv, const float* target, float clip_coef, float ent_coef, float vf_coef,
+                            float* partials, float* stats5, hipStream_t st) {
+  const int nblk = (B + 15) / 16;
+  if (L.hid == 512)
+    hipLaunchKernelGGL(ppo_heads_fused_kernel<512>, dim3(nblk), dim3(256), 0, st, ws.hid, P + L.w[4], P + L.b[4], P + L.w[5], P + L.b[5], B, L.A, idx, actions,
+                       old_logprob, adv, target, clip_coef, ent_coef, vf_coef, ws.logits, ws.value, ws.dzv, ws.dhid, partials);
+  else
+    hipLaunchKernelGGL(ppo_heads_fused_kernel<256>, dim3(nblk), dim3(256), 0, st, ws.hid, P + L.w[4], P + L.b[4], P + L.w[5], P + L.b[5], B, L.A, idx, actions,
+                       old_logprob, adv, target, clip_coef, ent_coef, vf_coef, ws.logits, ws.value, ws.dzv, ws.dhid, partials);
+  launch_ppo_stats(partials, nblk, B, ent_coef, vf_coef, stats5, st);
+}
+
 static void launch_heads_dgrad(const float* dzv, const float* Wa, const float* Wc, const float* hid, int B, int A, int HD, float* dhid, hipStream_t st) {
   const int nb = (B + HG_FR - 1) / HG_FR;
   if (HD == 512) hipLaunchKernelGGL(heads_dgrad_kernel<512>, dim3(nb), dim3(512), 0, st, dzv, Wa, Wc, hid, B, A, dhid);
@@ -1293,7 +1410,7 @@ int nature_forward(const NatureLayout& L, const float* P, const uint8_t* obs, co
       DenseFwd<T64x64k16, false> pd{ws.act3, P + L.w[3], P + L.b[3], ws.hid, B, 3136, 512, 3136};
       igemm_s16_launch<32, 32, 64>(pd, 1, st);
     }
-    launch_heads_fwd(ws.hid, P + L.w[4], P + L.b[4], P + L.w[5], P + L.b[5], B, L.A, 512, ws.logits, ws.value, st);
+    if (!ws.skip_heads) launch_heads_fwd(ws.hid, P + L.w[4], P + L.b[4], P + L.w[5], P + L.b[5], B, L.A, 512, ws.logits, ws.value, st);
     return 0;
   }
 #ifndef C1_FRAMES_MIN
@@ -1341,7 +1458,7 @@ int nature_forward(const NatureLayout& L, const float* P, const uint8_t* obs, co
     if (DENSE_FWD_PF2 && !ws.bf16_fwd && B >= 1024) plaunch_fn(ws, K_DENSE_FWD, st, [&] { igemm_pf2_launch(pd, 1, st); });
     else plaunch_fwd(ws, K_DENSE_FWD, pd, 1, st);
   }
-  launch_heads_fwd(ws.hid, P + L.w[4], P + L.b[4], P + L.w[5], P + L.b[5], B, L.A, 512, ws.logits, ws.value, st);
+  if (!ws.skip_heads) launch_heads_fwd(ws.hid, P + L.w[4], P + L.b[4], P + L.w[5], P + L.b[5], B, L.A, 512, ws.logits, ws.value, st);
   return false;
 }
 
@@ -1379,7 +1496,7 @@ void nature_backward(const NatureLayout& L, const float* P, const uint8_t* obs, 
   float* const bp = ws.bias_part;
   RedBatch tail_red(A), conv_red(A);
   // heads: dgrad (VALU) and wgrad (MFMA, Y = A+1 padded to 32)
-  launch_heads_dgrad(ws.dzv, P + L.w[4], P + L.w[5], ws.hid, B, A, 512, ws.dhid, st);
+  if (!ws.skip_heads) launch_heads_dgrad(ws.dzv, P + L.w[4], P + L.w[5], ws.hid, B, A, 512, ws.dhid, st);
   {
     const int nz = ceil_div(B, RPS_HEADS);
     MatWgrad<T128x32> p{ws.hid, ws.dzv, wp + rg.w[0], bp + rg.b[0], B, 512, 32, 32, RPS_HEADS};

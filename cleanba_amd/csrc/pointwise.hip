@@ -2,6 +2,7 @@
 // normalisation, jax-compatible permutation, PPO and IMPALA(V-trace) loss heads, Adam / RMSProp.
 // Reference lines are cited per kernel ("ppo" = cleanba_ppo.py, "impala" = cleanba_impala.py).
 #include "cbm_internal.h"
+#include "ppo_loss.h"
 #include <math.h>
 #include <float.h>
 
@@ -279,50 +280,13 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(const float* logits, cons
   const int n = idx ? idx[ii] : ii;
   const int a = actions[n];
   const float invN = 1.0f / (float)N;
-  const bool act = j < A;
-  const float zj = logits[(size_t)ii * A + (act ? j : A - 1)];
-  float mx = act ? zj : -INFINITY;
-  for (int o = 16; o > 0; o >>= 1) { const float t = __shfl_xor(mx, o, 32); mx = t > mx ? t : mx; }
-  const float ej = act ? cbm_expf(zj - mx) : 0.0f;
-  float se = 0.0f;
-  for (int q = 0; q < A; ++q) se += __shfl(ej, q, 32);
-  const float lse_shift = cbm_logf(se);
-  const float za = __shfl(zj, a, 32);
-  const float newlp = (za - mx) - lse_shift;
-  const float lse = lse_shift + mx;
-  float zn = zj - lse;
-  if (zn < -FLT_MAX) zn = -FLT_MAX;
-  float mx2 = act ? zn : -INFINITY;
-  for (int o = 16; o > 0; o >>= 1) { const float t = __shfl_xor(mx2, o, 32); mx2 = t > mx2 ? t : mx2; }
-  const float e2 = act ? cbm_expf(zn - mx2) : 0.0f;
-  float s2 = 0.0f;
-  for (int q = 0; q < A; ++q) s2 += __shfl(e2, q, 32);
-  const float pj = e2 / s2;
-  const float tj = act ? zn * pj : 0.0f;
-  float ent = 0.0f;
-  for (int q = 0; q < A; ++q) ent += __shfl(tj, q, 32);
-  ent = -ent;
-  const float logratio = newlp - old_logprob[n];
-  const float ratio = cbm_expf(logratio);
-  const float ad = adv[n];
-  const float lo = 1.0f - clip_coef, hi = 1.0f + clip_coef;
-  const float rc = ratio < lo ? lo : (ratio > hi ? hi : ratio);
-  const float pg1 = -ad * ratio, pg2 = -ad * rc;
-  const float pg = pg1 > pg2 ? pg1 : pg2;
-  const float dv = value[ii] - target[n];
-  const float w1 = pg1 > pg2 ? 1.0f : (pg1 == pg2 ? 0.5f : 0.0f);
-  const float dclip = (ratio > lo && ratio < hi) ? 1.0f : ((ratio == lo || ratio == hi) ? 0.5f : 0.0f);
-  const float dpg_dratio = w1 * (-ad) + (1.0f - w1) * (-ad) * dclip;
-  const float c_lp = dpg_dratio * ratio * invN;
-  if (live) {
-    float d = 0.0f;
-    if (act) d = c_lp * ((j == a ? 1.0f : 0.0f) - pj) + ent_coef * invN * pj * (zn + ent);
-    else if (j == A) d = vf_coef * dv * invN;
-    dzv[(size_t)i * 32 + j] = d;
-  }
+  const float zj = logits[(size_t)ii * A + (j < A ? j : A - 1)];
+  PpoSampleStats ss;
+  const float d = ppo_loss_lane(zj, j, A, a, value[ii], old_logprob[n], adv[n], target[n], clip_coef, ent_coef, vf_coef, invN, ss);
+  if (live) dzv[(size_t)i * 32 + j] = d;
   if (j == 0) {
-    red[g][0] = live ? pg : 0.0f; red[g][1] = live ? dv * dv : 0.0f; red[g][2] = live ? ent : 0.0f;
-    red[g][3] = live ? (ratio - 1.0f) - logratio : 0.0f;
+    red[g][0] = live ? ss.pg : 0.0f; red[g][1] = live ? ss.dv2 : 0.0f; red[g][2] = live ? ss.ent : 0.0f;
+    red[g][3] = live ? ss.kl : 0.0f;
   }
   __syncthreads();
   if (threadIdx.x < 4) {
@@ -342,6 +306,9 @@ __global__ void ppo_stats_kernel(const float* partials, int nblk, int N, float e
   const float pg = s[0] / n, v = 0.5f * (s[1] / n), e = s[2] / n, kl = s[3] / n;
   stats5[0] = pg - ent_coef * e + v * vf_coef;
   stats5[1] = pg; stats5[2] = v; stats5[3] = e; stats5[4] = kl;
+}
+void launch_ppo_stats(const float* partials, int nblk, int N, float ent_coef, float vf_coef, float* stats5, hipStream_t st) {
+  hipLaunchKernelGGL(ppo_stats_kernel, dim3(1), dim3(64), 0, st, partials, nblk, N, ent_coef, vf_coef, stats5);
 }
 void launch_ppo_loss(const float* logits, const float* value, int N, int A, const int32_t* idx, const int32_t* actions,
                      const float* old_logprob, const float* adv, const float* target, float clip_coef, float ent_coef, float vf_coef,
