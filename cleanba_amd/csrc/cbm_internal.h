@@ -90,13 +90,16 @@ void nature_backward(const NatureLayout& L, const float* P, const uint8_t* obs, 
 void launch_conv1_fwd_frames(const uint8_t* obs, const int32_t* idx, const float* W, const float* bias, float* out, uint32_t* mask, int S,
                              hipStream_t st);
 int conv1_wgrad_frames_splits(int S);
+int conv1_wgrad_frames_splits_bound(int maxS);   // >= conv1_wgrad_frames_splits(S) for every S <= maxS (the split count is not monotone in S)
 void launch_conv1_wgrad_frames(const uint8_t* obs, const int32_t* idx, const float* dy, float* part, float* bpart, int S, hipStream_t st,
                                bool split = false);
 
 // frame-resident conv2 / conv3 weight gradients (wgrad_frames.hip): partials part[z][(kh,kw,ci)][co], bpart[z][co]
 int conv2_wgrad_frames_splits(int S);
+int conv2_wgrad_frames_splits_bound(int maxS);
 void launch_conv2_wgrad_frames(const float* act1, const float* dypad, float* part, float* bpart, int S, hipStream_t st);
 int conv3_wgrad_frames_splits(int S);
+int conv3_wgrad_frames_splits_bound(int maxS);
 void launch_conv3_wgrad_frames(const float* act2, const float* dypad, float* part, float* bpart, int S, hipStream_t st);
 
 // ---- pointwise / scan kernels -----------------------------------------------------------

@@ -506,6 +506,7 @@ int conv1_wgrad_frames_splits(int S) {
   const int fpb = (S + blocks - 1) / blocks;
   return (S + fpb - 1) / fpb;
 }
+int conv1_wgrad_frames_splits_bound(int maxS) { return maxS < C1W_BLOCKS ? maxS : C1W_BLOCKS; }
 void launch_conv1_wgrad_frames(const uint8_t* obs, const int32_t* idx, const float* dy, float* part, float* bpart, int S, hipStream_t st, bool split) {
   const int nz = conv1_wgrad_frames_splits(S);
   const int fpb = (S + nz - 1) / nz;

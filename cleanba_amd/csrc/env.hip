@@ -153,6 +153,8 @@ struct HostPool {
       });
   }
   ~HostPool() {
+    // in a fork()ed child the std::thread objects name threads that do not exist there: joining a stale tid can block for ever at exit
+    if (owner != getpid()) { for (auto& x : th) x.detach(); return; }
     stop.store(true, std::memory_order_release);
     gen.fetch_add(1, std::memory_order_release);
     gen.notify_all();

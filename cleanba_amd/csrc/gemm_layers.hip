@@ -1156,15 +1156,18 @@ static const int RPS_C1 = 1600, RPS_C2 = RPS_C2_V, RPS_C3 = RPS_C3_V, RPS_HEADS 
 #endif
 static int dense_wgrad_splits(int B) { return B >= 2048 ? DENSE_WGRAD_NZ : 1; }
 
-// offsets (floats) of the per-layer partial regions inside ws.wg_part / ws.bias_part for a batch of B frames
+// offsets (floats) of the per-layer partial regions inside ws.wg_part / ws.bias_part.  Built ONCE from the workspace's maxB and used for every
+// batch B <= maxB: nz[i] is an upper bound of the slices any such B produces.  The frame-split counts are NOT monotone in B (they saturate at
+// the block count: 256 blocks at B = 256, 129..256 for B = 257..511), so the bound is min(maxB, blocks), not splits(maxB).
 struct WgRegions {
   int nz[5];            // 0 heads, 1 dense, 2 conv3, 3 conv2, 4 conv1
   size_t w[5], b[5], w_total, b_total;
-  explicit WgRegions(int B) {
-    nz[0] = ceil_div(B, RPS_HEADS);
-    nz[1] = std::max(dense_wgrad_splits(B), 4);   // room for the split-bf16 mode's 4 splits
-    nz[2] = std::max(ceil_div(B * 49, RPS_C3), conv3_wgrad_frames_splits(B)); nz[3] = std::max(ceil_div(B * 81, RPS_C2), conv2_wgrad_frames_splits(B));
-    nz[4] = std::max(ceil_div(B * 400, RPS_C1), conv1_wgrad_frames_splits(B));
+  explicit WgRegions(int maxB) {
+    nz[0] = ceil_div(maxB, RPS_HEADS);
+    nz[1] = std::max(dense_wgrad_splits(maxB), 4);   // room for the split-bf16 mode's 4 splits
+    nz[2] = std::max(ceil_div(maxB * 49, RPS_C3), conv3_wgrad_frames_splits_bound(maxB));
+    nz[3] = std::max(ceil_div(maxB * 81, RPS_C2), conv2_wgrad_frames_splits_bound(maxB));
+    nz[4] = std::max(ceil_div(maxB * 400, RPS_C1), conv1_wgrad_frames_splits_bound(maxB));
     const size_t wsz[5] = {512 * 32, 3136 * 512, 576 * 64, 512 * 64, 256 * 32}, bsz[5] = {32, 512, 64, 64, 32};
     size_t ow = 0, ob = 0;
     for (int i = 0; i < 5; ++i) { w[i] = ow; b[i] = ob; ow += (size_t)nz[i] * wsz[i]; ob += (size_t)nz[i] * bsz[i] + 64; }
@@ -1491,7 +1494,8 @@ void nature_backward(const NatureLayout& L, const float* P, const uint8_t* obs, 
                      hipStream_t st) {
   if (L.kind == CBM_NET_IMPALA_RESNET) { resnet_backward(L, P, obs, idx, B, ws, grads, st); return; }
   const int A = L.A;
-  const WgRegions rg(B);
+  const WgRegions rg(ws.maxB);   // the layout the workspace was allocated with; every slice count below is checked against it
+  auto fits = [&](int layer, int nz) { if (nz > rg.nz[layer]) { fprintf(stderr, "cleanba_mi: wgrad partial region %d: %d slices > %d allocated\n", layer, nz, rg.nz[layer]); abort(); } };
   float* const wp = ws.wg_part;
   float* const bp = ws.bias_part;
   RedBatch tail_red(A), conv_red(A);
@@ -1499,6 +1503,7 @@ void nature_backward(const NatureLayout& L, const float* P, const uint8_t* obs, 
   if (!ws.skip_heads) launch_heads_dgrad(ws.dzv, P + L.w[4], P + L.w[5], ws.hid, B, A, 512, ws.dhid, st);
   {
     const int nz = ceil_div(B, RPS_HEADS);
+    fits(0, nz);
     MatWgrad<T128x32> p{ws.hid, ws.dzv, wp + rg.w[0], bp + rg.b[0], B, 512, 32, 32, RPS_HEADS};
     plaunch(ws, K_HEADS_WGRAD, p, nz, st);   // (fp32 also in split mode: 9 vs 15 us)
     tail_red.add(wp + rg.w[0], nz, 512 * 32, 32, 2, grads + L.w[4], grads + L.w[5]);
@@ -1511,6 +1516,7 @@ void nature_backward(const NatureLayout& L, const float* P, const uint8_t* obs, 
     // split-bf16 mode: the staging of a tile is the bottleneck, so it wants the bigger 128x64 tile (and more splits to fill the chip)
     const int nz = ws.bwd_split == 2 ? (B >= 2048 ? 4 : 1) : dense_wgrad_splits(B);
     const int rps = round_up(ceil_div(B, nz), 32);
+    fits(1, nz);
     if (ws.bwd_split == 2) {
       MatWgrad<T128x64> pw{ws.act3, ws.dhid, wp + rg.w[1], bp + rg.b[1], B, 3136, 512, 512, rps};
       plaunch_bwd(ws, K_DENSE_WGRAD, pw, nz, st);
@@ -1536,9 +1542,11 @@ void nature_backward(const NatureLayout& L, const float* P, const uint8_t* obs, 
     // (fp32 MFMA also in split mode: the split weight-gradient kernel measured slower than the im2col fp32 one already)
 #if CONV_WGRAD_FRAMES
     const int nz = conv3_wgrad_frames_splits(B);
+    fits(2, nz);
     plaunch_fn(ws, K_CONV3_WGRAD, st, [&] { launch_conv3_wgrad_frames(ws.act2, ws.dact3pad, wp + rg.w[2], bp + rg.b[2], B, st); });
 #else
     const int M = B * 49, nz = ceil_div(M, RPS_C3);
+    fits(2, nz);
     ConvWgrad<TILE_C3W, 3, 3, 1, 64, 64, 9, 9, 7, 7, 2> pw{ws.act2, ws.dact3pad, wp + rg.w[2], bp + rg.b[2], M, RPS_C3};
     plaunch(ws, K_CONV3_WGRAD, pw, nz, st);
 #endif
@@ -1566,8 +1574,9 @@ void nature_backward(const NatureLayout& L, const float* P, const uint8_t* obs, 
     }
     const int M = B * 81;
     int nz = ceil_div(M, RPS_C2);
+    if (CONV_WGRAD_FRAMES && ws.bwd_split != 2) nz = conv2_wgrad_frames_splits(B);
+    fits(3, nz);
     if (CONV_WGRAD_FRAMES && ws.bwd_split != 2) {
-      nz = conv2_wgrad_frames_splits(B);
       plaunch_fn(ws, K_CONV2_WGRAD, st, [&] { launch_conv2_wgrad_frames(ws.act1, ws.dact2pad, wp + rg.w[3], bp + rg.b[3], B, st); });
     } else if (ws.bwd_split == 2) {   // the split kernel wants the bigger tile (staging-bound)
       ConvWgrad<T128x64, 4, 4, 2, 32, 64, 20, 20, 9, 9, 1> pw{ws.act1, ws.dact2pad, wp + rg.w[3], bp + rg.b[3], M, RPS_C2};
@@ -1582,6 +1591,7 @@ void nature_backward(const NatureLayout& L, const float* P, const uint8_t* obs, 
   // conv1: wgrad only (frames need no gradient); frame-resident kernel, pixels as integers, 1/255 in the reduce
   {
     const int nz = conv1_wgrad_frames_splits(B);
+    fits(4, nz);
     plaunch_fn(ws, K_CONV1_WGRAD, st, [&] { launch_conv1_wgrad_frames(obs, idx, ws.dact1, wp + rg.w[4], bp + rg.b[4], B, st, ws.bwd_split == 2); });
     conv_red.add(wp + rg.w[4], nz, 256 * 32, 32, 1, grads + L.w[0], nullptr, 1.0f / 255.0f);
     conv_red.add(bp + rg.b[4], nz, 32, 32, 0, grads + L.b[0], nullptr);

@@ -135,6 +135,7 @@ int conv2_wgrad_frames_splits(int S) {
   const int fpb = (S + blocks - 1) / blocks;
   return (S + fpb - 1) / fpb;
 }
+int conv2_wgrad_frames_splits_bound(int maxS) { return maxS < C2W_BLOCKS ? maxS : C2W_BLOCKS; }
 void launch_conv2_wgrad_frames(const float* act1, const float* dypad, float* part, float* bpart, int S, hipStream_t st) {
   const int nz = conv2_wgrad_frames_splits(S);
   const int fpb = (S + nz - 1) / nz;
@@ -232,6 +233,7 @@ int conv3_wgrad_frames_splits(int S) {
   const int fpb = (S + blocks - 1) / blocks;
   return (S + fpb - 1) / fpb;
 }
+int conv3_wgrad_frames_splits_bound(int maxS) { return maxS < C3W_BLOCKS ? maxS : C3W_BLOCKS; }
 void launch_conv3_wgrad_frames(const float* act2, const float* dypad, float* part, float* bpart, int S, hipStream_t st) {
   const int nz = conv3_wgrad_frames_splits(S);
   const int fpb = (S + nz - 1) / nz;

@@ -157,6 +157,7 @@ class ActorShipper:
         self.q = [queue.Queue() for _ in range(layout.threads)]
         self.thread = threading.Thread(target=self._run, daemon=True)
         self.error = None
+        self.stop = threading.Event()   # set by a failing sibling (a rollout thread that died will never commit): _run must not wait for it forever
         g = layout.group
         # map every learner's ring (ppo:358-363's device_put_sharded targets)
         self.peer = [engine.open_peer_ring(pickle.loads(rdv.get(f"g{g}/ring/{li}"))) for li in range(layout.nl)]
@@ -165,13 +166,22 @@ class ActorShipper:
         """Called by the thread's rollout loop right after cbm_actor_commit (the commit event orders the copies after the rollout)."""
         self.q[slot].put((update, ring_index))
 
+    def _next(self, s):
+        """Queue.get that gives up when a sibling thread failed (self.stop) instead of blocking the actor process for ever."""
+        while True:
+            try:
+                return self.q[s].get(timeout=0.2)
+            except queue.Empty:
+                if self.stop.is_set():
+                    raise RuntimeError(f"actor thread {s} stopped before committing its next rollout") from None
+
     def _run(self):
         try:
             lay = self.lay
             cols = lay.ports * lay.shard_envs
             for u in range(1, self.n + 1):
                 for s in range(lay.threads):
-                    upd, ring = self.q[s].get()
+                    upd, ring = self._next(s)
                     assert upd == u
                     port = lay.actor_index * lay.threads + s
                     for li in range(lay.nl):

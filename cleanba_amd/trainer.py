@@ -81,7 +81,8 @@ def make_config(args, algo):
     return cfg
 
 
-def rollout(key, args, algo, engine, writer, slot, world_size, process_index, stop_event, errors, on_commit=None, device_thread_id=None):
+def rollout(key, args, algo, engine, writer, slot, world_size, process_index, stop_event, errors, on_commit=None, device_thread_id=None,
+            on_error=None):
     """One actor thread.  Mirrors rollout() ppo:226-406 / impala:268-446.  `slot` is the thread's slot in this process's context,
     `device_thread_id` its index among ALL actor threads of the group (d_idx * num_actor_threads + thread_id, ppo:680), which seeds its envs."""
     try:
@@ -92,6 +93,8 @@ def rollout(key, args, algo, engine, writer, slot, world_size, process_index, st
             errors.append(e)
             stop_event.set()
             engine.abort()            # the learner blocked in cbm_learner_wait returns with an error instead of waiting forever
+            if on_error is not None:  # split topologies: wake the shipper (it waits for THIS thread's commits) and tell the peers now
+                on_error()
             raise
 
 
@@ -481,9 +484,14 @@ def _train_split(args, algo, engine, lay, rdv, writer, key, rank, run_name, on_u
         shipper = topology.ActorShipper(engine, lay, rdv, args, algo, args.num_updates)   # maps the learners' rings
         stop_event, errors, threads = threading.Event(), [], []
         dummy_writer = SimpleNamespace(add_scalar=lambda x, y, z: None)
+
+        def on_error():   # a rollout thread died: the shipper must stop waiting for its commits, learners / receivers must stop waiting for us
+            shipper.stop.set()
+            rdv.abort()
         for slot in range(lay.threads):
             th = threading.Thread(target=rollout, args=(key.copy(), args, algo, engine, writer if slot == 0 else dummy_writer, slot, lay.groups,
-                                                        lay.group, stop_event, errors, shipper.on_commit, lay.actor_index * lay.threads + slot),
+                                                        lay.group, stop_event, errors, shipper.on_commit, lay.actor_index * lay.threads + slot,
+                                                        on_error),
                                   daemon=True)
             th.start()
             threads.append(th)

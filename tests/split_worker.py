@@ -28,6 +28,19 @@ argv = ["--local-num-envs", str(E), "--num-actor-threads", "1", "--num-steps", "
         "--actor-device-ids"] + aids + ["--learner-device-ids"] + lids
 args = parse_args(argv, algo)
 os.chdir(os.environ.get("CBM_TEST_TMP", "/tmp"))
-res = train(args, algo, engine_factory=OracleEngine)
+factory = OracleEngine
+fail_at = int(os.environ.get("CBM_TEST_FAIL_ROLLOUT", "0"))
+if fail_at:
+    # failure injection: the actor's rollout thread dies when it begins rollout `fail_at`; every role must stop promptly
+    class FailingEngine(OracleEngine):
+        _begun = 0
+
+        def actor_begin_rollout(self, *a, **k):
+            FailingEngine._begun += 1
+            if FailingEngine._begun == fail_at:
+                raise RuntimeError("injected rollout failure")
+            return super().actor_begin_rollout(*a, **k)
+    factory = FailingEngine
+res = train(args, algo, engine_factory=factory)
 np.savez(out, params=res["params"], role=np.array(res["role"]), updates=res["updates"])
 print("rank", rank, res["role"], "updates", res["updates"])

@@ -195,6 +195,26 @@ def test_split_topology_two_actor_gpus_two_learner_gpus(tmp_path):
     assert np.array_equal(a0["params"], l0["params"]) and np.array_equal(a1["params"], l0["params"])
 
 
+def test_split_topology_failed_rollout_thread_stops_every_role(tmp_path):
+    """A rollout thread that dies must not leave the actor's shipper blocked on its queue (and the learners on the rendezvous) until the
+    1800 s store timeout: every role exits with an error within seconds."""
+    import time
+    port = _free_port()
+    env = dict(os.environ, CBM_TEST_TMP=str(tmp_path), OMP_NUM_THREADS="2", CBM_TEST_FAIL_ROLLOUT="2")
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "split_worker.py"), str(r), "2", str(port), os.path.join(str(tmp_path), f"f{r}.npz"), "ppo", "1"],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    t0 = time.time()
+    try:
+        logs = [p.communicate(timeout=120)[0].decode() for p in procs]
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    assert all(p.returncode not in (0, None) for p in procs), [p.returncode for p in procs]
+    assert "injected rollout failure" in logs[0]
+    assert time.time() - t0 < 110
+
+
 def test_unsupported_device_lists_fail_before_spawning():
     from cleanba_amd.args import parse_args
     from cleanba_amd import topology
