@@ -47,8 +47,12 @@ KERNELS = {
 # the taps that fall into dY's zero border per tile, so they EXECUTE exactly the algorithmic count.
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 HBM_PEAK_GBPS = 8000.0         # MI355X_MICROARCH.md: HBM3E ~8 TB/s
-ALG_FLOPS_PER_ENV_STEP = 243.2e6   # SURVEY §8d (PPO, Nature-CNN, A=18): rollout forward + 4 epochs x (forward + backward)
+ALG_FLOPS_PER_ENV_STEP = 243.2e6   # SURVEY §8d (PPO, Nature-CNN, A=18): rollout forward + 4 epochs x (forward + "2 x forward" backward)
 ALG_BYTES_PER_ENV_STEP = 345.8e3
+# EXECUTED flops per env-step: SURVEY's "backward = 2 x forward" prices a conv1 INPUT gradient that nobody computes (frames need no gradient:
+# not XLA, not this build).  What is launched: the rollout's forward + 4 epochs x the twelve GEMMs of KERNELS (+ the A+1-wide heads forward).
+FWD_FLOPS_PER_FRAME = 2.0 * (400 * 32 * 256 + 81 * 64 * 512 + 49 * 64 * 576 + 512 * 3136 + 512 * (A + 1))
+EXEC_FLOPS_PER_ENV_STEP = FWD_FLOPS_PER_FRAME + EPOCHS * (sum(f for _, f in KERNELS.values()) / MB + 2.0 * 512 * (A + 1))
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/pmc_traffic.py)
 
 
@@ -60,7 +64,7 @@ def _free_port():
 
 
 # --------------------------------------------------------------------------------------------- CPU baseline (same harness)
-def cpu_baseline(n_envs=16, n_steps=32, updates=3):
+def cpu_baseline(n_envs=16, n_steps=32, updates=3, full_updates=1):
     """The CPU restatement (oracle/, kind "port") driven by the SAME host program as the GPU run — cleanba_amd.trainer.train with the
     oracle-backed engine (tests/oracle_engine.py) in place of the HIP library: same actor thread, same ring hand-off, same counters — on a
     bounded sample of the workload: Nature-CNN PPO, 4 epochs x 4 minibatches, A=18, host synthetic env, `n_envs` envs x `n_steps` steps per
@@ -73,7 +77,7 @@ def cpu_baseline(n_envs=16, n_steps=32, updates=3):
     from cleanba_amd.args import parse_args
     from cleanba_amd.trainer import train
 
-    def run(threads):
+    def run(threads, n_envs=n_envs, n_steps=n_steps, updates=updates):
         oracle.set_threads(threads)
         stamps = []
         argv = ["--local-num-envs", str(n_envs), "--num-actor-threads", "1", "--num-steps", str(n_steps), "--env-backend", "host", "--network", "nature",
@@ -94,16 +98,25 @@ def cpu_baseline(n_envs=16, n_steps=32, updates=3):
         return float(n_envs * n_steps / np.median(dts)), [round(float(x), 3) for x in dts]
 
     ncpu = os.cpu_count() or 1
+    # value: the benchmark's OWN configuration (E = 120 envs x T = 128 steps, 3840-frame minibatches) on all the cores the oracle's OpenMP-over-frames
+    # can use, `full_updates` timed update interval(s) after one warm-up update (~10-20 s each)
+    cores_full = max(1, min(ncpu, 64))
+    sps_full, dts_full = run(cores_full, E, T, full_updates)
+    # reduced sample (16 envs x 32 steps, 128-frame minibatches) for the one-thread-per-role row, which would take minutes per update at full size
     cores = max(1, min(ncpu, 32, (n_envs * n_steps // NMB) // 6))   # OpenMP over frames: more threads than frames/6 only adds reduction cost
     sps, dts = run(cores)
     sps1, dts1 = run(1)
-    return {"value": round(sps, 2), "unit": "env-steps/s", "cores": cores + 1, "kind": "port", "estimate": False,
-            "reference_threading": {"value": round(sps1, 2), "cores": 2,
-                                    "note": "one intra-op thread per role like the reference pins XLA-CPU (ppo:28): one actor thread + one learner thread"},
-            "sample": f"same harness as the GPU run (cleanba_amd.trainer.train, actor thread + learner thread, --concurrency) on the oracle engine: "
-                      f"PPO Nature-CNN fp32, {n_envs} envs x {n_steps} steps per rollout, 4 epochs x 4 minibatches, host synthetic env; median of "
-                      f"{updates} update intervals {dts} s with {cores} OpenMP threads in the learner (+1 actor thread) on {ncpu} host cores; "
-                      f"single-thread intervals {dts1} s.  A timing of the C restatement, not of JAX."}
+    return {"value": round(sps_full, 2), "unit": "env-steps/s", "cores": cores_full + 1, "kind": "port", "estimate": False,
+            "sample": f"the benchmark's configuration itself: same harness as the GPU run (cleanba_amd.trainer.train, actor thread + learner thread, "
+                      f"--concurrency) on the oracle engine, PPO Nature-CNN fp32, {E} envs x {T} steps per rollout, 4 epochs x 4 minibatches of {MB} frames, "
+                      f"host synthetic env; {full_updates} timed update interval(s) {dts_full} s after one warm-up update, {cores_full} OpenMP threads in the "
+                      f"learner (+1 actor thread) on {ncpu} host cores.  A timing of the C restatement, not of JAX.",
+            "reduced_sample": {"value": round(sps, 2), "cores": cores + 1, "estimate": True,
+                               "note": f"{n_envs} envs x {n_steps} steps per rollout (128-frame minibatches cap OpenMP at {cores} threads): median of {updates} "
+                                       f"update intervals {dts} s — small batches depress CPU efficiency; NOT the benchmark's configuration"},
+            "reference_threading": {"value": round(sps1, 2), "cores": 2, "estimate": True,
+                                    "note": f"one intra-op thread per role like the reference pins XLA-CPU (ppo:28): one actor thread + one learner thread, on the "
+                                            f"reduced sample ({n_envs} x {n_steps}); intervals {dts1} s"}}
 
 
 # --------------------------------------------------------------------------------------------- data-parallel bench (a0_l0_dN)
@@ -243,8 +256,10 @@ def roofline(ctx, a, dt, prof_steps):
             continue
         avg_s = ms[k] / cnt[k] / 1e3
         tf = flops / avg_s / 1e12
-        tr = traffic_tab.get(str(k), {}).get("traffic_bytes")
-        rows[k] = {"kernel": name, "avg_us": round(avg_s * 1e6, 1), "launches": int(cnt[k]), "achieved": round(tf, 2),
+        launched = ctx.profile_kernel_name(k)                 # "<kernel symbol> <functor type>" of what the library launched for this id
+        ent = traffic_tab.get(str(k), {})
+        tr = ent.get("traffic_bytes") if _same_kernel(launched, ent.get("kernel_full", "")) else None   # PMC numbers of another kernel are not reported
+        rows[k] = {"kernel": name, "launched": launched, "avg_us": round(avg_s * 1e6, 1), "launches": int(cnt[k]), "achieved": round(tf, 2),
                    "frac": round(tf / FP32_MFMA_PEAK_TFLOPS, 4), "time_share": round(ms[k] / 1e3 / (dt * prof_steps / a.steps), 4), "flops_per_launch": flops,
                    "traffic": tr, "hbm_gbps": None if tr is None else round(tr / avg_s / 1e9, 1),
                    "hbm_frac": None if tr is None else round(tr / avg_s / 1e9 / HBM_PEAK_GBPS, 4)}
@@ -253,17 +268,34 @@ def roofline(ctx, a, dt, prof_steps):
     dom = max(rows, key=lambda k: rows[k]["time_share"])
     r = rows[dom]
     whole_tf = ALG_FLOPS_PER_ENV_STEP * (a.steps * T * E) / dt / 1e12
+    exec_tf = EXEC_FLOPS_PER_ENV_STEP * (a.steps * T * E) / dt / 1e12
     out = {"bound": "mfma", "kernel": r["kernel"], "achieved": r["achieved"], "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": r["frac"],
            "traffic": r["traffic"], "hbm_gbps": r["hbm_gbps"], "hbm_frac": r["hbm_frac"], "launches": r["launches"], "avg_us": r["avg_us"],
            "flops_per_launch": r["flops_per_launch"], "time_share": r["time_share"],
-           "selection": "largest measured time share (HIP events around every learner-stream launch of kernel ids 0-11 during the first "
-                        "%d of the %d timed steps)" % (prof_steps, a.steps), "event_steps": prof_steps,
+           "selection": "largest measured time share; source = HIP events on the learner stream around every launch of kernel ids 0-11 during the "
+                        "first %d of the %d timed steps (an event pair serialises back-to-back launches, so a kernel is timed from the end of its "
+                        "predecessor; rocprofv3's per-dispatch durations of the same run include the overlap with the predecessor's drain and are "
+                        "longer for kernels that follow a one-block-per-CU kernel: profiles/r03_bench_kernel_stats.md lists both)" % (prof_steps, a.steps),
+           "event_steps": prof_steps,
            "min_frac": min(v["frac"] for k, v in rows.items() if k != 4),   # (id 4, the 32-wide heads wgrad, is 0.2 % of the flops)
-           "whole_step": {"achieved": round(whole_tf, 2), "frac": round(whole_tf / FP32_MFMA_PEAK_TFLOPS, 4),
+           "whole_step": {"executed_flops_per_env_step": round(EXEC_FLOPS_PER_ENV_STEP), "executed_achieved": round(exec_tf, 2),
+                          "executed_frac": round(exec_tf / FP32_MFMA_PEAK_TFLOPS, 4),
+                          "algorithmic_flops_per_env_step": ALG_FLOPS_PER_ENV_STEP, "achieved": round(whole_tf, 2), "frac": round(whole_tf / FP32_MFMA_PEAK_TFLOPS, 4),
                           "algorithmic_hbm_gbps": round(ALG_BYTES_PER_ENV_STEP * (a.steps * T * E) / dt / 1e9, 1),
-                          "note": "243.2 MFLOP and 345.8 KB per env-step (SURVEY 8d) x env-steps / wall time, this GPU"},
+                          "note": "executed_*: the flops of the launched kernels (rollout forward + 4 epochs x the twelve GEMMs; no conv1 input gradient exists) "
+                                  "x env-steps / wall time — the yardstick to compare rounds on; achieved / frac: SURVEY 8d's 243.2 MFLOP per env-step "
+                                  "(backward priced as 2 x forward, i.e. including that non-existent conv1 dgrad) and 345.8 KB per env-step"},
            "kernels": [rows[k] for k in sorted(rows)]}
     return out
+
+
+def _same_kernel(launched, profiled_full):
+    """launched = '<symbol> <functor type>' from the library; profiled_full = the demangled kernel name rocprofv3 recorded.  Same kernel iff the
+    symbol and the functor type both occur in the profiled name (white space differs between demanglers)."""
+    if not launched or not profiled_full:
+        return False
+    full = profiled_full.replace(" ", "")
+    return all(part.replace(" ", "") in full for part in launched.split(" ", 1))
 
 
 def host_env_value(a, params):
@@ -400,12 +432,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if a.topology == "dp" and world != a.gpus and rank == 0:
         print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: running the {world} ranks that were launched", file=sys.stderr)
-    if a.topology != "dp":
-        line = run_topology(a, world, rank)
-        if line is not None:
-            _emit(json.dumps(line))
-        return
-    line, params = run_dp(a, world, rank, local_rank)
+    try:
+        if a.topology != "dp":
+            line = run_topology(a, world, rank)
+            if line is not None:
+                _emit(json.dumps(line))
+            return
+        line, params = run_dp(a, world, rank, local_rank)
+    except BaseException as e:  # noqa: BLE001  a failed rank (RCCL init, IPC mapping, a dead peer) still leaves ONE parsable line on stdout
+        if rank == 0 and not isinstance(e, SystemExit):
+            _emit(json.dumps({"error": f"{type(e).__name__}: {e}", "n_gpus": world, "topology": a.topology, "rank": rank,
+                              "metric": "env-steps/sec (whole node), Breakout-v5 84x84x4, num_envs=120", "value": None}))
+        raise
     if rank == 0:
         if world == 1 and not a.no_host_env:
             line["host_env"] = host_env_value(a, params)

@@ -749,6 +749,15 @@ extern "C" int cbm_profile_read_all(cbm_ctx* c, double* total_ms, int32_t* count
   return 0;
 }
 
+extern "C" int cbm_profile_kernel_name(cbm_ctx* c, int32_t kernel_id, char* buf, int32_t buf_len) {
+  if (kernel_id < 0 || kernel_id >= K_NUM || !buf || buf_len < 1) { cbm_set_error("cbm_profile_kernel_name: bad arguments"); return -1; }
+  const char* k = c->prof.kernel[kernel_id];
+  const char* f = c->prof.functor[kernel_id];
+  if (k) snprintf(buf, (size_t)buf_len, "%s%s%s", k, f && f[0] ? " " : "", f ? f : "");
+  if (!k) buf[0] = 0;
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------------ pure functions
 static int check_B(cbm_ctx* c, int B) {
   if (B > c->lws.maxB) { cbm_set_error("B=%d exceeds the learner workspace (%d frames)", B, c->lws.maxB); return -1; }

@@ -32,6 +32,9 @@ struct CbmProf {
   int8_t kid[CBM_PROF_MAX];
   hipEvent_t ev[2 * CBM_PROF_MAX];
   bool created = false;
+  // what was launched for each id the last time it was timed: kernel symbol + problem functor (static strings; cbm_profile_kernel_name)
+  const char* kernel[16] = {};
+  const char* functor[16] = {};
 };
 
 // ---- workspace for running the network on up to maxB frames ----------------------------

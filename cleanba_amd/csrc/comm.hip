@@ -259,7 +259,24 @@ extern "C" int cbm_ipc_open(cbm_ctx* c, const uint8_t handle[CBM_IPC_HANDLE_BYTE
   CBM_HIP(hipSetDevice(c->cfg.device));
   hipIpcMemHandle_t h;
   memcpy(&h, handle, sizeof(h));
-  CBM_HIP(hipIpcOpenMemHandle(dev_ptr, h, hipIpcMemLazyEnablePeerAccess));
+  const hipError_t e = hipIpcOpenMemHandle(dev_ptr, h, hipIpcMemLazyEnablePeerAccess);
+  if (e != hipSuccess) {
+    cbm_set_error("hipIpcOpenMemHandle failed on GPU %d: %s — the peer's buffer cannot be mapped here (needs HSA_ENABLE_IPC_MODE_LEGACY=0 in BOTH "
+                  "processes and peer access between the two GPUs)", c->cfg.device, hipGetErrorString(e));
+    return -1;
+  }
+  // the mapping exists; make sure this GPU can actually reach the owner's memory, and say which two devices when it cannot
+  hipPointerAttribute_t at;
+  if (hipPointerGetAttributes(&at, *dev_ptr) == hipSuccess && at.device != c->cfg.device) {
+    int can = 0;
+    if (hipDeviceCanAccessPeer(&can, c->cfg.device, at.device) == hipSuccess && !can) {
+      (void)hipIpcCloseMemHandle(*dev_ptr);
+      *dev_ptr = nullptr;
+      cbm_set_error("GPU %d cannot access the memory of GPU %d (hipDeviceCanAccessPeer = 0): the split topology writes shards / parameters "
+                    "peer to peer and needs an xGMI or PCIe P2P path between every actor GPU and every learner GPU of a group", c->cfg.device, at.device);
+      return -1;
+    }
+  }
   return 0;
 }
 extern "C" int cbm_ipc_close(cbm_ctx* c, void* dev_ptr) {

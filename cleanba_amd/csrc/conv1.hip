@@ -35,170 +35,15 @@ static __device__ __forceinline__ void frame_to_lds(const uint8_t* frame, unsign
   }
 }
 // ------------------------------------------------------------------------------------------ forward
-#ifndef C1F_ABL
-#define C1F_ABL 0   // timing builds: 1 no epilogue stores / masks, 2 no frame copies after the first, 4 byte -> float without the /255 math
-#endif
-// LDS: W1 as [k=(c,kh,kw)][32] f32 (32 KB) + one frame of bytes (28,224 B) = 60,992 B -> two blocks per CU, i.e. two
-// waves per SIMD whose conversion chains and MFMAs interleave.  A frame is 400 positions = 12.5 tiles of 32: wave
-// (w + f) % 4 takes tiles {first, first+4, first+8, (12)}; the rotation evens out who owns the 13th half tile.
-__global__ __launch_bounds__(256, 2) void conv1_fwd_frames_kernel(const uint8_t* obs, const int32_t* idx, const float* W, const float* bias,
-                                                                  float* out, uint32_t* mask, int S, int frames_per_block) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem_raw[256 * 32 * 4 + FR];
-  float* Wl = reinterpret_cast<float*>(smem_raw);            // [256][32]
-  unsigned char* F = smem_raw + 256 * 32 * 4;                // [28224]
-  const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, h = lane >> 5;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // weights: HWIO [kh][kw][c][n] -> k = (c,kh,kw) rows
-  for (int i = tid; i < 256 * 32 / 4; i += 256) {
-    const int k = i >> 3, n4 = (i & 7) * 4;
-    const int c = k >> 6, kh = (k >> 3) & 7, kw = k & 7;
-    *reinterpret_cast<float4*>(Wl + k * 32 + n4) = *reinterpret_cast<const float4*>(W + ((kh * 8 + kw) * 4 + c) * 32 + n4);
-  }
-  const int s_lo = blockIdx.x * frames_per_block, s_hi = min(S, s_lo + frames_per_block);
-  const float bn = bias[li];
-  constexpr int MAXT = 3;
-  typedef float f32x4_t __attribute__((ext_vector_type(4)));
-  const int r16 = lane & 15, g4 = lane >> 4;   // 16x16x4 MFMA roles of the tail tile: position / column r16, k = 4*step + g4
-  if (s_lo < s_hi) {
-    const int f = idx ? idx[s_lo] : s_lo;
-    frame_to_lds(obs + (size_t)f * FR, F, wave, lane);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  for (int s = s_lo; s < s_hi; ++s) {
-    const int first = (wave + (s - s_lo)) & 3;
-    // 400 positions = 12 tiles of 32 (three per wave) + 16 left over.  A fourth 32-row tile for one wave made that wave 33 % longer than the
-    // others at every per-frame barrier (measured: dropping it took the kernel 310 -> 265 us); the 16 positions are instead a 16x16x4
-    // MFMA tile (two column tiles, k = 4 consecutive kw per instruction: still the oracle's k-ascending chain), half the extra work.
-    // The tail's two 16-column tiles go to two different waves (first == 0 and first == 1): 13 vs 12 MFMA-equivalents per k-row.
-    const bool four = first < 2;   // wave-uniform: owns column tile `first` of the tail tile (positions 384..399)
-    const int tj = first & 1;
-    int base[MAXT];
-#pragma unroll
-    for (int t = 0; t < MAXT; ++t) {
-      const int p = min((first + 4 * t) * 32 + li, 399);
-      const int oh = p / 20, ow = p - oh * 20;
-      base[t] = oh * 4 * 84 + ow * 4;
-    }
-    f32x16 acc[MAXT];
-#pragma unroll
-    for (int t = 0; t < MAXT; ++t)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[t][e] = 0.0f;
-    f32x4_t tacc = {0.f, 0.f, 0.f, 0.f};
-    const int tbase = ((384 + r16) / 20) * 4 * 84 + ((384 + r16) % 20) * 4;
-    // One (c,kh) row of the patch = 8 contiguous pixels per position = one ds_read2_b32 per tile, feeding the four
-    // kw-pairs; the reads of row ckh+1 are issued before the MFMAs of row ckh.
-    uint2 pxa[MAXT + 1], pxb[MAXT + 1];   // [MAXT] = the tail tile's 8 bytes
-    float wa[6], wb[6];                   // [4..5] = the tail tile's B values of the two k-steps
-    auto fetch = [&](int ckh, uint2(&px)[MAXT + 1], float(&wv)[6]) __attribute__((always_inline)) {
-      const int koff = (ckh >> 3) * 7056 + (ckh & 7) * 84;
-#pragma unroll
-      for (int t = 0; t < MAXT; ++t) {
-        const unsigned char* q = F + base[t] + koff;  // 4-byte aligned
-        px[t] = make_uint2(*reinterpret_cast<const uint32_t*>(q), *reinterpret_cast<const uint32_t*>(q + 4));
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) wv[j] = Wl[(ckh * 8 + 2 * j + h) * 32 + li];
-      if (four) {
-        const unsigned char* q = F + tbase + koff;
-        px[MAXT] = make_uint2(*reinterpret_cast<const uint32_t*>(q), *reinterpret_cast<const uint32_t*>(q + 4));
-#pragma unroll
-        for (int st = 0; st < 2; ++st) wv[4 + st] = Wl[(ckh * 8 + 4 * st + g4) * 32 + 16 * tj + r16];
-      }
-    };
-    auto fma_row = [&](const uint2(&px)[MAXT + 1], const float(&wv)[6]) __attribute__((always_inline)) {
-      // kw-pair outer / tile inner: consecutive MFMAs hit different accumulators; each accumulator still sees its
-      // k-pairs in ascending order (bit-exact with the oracle's chain).
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-#pragma unroll
-        for (int t = 0; t < MAXT; ++t) {
-          const uint32_t w32 = (j < 2 ? px[t].x : px[t].y) >> (8 * h + 16 * (j & 1));  // pixel kw = 2j + h
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32((C1F_ABL & 4) ? (float)(w32 & 255u) : cbm_u8_unit(w32 & 255u), wv[j], acc[t], 0, 0, 0);
-        }
-      }
-      if (four) {   // tail tile: kw = 4*st + g4
-#pragma unroll
-        for (int st = 0; st < 2; ++st) {
-          const float a = cbm_u8_unit(((st == 0 ? px[MAXT].x : px[MAXT].y) >> (8 * g4)) & 255u);
-          tacc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wv[4 + st], tacc, 0, 0, 0);
-        }
-      }
-    };
-    fetch(0, pxa, wa);
-#pragma unroll 1
-    for (int ckh = 0; ckh < 32; ckh += 2) {
-      fetch(ckh + 1, pxb, wb);
-      __builtin_amdgcn_sched_barrier(0);
-      fma_row(pxa, wa);
-      __builtin_amdgcn_sched_barrier(0);
-      if (ckh + 2 < 32) fetch(ckh + 2, pxa, wa);
-      __builtin_amdgcn_sched_barrier(0);
-      fma_row(pxb, wb);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    __syncthreads();  // every wave is done reading this frame's bytes
-    if (s + 1 < s_hi && !(C1F_ABL & 2)) {
-      const int f = idx ? idx[s + 1] : s + 1;
-      frame_to_lds(obs + (size_t)f * FR, F, wave, lane);  // lands while the epilogue stores drain
-    }
-    // epilogue: out[s][pos][n] = relu(acc + bias); the ReLU mask of each output pixel's 32 channels is a ballot word — lane r of the
-    // lower half collects the word of tile row r, one coalesced 128-byte store per tile (read by the conv2 dgrad epilogue)
-    float* o = out + (size_t)s * 400 * 32 + li;
-    if (C1F_ABL & 1) {   // timing build: one store per lane keeps the accumulators alive
-      float sum = tacc[0] + tacc[1] + tacc[2] + tacc[3];
-#pragma unroll
-      for (int t = 0; t < MAXT; ++t)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) sum += acc[t][e];
-      o[(first * 32 + 4 * h) * 32] = sum;
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      continue;
-    }
-#pragma unroll
-    for (int t = 0; t < MAXT; ++t) {
-      const int m0 = (first + 4 * t) * 32 + 4 * h;
-      uint32_t word = 0;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int r0 = (e & 3) + 8 * (e >> 2);
-        const float v = relu_(acc[t][e] + bn);
-        o[(m0 + r0) * 32] = v;
-        const unsigned long long bal = __ballot(v > 0.0f);   // all 64 lanes: rows r0 (lower half) and r0 + 4 (upper half)
-        // lane r0 <- the lower wave half's row, lane r0 + 4 <- the upper half's (no writelane builtin in this clang)
-        asm volatile("s_nop 4\n\tv_writelane_b32 %0, %1, %2" : "+v"(word) : "s"((uint32_t)bal), "n"(r0));
-        asm volatile("s_nop 4\n\tv_writelane_b32 %0, %1, %2" : "+v"(word) : "s"((uint32_t)(bal >> 32)), "n"(r0 + 4));
-      }
-      if (mask && lane < 32) mask[(size_t)s * 400 + (first + 4 * t) * 32 + lane] = word;
-    }
-    if (four) {   // tail tile: lane (g4, r16) holds rows 384 + 4*g4 + i, column 16*tj + r16; its 16 mask bits go to half a word
-      const float bt = bias[16 * tj + r16];
-      uint32_t word = 0;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float v = relu_(tacc[i] + bt);
-        out[((size_t)s * 400 + 384 + 4 * g4 + i) * 32 + 16 * tj + r16] = v;
-        const unsigned long long bal = __ballot(v > 0.0f);   // 16 bits per row group g4
-#pragma unroll
-        for (int g = 0; g < 4; ++g) asm volatile("s_nop 4\n\tv_writelane_b32 %0, %1, %2" : "+v"(word) : "s"((uint32_t)((bal >> (16 * g)) & 0xFFFFull)), "n"(4 * g + i));
-      }
-      if (mask && lane < 16) reinterpret_cast<uint16_t*>(mask + (size_t)s * 400 + 384 + lane)[tj] = (uint16_t)word;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-  }
-}
-
-// Plane-streamed flavour (C1F_PLANES): the byte -> x/255 conversion leaves the MFMA loop.  In conv1_fwd_frames_kernel every A fragment is
-// made from its byte at the moment it is consumed — a pixel sits in 2x2 patches, so each is converted four times, 3-4 VALU instructions per
-// MFMA, and VALU instructions take matrix-pipe issue slots on this chip.  Here a frame goes through LDS one channel plane at a
+// Plane-streamed forward: a frame is 400 output positions = 12 tiles of 32 (three per wave; wave (w + f) % 4 takes tiles {first, first+4, first+8})
+// + 16 left over, which are a 16x16x4 MFMA tile whose two 16-column halves go to two different waves (a fourth 32-row tile made one wave 33 % longer
+// than the others at every barrier: 310 -> 265 us).  A first version built every A fragment from its byte at the moment of use — a pixel sits in
+// 2x2 patches, so each was converted four times, 3-4 VALU instructions per MFMA, and VALU instructions take matrix-pipe issue slots on this chip
+// (that kernel is in the git history, 306 us under load).  Here a frame goes through LDS one channel plane at a
 // time AS FLOATS: the 7056 bytes of plane c are loaded to registers while plane c-1 is multiplied, converted once (1 VALU instruction per
 // MFMA) and written as two half-planes [kw parity][84][42] — lane half h of a 32x32x2 MFMA supplies k = 2j + h, i.e. always one parity — so
 // a tile's four kw-pairs of one (c,kh) patch row are 4 consecutive floats: two conflict-free ds_read_b64, no extraction, no conversion.
-// Same LDS footprint as the byte kernel (28,224 B plane + 32 KB weights, two blocks per CU), same tile ownership, same k = (c,kh,kw)
-// ascending chain per output -> the same bits.
+// LDS: 28,224 B plane + 32 KB weights, two blocks per CU; k = (c,kh,kw) ascending chain per output -> the oracle's bits.
 __global__ __launch_bounds__(256, 2) void conv1_fwd_planes_kernel(const uint8_t* obs, const int32_t* idx, const float* W, const float* bias,
                                                                   float* out, uint32_t* mask, int S, int frames_per_block) {
   __shared__ __attribute__((aligned(16))) float smem_f[256 * 32 + 2 * 84 * 42];
@@ -338,21 +183,14 @@ __global__ __launch_bounds__(256, 2) void conv1_fwd_planes_kernel(const uint8_t*
 
 void launch_conv1_fwd_frames(const uint8_t* obs, const int32_t* idx, const float* W, const float* bias, float* out, uint32_t* mask, int S,
                              hipStream_t st) {
-#ifndef C1F_BLOCKS
-#define C1F_BLOCKS 2048   // two frames per block at 3840 frames.  512 persistent blocks (exactly two per CU) were fragile under the concurrent
-                          // rollout: a CU that could not take its second block (LDS held by actor blocks) left a straggler — 375 us under load
-                          // against 286 isolated; with many short blocks the dispatcher balances.  Plane-streamed kernel under load / isolated:
-                          // 4096 blocks 279 / 260 us, 2048 275 / 253, 1280 283 / 276, 768 292 / 245 (the byte kernel: 308 / 282)
-#endif
-  int blocks = C1F_BLOCKS;
+  // two frames per block at 3840 frames.  512 persistent blocks (exactly two per CU) were fragile under the concurrent rollout: a CU that could
+  // not take its second block (LDS held by actor blocks) left a straggler — 375 us under load against 286 isolated; with many short blocks the
+  // dispatcher balances.  Under load / isolated: 4096 blocks 279 / 260 us, 2048 275 / 253, 1280 283 / 276, 768 292 / 245
+  int blocks = 2048;
   if (S < blocks) blocks = S;
   const int fpb = (S + blocks - 1) / blocks;
   blocks = (S + fpb - 1) / fpb;
-#ifndef C1F_PLANES
-#define C1F_PLANES 1
-#endif
-  if (C1F_PLANES) hipLaunchKernelGGL(conv1_fwd_planes_kernel, dim3(blocks), dim3(256), 0, st, obs, idx, W, bias, out, mask, S, fpb);
-  else hipLaunchKernelGGL(conv1_fwd_frames_kernel, dim3(blocks), dim3(256), 0, st, obs, idx, W, bias, out, mask, S, fpb);
+  hipLaunchKernelGGL(conv1_fwd_planes_kernel, dim3(blocks), dim3(256), 0, st, obs, idx, W, bias, out, mask, S, fpb);
 }
 
 // ------------------------------------------------------------------------------------------ wgrad
@@ -497,10 +335,8 @@ __global__ __launch_bounds__(256, 2) void conv1_wgrad_frames_split_kernel(const 
   }
 }
 
+static const int C1W_BLOCKS = 768;   // 3840-frame minibatch: 5 frames per block; 225 vs 233 us for 1024 blocks (and 25 MB of partials instead of 31)
 int conv1_wgrad_frames_splits(int S) {
-#ifndef C1W_BLOCKS
-#define C1W_BLOCKS 768   // 3840-frame minibatch: 5 frames per block; 225 vs 233 us for 1024 blocks (and 25 MB of partials instead of 31)
-#endif
   int blocks = C1W_BLOCKS;
   if (S < blocks) blocks = S;
   const int fpb = (S + blocks - 1) / blocks;

@@ -10,33 +10,17 @@
 // gradients of conv2/conv3 outputs live in zero-bordered 11x11 buffers so that both dgrads are
 // plain VALID correlations (stride-2 conv2 as 4 parity classes).
 #include "cbm_internal.h"
-// Sibling-aware tile orders (igemm.h ORDER 1/2), measured on MI355X.  ORDER 1 (the tap tiles of a weight-gradient reduction slice on one
-// XCD) is OFF: conv3 wgrad 161 -> 201 us, conv2 wgrad 251 -> 293 us — with all XCDs walking the same rows together the re-fetches
-// FETCH_SIZE reports are Infinity-Cache hits, and private rows per XCD lose that sharing.  ORDER 2 (the four parity classes of a conv2
-// dgrad pixel tile back to back on one XCD) is ON: the kernel time does not move (320 vs 318 us) but its L2-miss traffic falls from
-// 1.56 GB to 0.13 GB per launch (rocprofv3 --pmc FETCH_SIZE, x2 corrected) — the four classes read the same dY rows, and dispatched
-// class-major they were 3000 tiles apart.
-#ifndef IGEMM_ORDER_1
-#define IGEMM_ORDER_1 0
-#endif
-#ifndef IGEMM_ORDER_2
-#define IGEMM_ORDER_2 2
-#endif
-#ifndef IGEMM_ORDER_MW
-#define IGEMM_ORDER_MW 0   // MatWgrad (dense / heads weight gradients)
-#endif
-#ifndef S16_ROWPTR
-#define S16_ROWPTR 1   // small-batch (actor) kernels: row / chunk split gather addresses
-#endif
-#ifndef IGEMM_ROWPTR
-#define IGEMM_ROWPTR 1   // row / chunk split gather addresses in igemm_pf2_kernel (igemm.h): bit 0 conv3 dgrad, 1 conv fwd, 2 conv2 dgrad
-#endif
+// (Tile order: igemm.h ORDER 2 — the four parity classes of a conv2 dgrad pixel tile back to back on one XCD — is what the merged position-major
+// conv2 dgrad does by construction; ORDER 1 for the weight-gradient tap tiles measured slower and is gone with the im2col wgrads.)
 #include "igemm.h"
 #include "env_model.h"
 #include "ppo_loss.h"
 #include <algorithm>
 #include <vector>
 #include <type_traits>
+#include <typeinfo>
+#include <string>
+#include <cxxabi.h>
 
 NatureLayout nature_layout(int A) {
   NatureLayout L;
@@ -90,7 +74,7 @@ struct Conv1Fwd {
   }
   // row / chunk split of the same addresses for the small-batch kernel (K chunks of 32 = 4 patch rows of 8 pixels, 64 = one channel plane's
   // patch): A offsets are BYTES into obs, B offsets floats into the HWIO weights
-  static constexpr bool ROWPTR_S16 = S16_ROWPTR;
+  static constexpr bool ROWPTR_S16 = true;
   __device__ uint32_t a_off(int m, int rl, int) const {
     m = min(m, M - 1);
     const int s = m / 400, p = m - s * 400, oh = p / 20, ow = p - oh * 20;
@@ -139,8 +123,8 @@ struct ConvFwd {
   }
   __device__ float4 load_b(int r, int y, int, int) const { return *reinterpret_cast<const float4*>(W + (size_t)r * CO + y); }
   // row / chunk split of the same addresses (igemm.h ROWPTR): a chunk never leaves one kernel row (KW*CI is a multiple of the K chunk)
-  static constexpr bool ROWPTR = (IGEMM_ROWPTR & 2) && (KW * CI) % TileT::BR == 0;   // measured: conv3 fwd neutral, conv2 fwd (64x64x32 tile) spills
-  static constexpr bool ROWPTR_S16 = S16_ROWPTR;   // small-batch kernel (K chunks of 32 / 64 never leave a kernel row either)
+  // (used by the small-batch kernel only: on igemm_pf2_kernel the split measured neutral for the conv3 forward and slower for the conv2 forward)
+  static constexpr bool ROWPTR_S16 = true;   // K chunks of 32 / 64 never leave a kernel row
   __device__ float4 rp_a(uint32_t off) const { return ig_ld4(in + off); }
   __device__ float4 rp_b(uint32_t off) const { return ig_ld4(W + off); }
   __device__ const float* a_origin() const { return in; }
@@ -153,16 +137,7 @@ struct ConvFwd {
   __device__ uint32_t a_chunk(int r0) const { const int kh = r0 / (KW * CI); return (uint32_t)(kh * IW * CI + (r0 - kh * (KW * CI))); }
   __device__ uint32_t b_off(int rl, int y, int) const { return (uint32_t)(rl * CO + y); }
   __device__ uint32_t b_chunk(int r0) const { return (uint32_t)(r0 * CO); }
-  // DMA-staged variant (igemm_dma_kernel): plain addresses, nothing to zero-fill in a VALID conv.  Measured slower for the convs
-  // (conv3 148 -> 194 us: the 16-byte-stride A fragments cost more than the saved staging), faster for the dense layer (155 -> 136 us).
-  static constexpr bool DMA_OK = false;
-  __device__ const float* a_ptr(int m, int r, int) const {
-    m = min(m, M - 1);
-    const int s = m / (OH * OW), p = m - s * (OH * OW), oh = p / OW, ow = p - oh * OW;
-    const int kh = r / (KW * CI), rem = r - kh * (KW * CI);
-    return in + ((size_t)(s * IH + oh * ST + kh) * IW + ow * ST) * CI + rem;
-  }
-  __device__ const float* b_ptr(int r, int y, int) const { return W + (size_t)r * CO + y; }
+  static constexpr bool DMA_OK = false;   // (igemm_dma_kernel measured slower for the convs: conv3 148 -> 194 us; faster for the dense layer)
   __device__ void store(int m, int n, float v, int, int) const {
     if (m < M) {
       const float o = relu(v + bias[n]);
@@ -200,7 +175,7 @@ struct DenseFwd {
     return f4sel(ok, *reinterpret_cast<const float4*>(W + (size_t)min(r, K - 1) * N + min(y, N - 4)));
   }
   static constexpr bool DMA_OK = !PRE_RELU;   // needs seg % BR == 0 and N % BY == 0 (checked at the call site)
-  static constexpr bool ROWPTR_S16 = S16_ROWPTR && !PRE_RELU;   // same preconditions (whole chunks, whole column tiles)
+  static constexpr bool ROWPTR_S16 = !PRE_RELU;   // same preconditions (whole chunks, whole column tiles)
   __device__ float4 rp_a(uint32_t off) const { return ig_ld4(A + off); }
   __device__ float4 rp_b(uint32_t off) const { return ig_ld4(W + off); }
   __device__ const float* a_origin() const { return A; }
@@ -338,15 +313,12 @@ __global__ __launch_bounds__(256) void actor_tail_kernel(const float* hid, const
     }
   }
 }
-// Actor tail, one block per frame (ACTOR_TAIL_ROWS): the dense layer's split-K reduction, the two heads and the sampling in ONE launch.
+// Actor tail, one block per frame: the dense layer's split-K reduction, the two heads and the sampling in ONE launch.
 // The 16-row MFMA tail above needs the reduced hidden rows in HBM first (dense_reduce_kernel, 4.9 us + a launch); folding the reduction into
 // its 8 blocks made them the bottleneck (15.8 ms rollouts).  With a block per frame the reduction is 120-way parallel again: every thread
 // sums its two hidden units over the S partial slices in slice order (dense_reduce_kernel's chain), the A + 1 head outputs are 512-long
 // k-ascending fmaf chains on A + 1 lanes (bitwise the MFMA's chain: DESIGN 3) fed from LDS, and the frame's 32 sampling lanes run
 // sample_kernel's code.  hid never reaches HBM.
-#ifndef TAIL_ABL
-#define TAIL_ABL 0   // timing builds: 1 no partial-slice loads, 2 no head chains, 4 no sampling math, 8 no weight staging
-#endif
 template <int HD>
 __global__ __launch_bounds__(256) void actor_tail_rows_kernel(const float* part, const float* bd, int S, const float* Wa, const float* ba, const float* Wc,
                                                               const float* bc, int B, int A, ActorSample smp) {
@@ -365,8 +337,8 @@ __global__ __launch_bounds__(256) void actor_tail_rows_kernel(const float* part,
 #pragma unroll
   for (int s = 0; s < 16; ++s) {
     const int ss = s < S ? s : 0;
-    v0[s] = (TAIL_ABL & 1) && s ? 0.0f : part[ss * MN + (size_t)b * HD + tid];
-    v1[s] = (TAIL_ABL & 1) && s ? 0.0f : part[ss * MN + (size_t)b * HD + tid + 256];
+    v0[s] = part[ss * MN + (size_t)b * HD + tid];
+    v1[s] = part[ss * MN + (size_t)b * HD + tid + 256];
   }
   // heads on v_mfma_f32_16x16x4_f32 with ONE live row (row 0 = this frame; the instruction's other 15 rows repeat it and are ignored): waves
   // 0 / 1 own output columns 0-15 / 16-31 and take their B fragments (HD/4 floats per lane, L2-resident weights) straight into registers,
@@ -378,7 +350,7 @@ __global__ __launch_bounds__(256) void actor_tail_rows_kernel(const float* part,
   float bw[HD / 4];
   if (wave < 2) {
 #pragma unroll
-    for (int st = 0; st < HD / 4; ++st) bw[st] = on && !(TAIL_ABL & 8) ? wp[(size_t)(4 * st + g4) * wstride] : 0.0f;
+    for (int st = 0; st < HD / 4; ++st) bw[st] = on ? wp[(size_t)(4 * st + g4) * wstride] : 0.0f;
   }
   float t0 = v0[0], t1 = v1[0];
 #pragma unroll
@@ -390,7 +362,7 @@ __global__ __launch_bounds__(256) void actor_tail_rows_kernel(const float* part,
   if (wave < 2) {
     f32x4_mfma acc = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-    for (int q = 0; q < ((TAIL_ABL & 2) ? 1 : HD / 16); ++q) {
+    for (int q = 0; q < HD / 16; ++q) {
       const float4 h4 = *reinterpret_cast<const float4*>(hsT + g4 * (HD / 4) + 4 * q);   // k = 4*(4q + i) + g4, i = 0..3
       acc = __builtin_amdgcn_mfma_f32_16x16x4f32(h4.x, bw[4 * q], acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_16x16x4f32(h4.y, bw[4 * q + 1], acc, 0, 0, 0);
@@ -408,7 +380,7 @@ __global__ __launch_bounds__(256) void actor_tail_rows_kernel(const float* part,
     const int bg = b;
     const float z = lg[aa];
     const float u = cbm_bits_to_uniform(cbm_random_bits_at(smp.sk0, smp.sk1, nn, (uint32_t)(bg * A + aa)));
-    float g = live ? ((TAIL_ABL & 4) ? z - u : z - cbm_logf(-cbm_logf(u))) : -INFINITY;
+    float g = live ? z - cbm_logf(-cbm_logf(u)) : -INFINITY;
     if (live && smp.logits_out) smp.logits_out[(size_t)b * A + a] = z;
     int bi = a;
     float bv = g, mx = live ? z : -INFINITY;
@@ -419,7 +391,7 @@ __global__ __launch_bounds__(256) void actor_tail_rows_kernel(const float* part,
       if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
       mx = om > mx ? om : mx;
     }
-    const float e = live ? ((TAIL_ABL & 4) ? z - mx : cbm_expf(z - mx)) : 0.0f;
+    const float e = live ? cbm_expf(z - mx) : 0.0f;
     const float zb = __shfl(z, bi, 32);
     float ssum = 0.0f;
     for (int j = 0; j < A; ++j) ssum += __shfl(e, j, 32);
@@ -435,12 +407,9 @@ __global__ __launch_bounds__(256) void actor_tail_rows_kernel(const float* part,
     env_step_block(ea, b, act_s, older);
   }
 }
-#ifndef HEADS_S16
-#define HEADS_S16 1
-#endif
 static void launch_heads_fwd(const float* hid, const float* Wa, const float* ba, const float* Wc, const float* bc, int B, int A, int HD,
                              float* logits, float* value, hipStream_t st) {
-  if (HEADS_S16 && HD % 64 == 0 && A + 1 <= 32) {
+  if (HD % 64 == 0 && A + 1 <= 32) {
     HeadsFwd p{hid, Wa, ba, Wc, bc, logits, value, B, A, HD};
     igemm_s16_launch<32, 32, 64>(p, 1, st);
     return;
@@ -482,9 +451,6 @@ __global__ __launch_bounds__(HD) void heads_dgrad_kernel(const float* dzv, const
 // same logits bits); (B) logits / value -> LDS; (C) the loss head of ppo_loss.h on 32 lanes per sample, dzv -> LDS + HBM (the heads weight
 // gradient reads it), block partial of the four statistics; (D) dhid[m][k] = (sum_j dzv[m][j] Wac[k][j]) * (hid > 0) as 16x16x4 MFMAs over
 // j (5 steps for A = 18), eight 16-column tiles per wave, the weight fragments requested before the loss math.
-#ifndef HF_ABL
-#define HF_ABL 0   // timing builds: 1 no dgrad phase, 2 no loss math, 4 short heads chain, 8 no dgrad weight loads
-#endif
 template <int HD>
 __global__ __launch_bounds__(256) void ppo_heads_fused_kernel(const float* hid, const float* Wa, const float* ba, const float* Wc, const float* bc, int B, int A,
                                                               const int32_t* idx, const int32_t* actions, const float* old_logprob, const float* adv,
@@ -522,7 +488,7 @@ __global__ __launch_bounds__(256) void ppo_heads_fused_kernel(const float* hid, 
       const bool on = n <= A;
       f32x4_mfma acc = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll 16
-      for (int st = 0; st < ((HF_ABL & 4) ? 4 : HD / 4); ++st) {
+      for (int st = 0; st < HD / 4; ++st) {
         const float bv = on ? wp[(4 * st + g4) * wstride] : 0.0f;
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(hs[r16 * PH + 4 * st + g4], bv, acc, 0, 0, 0);
       }
@@ -541,7 +507,7 @@ __global__ __launch_bounds__(256) void ppo_heads_fused_kernel(const float* hid, 
     const float zj = lg[row][j < A ? j : A - 1], val = lg[row][A];
     PpoSampleStats ss;
     ss.pg = ss.dv2 = ss.ent = ss.kl = 0.0f;
-    const float d = (HF_ABL & 2) ? zj * s_adv[row] : ppo_loss_lane(zj, j, A, s_act[row], val, s_olp[row], s_adv[row], s_tgt[row], clip_coef, ent_coef, vf_coef, invN, ss);
+    const float d = ppo_loss_lane(zj, j, A, s_act[row], val, s_olp[row], s_adv[row], s_tgt[row], clip_coef, ent_coef, vf_coef, invN, ss);
     dz[row][j] = live ? d : 0.0f;
     if (live) {
       dzv[(size_t)i * 32 + j] = d;
@@ -556,7 +522,6 @@ __global__ __launch_bounds__(256) void ppo_heads_fused_kernel(const float* hid, 
     for (int q = 0; q < 16; ++q) v += red[q][tid];
     partials[blockIdx.x * 4 + tid] = v;
   }
-  if (!(HF_ABL & 1))
 #pragma unroll
   for (int ti = 0; ti < NT; ++ti) {
     const int k = (wave * NT + ti) * 16 + r16;
@@ -565,7 +530,7 @@ __global__ __launch_bounds__(256) void ppo_heads_fused_kernel(const float* hid, 
     for (int st = 0; st < 8; ++st)
       if (st < nst) {
         const int jc = 4 * st + g4;
-        const float bv = (HF_ABL & 8) ? 0.0f : (jc < A ? wl[k * A + jc] : (jc == A ? wc[k] : 0.0f));
+        const float bv = jc < A ? wl[k * A + jc] : (jc == A ? wc[k] : 0.0f);
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(dz[r16][jc], bv, acc, 0, 0, 0);
       }
 #pragma unroll
@@ -575,10 +540,7 @@ __global__ __launch_bounds__(256) void ppo_heads_fused_kernel(const float* hid, 
     }
   }
 }
-#ifndef PPO_HEADS_FUSED
-#define PPO_HEADS_FUSED 1
-#endif
-bool ppo_heads_fusable(const NatureLayout& L) { return PPO_HEADS_FUSED && L.A + 1 <= 32 && (L.hid == 512 || L.hid == 256); }
+bool ppo_heads_fusable(const NatureLayout& L) { return L.A + 1 <= 32 && (L.hid == 512 || L.hid == 256); }
 void launch_ppo_heads_fused(const NatureLayout& L, const float* P, NatureWs& ws, int B, const int32_t* idx, const int32_t* actions,
                             const float* old_logprob, const float* adv, const float* target, float clip_coef, float ent_coef, float vf_coef,
                             float* partials, float* stats5, hipStream_t st) {
@@ -600,9 +562,6 @@ static void launch_heads_dgrad(const float* dzv, const float* Wa, const float* W
 
 // dense dgrad: dact3[m][j] = sum_n dhid[m][n] * Wd[j][n]; stored masked into the zero-bordered
 // dact3pad [S][11][11][64] (data at rows/cols 2..8).
-#ifndef EPI_ROWCTX
-#define EPI_ROWCTX 1   // dgrad epilogues through igemm.h's EpiRow (one pointer per tile and lane instead of a (frame, pixel) decode per stored value)
-#endif
 template <class TileT>
 struct DenseDgrad {
   using Tile = TileT;
@@ -633,50 +592,19 @@ struct DenseDgrad {
     const int pos = j >> 6, c = j & 63, hh = pos / 7, ww = pos - hh * 7;
     dact3pad[((size_t)(m * 11 + hh + 2) * 11 + ww + 2) * 64 + c] = on ? v : 0.0f;
   }
-  static constexpr bool ROWEPI = EPI_ROWCTX;   // consecutive frames m are 121*64 floats apart in dact3pad
+  static constexpr bool ROWEPI = true;   // consecutive frames m are 121*64 floats apart in dact3pad
   __device__ EpiRow epi_row(int m0, int j, int) const {
     const int jj = min(j, 3135), pos = jj >> 6, c = jj & 63, hh = pos / 7, ww = pos - hh * 7;
     return EpiRow{dact3pad + ((size_t)(m0 * 11 + hh + 2) * 11 + ww + 2) * 64 + c, j < 3136 ? M - m0 : 0, 7744u};
   }
 };
 
-// conv3 dgrad (3x3 s1): X = (s, ih, iw) over 9x9, Y = ci (64), r = (jh, jw, co), reads dact3pad,
-// writes masked into dact2pad [S][11][11][64] (data at 1..9).
-template <class TileT>
-struct Conv3Dgrad {
-  using Tile = TileT;
-  static constexpr bool A_RX = false, B_YR = true, BIAS_GRAD = false;
-  static constexpr int NCLS = 1;
-  const float* dypad; const float* W; const float* act2; float* dxpad; int M;  // M = S*81
-  __host__ __device__ int X() const { return M; }
-  __host__ __device__ int Y() const { return 64; }
-  __device__ void r_range(int, int& lo, int& hi) const { lo = 0; hi = 576; }
-  __device__ float4 load_a(int m, int r, int, int) const {
-    m = min(m, M - 1);
-    const int s = m / 81, p = m - s * 81, ih = p / 9, iw = p - ih * 9;
-    const int jh = r / 192, rem = r - jh * 192;
-    return *reinterpret_cast<const float4*>(dypad + ((size_t)(s * 11 + ih + jh) * 11 + iw) * 64 + rem);
-  }
-  __device__ float4 load_b(int r, int ci, int, int) const {  // B[(jh,jw,co..co+3)][ci] = W[2-jh][2-jw][ci][co..]
-    const int jh = r / 192, rem = r - jh * 192, jw = rem >> 6, co = rem & 63;
-    return *reinterpret_cast<const float4*>(W + ((size_t)((2 - jh) * 3 + (2 - jw)) * 64 + ci) * 64 + co);
-  }
-  __device__ void store(int m, int ci, float v, int, int) const {
-    if (m >= M) return;
-    const int s = m / 81, p = m - s * 81, ih = p / 9, iw = p - ih * 9;
-    const bool on = act2[(size_t)m * 64 + ci] > 0.0f;
-    dxpad[((size_t)(s * 11 + ih + 1) * 11 + iw + 1) * 64 + ci] = on ? v : 0.0f;
-  }
-};
-
-// conv3 dgrad, position-major: the frame-major form above multiplies all 9 taps for every output pixel although the 7x7 dY sits in a
+// conv3 dgrad (3x3 s1), position-major: reads dact3pad, writes masked into dact2pad [S][11][11][64] (data at 1..9); r = (jh, jw, co) over the
+// flipped taps.  A frame-major GEMM (x = (frame, 9x9 pixel)) multiplies all 9 taps for every output pixel although the 7x7 dY sits in a
 // zero border — only 49/81 of its flops touch data.  Here an x-tile is ONE output pixel (ih, iw) of BX consecutive frames, so the taps
 // that can be non-zero are the same for all its rows (jh in [max(0,2-ih), min(2,8-ih)], same for jw: 1, 2 or 3 per axis) and the block
 // reduces over exactly those (igemm.h KSKIP): 441 instead of 729 tap-tiles per frame tile.  Tiles are ordered frame-tile-major, pixel-minor, so
 // the 81 blocks that read the same BX frames of dY run back to back on one XCD.  Rows beyond S (last frame tile) load frame S-1 and store nothing.
-#ifndef POS_UNIFORM_TILE
-#define POS_UNIFORM_TILE 0   // 1: x-tile index through readfirstlane (wave-uniform decode on the SALU): conv3 dgrad 155 -> 153 us, conv2 dgrad 234 -> 250 (the intrinsic blocks the CSE of the decode across the 64 epilogue stores)
-#endif
 template <class TileT>
 struct Conv3DgradPos {
   using Tile = TileT;
@@ -699,8 +627,7 @@ struct Conv3DgradPos {
     return ((ctx & 3) + q) * 192 + (((ctx >> 2) & 3) + (t - q * njw)) * 64 + (rc & 63);
   }
   __device__ void decode(int x, int& s, int& ih, int& iw) const {
-    // every row a wave touches lies in its block's x-tile: the tile index (and the divisions / table read that decode it) is wave-uniform -> SALU
-    const int xt = POS_UNIFORM_TILE ? __builtin_amdgcn_readfirstlane(x / Tile::BX) : x / Tile::BX, tile = order[xt], t = tile / 81, p = tile - t * 81;
+    const int xt = x / Tile::BX, tile = order[xt], t = tile / 81, p = tile - t * 81;
     s = t * Tile::BX + (x - xt * Tile::BX); ih = p / 9; iw = p - ih * 9;
   }
   __device__ float4 load_a(int x, int r, int, int) const {
@@ -714,7 +641,7 @@ struct Conv3DgradPos {
     const int jh = r / 192, rem = r - jh * 192, jw = rem >> 6, co = rem & 63;
     return *reinterpret_cast<const float4*>(W + ((size_t)((2 - jh) * 3 + (2 - jw)) * 64 + ci) * 64 + co);
   }
-  static constexpr bool ROWPTR = (IGEMM_ROWPTR & 1) && 64 % TileT::BR == 0;   // a chunk stays inside one 64-wide tap; 189 -> 168 us
+  static constexpr bool ROWPTR = 64 % TileT::BR == 0;   // a chunk stays inside one 64-wide tap; 189 -> 168 us
   __device__ const float* a_origin() const { return dypad; }
   __device__ const float* b_origin() const { return W; }
   __device__ uint32_t a_off(int x, int rl, int) const {
@@ -749,7 +676,7 @@ struct Conv3DgradPos {
     if (s >= S) return;
     dxpad[((size_t)(s * 11 + ih + 1) * 11 + iw + 1) * 64 + ci] = on ? v : 0.0f;
   }
-  static constexpr bool ROWEPI = EPI_ROWCTX;   // the rows of an x-tile are consecutive frames at one pixel: 121*64 floats apart in dact2pad
+  static constexpr bool ROWEPI = true;   // the rows of an x-tile are consecutive frames at one pixel: 121*64 floats apart in dact2pad
   __device__ EpiRow epi_row(int xt0, int ci, int) const {
     int s, ih, iw;
     decode(xt0, s, ih, iw);
@@ -757,141 +684,11 @@ struct Conv3DgradPos {
   }
 };
 
-// conv2 dgrad (4x4 s2) as 4 parity classes (ph,pw): X = (s, ih', iw') over 10x10, Y = ci (32),
-// r = (jh, jw, co) with kh = ph + 2(1-jh), kw = pw + 2(1-jw); reads dact2pad, writes masked dact1.
-template <class TileT>
-struct Conv2Dgrad {
-  using Tile = TileT;
-  static constexpr int ORDER = IGEMM_ORDER_2;   // sibling tiles share an XCD's L2 (igemm.h)
-  static constexpr bool A_RX = false, B_YR = true, BIAS_GRAD = false;
-  static constexpr int NCLS = 4;
-  const float* dypad; const float* W; const float* act1; float* dact1; int M;  // M = S*100
-  __host__ __device__ int X() const { return M; }
-  __host__ __device__ int Y() const { return 32; }
-  __device__ void r_range(int, int& lo, int& hi) const { lo = 0; hi = 256; }
-  __device__ float4 load_a(int m, int r, int, int) const {
-    m = min(m, M - 1);
-    const int s = m / 100, p = m - s * 100, ihh = p / 10, iwh = p - ihh * 10;
-    const int jh = r >> 7, rem = r & 127;
-    return *reinterpret_cast<const float4*>(dypad + ((size_t)(s * 11 + ihh + jh) * 11 + iwh) * 64 + rem);
-  }
-  __device__ float4 load_b(int r, int ci, int, int cls) const {
-    const int jh = r >> 7, jw = (r >> 6) & 1, co = r & 63;
-    const int kh = (cls >> 1) + 2 * (1 - jh), kw = (cls & 1) + 2 * (1 - jw);
-    return *reinterpret_cast<const float4*>(W + ((size_t)(kh * 4 + kw) * 32 + ci) * 64 + co);
-  }
-  __device__ void store(int m, int ci, float v, int, int cls) const {
-    if (m >= M) return;
-    const int s = m / 100, p = m - s * 100, ihh = p / 10, iwh = p - ihh * 10;
-    const size_t pos = ((size_t)(s * 20 + 2 * ihh + (cls >> 1)) * 20 + 2 * iwh + (cls & 1)) * 32 + ci;
-    dact1[pos] = act1[pos] > 0.0f ? v : 0.0f;
-  }
-  static constexpr bool BITMASK = true;
-  const uint32_t* mask;   // act1 ReLU bits, one word per output pixel [S*400]
-  __device__ size_t pixel(int m, int cls) const {
-    const int s = m / 100, p = m - s * 100, ihh = p / 10, iwh = p - ihh * 10;
-    return (size_t)(s * 20 + 2 * ihh + (cls >> 1)) * 20 + 2 * iwh + (cls & 1);
-  }
-  __device__ uint32_t mask_word(int m, int, int cls) const { return mask[pixel(min(m, M - 1), cls)]; }
-  __device__ void store_on(int m, int ci, float v, bool on, int, int cls) const {
-    if (m >= M) return;
-    dact1[pixel(m, cls) * 32 + ci] = on ? v : 0.0f;
-  }
-};
-
-// conv2 dgrad, position-major (CONV2_DGRAD_POS, on: 316 -> 286 us under load, 268 with the two-chunk prefetch): an x-tile is ONE half-resolution pixel (ihh, iwh) of BX consecutive frames, so the
-// taps that fall on dY's zero border are the same for all its rows and are skipped per block (igemm.h KSKIP): ihh = 0 keeps only jh = 1,
-// ihh = 9 only jh = 0, likewise for iwh — 324 instead of 400 tap-tiles per class and frame tile.
-template <class TileT>
-struct Conv2DgradPos {
-  using Tile = TileT;
-  static constexpr int ORDER = IGEMM_ORDER_2;
-  static constexpr bool A_RX = false, B_YR = true, BIAS_GRAD = false, KSKIP = true, BITMASK = true;
-  static constexpr int NCLS = 4;
-  const float* dypad; const float* W; float* dact1; int S; const uint32_t* mask;
-  __host__ __device__ int X() const { return ((S + Tile::BX - 1) / Tile::BX) * 100 * Tile::BX; }
-  __host__ __device__ int Y() const { return 32; }
-  __device__ void r_range(int, int& lo, int& hi) const { lo = 0; hi = 256; }
-  __device__ int block_ctx(int x0, int) const {
-    const int p = (x0 / Tile::BX) % 100, ihh = p / 10, iwh = p - ihh * 10;
-    const int jh0 = ihh == 0 ? 1 : 0, jh1 = ihh == 9 ? 0 : 1, jw0 = iwh == 0 ? 1 : 0, jw1 = iwh == 9 ? 0 : 1;
-    const int njw = jw1 - jw0 + 1, nt = (jh1 - jh0 + 1) * njw;
-    return jh0 | (jw0 << 2) | (njw << 4) | (nt << 8);
-  }
-  __device__ int block_k(int ctx) const { return (ctx >> 8) * 64; }
-  __device__ int r_map(int ctx, int rc) const {
-    const int t = rc >> 6, njw = (ctx >> 4) & 15, q = t / njw;
-    return ((ctx & 3) + q) * 128 + (((ctx >> 2) & 3) + (t - q * njw)) * 64 + (rc & 63);
-  }
-  __device__ void decode(int x, int& s, int& ihh, int& iwh) const {
-    const int tile = POS_UNIFORM_TILE ? __builtin_amdgcn_readfirstlane(x / Tile::BX) : x / Tile::BX, t = tile / 100, p = tile - t * 100;
-    s = t * Tile::BX + (x - tile * Tile::BX); ihh = p / 10; iwh = p - ihh * 10;
-  }
-  __device__ float4 load_a(int x, int r, int, int) const {
-    int s, ihh, iwh;
-    decode(x, s, ihh, iwh);
-    s = min(s, S - 1);
-    const int jh = r >> 7, rem = r & 127;
-    return *reinterpret_cast<const float4*>(dypad + ((size_t)(s * 11 + ihh + jh) * 11 + iwh) * 64 + rem);
-  }
-  __device__ float4 load_b(int r, int ci, int, int cls) const {
-    const int jh = r >> 7, jw = (r >> 6) & 1, co = r & 63;
-    const int kh = (cls >> 1) + 2 * (1 - jh), kw = (cls & 1) + 2 * (1 - jw);
-    return *reinterpret_cast<const float4*>(W + ((size_t)(kh * 4 + kw) * 32 + ci) * 64 + co);
-  }
-  __device__ size_t pixel(int x, int cls, bool& ok) const {
-    int s, ihh, iwh;
-    decode(x, s, ihh, iwh);
-    ok = s < S;
-    return (size_t)(min(s, S - 1) * 20 + 2 * ihh + (cls >> 1)) * 20 + 2 * iwh + (cls & 1);
-  }
-  __device__ uint32_t mask_word(int x, int, int cls) const { bool ok; return mask[pixel(x, cls, ok)]; }
-  __device__ void store_on(int x, int ci, float v, bool on, int, int cls) const {
-    bool ok;
-    const size_t px = pixel(x, cls, ok);
-    if (ok) dact1[px * 32 + ci] = on ? v : 0.0f;
-  }
-  __device__ void store(int x, int ci, float v, int, int cls) const { store_on(x, ci, v, true, 0, cls); }
-};
-
-// conv2 dgrad with its four parity classes as ONE GEMM: the classes gather IDENTICAL rows of dY (A[p][(jh,jw,co)] does not depend on the
-// class), only the weights differ, so y = cls*32 + ci gives N = 128 with a [256][128] weight gather.  On fp32 MFMA this measured slower
-// than four N = 32 launches (MFMA-bound, and the big tile costs occupancy); the split-bf16 kernel is bound by tile STAGING, and here the A
-// tile is staged once for all four classes.  Used by backward_split only.
-template <class TileT>
-struct Conv2DgradMerged {
-  using Tile = TileT;
-  static constexpr bool A_RX = false, B_YR = true, BIAS_GRAD = false, BITMASK = true;
-  static constexpr int NCLS = 1;
-  const float* dypad; const float* W; float* dact1; int M; const uint32_t* mask;  // M = S*100
-  __host__ __device__ int X() const { return M; }
-  __host__ __device__ int Y() const { return 128; }
-  __device__ void r_range(int, int& lo, int& hi) const { lo = 0; hi = 256; }
-  __device__ float4 load_a(int m, int r, int, int) const {
-    m = min(m, M - 1);
-    const int s = m / 100, p = m - s * 100, ihh = p / 10, iwh = p - ihh * 10;
-    const int jh = r >> 7, rem = r & 127;
-    return *reinterpret_cast<const float4*>(dypad + ((size_t)(s * 11 + ihh + jh) * 11 + iwh) * 64 + rem);
-  }
-  __device__ float4 load_b(int r, int y, int, int) const {
-    const int cls = y >> 5, ci = y & 31;
-    const int jh = r >> 7, jw = (r >> 6) & 1, co = r & 63;
-    const int kh = (cls >> 1) + 2 * (1 - jh), kw = (cls & 1) + 2 * (1 - jw);
-    return *reinterpret_cast<const float4*>(W + ((size_t)(kh * 4 + kw) * 32 + ci) * 64 + co);
-  }
-  __device__ size_t pixel(int m, int cls) const {
-    const int s = m / 100, p = m - s * 100, ihh = p / 10, iwh = p - ihh * 10;
-    return (size_t)(s * 20 + 2 * ihh + (cls >> 1)) * 20 + 2 * iwh + (cls & 1);
-  }
-  __device__ uint32_t mask_word(int m, int y32, int) const { return mask[pixel(min(m, M - 1), y32 >> 5)]; }
-  __device__ void store_on(int m, int y, float v, bool on, int, int) const {
-    if (m >= M) return;
-    dact1[pixel(m, y >> 5) * 32 + (y & 31)] = on ? v : 0.0f;
-  }
-  __device__ void store(int m, int y, float v, int, int) const { store_on(m, y, v, true, 0, 0); }   // (BITMASK path is the one used)
-};
-
-// position-major AND class-merged conv2 dgrad: one half-resolution pixel of BX frames per x-tile, y = cls*32 + ci (N = 128), zero taps skipped
+// conv2 dgrad (4x4 s2): reads dact2pad, writes masked dact1.  The stride-2 transposed conv splits into 4 parity classes (ph, pw) of the input
+// pixel, each a 2x2-tap VALID correlation: r = (jh, jw, co) with kh = ph + 2(1-jh), kw = pw + 2(1-jw).  Position-major AND class-merged: an
+// x-tile is ONE half-resolution pixel (ihh, iwh) of BX consecutive frames — so the taps that fall on dY's zero border are the same for all
+// its rows and are skipped per block (igemm.h KSKIP: ihh = 0 keeps only jh = 1, ihh = 9 only jh = 0, likewise iwh; exactly the algorithmic
+// MACs) — and the four classes, which gather IDENTICAL rows of dY, are one GEMM with y = cls*32 + ci (N = 128).
 template <class TileT>
 struct Conv2DgradMergedPos {
   using Tile = TileT;
@@ -913,7 +710,7 @@ struct Conv2DgradMergedPos {
     return ((ctx & 3) + q) * 128 + (((ctx >> 2) & 3) + (t - q * njw)) * 64 + (rc & 63);
   }
   __device__ void decode(int x, int& s, int& ihh, int& iwh) const {
-    const int tile = POS_UNIFORM_TILE ? __builtin_amdgcn_readfirstlane(x / Tile::BX) : x / Tile::BX, t = tile / 100, p = tile - t * 100;
+    const int tile = x / Tile::BX, t = tile / 100, p = tile - t * 100;
     s = t * Tile::BX + (x - tile * Tile::BX); ihh = p / 10; iwh = p - ihh * 10;
   }
   __device__ float4 load_a(int x, int r, int, int) const {
@@ -929,24 +726,6 @@ struct Conv2DgradMergedPos {
     const int kh = (cls >> 1) + 2 * (1 - jh), kw = (cls & 1) + 2 * (1 - jw);
     return *reinterpret_cast<const float4*>(W + ((size_t)(kh * 4 + kw) * 32 + ci) * 64 + co);
   }
-  static constexpr bool ROWPTR = (IGEMM_ROWPTR & 4) && 64 % TileT::BR == 0;   // measured neutral (245 -> 250 us): off
-  __device__ const float* a_origin() const { return dypad; }
-  __device__ const float* b_origin() const { return W; }
-  __device__ uint32_t a_off(int x, int rl, int) const {
-    int s, ihh, iwh;
-    decode(x, s, ihh, iwh);
-    s = min(s, S - 1);
-    return (uint32_t)(((s * 11 + ihh) * 11 + iwh) * 64 + rl);
-  }
-  __device__ uint32_t a_chunk(int r0) const { return (uint32_t)((r0 >> 7) * 11 * 64 + (r0 & 127)); }
-  __device__ uint32_t b_off(int rl, int y, int) const {
-    const int cls = y >> 5, ci = y & 31;
-    return (uint32_t)((((cls >> 1) * 4 + (cls & 1)) * 32 + ci) * 64 + rl);
-  }
-  __device__ uint32_t b_chunk(int r0) const {
-    const int jh = r0 >> 7, jw = (r0 >> 6) & 1;
-    return (uint32_t)((8 * (1 - jh) + 2 * (1 - jw)) * 2048 + (r0 & 63));
-  }
   __device__ size_t pixel(int x, int cls, bool& ok) const {
     int s, ihh, iwh;
     decode(x, s, ihh, iwh);
@@ -960,7 +739,7 @@ struct Conv2DgradMergedPos {
     if (ok) dact1[px * 32 + (y & 31)] = on ? v : 0.0f;
   }
   __device__ void store(int x, int y, float v, int, int) const { store_on(x, y, v, true, 0, 0); }
-  static constexpr bool ROWEPI = EPI_ROWCTX;   // the rows of an x-tile are consecutive frames at one half-resolution pixel: 400*32 floats apart in dact1
+  static constexpr bool ROWEPI = true;   // the rows of an x-tile are consecutive frames at one half-resolution pixel: 400*32 floats apart in dact1
   __device__ EpiRow epi_row(int xt0, int y, int) const {
     int s, ihh, iwh;
     decode(xt0, s, ihh, iwh);
@@ -971,36 +750,9 @@ struct Conv2DgradMergedPos {
 
 // ---- weight gradients: C[x = k][y = co] = sum_{r = m} A[m][k] * dY[m][co], split over r into
 // partials [z][X][Y] (+ bias partial [z][Y]) reduced in ascending z (deterministic, ppo:30).
-template <class TileT>
-struct Conv1Wgrad {
-  using Tile = TileT;
-  static constexpr bool A_RX = true, B_YR = false, BIAS_GRAD = true;
-  static constexpr int NCLS = 1;
-  const uint8_t* obs; const int32_t* idx; const float* dy; float* part; float* bpart; int M, rps;
-  __host__ __device__ int X() const { return 256; }
-  __host__ __device__ int Y() const { return 32; }
-  __device__ void r_range(int z, int& lo, int& hi) const { lo = z * rps; hi = min(lo + rps, M); }
-  __device__ float4 load_a(int k, int m, int rhi, int) const {
-    const bool ok = m < rhi;
-    m = min(m, rhi - 1);
-    const int s = m / 400, p = m - s * 400, oh = p / 20, ow = p - oh * 20;
-    const int f = idx ? idx[s] : s;
-    const int c = k >> 6, kh = (k >> 3) & 7, kw = k & 7;
-    uint32_t w = *reinterpret_cast<const uint32_t*>(obs + (size_t)f * CBM_FRAME + c * 7056 + (oh * 4 + kh) * 84 + ow * 4 + kw);
-    w = ok ? w : 0u;
-    return make_float4(cbm_u8_unit(w & 255u), cbm_u8_unit((w >> 8) & 255u), cbm_u8_unit((w >> 16) & 255u), cbm_u8_unit(w >> 24));
-  }
-  __device__ float4 load_b(int m, int y, int rhi, int) const {
-    return f4sel(m < rhi, *reinterpret_cast<const float4*>(dy + (size_t)min(m, rhi - 1) * 32 + y));
-  }
-  __device__ void store(int k, int y, float v, int z, int) const { part[((size_t)z * 256 + k) * 32 + y] = v; }
-  __device__ void store_bias(int y, float v, int z) const { bpart[z * 32 + y] = v; }
-};
-
 template <class TileT, int KH, int KW, int ST, int CI, int CO, int IH, int IW, int OH, int OW, int PADO>
 struct ConvWgrad {  // dY lives in a zero-bordered [S][OH+2*PADO... = 11][11][CO] buffer
   using Tile = TileT;
-  static constexpr int ORDER = IGEMM_ORDER_1;   // sibling tiles share an XCD's L2 (igemm.h)
   static constexpr bool A_RX = true, B_YR = false, BIAS_GRAD = true;
   static constexpr int NCLS = 1;
   static constexpr int KX = KH * KW * CI;
@@ -1031,7 +783,6 @@ struct ConvWgrad {  // dY lives in a zero-bordered [S][OH+2*PADO... = 11][11][CO
 template <class TileT, bool PRE_RELU = false>
 struct MatWgrad {
   using Tile = TileT;
-  static constexpr int ORDER = IGEMM_ORDER_MW;   // sibling tiles share an XCD's L2 (igemm.h)
   static constexpr bool A_RX = true, B_YR = false, BIAS_GRAD = true;
   static constexpr int NCLS = 1;
   const float* A; const float* G; float* part; float* bpart; int M, XK, YN, ldg, rps;
@@ -1143,17 +894,10 @@ static int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static int round_up(int a, int b) { return ceil_div(a, b) * b; }
 
 // rows of the reduction handled by one split block (multiples of BR = 32)
-#ifndef RPS_C2_V
-#define RPS_C2_V 1280
-#endif
-#ifndef RPS_C3_V
-#define RPS_C3_V 1664
-#endif
-static const int RPS_C1 = 1600, RPS_C2 = RPS_C2_V, RPS_C3 = RPS_C3_V, RPS_HEADS = 128;
-#ifndef DENSE_WGRAD_NZ
-#define DENSE_WGRAD_NZ 10  // 128x256 tiles (2x4 accumulators per wave): 50 tiles x 10 reduction slices, 133 -> 124 us isolated (128x128 x 5: 133; 64x64 x 2: 170;
-                           // 5 / 8 / 15 slices of the 128x256 tile: 143 / 148 / 160)
-#endif
+static const int RPS_C2 = 1280, RPS_HEADS = 128;   // (RPS_C2: the im2col conv2 weight gradient of the split-bf16 mode)
+// dense weight gradient: 128x256 tiles (2x4 accumulators per wave): 50 tiles x 10 reduction slices, 133 -> 124 us isolated (128x128 x 5: 133;
+// 64x64 x 2: 170; 5 / 8 / 15 slices of the 128x256 tile: 143 / 148 / 160)
+static const int DENSE_WGRAD_NZ = 10;
 static int dense_wgrad_splits(int B) { return B >= 2048 ? DENSE_WGRAD_NZ : 1; }
 
 // offsets (floats) of the per-layer partial regions inside ws.wg_part / ws.bias_part.  Built ONCE from the workspace's maxB and used for every
@@ -1165,9 +909,9 @@ struct WgRegions {
   explicit WgRegions(int maxB) {
     nz[0] = ceil_div(maxB, RPS_HEADS);
     nz[1] = std::max(dense_wgrad_splits(maxB), 4);   // room for the split-bf16 mode's 4 splits
-    nz[2] = std::max(ceil_div(maxB * 49, RPS_C3), conv3_wgrad_frames_splits_bound(maxB));
+    nz[2] = conv3_wgrad_frames_splits_bound(maxB);
     nz[3] = std::max(ceil_div(maxB * 81, RPS_C2), conv2_wgrad_frames_splits_bound(maxB));
-    nz[4] = std::max(ceil_div(maxB * 400, RPS_C1), conv1_wgrad_frames_splits_bound(maxB));
+    nz[4] = conv1_wgrad_frames_splits_bound(maxB);
     const size_t wsz[5] = {512 * 32, 3136 * 512, 576 * 64, 512 * 64, 256 * 32}, bsz[5] = {32, 512, 64, 64, 32};
     size_t ow = 0, ob = 0;
     for (int i = 0; i < 5; ++i) { w[i] = ow; b[i] = ob; ow += (size_t)nz[i] * wsz[i]; ob += (size_t)nz[i] * bsz[i] + 64; }
@@ -1188,10 +932,8 @@ int nature_ws_alloc(NatureWs& ws, int maxB, bool with_grad, int dense_ksplit_sma
   if (with_grad) {
     if (dmalloc(&ws.dzv, B * 32) || dmalloc(&ws.dhid, B * 512) || dmalloc(&ws.dact3pad, B * 7744) || dmalloc(&ws.dact2pad, B * 7744) ||
         dmalloc(&ws.dact1, B * 12800)) return -1;
-#if IGEMM_USE_BITMASK
     if (hipMalloc((void**)&ws.mask1, B * 400 * 4) != hipSuccess || hipMalloc((void**)&ws.mask2, B * 81 * 2 * 4) != hipSuccess ||
         hipMalloc((void**)&ws.mask3, B * 49 * 2 * 4) != hipSuccess) { cbm_set_error("hipMalloc failed"); return -1; }
-#endif
     if (hipMalloc((void**)&ws.c3_order, ((B + 127) / 128) * 81 * sizeof(int32_t)) != hipSuccess) { cbm_set_error("hipMalloc failed"); return -1; }
     hipMemset(ws.dact3pad, 0, B * 7744 * sizeof(float));
     hipMemset(ws.dact2pad, 0, B * 7744 * sizeof(float));
@@ -1222,145 +964,69 @@ void nature_ws_free(NatureWs& ws) {
 }
 
 // ------------------------------------------------------------------------------------------ drivers
-template <class P>
-static inline void plaunch(NatureWs& ws, int kid, const P& p, int nz, hipStream_t st) {
-  CbmProf* pf = ws.prof;
-  const bool on = pf && (pf->sel == kid || pf->sel == CBM_PROF_ALL) && pf->n < CBM_PROF_MAX;
-  if (on) hipEventRecord(pf->ev[2 * pf->n], st);
-  igemm_launch(p, nz, st);
-  if (on) { hipEventRecord(pf->ev[2 * pf->n + 1], st); pf->kid[pf->n] = (int8_t)kid; pf->n += 1; }
+// every launch of the twelve GEMM kernel ids goes through prof_launch: optional HIP events around it (cbm_profile_select) and the name of the
+// kernel that was ACTUALLY launched for the id (cbm_profile_kernel_name: bench.py checks it against the kernel the PMC traffic was collected on)
+// demangled type of the problem functor, e.g. "DenseDgrad<IgemmTile<128, 128, 16, 2, 2, 2> >" — the same Itanium demangling a profiler prints
+// inside the kernel's name, defaults included (__PRETTY_FUNCTION__ would drop defaulted template arguments)
+template <class P> static const char* functor_name() {
+  static const std::string s = [] {
+    int status = 0;
+    char* d = abi::__cxa_demangle(typeid(P).name(), nullptr, nullptr, &status);
+    std::string r = status == 0 && d ? d : typeid(P).name();
+    free(d);
+    return r;
+  }();
+  return s.c_str();
 }
-// forward GEMMs: fp32 chain (default) or the bf16-MFMA variant when the context was created with forward_bf16
-#ifndef IGEMM_USE_DMA
-#define IGEMM_USE_DMA 1
-#endif
-template <class P>
-static inline void plaunch_fwd(NatureWs& ws, int kid, const P& p, int nz, hipStream_t st) {
-  if (!ws.bf16_fwd) {
-    if constexpr (P::DMA_OK) {
-      if (IGEMM_USE_DMA && p.X() >= 1024) {   // learner-size grids: tiles staged by the load unit (igemm_dma_kernel), same bits
-        CbmProf* pf = ws.prof;
-        const bool on = pf && (pf->sel == kid || pf->sel == CBM_PROF_ALL) && pf->n < CBM_PROF_MAX;
-        if (on) hipEventRecord(pf->ev[2 * pf->n], st);
-        igemm_dma_launch(p, nz, st);
-        if (on) { hipEventRecord(pf->ev[2 * pf->n + 1], st); pf->kid[pf->n] = (int8_t)kid; pf->n += 1; }
-        return;
-      }
-    }
-    plaunch(ws, kid, p, nz, st);
-    return;
-  }
-  CbmProf* pf = ws.prof;
-  const bool on = pf && (pf->sel == kid || pf->sel == CBM_PROF_ALL) && pf->n < CBM_PROF_MAX;
-  if (on) hipEventRecord(pf->ev[2 * pf->n], st);
-  igemm_bf16_launch(p, nz, st);
-  if (on) { hipEventRecord(pf->ev[2 * pf->n + 1], st); pf->kid[pf->n] = (int8_t)kid; pf->n += 1; }
-}
-// backward GEMM launch: fp32 MFMA (default) or, with cbm_config.backward_split = 2 / 3, the split-bf16 kernel
-#ifndef DGRAD_PF2
-#define DGRAD_PF2 0x7   // bit 0 dense, 1 conv3, 2 conv2 dgrad on the two-chunk prefetch kernel (igemm_pf2_kernel): 147 -> 143, 198 -> 190, 286 -> 268 us
-                        // (the frame-major conv2 dgrad did not profit, 318 -> 322; the position-major one with its shorter K loops does)
-#endif
-template <class P>
-static inline void plaunch_bwd(NatureWs& ws, int kid, const P& p, int nz, hipStream_t st) {
-  // (three-term weight gradients measured slower than fp32 MFMA: with backward_split = 3 only the input gradients are split)
-  if (ws.bwd_split == 0 || (P::A_RX && ws.bwd_split != 2)) {
-    if constexpr (!P::A_RX) {
-      const int bit = kid == K_DENSE_DGRAD ? 1 : (kid == K_CONV3_DGRAD ? 2 : (kid == K_CONV2_DGRAD ? 4 : 0));
-      if (DGRAD_PF2 & bit) {
-        CbmProf* pf = ws.prof;
-        const bool on = pf && (pf->sel == kid || pf->sel == CBM_PROF_ALL) && pf->n < CBM_PROF_MAX;
-        if (on) hipEventRecord(pf->ev[2 * pf->n], st);
-        igemm_pf2_launch(p, nz, st);
-        if (on) { hipEventRecord(pf->ev[2 * pf->n + 1], st); pf->kid[pf->n] = (int8_t)kid; pf->n += 1; }
-        return;
-      }
-    }
-    plaunch(ws, kid, p, nz, st);
-    return;
-  }
-  CbmProf* pf = ws.prof;
-  const bool on = pf && (pf->sel == kid || pf->sel == CBM_PROF_ALL) && pf->n < CBM_PROF_MAX;
-  if (on) hipEventRecord(pf->ev[2 * pf->n], st);
-  if constexpr (P::A_RX) igemm_split_wgrad_launch<P, 2>(p, nz, st);
-  else { if (ws.bwd_split == 2) igemm_split_launch<P, 2>(p, nz, st); else igemm_split_launch<P, 3>(p, nz, st); }
-  if (on) { hipEventRecord(pf->ev[2 * pf->n + 1], st); pf->kid[pf->n] = (int8_t)kid; pf->n += 1; }
-}
-#ifndef FWD_PF2
-#define FWD_PF2 3   // learner-size conv2 / conv3 forward on the two-chunk prefetch kernel (bit-identical to igemm_kernel)
-#endif
-#ifndef DENSE_FWD_PF2
-#define DENSE_FWD_PF2 0
-#define DENSE_FWD_TILE T64x64
-#endif
-#ifndef TILE_C2W
-#define TILE_C2W T64x64   // 256 vs 267 us under load for T128x64 (K chunks of 16), 274 for 64x64 with chunks of 16
-#endif
-#ifndef CONV2_SPLIT_POS
-#define CONV2_SPLIT_POS 1
-#endif
-#ifndef CONV2_FP32_MERGED_POS
-#define CONV2_FP32_MERGED_POS 1           // fp32 MFMA: the merged position-major form (N = 128, one dY tile for the four classes): 268 -> 246 us
-#define CONV2_FP32_MERGED_TILE T128x128k16
-#endif
-#ifndef CONV2_DGRAD_POS
-#define CONV2_DGRAD_POS 1
-#endif
-#ifndef CONV_WGRAD_FRAMES
-#define CONV_WGRAD_FRAMES 1   // conv2 / conv3 weight gradients by the frame-resident kernels of wgrad_frames.hip (0: im2col igemm)
-#endif
-#ifndef CONV3_DGRAD_POS
-#define CONV3_DGRAD_POS 1   // position-major conv3 dgrad with tap skipping
-#endif
 template <class F>
-static inline void plaunch_fn(NatureWs& ws, int kid, hipStream_t st, F&& launch) {
+static inline void prof_launch(NatureWs& ws, int kid, hipStream_t st, const char* kernel, const char* functor, F&& launch) {
   CbmProf* pf = ws.prof;
   const bool on = pf && (pf->sel == kid || pf->sel == CBM_PROF_ALL) && pf->n < CBM_PROF_MAX;
   if (on) hipEventRecord(pf->ev[2 * pf->n], st);
   launch();
-  if (on) { hipEventRecord(pf->ev[2 * pf->n + 1], st); pf->kid[pf->n] = (int8_t)kid; pf->n += 1; }
+  if (on) { hipEventRecord(pf->ev[2 * pf->n + 1], st); pf->kid[pf->n] = (int8_t)kid; pf->n += 1; pf->kernel[kid] = kernel; pf->functor[kid] = functor; }
 }
-using T128x32 = IgemmTile<128, 32, 32, 4, 1>;
-using T128x32k16 = IgemmTile<128, 32, 16, 4, 1>;
-using T256x32 = IgemmTile<256, 32, 32, 4, 1>;
-#ifndef BR_128x64
-#define BR_128x64 16
-#endif
-#ifndef BR_64x64
-#define BR_64x64 32
-#endif
-using T128x64 = IgemmTile<128, 64, BR_128x64, 2, 2>;
-using T128x128k16 = IgemmTile<128, 128, 16, 2, 2, 2>;   // split-bf16 merged conv2 dgrad
-using T128x128k32 = IgemmTile<128, 128, 32, 2, 2, 2>;
-using T128x256k16 = IgemmTile<128, 256, 16, 2, 2, 2>;   // 2x4 accumulators per wave
-using T256x128k16 = IgemmTile<256, 128, 16, 2, 2, 2>;
-using T256x64k16 = IgemmTile<256, 64, 16, 4, 1, 2>;
-using T64x64w3 = IgemmTile<64, 64, 32, 2, 2, 3>;        // 170-VGPR budget (3 waves per SIMD)
-using T64x64w2 = IgemmTile<64, 64, 32, 2, 2, 2>;     // 2x2 accumulators per wave on the N = 64 convs
-using T64x64 = IgemmTile<64, 64, BR_64x64, 2, 2>;
+template <class P>
+static inline void plaunch(NatureWs& ws, int kid, const P& p, int nz, hipStream_t st) {
+  prof_launch(ws, kid, st, "igemm_kernel", functor_name<P>(), [&] { igemm_launch(p, nz, st); });
+}
+template <class P>
+static inline void plaunch_pf2(NatureWs& ws, int kid, const P& p, int nz, hipStream_t st) {
+  prof_launch(ws, kid, st, "igemm_pf2_kernel", functor_name<P>(), [&] { igemm_pf2_launch(p, nz, st); });
+}
+// forward GEMMs: fp32 chain (default) or the bf16-MFMA variant when the context was created with forward_bf16
+template <class P>
+static inline void plaunch_fwd(NatureWs& ws, int kid, const P& p, int nz, hipStream_t st) {
+  if (ws.bf16_fwd) { prof_launch(ws, kid, st, "igemm_bf16_kernel", functor_name<P>(), [&] { igemm_bf16_launch(p, nz, st); }); return; }
+  if constexpr (P::DMA_OK) {
+    if (p.X() >= 1024) {   // learner-size grids: tiles staged by the load unit (igemm_dma_kernel), same bits
+      prof_launch(ws, kid, st, "igemm_dma_kernel", functor_name<P>(), [&] { igemm_dma_launch(p, nz, st); });
+      return;
+    }
+  }
+  plaunch(ws, kid, p, nz, st);
+}
+// backward GEMM launch: fp32 MFMA (default: input gradients on the two-chunk prefetch kernel igemm_pf2_kernel — dense 147 -> 143, conv3 198 -> 190,
+// conv2 286 -> 268 us) or, with cbm_config.backward_split = 2 / 3, the split-bf16 kernels
+template <class P>
+static inline void plaunch_bwd(NatureWs& ws, int kid, const P& p, int nz, hipStream_t st) {
+  // (three-term weight gradients measured slower than fp32 MFMA: with backward_split = 3 only the input gradients are split)
+  if (ws.bwd_split == 0 || (P::A_RX && ws.bwd_split != 2)) {
+    if constexpr (!P::A_RX) plaunch_pf2(ws, kid, p, nz, st);
+    else plaunch(ws, kid, p, nz, st);
+    return;
+  }
+  if constexpr (P::A_RX) prof_launch(ws, kid, st, "igemm_split_wgrad_kernel", functor_name<P>(), [&] { igemm_split_wgrad_launch<P, 2>(p, nz, st); });
+  else prof_launch(ws, kid, st, "igemm_split_kernel", functor_name<P>(), [&] { if (ws.bwd_split == 2) igemm_split_launch<P, 2>(p, nz, st); else igemm_split_launch<P, 3>(p, nz, st); });
+}
+using T128x32 = IgemmTile<128, 32, 32, 4, 1>;           // heads weight gradient
+using T128x32k16 = IgemmTile<128, 32, 16, 4, 1>;        // conv1 gather at 513..1023-frame batches
+using T128x64 = IgemmTile<128, 64, 16, 2, 2>;           // conv3 fwd (256x64 tiles, 2x2 accumulators per wave: 167 -> 163 us, conv2 fwd 218 -> 270: not taken), conv3 dgrad
+using T128x128k16 = IgemmTile<128, 128, 16, 2, 2, 2>;   // dense dgrad (143 -> 138 us), merged conv2 dgrad
+using T128x256k16 = IgemmTile<128, 256, 16, 2, 2, 2>;   // dense wgrad: 2x4 accumulators per wave
+using T64x64 = IgemmTile<64, 64, 32, 2, 2>;             // conv2 fwd, dense fwd
 // actor-step (small batch) tiles: half the K chunk = half the LDS, so a block still finds room on CUs mostly held by learner blocks
 using T64x64k16 = IgemmTile<64, 64, 16, 2, 2>;
-#ifndef ACTOR_K16
-#define ACTOR_K16 1
-#endif
-#ifndef TILE_C2D
-#define TILE_C2D T128x32k16
-#endif
-#ifndef TILE_C2F
-#define TILE_C2F T64x64
-#endif
-#ifndef TILE_C3W
-#define TILE_C3W T64x64
-#endif
-#ifndef TILE_DW
-#define TILE_DW T128x256k16
-#endif
-#ifndef TILE_DD
-#define TILE_DD T128x128k16   // 143 -> 138 us
-#endif
-#ifndef TILE_C3F
-#define TILE_C3F T128x64      // (256x64 tiles, 2x2 accumulators per wave: 167 -> 163 us, conv2 fwd 218 -> 270: not taken)
-#endif
 
 #include "resnet_layers.inc"
 
@@ -1368,43 +1034,25 @@ int nature_forward(const NatureLayout& L, const float* P, const uint8_t* obs, co
                     NatureWs& ws, hipStream_t st, const ActorSample* sample) {
   if (L.kind == CBM_NET_IMPALA_RESNET) { resnet_forward(L, P, obs, idx, B, dense_ksplit, ws, st); return 0; }
   const bool small = B <= 512;
-#ifndef ACTOR_S16
-#define ACTOR_S16 1   // actor-size forward passes (no ReLU masks wanted) on the 16x16x4 small-batch kernel (igemm.h igemm_s16_kernel), same bits
-#endif
+  // actor-size forward passes (no ReLU masks wanted) run on the 16x16x4 small-batch kernel (igemm.h igemm_s16_kernel), same bits
   // (forward_bf16 too: at <= 512 frames the bf16 MFMA buys nothing over these latency-bound launches, so the actor's behaviour logits stay fp32)
-  if (ACTOR_S16 && small && !ws.mask1 && !ws.prof) {
+  if (small && !ws.mask1 && !ws.prof) {
     Conv1Fwd<T64x64k16> p1{obs, idx, P + L.w[0], P + L.b[0], ws.act1, B * 400, nullptr};
-#ifndef ACTOR_C1_BX
-#define ACTOR_C1_BX 32
-#define ACTOR_C1_BR 32
-#endif
-    igemm_s16_launch<ACTOR_C1_BX, 32, ACTOR_C1_BR>(p1, 1, st);
+    igemm_s16_launch<32, 32, 32>(p1, 1, st);
     ConvFwd<T64x64k16, 4, 4, 2, 32, 64, 20, 20, 9, 9> p2{ws.act1, P + L.w[1], P + L.b[1], ws.act2, B * 81, nullptr};
-#ifndef ACTOR_CV
-#define ACTOR_CV 32, 32, 64
-#endif
-#ifndef ACTOR_DN
-#define ACTOR_DN 32, 32, 32
-#endif
-    igemm_s16_launch<ACTOR_CV>(p2, 1, st);
+    igemm_s16_launch<32, 32, 64>(p2, 1, st);
     ConvFwd<T64x64k16, 3, 3, 1, 64, 64, 9, 9, 7, 7> p3{ws.act2, P + L.w[2], P + L.b[2], ws.act3, B * 49, nullptr};
-    igemm_s16_launch<ACTOR_CV>(p3, 1, st);
+    igemm_s16_launch<32, 32, 64>(p3, 1, st);
     if (dense_ksplit > 1) {
       DenseFwd<T64x64k16, true> pd{ws.act3, P + L.w[3], P + L.b[3], ws.dense_part, B, 3136, 512, 3136 / dense_ksplit};
-      igemm_s16_launch<ACTOR_DN>(pd, dense_ksplit, st);
-#ifndef ACTOR_TAIL_FUSED
-#define ACTOR_TAIL_FUSED 1
-#endif
-#ifndef ACTOR_TAIL_ROWS
-#define ACTOR_TAIL_ROWS 1
-#endif
-      if (ACTOR_TAIL_ROWS && sample && L.A + 1 <= 32 && dense_ksplit <= 16) {
+      igemm_s16_launch<32, 32, 32>(pd, dense_ksplit, st);
+      if (sample && L.A + 1 <= 32 && dense_ksplit <= 16) {   // split-K reduction + heads + sampling (+ the device env's step) in one launch
         hipLaunchKernelGGL(actor_tail_rows_kernel<512>, dim3(B), dim3(256), 0, st, ws.dense_part, P + L.b[3], dense_ksplit, P + L.w[4], P + L.b[4],
                            P + L.w[5], P + L.b[5], B, L.A, *sample);
         return sample->env_obs_next ? 2 : 1;
       }
       hipLaunchKernelGGL(dense_reduce_kernel, dim3(ceil_div(B * 512, 256)), dim3(256), 0, st, ws.dense_part, P + L.b[3], ws.hid, B, 512, dense_ksplit);
-      if (ACTOR_TAIL_FUSED && sample && L.A + 1 <= 32) {
+      if (sample && L.A + 1 <= 32) {   // more than 16 K segments: reduce first, then the 16-row tail
         hipLaunchKernelGGL(actor_tail_kernel<512>, dim3(ceil_div(B, 16)), dim3(256), 0, st, ws.hid, P + L.w[4], P + L.b[4], P + L.w[5], P + L.b[5], B, L.A,
                            *sample);
         return 1;
@@ -1416,50 +1064,33 @@ int nature_forward(const NatureLayout& L, const float* P, const uint8_t* obs, co
     if (!ws.skip_heads) launch_heads_fwd(ws.hid, P + L.w[4], P + L.b[4], P + L.w[5], P + L.b[5], B, L.A, 512, ws.logits, ws.value, st);
     return 0;
   }
-#ifndef C1_FRAMES_MIN
-#define C1_FRAMES_MIN 513   // batches from this size on run conv1 on the frame-resident kernel (actor steps: the igemm gather)
-#endif
-  if (B < C1_FRAMES_MIN) {
-#if ACTOR_K16
+  if (B <= 512) {   // small batches WITH masks / profiling (parity tests): conv1 through the igemm gather; larger ones on the frame-resident kernel
     Conv1Fwd<T128x32k16> p{obs, idx, P + L.w[0], P + L.b[0], ws.act1, B * 400, ws.mask1};
-#else
-    Conv1Fwd<T128x32> p{obs, idx, P + L.w[0], P + L.b[0], ws.act1, B * 400, ws.mask1};
-#endif
     plaunch(ws, K_CONV1_FWD, p, 1, st);
   } else {
-    plaunch_fn(ws, K_CONV1_FWD, st, [&] { launch_conv1_fwd_frames(obs, idx, P + L.w[0], P + L.b[0], ws.act1, ws.mask1, B, st); });
+    prof_launch(ws, K_CONV1_FWD, st, "conv1_fwd_planes_kernel", "", [&] { launch_conv1_fwd_frames(obs, idx, P + L.w[0], P + L.b[0], ws.act1, ws.mask1, B, st); });
   }
   if (small) {
-#if ACTOR_K16
-    using TS = T64x64k16;
-#else
-    using TS = T64x64;
-#endif
-    ConvFwd<TS, 4, 4, 2, 32, 64, 20, 20, 9, 9> p2{ws.act1, P + L.w[1], P + L.b[1], ws.act2, B * 81, ws.mask2};
+    ConvFwd<T64x64k16, 4, 4, 2, 32, 64, 20, 20, 9, 9> p2{ws.act1, P + L.w[1], P + L.b[1], ws.act2, B * 81, ws.mask2};
     plaunch_fwd(ws, K_CONV2_FWD, p2, 1, st);
-    ConvFwd<TS, 3, 3, 1, 64, 64, 9, 9, 7, 7> p3{ws.act2, P + L.w[2], P + L.b[2], ws.act3, B * 49, ws.mask3};
+    ConvFwd<T64x64k16, 3, 3, 1, 64, 64, 9, 9, 7, 7> p3{ws.act2, P + L.w[2], P + L.b[2], ws.act3, B * 49, ws.mask3};
     plaunch_fwd(ws, K_CONV3_FWD, p3, 1, st);
-  } else {
-    ConvFwd<TILE_C2F, 4, 4, 2, 32, 64, 20, 20, 9, 9> p2{ws.act1, P + L.w[1], P + L.b[1], ws.act2, B * 81, ws.mask2};
-    if ((FWD_PF2 & 1) && !ws.bf16_fwd) plaunch_fn(ws, K_CONV2_FWD, st, [&] { igemm_pf2_launch(p2, 1, st); });
+  } else {   // learner-size conv2 / conv3 forward on the two-chunk prefetch kernel (bit-identical to igemm_kernel)
+    ConvFwd<T64x64, 4, 4, 2, 32, 64, 20, 20, 9, 9> p2{ws.act1, P + L.w[1], P + L.b[1], ws.act2, B * 81, ws.mask2};
+    if (!ws.bf16_fwd) plaunch_pf2(ws, K_CONV2_FWD, p2, 1, st);
     else plaunch_fwd(ws, K_CONV2_FWD, p2, 1, st);
-    ConvFwd<TILE_C3F, 3, 3, 1, 64, 64, 9, 9, 7, 7> p3{ws.act2, P + L.w[2], P + L.b[2], ws.act3, B * 49, ws.mask3};
-    if ((FWD_PF2 & 2) && !ws.bf16_fwd) plaunch_fn(ws, K_CONV3_FWD, st, [&] { igemm_pf2_launch(p3, 1, st); });
+    ConvFwd<T128x64, 3, 3, 1, 64, 64, 9, 9, 7, 7> p3{ws.act2, P + L.w[2], P + L.b[2], ws.act3, B * 49, ws.mask3};
+    if (!ws.bf16_fwd) plaunch_pf2(ws, K_CONV3_FWD, p3, 1, st);
     else plaunch_fwd(ws, K_CONV3_FWD, p3, 1, st);
   }
   if (dense_ksplit > 1) {
-#if ACTOR_K16
     DenseFwd<T64x64k16, true> pd{ws.act3, P + L.w[3], P + L.b[3], ws.dense_part, B, 3136, 512, 3136 / dense_ksplit};
-#else
-    DenseFwd<T64x64, true> pd{ws.act3, P + L.w[3], P + L.b[3], ws.dense_part, B, 3136, 512, 3136 / dense_ksplit};
-#endif
     plaunch_fwd(ws, K_DENSE_FWD, pd, dense_ksplit, st);
     hipLaunchKernelGGL(dense_reduce_kernel, dim3(ceil_div(B * 512, 256)), dim3(256), 0, st, ws.dense_part, P + L.b[3], ws.hid, B, 512,
                        dense_ksplit);
   } else {
-    DenseFwd<DENSE_FWD_TILE, false> pd{ws.act3, P + L.w[3], P + L.b[3], ws.hid, B, 3136, 512, 3136};
-    if (DENSE_FWD_PF2 && !ws.bf16_fwd && B >= 1024) plaunch_fn(ws, K_DENSE_FWD, st, [&] { igemm_pf2_launch(pd, 1, st); });
-    else plaunch_fwd(ws, K_DENSE_FWD, pd, 1, st);
+    DenseFwd<T64x64, false> pd{ws.act3, P + L.w[3], P + L.b[3], ws.hid, B, 3136, 512, 3136};
+    plaunch_fwd(ws, K_DENSE_FWD, pd, 1, st);
   }
   if (!ws.skip_heads) launch_heads_fwd(ws.hid, P + L.w[4], P + L.b[4], P + L.w[5], P + L.b[5], B, L.A, 512, ws.logits, ws.value, st);
   return false;
@@ -1511,7 +1142,7 @@ void nature_backward(const NatureLayout& L, const float* P, const uint8_t* obs, 
   }
   // dense: dgrad -> dact3pad, wgrad
   {
-    DenseDgrad<TILE_DD> pd{ws.dhid, P + L.w[3], ws.act3, ws.dact3pad, B, ws.mask3};
+    DenseDgrad<T128x128k16> pd{ws.dhid, P + L.w[3], ws.act3, ws.dact3pad, B, ws.mask3};
     plaunch_bwd(ws, K_DENSE_DGRAD, pd, 1, st);
     // split-bf16 mode: the staging of a tile is the bottleneck, so it wants the bigger 128x64 tile (and more splits to fill the chip)
     const int nz = ws.bwd_split == 2 ? (B >= 2048 ? 4 : 1) : dense_wgrad_splits(B);
@@ -1521,7 +1152,7 @@ void nature_backward(const NatureLayout& L, const float* P, const uint8_t* obs, 
       MatWgrad<T128x64> pw{ws.act3, ws.dhid, wp + rg.w[1], bp + rg.b[1], B, 3136, 512, 512, rps};
       plaunch_bwd(ws, K_DENSE_WGRAD, pw, nz, st);
     } else {
-      MatWgrad<TILE_DW> pw{ws.act3, ws.dhid, wp + rg.w[1], bp + rg.b[1], B, 3136, 512, 512, rps};
+      MatWgrad<T128x256k16> pw{ws.act3, ws.dhid, wp + rg.w[1], bp + rg.b[1], B, 3136, 512, 512, rps};
       plaunch(ws, K_DENSE_WGRAD, pw, nz, st);
     }
     tail_red.add(wp + rg.w[1], nz, 3136 * 512, 512, 0, grads + L.w[3], nullptr);
@@ -1529,70 +1160,44 @@ void nature_backward(const NatureLayout& L, const float* P, const uint8_t* obs, 
     tail_red.launch(st);
   }
   if (ws.tail_ev) hipEventRecord(ws.tail_ev, st);   // 95 % of the flat gradient is final here: its all-reduce can overlap the conv backward
-  // conv3: dgrad -> dact2pad, wgrad
+  // conv3: dgrad -> dact2pad (position-major with tap skipping), wgrad
   {
-#if CONV3_DGRAD_POS
     conv3_order_build(ws, B, T128x64::BX, st);
     Conv3DgradPos<T128x64> pd{ws.dact3pad, P + L.w[2], ws.act2, ws.dact2pad, B, ws.c3_order, ws.mask2};
-#else
-    Conv3Dgrad<T128x64> pd{ws.dact3pad, P + L.w[2], ws.act2, ws.dact2pad, B * 81};
-#endif
     plaunch_bwd(ws, K_CONV3_DGRAD, pd, 1, st);
     // frame-resident kernel (wgrad_frames.hip): the whole 576x64 gradient in the block's accumulators, act2 / dY frames copied once into LDS
     // (fp32 MFMA also in split mode: the split weight-gradient kernel measured slower than the im2col fp32 one already)
-#if CONV_WGRAD_FRAMES
     const int nz = conv3_wgrad_frames_splits(B);
     fits(2, nz);
-    plaunch_fn(ws, K_CONV3_WGRAD, st, [&] { launch_conv3_wgrad_frames(ws.act2, ws.dact3pad, wp + rg.w[2], bp + rg.b[2], B, st); });
-#else
-    const int M = B * 49, nz = ceil_div(M, RPS_C3);
-    fits(2, nz);
-    ConvWgrad<TILE_C3W, 3, 3, 1, 64, 64, 9, 9, 7, 7, 2> pw{ws.act2, ws.dact3pad, wp + rg.w[2], bp + rg.b[2], M, RPS_C3};
-    plaunch(ws, K_CONV3_WGRAD, pw, nz, st);
-#endif
+    prof_launch(ws, K_CONV3_WGRAD, st, "conv3_wgrad_frames_kernel", "", [&] { launch_conv3_wgrad_frames(ws.act2, ws.dact3pad, wp + rg.w[2], bp + rg.b[2], B, st); });
     conv_red.add(wp + rg.w[2], nz, 576 * 64, 64, 0, grads + L.w[2], nullptr);
     conv_red.add(bp + rg.b[2], nz, 64, 64, 0, grads + L.b[2], nullptr);
   }
-  // conv2: dgrad -> dact1, wgrad
+  // conv2: dgrad -> dact1 (merged position-major form, N = 128, one dY tile for the four classes: 268 -> 246 us), wgrad
   {
-    if (ws.bwd_split && IGEMM_USE_BITMASK) {
-#if CONV2_SPLIT_POS
-      Conv2DgradMergedPos<T128x128k16> pd{ws.dact2pad, P + L.w[1], ws.dact1, B, ws.mask1};
-#else
-      Conv2DgradMerged<T128x128k16> pd{ws.dact2pad, P + L.w[1], ws.dact1, B * 100, ws.mask1};
-#endif
-      plaunch_bwd(ws, K_CONV2_DGRAD, pd, 1, st);
-    } else if (CONV2_FP32_MERGED_POS && IGEMM_USE_BITMASK) {
-      Conv2DgradMergedPos<CONV2_FP32_MERGED_TILE> pd{ws.dact2pad, P + L.w[1], ws.dact1, B, ws.mask1};
-      plaunch_bwd(ws, K_CONV2_DGRAD, pd, 1, st);
-    } else if (CONV2_DGRAD_POS && IGEMM_USE_BITMASK) {
-      Conv2DgradPos<TILE_C2D> pd{ws.dact2pad, P + L.w[1], ws.dact1, B, ws.mask1};
-      plaunch_bwd(ws, K_CONV2_DGRAD, pd, 1, st);
-    } else {
-      Conv2Dgrad<TILE_C2D> pd{ws.dact2pad, P + L.w[1], ws.act1, ws.dact1, B * 100, ws.mask1};
-      plaunch_bwd(ws, K_CONV2_DGRAD, pd, 1, st);
-    }
-    const int M = B * 81;
-    int nz = ceil_div(M, RPS_C2);
-    if (CONV_WGRAD_FRAMES && ws.bwd_split != 2) nz = conv2_wgrad_frames_splits(B);
-    fits(3, nz);
-    if (CONV_WGRAD_FRAMES && ws.bwd_split != 2) {
-      plaunch_fn(ws, K_CONV2_WGRAD, st, [&] { launch_conv2_wgrad_frames(ws.act1, ws.dact2pad, wp + rg.w[3], bp + rg.b[3], B, st); });
-    } else if (ws.bwd_split == 2) {   // the split kernel wants the bigger tile (staging-bound)
+    Conv2DgradMergedPos<T128x128k16> pd{ws.dact2pad, P + L.w[1], ws.dact1, B, ws.mask1};
+    plaunch_bwd(ws, K_CONV2_DGRAD, pd, 1, st);
+    if (ws.bwd_split != 2) {   // frame-resident kernel
+      const int nz = conv2_wgrad_frames_splits(B);
+      fits(3, nz);
+      prof_launch(ws, K_CONV2_WGRAD, st, "conv2_wgrad_frames_kernel", "", [&] { launch_conv2_wgrad_frames(ws.act1, ws.dact2pad, wp + rg.w[3], bp + rg.b[3], B, st); });
+      conv_red.add(wp + rg.w[3], nz, 512 * 64, 64, 0, grads + L.w[1], nullptr);
+      conv_red.add(bp + rg.b[3], nz, 64, 64, 0, grads + L.b[1], nullptr);
+    } else {                   // split-bf16: im2col GEMM; the split kernel wants the bigger tile (staging-bound)
+      const int M = B * 81, nz = ceil_div(M, RPS_C2);
+      fits(3, nz);
       ConvWgrad<T128x64, 4, 4, 2, 32, 64, 20, 20, 9, 9, 1> pw{ws.act1, ws.dact2pad, wp + rg.w[3], bp + rg.b[3], M, RPS_C2};
       plaunch_bwd(ws, K_CONV2_WGRAD, pw, nz, st);
-    } else {
-      ConvWgrad<TILE_C2W, 4, 4, 2, 32, 64, 20, 20, 9, 9, 1> pw{ws.act1, ws.dact2pad, wp + rg.w[3], bp + rg.b[3], M, RPS_C2};
-      plaunch(ws, K_CONV2_WGRAD, pw, nz, st);
+      conv_red.add(wp + rg.w[3], nz, 512 * 64, 64, 0, grads + L.w[1], nullptr);
+      conv_red.add(bp + rg.b[3], nz, 64, 64, 0, grads + L.b[1], nullptr);
     }
-    conv_red.add(wp + rg.w[3], nz, 512 * 64, 64, 0, grads + L.w[1], nullptr);
-    conv_red.add(bp + rg.b[3], nz, 64, 64, 0, grads + L.b[1], nullptr);
   }
   // conv1: wgrad only (frames need no gradient); frame-resident kernel, pixels as integers, 1/255 in the reduce
   {
     const int nz = conv1_wgrad_frames_splits(B);
     fits(4, nz);
-    plaunch_fn(ws, K_CONV1_WGRAD, st, [&] { launch_conv1_wgrad_frames(obs, idx, ws.dact1, wp + rg.w[4], bp + rg.b[4], B, st, ws.bwd_split == 2); });
+    prof_launch(ws, K_CONV1_WGRAD, st, ws.bwd_split == 2 ? "conv1_wgrad_frames_split_kernel" : "conv1_wgrad_frames_kernel", "",
+                [&] { launch_conv1_wgrad_frames(obs, idx, ws.dact1, wp + rg.w[4], bp + rg.b[4], B, st, ws.bwd_split == 2); });
     conv_red.add(wp + rg.w[4], nz, 256 * 32, 32, 1, grads + L.w[0], nullptr, 1.0f / 255.0f);
     conv_red.add(bp + rg.b[4], nz, 32, 32, 0, grads + L.b[0], nullptr);
     conv_red.launch(st);

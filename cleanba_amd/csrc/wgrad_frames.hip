@@ -126,9 +126,7 @@ __global__ __launch_bounds__(256, 1) void conv2_wgrad_frames_kernel(const float*
   }
 }
 
-#ifndef C2W_BLOCKS
-#define C2W_BLOCKS 256
-#endif
+static const int C2W_BLOCKS = 256;   // one block per CU
 int conv2_wgrad_frames_splits(int S) {
   int blocks = C2W_BLOCKS;
   if (S < blocks) blocks = S;
@@ -224,9 +222,7 @@ __global__ __launch_bounds__(256, 2) void conv3_wgrad_frames_kernel(const float*
   }
 }
 
-#ifndef C3W_BLOCKS
-#define C3W_BLOCKS 256   // one block per CU (two fit): 146 -> 127 us and half the partials of 512
-#endif
+static const int C3W_BLOCKS = 256;   // one block per CU (two fit): 146 -> 127 us and half the partials of 512
 int conv3_wgrad_frames_splits(int S) {
   int blocks = C3W_BLOCKS;
   if (S < blocks) blocks = S;

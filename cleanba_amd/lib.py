@@ -55,7 +55,7 @@ SYMBOLS = [
     "cbm_synth_env_step_host_ids", "cbm_synth_env_step_host_to", "cbm_synth_env_render_host", "cbm_learner_grad_tail_offset", "cbm_vtrace", "cbm_comm_init_loopback",
     "cbm_comm_load", "cbm_comm_unique_id", "cbm_comm_init", "cbm_comm_size", "cbm_comm_allreduce_f64", "cbm_comm_barrier",
     "cbm_learner_allreduce_grads", "cbm_comm_profile", "cbm_comm_profile_read", "cbm_ipc_export", "cbm_ipc_open", "cbm_ipc_close",
-    "cbm_host_register", "cbm_host_unregister", "cbm_actor_ship_shard", "cbm_io_sync", "cbm_params_push", "cbm_params_mark_published", "cbm_ctx_abort", "cbm_profile_read_all",
+    "cbm_host_register", "cbm_host_unregister", "cbm_actor_ship_shard", "cbm_io_sync", "cbm_params_push", "cbm_params_mark_published", "cbm_ctx_abort", "cbm_profile_read_all", "cbm_profile_kernel_name",
 ]
 
 COMM_LEARNERS, COMM_WORLD = 0, 1
@@ -301,6 +301,12 @@ class Context:
         ms, n = C.c_double(), C.c_int32()
         _chk(self.lib.cbm_profile_read(self.h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def profile_kernel_name(self, kernel_id):
+        """'<kernel symbol> <problem functor>' of the kernel launched for `kernel_id` the last time it was timed ('' if never)."""
+        buf = C.create_string_buffer(512)
+        _chk(self.lib.cbm_profile_kernel_name(self.h, int(kernel_id), buf, 512))
+        return buf.value.decode()
 
     def profile_read_all(self, n_ids=12):
         ms, n = np.zeros(n_ids, np.float64), np.zeros(n_ids, np.int32)

@@ -252,6 +252,9 @@ int cbm_rmsprop_step(cbm_ctx* ctx, float* p, const float* g, float* nu, int64_t 
 int cbm_profile_select(cbm_ctx* ctx, int32_t kernel_id);
 int cbm_profile_read(cbm_ctx* ctx, double* total_ms, int32_t* count);
 int cbm_profile_read_all(cbm_ctx* ctx, double* total_ms, int32_t* count, int32_t n_ids);   /* per-id totals after cbm_profile_select(CBM_PROFILE_ALL) */
+/* the kernel that was LAUNCHED for `kernel_id` the last time it was timed, as "<kernel symbol> <problem functor type>" (empty string: never
+ * timed).  bench.py holds profiles/pmc_traffic.json's per-kernel HBM traffic to this name and reports null when they differ. */
+int cbm_profile_kernel_name(cbm_ctx* ctx, int32_t kernel_id, char* buf, int32_t buf_len);
 
 /* ---- synthetic Atari-shaped environment (stands in for envpool.make, ppo:128-139) ------- */
 typedef struct {

@@ -14,6 +14,11 @@ import cleanba_amd.model as M  # noqa: E402
 import cleanba_amd.prng as prng  # noqa: E402
 from bench import KERNELS  # noqa: E402
 
+names_out = None
+if "--names-out" in sys.argv:      # {id: "<kernel symbol> <functor type>"} of what the library launched (for tools/pmc_traffic.py)
+    i = sys.argv.index("--names-out")
+    names_out = sys.argv[i + 1]
+    del sys.argv[i:i + 2]
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 iters = int(args[0]) if args else 4
 plain = "--plain" in sys.argv
@@ -39,6 +44,13 @@ for i in range(iters):
     ctx.learner_minibatch_grad(0, i % 4)
 ctx.sync()
 ms = (time.time() - t0) / iters * 1e3
+if names_out:
+    import json
+    ctx.profile_select(-2)
+    ctx.learner_minibatch_grad(0, 0)
+    ctx.profile_read_all(12)
+    ctx.profile_select(-1)
+    json.dump({str(k): ctx.profile_kernel_name(k) for k in KERNELS}, open(names_out, "w"), indent=1)
 print(f"minibatch fwd+loss+bwd: {ms:.3f} ms  ({sum(f for _, f in KERNELS.values()) / ms / 1e9:.1f} TFLOP/s over all GEMM flops)")
 if not plain:
     tot = 0.0

@@ -14,7 +14,8 @@ pass fetch "FETCH_SIZE"
 pass write "WRITE_SIZE"
 db() { find $out/pmc_$1 -name "*.db" | head -1; }
 cd $R
+python tools/microbench.py 1 --plain --names-out $out/kernel_names.json > /dev/null 2>&1
 python tools/pmc_report.py $(db sq) $(db lds) $(db fetch) $(db write) > $out/pmc_summary.md 2>&1
-python tools/pmc_traffic.py $(db fetch) $(db write) > $out/pmc_traffic.json 2>$out/pmc_traffic.err
+python tools/pmc_traffic.py $(db fetch) $(db write) $out/kernel_names.json > $out/pmc_traffic.json 2>$out/pmc_traffic.err
 rm -rf $out/trace $out/pmc_sq $out/pmc_lds $out/pmc_fetch $out/pmc_write   # the .db files are tens of MB; the summaries are what gets committed
 head -30 $out/kernel_stats.md | cut -c1-150; cat $out/pmc_summary.md | cut -c1-170 | tail -22; head -c 600 $out/pmc_traffic.json

@@ -1,7 +1,10 @@
 #!/usr/bin/env python
 """profiles/pmc_traffic.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs as MI355X_MICROARCH.md prescribes).
-usage: pmc_traffic.py <fetch results.db> <write results.db> > traffic.json
-traffic_bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) KiB * 1024 — the gfx950 FETCH_SIZE x2 correction."""
+usage: pmc_traffic.py <fetch results.db> <write results.db> [names.json] > traffic.json
+traffic_bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) KiB * 1024 — the gfx950 FETCH_SIZE x2 correction.
+names.json (tools/microbench.py --names-out): {id: "<kernel symbol> <functor type>"} as the LIBRARY reports what it launched for every id
+(cbm_profile_kernel_name); with it the id <-> kernel mapping is the library's own, and every entry carries the full profiled kernel name and the
+git revision so that bench.py can refuse numbers that belong to another kernel."""
 import json
 import sqlite3
 import sys
@@ -24,11 +27,34 @@ def avg(path, counter):
     return {n: sum(v) / len(v) for n, v in acc.items()}
 
 
+def git_rev():
+    import os
+    import subprocess
+    try:
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        return subprocess.check_output(["git", "-C", root, "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
+    except Exception:  # noqa: BLE001  (the GPU box's snapshot has no .git: pmc_collect.sh passes GIT_REV)
+        return os.environ.get("GIT_REV", "unknown")
+
+
+def same_kernel(launched, full):
+    full = full.replace(" ", "")
+    return bool(launched) and all(part.replace(" ", "") in full for part in launched.split(" ", 1))
+
+
 fetch, write = avg(sys.argv[1], "FETCH_SIZE"), avg(sys.argv[2], "WRITE_SIZE")
+names = json.load(open(sys.argv[3])) if len(sys.argv) > 3 else None
+rev = git_rev()
 out = {}
 for name, f in fetch.items():
-    for pat, kid in IDS:
-        if pat in name and name in write and str(kid) not in out:
-            out[str(kid)] = {"kernel": short(name), "FETCH_SIZE_KiB_raw": round(f, 1), "WRITE_SIZE_KiB_raw": round(write[name], 1),
-                             "traffic_bytes": int((2 * f + write[name]) * 1024)}
+    if name not in write:
+        continue
+    if names is not None:
+        kids = [int(k) for k, launched in names.items() if same_kernel(launched, name)]
+    else:
+        kids = [kid for pat, kid in IDS if pat in name][:1]
+    for kid in kids:
+        if str(kid) not in out:
+            out[str(kid)] = {"kernel": short(name), "kernel_full": name, "git": rev, "FETCH_SIZE_KiB_raw": round(f, 1),
+                             "WRITE_SIZE_KiB_raw": round(write[name], 1), "traffic_bytes": int((2 * f + write[name]) * 1024)}
 print(json.dumps(dict(sorted(out.items(), key=lambda kv: int(kv[0]))), indent=1))
