@@ -206,3 +206,90 @@ def test_full_ppo_update_e120_t128_matches_oracle_engine(oracle):
     finally:
         ctx.close()
         eng.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------- IMPALA-ResNet at learner size
+# The reference's default torso (ppo:149-189) through the same bars as the Nature-CNN above: the slab convolutions with their strip / frame-pair
+# geometries, the fused conv0 + max-pool, the persistent weight-gradient blocks and the pool backward folded into the conv0 weight gradient
+# only take their learner-size paths (thousands of strips, every persistent block busy) at minibatch scale.
+def _check_resnet_grads(oracle, g, grads_o, bar=1e-5):
+    worst = {}
+    for name, (o, shp) in oracle.resnet_layout(A).items():
+        n = int(np.prod(shp))
+        ref = grads_o[o:o + n]
+        err = np.abs(g[o:o + n] - ref).max() / max(np.abs(ref).max(), 1e-7)
+        worst[name] = err
+        assert np.isfinite(g[o:o + n]).all() and err <= bar, (name, err)
+    return worst
+
+
+def test_resnet_ppo_minibatch_3840_of_15360_shuffled(oracle):
+    from test_oracle_resnet import make_resnet_params
+    _all_cores(oracle)
+    cfg = L.default_config(L.ALGO_PPO)
+    cfg.network = L.NET_IMPALA_RESNET
+    cfg.actor_dense_ksplit = 11
+    cfg.local_num_envs, cfg.num_actor_slots, cfg.num_steps = E, 1, T
+    ctx = L.Context(cfg)
+    try:
+        rng = np.random.default_rng(301)
+        pool = make_frames(E * T, 302)
+        P = make_resnet_params(oracle, 303)
+        idx = rng.permutation(E * T)[:MB].astype(np.int32)
+        actions = rng.integers(0, A, MB).astype(np.int32)
+        old_lp = (-np.log(A) + 0.2 * rng.normal(size=MB)).astype(np.float32)
+        adv = rng.normal(size=MB).astype(np.float32)
+        tgt = rng.normal(size=MB).astype(np.float32)
+        d = [L.DevBuf(ctx, x) for x in (P, pool, idx, actions, old_lp, adv, tgt)]
+        dS = L.DevBuf(ctx, nbytes=32, dtype=np.float32)
+        dG = L.DevBuf(ctx, nbytes=P.size * 4, dtype=np.float32)
+        dLg = L.DevBuf(ctx, nbytes=MB * A * 4, dtype=np.float32, shape=(MB, A))
+        dV = L.DevBuf(ctx, nbytes=MB * 4, dtype=np.float32)
+        L._chk(ctx.lib.cbm_ppo_loss_grad(ctx.h, L._p(d[0].ptr), L._p(d[1].ptr), L._p(d[2].ptr), MB, L._p(d[3].ptr), L._p(d[4].ptr),
+                                         L._p(d[5].ptr), L._p(d[6].ptr), L._p(dS.ptr), L._p(dG.ptr), L._p(dLg.ptr), L._p(dV.ptr)))
+        logits_o, value_o, acts = oracle.resnet_forward(P, A, pool, idx=idx, save_acts=True)      # 3840 x 1.84 MB of activations on the host
+        stats_o, dlog, dval = oracle.ppo_loss_head(logits_o, value_o, actions, old_lp, adv, tgt)
+        grads_o = oracle.resnet_backward(P, A, pool, idx, acts, dlog, dval)
+        del acts
+        assert (bits(dLg.download()) == bits(logits_o)).all(), "learner-size ResNet forward must be bit-exact against the oracle chain"
+        assert (bits(dV.download()) == bits(value_o)).all()
+        np.testing.assert_allclose(dS.download()[:5], stats_o, rtol=1e-5, atol=1e-6)
+        worst = _check_resnet_grads(oracle, dG.download(), grads_o)
+        print("resnet ppo 3840: worst per-tensor gradient error / max|ref|:", {k: f"{v:.1e}" for k, v in sorted(worst.items(), key=lambda kv: -kv[1])[:6]})
+    finally:
+        ctx.close()
+
+
+def test_resnet_impala_minibatch_21x30(oracle):
+    """IMPALA's default learner minibatch (T = 20, 120 envs / 4 minibatches) on the ResNet torso: V-trace loss head + the whole backward."""
+    from test_oracle_resnet import make_resnet_params
+    _all_cores(oracle)
+    T1, Bm = 21, 30
+    cfg = L.default_config(L.ALGO_IMPALA)
+    cfg.network = L.NET_IMPALA_RESNET
+    cfg.actor_dense_ksplit = 11
+    cfg.local_num_envs, cfg.num_actor_slots, cfg.num_steps, cfg.num_minibatches = 4 * Bm, 1, T1 - 1, 4
+    ctx = L.Context(cfg)
+    try:
+        rng = np.random.default_rng(311)
+        N = T1 * Bm
+        P = make_resnet_params(oracle, 312)
+        obs = make_frames(N, 313)
+        mu = rng.normal(0, 0.3, size=(T1, Bm, A)).astype(np.float32)
+        actions = rng.integers(0, A, (T1, Bm)).astype(np.int32)
+        rewards = (rng.random((T1, Bm)) < 0.3).astype(np.float32)
+        dones = (rng.random((T1, Bm)) < 0.05).astype(np.uint8)
+        first = (rng.random((T1, Bm)) < 0.05).astype(np.uint8)
+        d = [L.DevBuf(ctx, x) for x in (P, obs, mu, actions, rewards, dones, first)]
+        dS = L.DevBuf(ctx, nbytes=32, dtype=np.float32)
+        dG = L.DevBuf(ctx, nbytes=P.size * 4, dtype=np.float32)
+        L._chk(ctx.lib.cbm_impala_loss_grad(ctx.h, L._p(d[0].ptr), L._p(d[1].ptr), None, T1, Bm, L._p(d[2].ptr), L._p(d[3].ptr),
+                                            L._p(d[4].ptr), L._p(d[5].ptr), L._p(d[6].ptr), L._p(dS.ptr), L._p(dG.ptr)))
+        logits_o, value_o, acts = oracle.resnet_forward(P, A, obs, save_acts=True)      # (the pure-function entry runs the dense layer as one K segment)
+        stats_o, dlog, dval = oracle.impala_loss_head(logits_o.reshape(T1, Bm, A), value_o.reshape(T1, Bm), mu, actions, rewards, dones, first)
+        grads_o = oracle.resnet_backward(P, A, obs, None, acts, dlog.reshape(N, A), dval.reshape(N))
+        np.testing.assert_allclose(dS.download()[:4], stats_o, rtol=1e-5, atol=1e-5)
+        worst = _check_resnet_grads(oracle, dG.download(), grads_o)
+        print("resnet impala 21x30: worst per-tensor gradient error / max|ref|:", {k: f"{v:.1e}" for k, v in sorted(worst.items(), key=lambda kv: -kv[1])[:6]})
+    finally:
+        ctx.close()
