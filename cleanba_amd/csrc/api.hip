@@ -147,6 +147,8 @@ static int ctx_create_impl(const cbm_config* cfg, cbm_ctx** out, cbm_ctx** parti
     if (nature_ws_alloc(sl.ws, c->E, false, cfg->actor_dense_ksplit, cfg->network)) return -1;
     sl.ws.bf16_fwd = cfg->forward_bf16 != 0 && cfg->network == CBM_NET_NATURE;
     if (dalloc(&sl.env_state, (size_t)c->E) || dalloc(&sl.stats_dev, 2)) return -1;
+    sl.pin_stride = ((size_t)c->E * 16 + 255) & ~(size_t)255;
+    CBM_HIP(hipHostMalloc((void**)&sl.pin, sl.pin_stride * CBM_PIN_RING, hipHostMallocDefault));
     c->committed[s] = 0;
   }
   CBM_HIP(hipStreamCreateWithPriority(&c->lstream, hipStreamNonBlocking, prio_learner));
@@ -212,6 +214,7 @@ extern "C" int cbm_ctx_destroy(cbm_ctx* c) {
     nature_ws_free(c->slots[s].ws);
     if (c->slots[s].env_state) hipFree(c->slots[s].env_state);
     if (c->slots[s].stats_dev) hipFree(c->slots[s].stats_dev);
+    if (c->slots[s].pin) hipHostFree(c->slots[s].pin);
     hipStreamDestroy(c->slots[s].stream);
   }
   nature_ws_free(c->lws);
@@ -375,6 +378,13 @@ static bool actor_infer_row(cbm_ctx* c, int s, int t, const ActorEnvRows* env = 
   return false;
 }
 
+// small host array -> device through the slot's page-locked ring (see Slot::pin)
+static int stage_small(Slot& sl, void* dst, const void* src, size_t nbytes) {
+  uint8_t* p = sl.pin + (size_t)(sl.pin_cur++ % CBM_PIN_RING) * sl.pin_stride;
+  memcpy(p, src, nbytes);
+  CBM_HIP(hipMemcpyAsync(dst, p, nbytes, hipMemcpyHostToDevice, sl.stream));
+  return 0;
+}
 extern "C" int cbm_actor_step_host(cbm_ctx* c, int32_t s, const uint8_t* obs, const uint8_t* done, const uint8_t* firststep,
                                    const float* reward_with_obs, int32_t* actions_out) {
   Slot& sl = c->slots[s];
@@ -384,12 +394,14 @@ extern "C" int cbm_actor_step_host(cbm_ctx* c, int32_t s, const uint8_t* obs, co
   const size_t o = row_off(c, sl.t, s);
   const size_t E = (size_t)c->E;
   CBM_HIP(hipMemcpyAsync(R.obs + o * CBM_FRAME, obs, E * CBM_FRAME, hipMemcpyHostToDevice, sl.stream));
-  if (done) CBM_HIP(hipMemcpyAsync(R.dones + o, done, E, hipMemcpyHostToDevice, sl.stream));
-  if (firststep) CBM_HIP(hipMemcpyAsync(R.firststeps + o, firststep, E, hipMemcpyHostToDevice, sl.stream));
-  if (reward_with_obs) CBM_HIP(hipMemcpyAsync(R.rewards + o, reward_with_obs, E * 4, hipMemcpyHostToDevice, sl.stream));
+  if (done && stage_small(sl, R.dones + o, done, E)) return -1;
+  if (firststep && stage_small(sl, R.firststeps + o, firststep, E)) return -1;
+  if (reward_with_obs && stage_small(sl, R.rewards + o, reward_with_obs, E * 4)) return -1;
   actor_infer_row(c, s, sl.t);
-  CBM_HIP(hipMemcpyAsync(actions_out, R.actions + o, E * 4, hipMemcpyDeviceToHost, sl.stream));
+  uint8_t* pa = sl.pin + (size_t)(sl.pin_cur++ % CBM_PIN_RING) * sl.pin_stride;   // actions come back through page-locked memory too
+  CBM_HIP(hipMemcpyAsync(pa, R.actions + o, E * 4, hipMemcpyDeviceToHost, sl.stream));
   CBM_HIP(hipStreamSynchronize(sl.stream));  // the per-step D2H sync of ppo:317
+  memcpy(actions_out, pa, E * 4);
   sl.t += 1;
   return 0;
 }
@@ -432,8 +444,7 @@ extern "C" int cbm_actor_record_host(cbm_ctx* c, int32_t s, const float* reward)
   CBM_HIP(hipSetDevice(c->cfg.device));
   RingEntry& R = c->ring[sl.ring];
   const size_t o = row_off(c, sl.t - 1, s);
-  CBM_HIP(hipMemcpyAsync(R.rewards + o, reward, (size_t)c->E * 4, hipMemcpyHostToDevice, sl.stream));
-  return 0;
+  return stage_small(sl, R.rewards + o, reward, (size_t)c->E * 4);
 }
 
 extern "C" int cbm_actor_rollout_device(cbm_ctx* c, int32_t s, int32_t nsteps) {

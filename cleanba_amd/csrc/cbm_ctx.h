@@ -35,7 +35,13 @@ struct Slot {
   uint32_t env_seed = 0;
   bool env_inited = false;
   float* stats_dev = nullptr;
+  // page-locked staging ring for the small per-step host arrays of the envpool-API path (dones, firststeps, rewards, actions): a pageable
+  // hipMemcpyAsync of 120-480 bytes costs the host ~8 us each (runtime staging + bookkeeping), from page-locked memory it is a plain enqueue
+  uint8_t* pin = nullptr;
+  size_t pin_stride = 0;
+  int pin_cur = 0;
 };
+#define CBM_PIN_RING 8   // staging entries per slot: an entry is reused 8 enqueues later, long after its copy ran (every step ends in a stream sync)
 struct cbm_ctx {
   cbm_config cfg;
   NatureLayout L;

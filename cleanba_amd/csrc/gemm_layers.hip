@@ -322,6 +322,7 @@ __global__ __launch_bounds__(256) void actor_tail_kernel(const float* hid, const
 template <int HD>
 __global__ __launch_bounds__(256) void actor_tail_rows_kernel(const float* part, const float* bd, int S, const float* Wa, const float* ba, const float* Wc,
                                                               const float* bc, int B, int A, ActorSample smp) {
+  __builtin_amdgcn_s_setprio(3);   // (see igemm_s16_kernel)
   __shared__ int act_s;
   __shared__ __attribute__((aligned(16))) float hsT[HD];      // hid of this frame, stored as [k % 4][k / 4]: lane group g4 of a 16x16x4 MFMA reads its k = 4*st + g4 as consecutive floats
   __shared__ float lg[32];
