@@ -109,119 +109,181 @@ __device__ __forceinline__ void rn_stage_u8(float* slab, const uint8_t* obs, con
 //      2 out = v                   (dgrad)
 //      3 out = aux > 0 ? v : 0     (dgrad through the relu in front of the conv)
 //      4 out += aux > 0 ? v : 0    (dgrad joined with the residual path, in place)
-template <class G, bool U8, bool PRE_RELU, int EPI>
-__global__ __launch_bounds__(G::NTHR, G::MINW) void rn_conv_kernel(const void* in_, const int32_t* idx, const float* W, const float* bias, const float* aux,
-                                                      float* out, int B) {
+// Blocks are PERSISTENT over strips (grid = what fits on the chip): the global loads of strip s+1 — its input slab and, for EPI 1/3/4, the
+// residual / mask values its epilogue needs — are issued before the MFMA sweep of strip s and land during it; the first build ran one strip
+// per block as stage -> barrier -> multiply -> store, every phase exposed (MFMA phase ~40 % of a block's life, 0.41-0.46 of the peak).
+template <class G, bool PRE_RELU, int EPI>
+__global__ __launch_bounds__(G::NTHR, G::MINW) void rn_conv_kernel(const float* in, const float* W, const float* bias, const float* aux, float* out, int B,
+                                                                  int nstrips) {
   constexpr int H = G::H, CI = G::CI, CO = G::CO, WP = G::WP, TP = G::TP, NTW = G::NTW, NT = G::NT;
+  constexpr int NE = G::M16 ? 4 : 16;                                   // accumulator elements per lane per tile
+  constexpr bool AUX = EPI == 1 || EPI == 3 || EPI == 4;
   extern __shared__ __attribute__((aligned(16))) float rn_smem[];
   float* slab = rn_smem;
   float* Wl = rn_smem + G::SLAB;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  int b0, y0;
-  if (G::NF == 1) { b0 = blockIdx.x / G::STRIPS; y0 = (blockIdx.x % G::STRIPS) * G::R; }
-  else { b0 = blockIdx.x * G::NF; y0 = 0; }
-
   for (int v = tid; v < G::WSZ / 4; v += G::NTHR) reinterpret_cast<float4*>(Wl)[v] = reinterpret_cast<const float4*>(W)[v];
-  if constexpr (U8) rn_stage_u8<G>(slab, (const uint8_t*)in_, idx, b0, y0);
-  else rn_stage_f32<G, PRE_RELU>(slab, (const float*)in_, b0, y0, B);
-  __syncthreads();
-
-  if constexpr (G::M16) {
-    const int li = lane & 15, kq = lane >> 4;
-    rn_f32x4 acc[NTW];
+  // pad column of every slab row (index sr*WP + WP) and the leading pad (index 0): written once, the strip copies never touch them
+  for (int v = tid; v < (G::SROWS + 1) * G::NPL; v += G::NTHR) {
+    const int p = v % G::NPL, sr = v / G::NPL;
+    slab[G::poff(p) + sr * WP] = 0.0f;
+  }
+  // ---- per-thread index tables, decoded ONCE: which slab elements this thread copies and which outputs it stores is the same for every strip up
+  // to the strip's origin (the decode is a dozen integer divisions per element; done per strip it was ~400 VALU instructions per thread against
+  // ~100 MFMAs per wave — and VALU work takes the fp32 matrix pipe's slots on this chip)
+  constexpr int NVX = G::SROWS * H * (CI / 4), NIX = (NVX + G::NTHR - 1) / G::NTHR;
+  float4 rx[NIX];
+  int cp_col[NIX], cp_dst[NIX], cp_row[NIX];      // source column part (floats), slab index of channel 4g, slab row (NF = 1) / frame<<8 | row+1 (NF = 2)
 #pragma unroll
-    for (int i = 0; i < NTW; ++i) acc[i] = rn_f32x4{0.f, 0.f, 0.f, 0.f};
-    const float* abase = slab + (kq >> 1) * G::PL + (kq & 1) * G::PLH + wave * TP + li;   // plane of k = 4j + kq
-    const float* bbase = Wl + kq * CO + li;
-    // one tap per (rolled) iteration: bounds the scheduling region and with it the number of hoisted LDS reads (VGPRs)
-#pragma unroll 1
-    for (int t = 0; t < 9; ++t) {
-      const int kh = (t * 11) >> 5, off = kh * WP + (t - 3 * kh);
-      const float* bt = bbase + t * CI * CO;
+  for (int it = 0; it < NIX; ++it) {
+    const int v = min(tid + G::NTHR * it, NVX - 1);
+    const int g = v % (CI / 4), pix = v / (CI / 4), c = pix % H, sr = pix / H;
+    cp_col[it] = c * CI + 4 * g;
+    cp_dst[it] = G::poff(4 * g) + 1 + sr * WP + c;
+    cp_row[it] = G::NF == 1 ? sr : (((sr / (H + 1)) << 8) | (sr % (H + 1)));
+  }
+  const int li = G::M16 ? (lane & 15) : (lane & 31), kq = G::M16 ? (lane >> 4) : (lane >> 5);
+  // outputs: element e of tile i -> offset relative to the strip origin (bits 0..19), its strip row (NF = 1) or frame<<6 | row (NF = 2) in bits
+  // 20..30, bit 31 = never stored (pad column, row beyond the strip, tile beyond the strip)
+  uint32_t oc[NTW][NE];
 #pragma unroll
-      for (int j = 0; j < (CI < 4 ? 1 : CI / 4); ++j) {
-        const float bv = bt[4 * j * CO];
-        const float* ap = abase + 2 * j * G::PL + off;
+  for (int i = 0; i < NTW; ++i)
 #pragma unroll
-        for (int i = 0; i < NTW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[i * G::NW * TP], bv, acc[i], 0, 0, 0);
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < NTW; ++i) {
+    for (int e = 0; e < NE; ++e) {
       const int tile = wave + G::NW * i;
-      if (tile >= NT) continue;
+      const int q = tile * TP + (G::M16 ? 4 * kq + e : (e & 3) + 8 * (e >> 2) + 4 * kq);
+      const int orow = q / WP, c = q - orow * WP;
+      const bool dead = tile >= NT || c >= H || (G::NF == 1 ? orow >= G::R : (orow % (H + 1)) >= H);
+      const int fs = G::NF == 1 ? 0 : orow / (H + 1), y = G::NF == 1 ? orow : orow % (H + 1);
+      const uint32_t rel = (uint32_t)(((fs * H + y) * H + c) * CO + li);
+      oc[i][e] = dead ? 0x80000000u : (rel | ((uint32_t)(G::NF == 1 ? orow : ((fs << 6) | y)) << 20));
+    }
+  static_assert(((G::NF * H + H) * H + H) * CO < (1 << 20), "relative output offsets fit 20 bits");
+  auto where = [&](int st, int& b0, int& y0) {
+    if (G::NF == 1) { b0 = st / G::STRIPS; y0 = (st - b0 * G::STRIPS) * G::R; }
+    else { b0 = st * G::NF; y0 = 0; }
+  };
+  auto fetch = [&](int b0, int y0) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int q = tile * TP + 4 * kq + e;
-        const int orow = q / WP, c = q - orow * WP;
-        int f, y;
-        if (G::NF == 1) { f = b0; y = y0 + orow; }
-        else { f = b0 + orow / (H + 1); y = orow % (H + 1); }
-        if (c >= H || y >= H || f >= B || (G::NF == 1 && orow >= G::R)) continue;
-        const size_t o = ((size_t)(f * H + y) * H + c) * CO + li;
-        float v = acc[i][e];
-        if (EPI == 0) v = v + bias[li];
-        else if (EPI == 1) v = (v + bias[li]) + aux[o];
-        else if (EPI == 3) v = aux[o] > 0.0f ? v : 0.0f;
-        else if (EPI == 4) v = out[o] + (aux[o] > 0.0f ? v : 0.0f);
-        out[o] = v;
+    for (int it = 0; it < NIX; ++it) {
+      int f, y;
+      if (G::NF == 1) { f = b0; y = y0 + cp_row[it] - 1; }
+      else { f = b0 + (cp_row[it] >> 8); y = (cp_row[it] & 255) - 1; }
+      rx[it] = *reinterpret_cast<const float4*>(in + (size_t)((min(f, B - 1) * H + min(max(y, 0), H - 1)) * H * CI + cp_col[it]));
+    }
+  };
+  auto commit = [&](int b0, int y0) {
+#pragma unroll
+    for (int it = 0; it < NIX; ++it) {
+      if (NVX % G::NTHR != 0 && tid + G::NTHR * it >= NVX) break;
+      int f, y;
+      if (G::NF == 1) { f = b0; y = y0 + cp_row[it] - 1; }
+      else { f = b0 + (cp_row[it] >> 8); y = (cp_row[it] & 255) - 1; }
+      const bool ok = y >= 0 && y < H && f < B;
+      const float e[4] = {rx[it].x, rx[it].y, rx[it].z, rx[it].w};
+      float* d = slab + cp_dst[it];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float val = ok ? e[q] : 0.0f;
+        if (PRE_RELU) val = fmaxf(val, 0.0f);
+        d[G::poff(q)] = val;                       // poff(4g + q) - poff(4g) = poff(q): plane pairs / planes are a constant pitch apart
       }
     }
-  } else {
-    const int li = lane & 31, h = lane >> 5;
-    rn_f32x16 acc[NTW];
+  };
+  // offset of output (i, e) for the strip at (b0, y0), or -1
+  auto out_index = [&](uint32_t code, int b0, int y0) -> int {
+    if ((int)code < 0) return -1;
+    const int rw = (int)(code >> 20);
+    if (G::NF == 1) { if (y0 + rw >= H) return -1; }
+    else { if (b0 + (rw >> 6) >= B) return -1; }
+    return (b0 * H + y0) * H * CO + (int)(code & 0xFFFFFu);
+  };
+  using AccT = typename std::conditional<G::M16, rn_f32x4, rn_f32x16>::type;
+
+  int s = blockIdx.x, b0 = 0, y0 = 0;
+  if (s < nstrips) { where(s, b0, y0); fetch(b0, y0); }
+  const float bz = (EPI == 0 || EPI == 1) ? bias[li] : 0.0f;
+  for (; s < nstrips; s += gridDim.x) {
+    __syncthreads();            // the previous strip's sweep is done with the slab (and the weights / pads are staged)
+    commit(b0, y0);
+    const int cb0 = b0, cy0 = y0;
+    __syncthreads();
+    const int sn = s + gridDim.x;
+    if (sn < nstrips) { where(sn, b0, y0); fetch(b0, y0); }
+    float ax[AUX ? NTW : 1][AUX ? NE : 1];
+    if constexpr (AUX) {        // residual / mask values of THIS strip's outputs: requested before the sweep, used after it
+#pragma unroll
+      for (int i = 0; i < NTW; ++i)
+#pragma unroll
+        for (int e = 0; e < NE; ++e) { const int o = out_index(oc[i][e], cb0, cy0); ax[i][e] = aux[o < 0 ? 0 : o]; }
+    }
+    AccT acc[NTW];
 #pragma unroll
     for (int i = 0; i < NTW; ++i)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][e] = 0.0f;
-    const float* abase = slab + h * G::PL + wave * TP + li;
-    const float* bbase = Wl + h * CO + li;
+      for (int e = 0; e < NE; ++e) acc[i][e] = 0.0f;
+    if constexpr (G::M16) {
+      const float* abase = slab + (kq >> 1) * G::PL + (kq & 1) * G::PLH + wave * TP + li;   // plane of k = 4j + kq
+      const float* bbase = Wl + kq * CO + li;
+      // one tap per (rolled) iteration: bounds the scheduling region and with it the number of hoisted LDS reads (VGPRs)
 #pragma unroll 1
-    for (int t = 0; t < 9; ++t) {
-      const int kh = (t * 11) >> 5, off = kh * WP + (t - 3 * kh);
-      const float* bt = bbase + t * CI * CO;
+      for (int t = 0; t < 9; ++t) {
+        const int kh = (t * 11) >> 5, off = kh * WP + (t - 3 * kh);
+        const float* bt = bbase + t * CI * CO;
 #pragma unroll
-      for (int j = 0; j < CI / 2; ++j) {
-        const float bv = bt[2 * j * CO];
-        const float* ap = abase + 2 * j * G::PL + off;
+        for (int j = 0; j < (CI < 4 ? 1 : CI / 4); ++j) {
+          const float bv = bt[4 * j * CO];
+          const float* ap = abase + 2 * j * G::PL + off;
 #pragma unroll
-        for (int i = 0; i < NTW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[i * G::NW * TP], bv, acc[i], 0, 0, 0);
+          for (int i = 0; i < NTW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[i * G::NW * TP], bv, acc[i], 0, 0, 0);
+        }
+      }
+    } else {
+      const float* abase = slab + kq * G::PL + wave * TP + li;
+      const float* bbase = Wl + kq * CO + li;
+#pragma unroll 1
+      for (int t = 0; t < 9; ++t) {
+        const int kh = (t * 11) >> 5, off = kh * WP + (t - 3 * kh);
+        const float* bt = bbase + t * CI * CO;
+#pragma unroll
+        for (int j = 0; j < CI / 2; ++j) {
+          const float bv = bt[2 * j * CO];
+          const float* ap = abase + 2 * j * G::PL + off;
+#pragma unroll
+          for (int i = 0; i < NTW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[i * G::NW * TP], bv, acc[i], 0, 0, 0);
+        }
       }
     }
 #pragma unroll
-    for (int i = 0; i < NTW; ++i) {
-      const int tile = wave + G::NW * i;
-      if (tile >= NT) continue;
+    for (int i = 0; i < NTW; ++i)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int q = tile * TP + (e & 3) + 8 * (e >> 2) + 4 * h;
-        const int orow = q / WP, c = q - orow * WP;
-        int f, y;
-        if (G::NF == 1) { f = b0; y = y0 + orow; }
-        else { f = b0 + orow / (H + 1); y = orow % (H + 1); }
-        if (c >= H || y >= H || f >= B || (G::NF == 1 && orow >= G::R)) continue;
-        const size_t o = ((size_t)(f * H + y) * H + c) * CO + li;
+      for (int e = 0; e < NE; ++e) {
+        const int o = out_index(oc[i][e], cb0, cy0);
+        if (o < 0) continue;
         float v = acc[i][e];
-        if (EPI == 0) v = v + bias[li];
-        else if (EPI == 1) v = (v + bias[li]) + aux[o];
-        else if (EPI == 3) v = aux[o] > 0.0f ? v : 0.0f;
-        else if (EPI == 4) v = out[o] + (aux[o] > 0.0f ? v : 0.0f);
+        if (EPI == 0) v = v + bz;
+        else if (EPI == 1) v = (v + bz) + ax[i][e];
+        else if (EPI == 3) v = ax[i][e] > 0.0f ? v : 0.0f;
+        else if (EPI == 4) v = out[o] + (ax[i][e] > 0.0f ? v : 0.0f);
         out[o] = v;
       }
-    }
   }
 }
 
-template <class G, bool U8, bool PRE_RELU, int EPI>
-static void rn_conv_launch(const void* in, const int32_t* idx, const float* W, const float* bias, const float* aux, float* out, int B, hipStream_t st) {
+template <class G, bool PRE_RELU, int EPI>
+static void rn_conv_launch(const float* in, const float* W, const float* bias, const float* aux, float* out, int B, hipStream_t st) {
   constexpr size_t lds = (size_t)(G::SLAB + G::WSZ) * sizeof(float);
   static_assert(lds <= 160 * 1024, "slab + weights exceed the 160 KB LDS of a gfx950 CU");
   static bool attr = false;
   if (!attr) {
-    hipFuncSetAttribute((const void*)rn_conv_kernel<G, U8, PRE_RELU, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute((const void*)rn_conv_kernel<G, PRE_RELU, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr = true;
   }
-  hipLaunchKernelGGL((rn_conv_kernel<G, U8, PRE_RELU, EPI>), dim3(G::blocks(B)), dim3(G::NTHR), lds, st, in, idx, W, bias, aux, out, B);
+  const int nstrips = G::blocks(B);
+  int per_cu = G::OCC;                                              // blocks per CU by LDS, capped by the 32 wave slots
+  if (per_cu * G::NW > 32) per_cu = 32 / G::NW;
+  const int nb = nstrips < 256 * per_cu ? nstrips : 256 * per_cu;
+  hipLaunchKernelGGL((rn_conv_kernel<G, PRE_RELU, EPI>), dim3(nb), dim3(G::NTHR), lds, st, in, W, bias, aux, out, B, nstrips);
   if (hipError_t e = hipGetLastError(); e != hipSuccess) fprintf(stderr, "rn_conv launch failed: %s (threads %d, lds %zu)\n", hipGetErrorString(e), G::NTHR, lds);
 }
 
