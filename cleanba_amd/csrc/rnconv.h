@@ -13,6 +13,9 @@
 //   CO == 32: v_mfma_f32_32x32x2_f32  (A: lane -> position l%32, k = 2j + l/32)
 //   CO == 16: v_mfma_f32_16x16x4_f32  (A: lane -> position l%16, k = 4j + l/16)
 #pragma once
+#ifndef RNC_ABL
+#define RNC_ABL 0   // timing builds (temporary): 1 one tap instead of nine, 2 no slab commit after the first strip, 4 no output stores, 8 no next-strip loads
+#endif
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -205,55 +208,79 @@ __global__ __launch_bounds__(G::NTHR, G::MINW) void rn_conv_kernel(const float* 
   const float bz = (EPI == 0 || EPI == 1) ? bias[li] : 0.0f;
   for (; s < nstrips; s += gridDim.x) {
     __syncthreads();            // the previous strip's sweep is done with the slab (and the weights / pads are staged)
+#if !(RNC_ABL & 2)
     commit(b0, y0);
+#else
+    if (s == (int)blockIdx.x) commit(b0, y0);
+#endif
     const int cb0 = b0, cy0 = y0;
     __syncthreads();
     const int sn = s + gridDim.x;
-    if (sn < nstrips) { where(sn, b0, y0); fetch(b0, y0); }
-    float ax[AUX ? NTW : 1][AUX ? NE : 1];
-    if constexpr (AUX) {        // residual / mask values of THIS strip's outputs: requested before the sweep, used after it
+    if (sn < nstrips) { where(sn, b0, y0);
+#if !(RNC_ABL & 8)
+      fetch(b0, y0);
+#endif
+    }
+    float ax[AUX ? NTW : 1][AUX ? NE : 1], ao[EPI == 4 ? NTW : 1][EPI == 4 ? NE : 1];
+    if constexpr (AUX) {        // residual / mask values (EPI 4: and the running gradient) of THIS strip's outputs: requested before the sweep, used after it
 #pragma unroll
       for (int i = 0; i < NTW; ++i)
 #pragma unroll
-        for (int e = 0; e < NE; ++e) { const int o = out_index(oc[i][e], cb0, cy0); ax[i][e] = aux[o < 0 ? 0 : o]; }
+        for (int e = 0; e < NE; ++e) {
+          const int o = out_index(oc[i][e], cb0, cy0);
+          ax[i][e] = aux[o < 0 ? 0 : o];
+          if constexpr (EPI == 4) ao[i][e] = out[o < 0 ? 0 : o];
+        }
     }
     AccT acc[NTW];
 #pragma unroll
     for (int i = 0; i < NTW; ++i)
 #pragma unroll
       for (int e = 0; e < NE; ++e) acc[i][e] = 0.0f;
-    if constexpr (G::M16) {
-      const float* abase = slab + (kq >> 1) * G::PL + (kq & 1) * G::PLH + wave * TP + li;   // plane of k = 4j + kq
-      const float* bbase = Wl + kq * CO + li;
-      // one tap per (rolled) iteration: bounds the scheduling region and with it the number of hoisted LDS reads (VGPRs)
+    // tiles this wave really has in this strip (wave-uniform): tile t exists iff t * TP < rows * WP.  The first build multiplied all NTW slots
+    // of every wave — 24 tile slots for the 19 tiles of a 7-row strip of the 42x42 layers: a fifth of the matrix pipe's work was on positions
+    // nobody stores (a co-resident block cannot use slots that are busy with garbage)
+    int rows = G::NF == 1 ? min(G::R, H - cy0) : G::OROWS;
+    const int ntl = max(0, min(NTW, ((rows * WP + TP - 1) / TP - wave + G::NW - 1) / G::NW));
+    auto sweep = [&](auto NTL_) __attribute__((always_inline)) {
+      constexpr int NTL = decltype(NTL_)::value;
+      if constexpr (G::M16) {
+        const float* abase = slab + (kq >> 1) * G::PL + (kq & 1) * G::PLH + wave * TP + li;   // plane of k = 4j + kq
+        const float* bbase = Wl + kq * CO + li;
+        // one tap per (rolled) iteration: bounds the scheduling region and with it the number of hoisted LDS reads (VGPRs)
 #pragma unroll 1
-      for (int t = 0; t < 9; ++t) {
-        const int kh = (t * 11) >> 5, off = kh * WP + (t - 3 * kh);
-        const float* bt = bbase + t * CI * CO;
+        for (int t = 0; t < ((RNC_ABL & 1) ? 1 : 9); ++t) {
+          const int kh = (t * 11) >> 5, off = kh * WP + (t - 3 * kh);
+          const float* bt = bbase + t * CI * CO;
 #pragma unroll
-        for (int j = 0; j < (CI < 4 ? 1 : CI / 4); ++j) {
-          const float bv = bt[4 * j * CO];
-          const float* ap = abase + 2 * j * G::PL + off;
+          for (int j = 0; j < (CI < 4 ? 1 : CI / 4); ++j) {
+            const float bv = bt[4 * j * CO];
+            const float* ap = abase + 2 * j * G::PL + off;
 #pragma unroll
-          for (int i = 0; i < NTW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[i * G::NW * TP], bv, acc[i], 0, 0, 0);
+            for (int i = 0; i < NTL; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[i * G::NW * TP], bv, acc[i], 0, 0, 0);
+          }
+        }
+      } else {
+        const float* abase = slab + kq * G::PL + wave * TP + li;
+        const float* bbase = Wl + kq * CO + li;
+#pragma unroll 1
+        for (int t = 0; t < ((RNC_ABL & 1) ? 1 : 9); ++t) {
+          const int kh = (t * 11) >> 5, off = kh * WP + (t - 3 * kh);
+          const float* bt = bbase + t * CI * CO;
+#pragma unroll
+          for (int j = 0; j < CI / 2; ++j) {
+            const float bv = bt[2 * j * CO];
+            const float* ap = abase + 2 * j * G::PL + off;
+#pragma unroll
+            for (int i = 0; i < NTL; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[i * G::NW * TP], bv, acc[i], 0, 0, 0);
+          }
         }
       }
-    } else {
-      const float* abase = slab + kq * G::PL + wave * TP + li;
-      const float* bbase = Wl + kq * CO + li;
-#pragma unroll 1
-      for (int t = 0; t < 9; ++t) {
-        const int kh = (t * 11) >> 5, off = kh * WP + (t - 3 * kh);
-        const float* bt = bbase + t * CI * CO;
-#pragma unroll
-        for (int j = 0; j < CI / 2; ++j) {
-          const float bv = bt[2 * j * CO];
-          const float* ap = abase + 2 * j * G::PL + off;
-#pragma unroll
-          for (int i = 0; i < NTW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[i * G::NW * TP], bv, acc[i], 0, 0, 0);
-        }
-      }
-    }
+    };
+    if (ntl == NTW) sweep(std::integral_constant<int, NTW>{});
+    else if (NTW > 1 && ntl == NTW - 1) sweep(std::integral_constant<int, (NTW > 1 ? NTW - 1 : 1)>{});
+    else if (NTW > 2 && ntl == NTW - 2) sweep(std::integral_constant<int, (NTW > 2 ? NTW - 2 : 1)>{});
+    else if (ntl > 0) sweep(std::integral_constant<int, NTW>{});   // (deeper shortfalls do not occur with the shipped geometries; correct either way)
 #pragma unroll
     for (int i = 0; i < NTW; ++i)
 #pragma unroll
@@ -264,7 +291,10 @@ __global__ __launch_bounds__(G::NTHR, G::MINW) void rn_conv_kernel(const float* 
         if (EPI == 0) v = v + bz;
         else if (EPI == 1) v = (v + bz) + ax[i][e];
         else if (EPI == 3) v = ax[i][e] > 0.0f ? v : 0.0f;
-        else if (EPI == 4) v = out[o] + (ax[i][e] > 0.0f ? v : 0.0f);
+        else if (EPI == 4) v = ao[i][e] + (ax[i][e] > 0.0f ? v : 0.0f);
+#if RNC_ABL & 4
+        if (v == 123.456f)
+#endif
         out[o] = v;
       }
   }
