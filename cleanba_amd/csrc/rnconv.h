@@ -112,6 +112,7 @@ __device__ __forceinline__ void rn_stage_u8(float* slab, const uint8_t* obs, con
 //      2 out = v                   (dgrad)
 //      3 out = aux > 0 ? v : 0     (dgrad through the relu in front of the conv)
 //      4 out += aux > 0 ? v : 0    (dgrad joined with the residual path, in place)
+//      5 out = relu(v + bias)      (forward, for an output that is only ever read through a relu: the first conv of a residual block)
 // Blocks are PERSISTENT over strips (grid = what fits on the chip): the global loads of strip s+1 — its input slab and, for EPI 1/3/4, the
 // residual / mask values its epilogue needs — are issued before the MFMA sweep of strip s and land during it; the first build ran one strip
 // per block as stage -> barrier -> multiply -> store, every phase exposed (MFMA phase ~40 % of a block's life, 0.41-0.46 of the peak).
@@ -205,7 +206,7 @@ __global__ __launch_bounds__(G::NTHR, G::MINW) void rn_conv_kernel(const float* 
 
   int s = blockIdx.x, b0 = 0, y0 = 0;
   if (s < nstrips) { where(s, b0, y0); fetch(b0, y0); }
-  const float bz = (EPI == 0 || EPI == 1) ? bias[li] : 0.0f;
+  const float bz = (EPI == 0 || EPI == 1 || EPI == 5) ? bias[li] : 0.0f;
   for (; s < nstrips; s += gridDim.x) {
     __syncthreads();            // the previous strip's sweep is done with the slab (and the weights / pads are staged)
 #if !(RNC_ABL & 2)
@@ -289,6 +290,7 @@ __global__ __launch_bounds__(G::NTHR, G::MINW) void rn_conv_kernel(const float* 
         if (o < 0) continue;
         float v = acc[i][e];
         if (EPI == 0) v = v + bz;
+        else if (EPI == 5) v = fmaxf(v + bz, 0.0f);
         else if (EPI == 1) v = (v + bz) + ax[i][e];
         else if (EPI == 3) v = ax[i][e] > 0.0f ? v : 0.0f;
         else if (EPI == 4) v = ao[i][e] + (ax[i][e] > 0.0f ? v : 0.0f);
@@ -729,5 +731,190 @@ static int rn_wgrad_launch(const void* in, const int32_t* idx, const float* dy, 
   const int nstrips = WG::strips(B);
   const int nb = nstrips < max_blocks ? nstrips : max_blocks;
   hipLaunchKernelGGL((rn_wgrad_kernel<WG, U8, PRE_RELU, POOLB>), dim3(nb), dim3(256), lds, st, in, idx, dy, part, bpart, B, nstrips, pidx);
+  return nb;
+}
+
+// ================================================================================================ weight gradient, load-unit fed (round 3)
+// In dW[(tap,ci)][co] = sum_q X[q + tapoff][ci] * dY[q][co] BOTH MFMA operands have their lanes along a CHANNEL index (A: lane = ci of a tap tile,
+// B: lane = co) and the reduction index is the position — so, unlike the forward / input-gradient convs (lanes = positions: channel planes), the
+// weight gradient wants its slabs exactly as the activations lie in HBM (NHWC): X strip [(R+2) rows][WP pixels][CI] and dY strip [R rows][WP][CO],
+// one zero pad pixel per row for the flat-index tap trick.  rn_wgrad_kernel above stages X as channel planes through registers (4 ds_write_b32 per
+// float4 plus the index arithmetic, 256 VGPRs and spills for the 32-channel layers, no overlap with the sweep where the register budget is gone);
+// here every image row of the strip is ONE linear copy by the load unit (global_load_lds_dwordx4: no staging registers, no VALU), strips are double
+// buffered (the copy of strip s+1 runs under the sweep of strip s, one barrier per strip), one block per CU, NTI accumulator tiles per wave, the
+// waves interleave position steps.  Same summation structure as rn_wgrad_kernel (per wave: its steps ascending over its strips ascending; then
+// waves in order; then blocks in order by wgrad_reduce_kernel): deterministic, 1e-5 class.
+template <int CI_, int CO_, int H_, int R_, int NF_, int NW_ = 4>
+struct RnW2Geom {
+  static constexpr int CI = CI_, CO = CO_, H = H_, R = R_, NF = NF_, WP = H + 1, NW = NW_;   // NW waves interleave the position steps
+  static constexpr bool M16 = CO == 16;
+  static constexpr int KK = M16 ? 4 : 2, TPI = M16 ? 16 : 32;
+  static constexpr int OROWS = NF == 1 ? R : NF * (H + 1), SROWS = NF == 1 ? R + 2 : NF * (H + 1) + 1;
+  static constexpr int NQ = OROWS * WP;
+  static constexpr int NTI = (9 * CI + TPI - 1) / TPI;
+  static constexpr int NKS = (NQ + KK - 1) / KK, KSW = (NKS + NW - 1) / NW, NQP = KSW * NW * KK;
+  static constexpr int XPIX = NQP + 2 * WP + 3, XS = XPIX * CI, YS = NQP * CO;      // floats per stage
+  static constexpr int STAGE = XS + YS;
+  static constexpr int RED = NW * TPI * CO > NW * 64 ? NW * TPI * CO : NW * 64;
+  static constexpr int LDS_FLOATS = 2 * STAGE > RED ? 2 * STAGE : RED;
+  static constexpr int STRIPS = NF == 1 ? (H + R - 1) / R : 1;
+  static constexpr int KX = 9 * CI;
+  static int strips(int B) { return NF == 1 ? B * STRIPS : (B + NF - 1) / NF; }
+};
+
+static __device__ __forceinline__ void rn_glds16(const void* g_lane, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g_lane, (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <class WG, bool RELU_PASS>
+__global__ __launch_bounds__(WG::NW * 64, 1) void rn_wgrad2_kernel(const float* in, const float* dy, float* part, float* bpart, int B, int nstrips) {
+  constexpr int H = WG::H, CI = WG::CI, CO = WG::CO, WP = WG::WP, KK = WG::KK, NTI = WG::NTI, TPI = WG::TPI, NW = WG::NW, NTHR = NW * 64;
+  extern __shared__ __attribute__((aligned(16))) float rn_smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int v = tid; v < WG::LDS_FLOATS; v += NTHR) rn_smem[v] = 0.0f;   // pad pixels, gap rows and the slack behind a strip stay finite zeros
+  __syncthreads();
+
+  const int irow = WG::M16 ? (lane & 15) : (lane & 31), kpos = WG::M16 ? (lane >> 4) : (lane >> 5);
+  // per-lane A offsets (floats, relative to position q's pixel): row irow of tap tile T -> (tap, ci); rows beyond 9*CI read tap 0 and are dropped
+  int abase[NTI];
+#pragma unroll
+  for (int T = 0; T < NTI; ++T) {
+    const int k = T * TPI + irow;
+    int tap = k / CI;
+    const int ci = k - tap * CI;
+    if (tap > 8) tap = 0;
+    abase[T] = ((tap / 3) * WP + (tap % 3) + kpos) * CI + ci;
+  }
+  using AccT = typename std::conditional<WG::M16, rn_f32x4, rn_f32x16>::type;
+  AccT acc[NTI];
+#pragma unroll
+  for (int T = 0; T < NTI; ++T)
+#pragma unroll
+    for (int e = 0; e < (WG::M16 ? 4 : 16); ++e) acc[T][e] = 0.0f;
+  float bsum = 0.0f;
+
+  // one strip -> one stage: every image row is a contiguous run in HBM and (behind its pad pixel) in LDS; rows outside the image are zero-filled
+  auto stage = [&](int st, int buf) __attribute__((always_inline)) {
+    float* Xs = rn_smem + buf * WG::STAGE;
+    float* Ys = Xs + WG::XS;
+    int b0, y0;
+    if (WG::NF == 1) { b0 = st / WG::STRIPS; y0 = (st - b0 * WG::STRIPS) * WG::R; } else { b0 = st * WG::NF; y0 = 0; }
+    constexpr int PX = H * CI / 4, PY = H * CO / 4;                  // 16-byte pieces per image row
+    constexpr int IX = (PX + 63) / 64, IY = (PY + 63) / 64;          // wave instructions per row
+    // X rows: slab row sr holds image row y0 + sr - 1 (NF = 1) / row (sr % (H+1)) - 1 of frame b0 + sr / (H+1)
+    for (int j = wave; j < WG::SROWS * IX; j += NW) {                  // wave-uniform work items: (row, 64-piece group)
+      const int sr = j / IX, grp = j - sr * IX;
+      int f, y;
+      if (WG::NF == 1) { f = b0; y = y0 + sr - 1; } else { f = b0 + sr / (H + 1); y = sr % (H + 1) - 1; }
+      const bool ok = y >= 0 && y < H && f < B;
+      float* drow = Xs + (size_t)(1 + sr * WP) * CI + grp * 256;
+      const int piece = grp * 64 + lane;
+      if (ok) { if (piece < PX) rn_glds16(in + ((size_t)(f * H + y) * H) * CI + (size_t)piece * 4, drow); }
+      else if (piece < PX) *reinterpret_cast<float4*>(drow + lane * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int j = wave; j < WG::OROWS * IY; j += NW) {
+      const int orow = j / IY, grp = j - orow * IY;
+      int f, y;
+      if (WG::NF == 1) { f = b0; y = y0 + orow; } else { f = b0 + orow / (H + 1); y = orow % (H + 1); }
+      const bool ok = y < H && f < B && (WG::NF != 1 || orow < WG::R);
+      float* drow = Ys + (size_t)(orow * WP) * CO + grp * 256;
+      const int piece = grp * 64 + lane;
+      if (ok) { if (piece < PY) rn_glds16(dy + ((size_t)(f * H + y) * H) * CO + (size_t)piece * 4, drow); }
+      else if (piece < PY) *reinterpret_cast<float4*>(drow + lane * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+
+  int s = blockIdx.x, n = 0;
+  if (s < nstrips) stage(s, 0);
+  for (; s < nstrips; s += gridDim.x, ++n) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();            // strip s has landed for every wave, and every wave is done with the other stage (strip s - gridDim.x)
+    if (s + (int)gridDim.x < nstrips) stage(s + gridDim.x, (n + 1) & 1);
+    float* Xs = rn_smem + (n & 1) * WG::STAGE;
+    const float* Ys = Xs + WG::XS;
+    if constexpr (RELU_PASS) {   // X is read through a relu (ResidualBlock's input): one pass over the landed strip instead of a v_max per A fragment
+      for (int v = tid * 4; v < WG::XS; v += NTHR * 4) {
+        float4 x = *reinterpret_cast<float4*>(Xs + v);
+        x.x = fmaxf(x.x, 0.0f); x.y = fmaxf(x.y, 0.0f); x.z = fmaxf(x.z, 0.0f); x.w = fmaxf(x.w, 0.0f);
+        *reinterpret_cast<float4*>(Xs + v) = x;
+      }
+      __syncthreads();
+    }
+    // wave w takes position steps w, w+NW, ...: step t covers positions q = t*KK + kpos.  One pointer per tap tile, every step a compile-time offset
+    const float* bptr = Ys + (size_t)((wave * KK + kpos) * CO) + irow;
+    const float* pT[NTI];
+#pragma unroll
+    for (int T = 0; T < NTI; ++T) pT[T] = Xs + (size_t)(wave * KK) * CI + abase[T];
+    float fa[2][NTI], fb[2];
+    auto frag = [&](int it, int set) __attribute__((always_inline)) {
+      fb[set] = bptr[it * NW * KK * CO];
+#pragma unroll
+      for (int T = 0; T < NTI; ++T) fa[set][T] = pT[T][it * NW * KK * CI];
+    };
+    frag(0, 0);
+#pragma unroll
+    for (int it = 0; it < WG::KSW; ++it) {
+      if (it + 1 < WG::KSW) frag(it + 1, (it + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
+      const float bv = fb[it & 1];
+      bsum += bv;
+#pragma unroll
+      for (int T = 0; T < NTI; ++T) {
+        if constexpr (WG::M16) acc[T] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[it & 1][T], bv, acc[T], 0, 0, 0);
+        else acc[T] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[it & 1][T], bv, acc[T], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  // ---- one partial per block: sum the NW waves' tiles in wave order through LDS
+  __syncthreads();
+  float* red = rn_smem;
+  const int z = blockIdx.x;
+#pragma unroll
+  for (int T = 0; T < NTI; ++T) {
+    __syncthreads();
+    if constexpr (WG::M16) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) red[(wave * TPI + 4 * kpos + e) * CO + irow] = acc[T][e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) red[(wave * TPI + (e & 3) + 8 * (e >> 2) + 4 * kpos) * CO + irow] = acc[T][e];
+    }
+    __syncthreads();
+    for (int v = tid; v < TPI * CO; v += NTHR) {
+      const int i = v / CO, nn = v - i * CO, k = T * TPI + i;
+      if (k < WG::KX) {
+        float sum = red[v];
+        for (int w = 1; w < NW; ++w) sum += red[w * TPI * CO + v];
+        part[((size_t)z * WG::KX + k) * CO + nn] = sum;
+      }
+    }
+  }
+  // bias partial: lane (irow = co, kpos) of wave w holds the sum of dY[q][co] over its positions; fixed order: kpos ascending, then waves ascending
+  __syncthreads();
+  red[tid] = bsum;
+  __syncthreads();
+  if (tid < CO) {
+    float sum = 0.0f;
+    for (int w = 0; w < NW; ++w)
+      for (int kp = 0; kp < KK; ++kp) sum += red[w * 64 + kp * TPI + tid];
+    bpart[z * CO + tid] = sum;
+  }
+}
+
+template <class WG, bool RELU_PASS>
+static int rn_wgrad2_launch(const float* in, const float* dy, float* part, float* bpart, int B, int max_blocks, hipStream_t st) {
+  constexpr size_t lds = (size_t)WG::LDS_FLOATS * sizeof(float);
+  static_assert(lds <= 160 * 1024, "double-buffered wgrad strips exceed LDS");
+  static bool attr = false;
+  if (!attr) { hipFuncSetAttribute((const void*)rn_wgrad2_kernel<WG, RELU_PASS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+  const int nstrips = WG::strips(B);
+  const int per_cu = (int)(160 * 1024 / lds) < 1 ? 1 : (int)(160 * 1024 / lds);
+  int nb = 256 * per_cu;
+  if (nb > max_blocks) nb = max_blocks;
+  if (nb > nstrips) nb = nstrips;
+  hipLaunchKernelGGL((rn_wgrad2_kernel<WG, RELU_PASS>), dim3(nb), dim3(WG::NW * 64), lds, st, in, dy, part, bpart, B, nstrips);
   return nb;
 }
