@@ -840,7 +840,7 @@ static void launch_reduce(const float* part, int nz, int XY, int Ycols, int mode
 // and the reductions run as TWO launches: {heads, dense} right after the dense weight gradient (their result is the tail the data-parallel
 // all-reduce waits for) and {conv3, conv2, conv1} at the end.  Same per-output summation order as the single launches -> same bits.
 struct RedJob { const float* part; float* gw; float* gw2; int nz, XY, Ycols, mode, zg, block0; float scale; };
-#define RED_MAX_JOBS 6
+#define RED_MAX_JOBS 32   // Nature: 4 + 6 jobs in two launches; ResNet: 4 (dense + heads) and 30 (15 convs x {weights, bias}) in two launches
 struct RedJobs { RedJob j[RED_MAX_JOBS]; int n, A; };
 __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const RedJobs jobs) {
   // four consecutive outputs per thread (16-byte loads; every XY is a multiple of 32), same z order per output as the scalar form

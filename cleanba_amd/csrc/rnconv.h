@@ -13,9 +13,6 @@
 //   CO == 32: v_mfma_f32_32x32x2_f32  (A: lane -> position l%32, k = 2j + l/32)
 //   CO == 16: v_mfma_f32_16x16x4_f32  (A: lane -> position l%16, k = 4j + l/16)
 #pragma once
-#ifndef RNC_ABL
-#define RNC_ABL 0   // timing builds (temporary): 1 one tap instead of nine, 2 no slab commit after the first strip, 4 no output stores, 8 no next-strip loads
-#endif
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -209,19 +206,11 @@ __global__ __launch_bounds__(G::NTHR, G::MINW) void rn_conv_kernel(const float* 
   const float bz = (EPI == 0 || EPI == 1 || EPI == 5) ? bias[li] : 0.0f;
   for (; s < nstrips; s += gridDim.x) {
     __syncthreads();            // the previous strip's sweep is done with the slab (and the weights / pads are staged)
-#if !(RNC_ABL & 2)
     commit(b0, y0);
-#else
-    if (s == (int)blockIdx.x) commit(b0, y0);
-#endif
     const int cb0 = b0, cy0 = y0;
     __syncthreads();
     const int sn = s + gridDim.x;
-    if (sn < nstrips) { where(sn, b0, y0);
-#if !(RNC_ABL & 8)
-      fetch(b0, y0);
-#endif
-    }
+    if (sn < nstrips) { where(sn, b0, y0); fetch(b0, y0); }
     float ax[AUX ? NTW : 1][AUX ? NE : 1], ao[EPI == 4 ? NTW : 1][EPI == 4 ? NE : 1];
     if constexpr (AUX) {        // residual / mask values (EPI 4: and the running gradient) of THIS strip's outputs: requested before the sweep, used after it
 #pragma unroll
@@ -250,7 +239,7 @@ __global__ __launch_bounds__(G::NTHR, G::MINW) void rn_conv_kernel(const float* 
         const float* bbase = Wl + kq * CO + li;
         // one tap per (rolled) iteration: bounds the scheduling region and with it the number of hoisted LDS reads (VGPRs)
 #pragma unroll 1
-        for (int t = 0; t < ((RNC_ABL & 1) ? 1 : 9); ++t) {
+        for (int t = 0; t < 9; ++t) {
           const int kh = (t * 11) >> 5, off = kh * WP + (t - 3 * kh);
           const float* bt = bbase + t * CI * CO;
 #pragma unroll
@@ -265,7 +254,7 @@ __global__ __launch_bounds__(G::NTHR, G::MINW) void rn_conv_kernel(const float* 
         const float* abase = slab + kq * G::PL + wave * TP + li;
         const float* bbase = Wl + kq * CO + li;
 #pragma unroll 1
-        for (int t = 0; t < ((RNC_ABL & 1) ? 1 : 9); ++t) {
+        for (int t = 0; t < 9; ++t) {
           const int kh = (t * 11) >> 5, off = kh * WP + (t - 3 * kh);
           const float* bt = bbase + t * CI * CO;
 #pragma unroll
@@ -294,9 +283,6 @@ __global__ __launch_bounds__(G::NTHR, G::MINW) void rn_conv_kernel(const float* 
         else if (EPI == 1) v = (v + bz) + ax[i][e];
         else if (EPI == 3) v = ax[i][e] > 0.0f ? v : 0.0f;
         else if (EPI == 4) v = ao[i][e] + (ax[i][e] > 0.0f ? v : 0.0f);
-#if RNC_ABL & 4
-        if (v == 123.456f)
-#endif
         out[o] = v;
       }
   }
