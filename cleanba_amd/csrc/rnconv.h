@@ -317,9 +317,10 @@ struct RnPool0Geom {
   static constexpr int CV = R * H * CO;                           // conv rows held in LDS
   static constexpr int LDS_FLOATS = G::SLAB + G::WSZ + CV;
 };
+// Blocks are persistent over strips: the bytes of the next strip (3 uint32 per thread) are requested before the sweep of the current one.
 template <int PR>
 __global__ __launch_bounds__(256, 2) void rn_conv0_pool_kernel(const uint8_t* obs, const int32_t* idx, const float* W, const float* bias, float* pooled,
-                                                               uint8_t* pidx, int B) {
+                                                               uint8_t* pidx, int B, int nstrips) {
   using PG = RnPool0Geom<PR>;
   using G = typename PG::G;
   constexpr int H = 84, HP = 42, CO = 16, WP = G::WP, TP = G::TP, NTW = G::NTW, NT = G::NT, R = PG::R;
@@ -328,57 +329,94 @@ __global__ __launch_bounds__(256, 2) void rn_conv0_pool_kernel(const uint8_t* ob
   float* Wl = rn_smem + G::SLAB;
   float* cv = Wl + G::WSZ;                                        // [R][H][CO]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int b0 = blockIdx.x / PG::STRIPS, p0 = (blockIdx.x % PG::STRIPS) * PR, y0 = 2 * p0;   // pad_lo = 0 for 84 -> 42
   for (int v = tid; v < G::WSZ / 4; v += 256) reinterpret_cast<float4*>(Wl)[v] = reinterpret_cast<const float4*>(W)[v];
-  rn_stage_u8<G>(slab, obs, idx, b0, y0);
-  __syncthreads();
-  {
-    const int li = lane & 15, kq = lane >> 4;
-    rn_f32x4 acc[NTW];
+  for (int v = tid; v < (G::SROWS + 1) * 4; v += 256) {           // pad columns: written once
+    const int p = v % 4, sr = v / 4;
+    slab[G::poff(p) + sr * WP] = 0.0f;
+  }
+  // this thread's share of a strip: uint32 v = (plane p, slab row sr, 4 columns cq) — decoded once
+  constexpr int NV = G::SROWS * (H / 4) * 4, NI = (NV + 255) / 256;
+  uint32_t ru[NI];
+  int usrc[NI], udst[NI], urow[NI];
 #pragma unroll
-    for (int i = 0; i < NTW; ++i) acc[i] = rn_f32x4{0.f, 0.f, 0.f, 0.f};
-    const float* abase = slab + (kq >> 1) * G::PL + (kq & 1) * G::PLH + wave * TP + li;
-    const float* bbase = Wl + kq * CO + li;
-#pragma unroll 1
-    for (int t = 0; t < 9; ++t) {
-      const int kh = (t * 11) >> 5, off = kh * WP + (t - 3 * kh);
-      const float bv = bbase[t * 4 * CO];
-      const float* ap = abase + off;
+  for (int it = 0; it < NI; ++it) {
+    const int v = min(tid + 256 * it, NV - 1);
+    const int cq = v % (H / 4), t = v / (H / 4), sr = t % G::SROWS, p = t / G::SROWS;
+    usrc[it] = p * H * H + 4 * cq; udst[it] = G::poff(p) + 1 + sr * WP + 4 * cq; urow[it] = sr;
+  }
+  auto fetch = [&](int st) {
+    const int b0 = st / PG::STRIPS, y0 = 2 * ((st % PG::STRIPS) * PR);
+    const uint8_t* fr = obs + (size_t)(idx ? idx[b0] : b0) * CBM_FRAME;
 #pragma unroll
-      for (int i = 0; i < NTW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[i * 4 * TP], bv, acc[i], 0, 0, 0);
+    for (int it = 0; it < NI; ++it) {
+      const int y = y0 + urow[it] - 1;
+      ru[it] = *reinterpret_cast<const uint32_t*>(fr + min(max(y, 0), H - 1) * H + usrc[it]);
     }
-    const float bz = bias[li];
+  };
+  const int li = lane & 15, kq = lane >> 4;
+  const float bz = bias[li];
+  int s = blockIdx.x;
+  if (s < nstrips) fetch(s);
+  for (; s < nstrips; s += gridDim.x) {
+    const int b0 = s / PG::STRIPS, p0 = (s % PG::STRIPS) * PR, y0 = 2 * p0;   // pad_lo = 0 for 84 -> 42
+    __syncthreads();            // the previous strip's pooling pass is done with cv, its sweep with the slab
 #pragma unroll
-    for (int i = 0; i < NTW; ++i) {
-      const int tile = wave + 4 * i;
-      if (tile >= NT) continue;
+    for (int it = 0; it < NI; ++it) {
+      if (NV % 256 != 0 && tid + 256 * it >= NV) break;
+      const int y = y0 + urow[it] - 1;
+      const bool ok = y >= 0 && y < H;
+      float* d = slab + udst[it];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int q = tile * TP + 4 * kq + e;
-        const int orow = q / WP, c = q - orow * WP;
-        if (c < H && orow < R) cv[(orow * H + c) * CO + li] = acc[i][e] + bz;
+      for (int q = 0; q < 4; ++q) d[q] = ok ? cbm_u8_unit((uint8_t)((ru[it] >> (8 * q)) & 0xffu)) : 0.0f;
+    }
+    __syncthreads();
+    if (s + (int)gridDim.x < nstrips) fetch(s + gridDim.x);
+    {
+      rn_f32x4 acc[NTW];
+#pragma unroll
+      for (int i = 0; i < NTW; ++i) acc[i] = rn_f32x4{0.f, 0.f, 0.f, 0.f};
+      const float* abase = slab + (kq >> 1) * G::PL + (kq & 1) * G::PLH + wave * TP + li;
+      const float* bbase = Wl + kq * CO + li;
+#pragma unroll 1
+      for (int t = 0; t < 9; ++t) {
+        const int kh = (t * 11) >> 5, off = kh * WP + (t - 3 * kh);
+        const float bv = bbase[t * 4 * CO];
+        const float* ap = abase + off;
+#pragma unroll
+        for (int i = 0; i < NTW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[i * 4 * TP], bv, acc[i], 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < NTW; ++i) {
+        const int tile = wave + 4 * i;
+        if (tile >= NT) continue;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int q = tile * TP + 4 * kq + e;
+          const int orow = q / WP, c = q - orow * WP;
+          if (c < H && orow < R) cv[(orow * H + c) * CO + li] = acc[i][e] + bz;
+        }
       }
     }
-  }
-  __syncthreads();
-  // max_pool over the rows held in LDS
-  for (int i = tid; i < PR * HP * (CO / 4); i += 256) {
-    const int c4 = i % (CO / 4), ow = (i / (CO / 4)) % HP, ohl = i / ((CO / 4) * HP), oh = p0 + ohl;
-    if (oh >= HP) continue;
-    float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-    uint32_t bi = 0;
-    for (int kh = 0; kh < 3; ++kh) for (int kw = 0; kw < 3; ++kw) {
-      const int ih = oh * 2 + kh, iw = ow * 2 + kw;
-      if (ih >= H || iw >= H) continue;
-      const float4 v = *reinterpret_cast<const float4*>(cv + ((ih - y0) * H + iw) * CO + 4 * c4);
-      const float e[4] = {v.x, v.y, v.z, v.w};
+    __syncthreads();
+    // max_pool over the rows held in LDS
+    for (int i = tid; i < PR * HP * (CO / 4); i += 256) {
+      const int c4 = i % (CO / 4), ow = (i / (CO / 4)) % HP, ohl = i / ((CO / 4) * HP), oh = p0 + ohl;
+      if (oh >= HP) continue;
+      float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+      uint32_t bi = 0;
+      for (int kh = 0; kh < 3; ++kh) for (int kw = 0; kw < 3; ++kw) {
+        const int ih = oh * 2 + kh, iw = ow * 2 + kw;
+        if (ih >= H || iw >= H) continue;
+        const float4 v = *reinterpret_cast<const float4*>(cv + ((ih - y0) * H + iw) * CO + 4 * c4);
+        const float e[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
-        if (e[q] > best[q]) { best[q] = e[q]; bi = (bi & ~(0xffu << (8 * q))) | ((uint32_t)(kh * 3 + kw) << (8 * q)); }
+        for (int q = 0; q < 4; ++q)
+          if (e[q] > best[q]) { best[q] = e[q]; bi = (bi & ~(0xffu << (8 * q))) | ((uint32_t)(kh * 3 + kw) << (8 * q)); }
+      }
+      const size_t o = (((size_t)(b0 * HP + oh) * HP + ow) * (CO / 4) + c4) * 4;
+      *reinterpret_cast<float4*>(pooled + o) = make_float4(best[0], best[1], best[2], best[3]);
+      *reinterpret_cast<uint32_t*>(pidx + o) = bi;
     }
-    const size_t o = (((size_t)(b0 * HP + oh) * HP + ow) * (CO / 4) + c4) * 4;
-    *reinterpret_cast<float4*>(pooled + o) = make_float4(best[0], best[1], best[2], best[3]);
-    *reinterpret_cast<uint32_t*>(pidx + o) = bi;
   }
 }
 template <int PR>
@@ -389,7 +427,10 @@ static void rn_conv0_pool_launch(const uint8_t* obs, const int32_t* idx, const f
   static_assert(lds <= 160 * 1024, "conv0+pool strip exceeds LDS");
   static bool attr = false;
   if (!attr) { hipFuncSetAttribute((const void*)rn_conv0_pool_kernel<PR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
-  hipLaunchKernelGGL((rn_conv0_pool_kernel<PR>), dim3(B * PG::STRIPS), dim3(256), lds, st, obs, idx, W, bias, pooled, pidx, B);
+  const int nstrips = B * PG::STRIPS;
+  const int per_cu = (int)(160 * 1024 / lds) < 1 ? 1 : (int)(160 * 1024 / lds);
+  const int nb = nstrips < 256 * per_cu ? nstrips : 256 * per_cu;
+  hipLaunchKernelGGL((rn_conv0_pool_kernel<PR>), dim3(nb), dim3(256), lds, st, obs, idx, W, bias, pooled, pidx, B, nstrips);
 }
 
 // dgrad as a forward conv: Wt[(jh,jw)][co][ci] = W[(2-jh,2-jw)][ci][co]   (all 14 convs that need a dgrad, one launch)
@@ -902,5 +943,106 @@ static int rn_wgrad2_launch(const float* in, const float* dy, float* part, float
   if (nb > max_blocks) nb = max_blocks;
   if (nb > nstrips) nb = nstrips;
   hipLaunchKernelGGL((rn_wgrad2_kernel<WG, RELU_PASS>), dim3(nb), dim3(WG::NW * 64), lds, st, in, dy, part, bpart, B, nstrips);
+  return nb;
+}
+
+// ================================================================================================ first conv: weight gradient through the pool, sparse
+// dW0[(kh,kw,c)][co] = sum over frames and conv positions of X[c][y+kh-1][x+kw-1] * dC0[y][x][co], and dC0 is the max-pool backward of the pooled
+// gradient g: every pooled element (oh, ow, co) sends its gradient to ONE conv position, its window's arg-max.  rn_wgrad_kernel<.., POOLB> rebuilds
+// the dense 84x84x16 dC0 strip by strip (up to four window look-ups per element) and multiplies all 7056 positions of a frame, three quarters of them
+// zeros, on 16x16x4 MFMAs with a 36-row output (1.14-1.18 ms per 3840-frame minibatch, 27 TFLOP/s).  Here the sum runs over the POOLED elements:
+//     dW0[(kh,kw,c)][co] += g[oh][ow][co] * X[c][ih+kh-1][iw+kw-1],   (ih, iw) = (2*oh + pkh, 2*ow + pkw) from the arg-max byte
+// — a quarter of the multiply-adds, no pool-backward pass, no dense gradient.  The frame sits in LDS as BYTES with a zero border (pixels enter as exact
+// integers, the 1/255 is applied once to the block's partial, as in conv1.hip); lane = (position slot, co) keeps its 36 + 1 sums in registers; a tap
+// row's three pixels come from one ds_read2_b32 + v_alignbyte.  VALU work, not MFMA: 36 multiply-adds per pooled element is all there is.
+#define RNS_PITCH 88                       // bytes per frame row in LDS: 4 zero bytes, 84 pixels (x = -1 reads byte 3, x = 84 the next row's byte 0)
+#define RNS_PLANE (86 * RNS_PITCH)         // rows -1 .. 84
+__global__ __launch_bounds__(256, 4) void rn_wgrad0_sparse_kernel(const uint8_t* obs, const int32_t* idx, const float* g, const uint8_t* pidx, float* part,
+                                                                  float* bpart, int B) {
+  __shared__ __attribute__((aligned(16))) unsigned char fb[4 * RNS_PLANE + 64];
+  __shared__ float red[4][37][16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, co = lane & 15, slot = lane >> 4;
+  for (int v = tid; v < (4 * RNS_PLANE + 64) / 4; v += 256) reinterpret_cast<uint32_t*>(fb)[v] = 0u;   // borders stay zero for the whole kernel
+  float acc[36], bacc = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 36; ++k) acc[k] = 0.0f;
+  // a frame is 7056 uint32 (4 pixels each), 28 per thread: uint32 v lies at byte 4v of the frame and goes to plane p = v / 1764, row r, column 4*cq
+  constexpr int NV = 4 * 84 * 21, NI = (NV + 255) / 256;
+  uint32_t ru[NI];
+  auto fetch = [&](int f) {
+    const uint32_t* fr = reinterpret_cast<const uint32_t*>(obs + (size_t)(idx ? idx[f] : f) * CBM_FRAME);
+#pragma unroll
+    for (int it = 0; it < NI; ++it) ru[it] = fr[min(tid + 256 * it, NV - 1)];
+  };
+  int f = blockIdx.x;
+  if (f < B) fetch(f);
+  for (; f < B; f += gridDim.x) {
+    __syncthreads();            // everyone is done with the previous frame's bytes
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {
+      const int v = tid + 256 * it;
+      if (NV % 256 != 0 && v >= NV) break;
+      const int rg = v / 21, p = v / 1764;          // global row p*84 + r
+      // p * PLANE + (r + 1) * PITCH + 4 + 4 * cq with r = rg - 84 p, cq = v - 21 rg
+      *reinterpret_cast<uint32_t*>(fb + 4 * v + (RNS_PITCH - 84) * rg + (RNS_PLANE - 84 * RNS_PITCH) * p + RNS_PITCH + 4) = ru[it];
+    }
+    __syncthreads();
+    if (f + (int)gridDim.x < B) fetch(f + gridDim.x);
+    // 1764 pooled positions, 16 per iteration over the block: wave w, slot s takes p = 16*it + 4*w + s
+    const float* gf = g + (size_t)f * (1764 * 16) + co;
+    const uint8_t* pf = pidx + (size_t)f * (1764 * 16) + co;
+    int p = 4 * wave + slot, oh = 0, ow = p;          // p < 16 < 42
+    float gn = gf[p * 16];
+    uint32_t pn = pf[p * 16];
+#pragma unroll 1
+    for (int it = 0; it < 111; ++it) {
+      const float gv = gn;
+      const uint32_t pi = pn;
+      const bool live = p < 1764;
+      const int pnext = p + 16;
+      if (pnext < 1764) { gn = gf[pnext * 16]; pn = pf[pnext * 16]; }
+      if (live) {
+        const int pkh = (int)((pi * 11u) >> 5), pkw = (int)pi - 3 * pkh;          // pi / 3, pi % 3 for pi in 0..8
+        const int b0 = (2 * oh + pkh) * RNS_PITCH + 2 * ow + pkw + 3;               // byte of tap (0,0): pixel (ih-1, iw-1)
+        const int sh = b0 & 3;
+        const unsigned char* a0 = fb + (b0 & ~3);
+        bacc += gv;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int kh = 0; kh < 3; ++kh) {
+            const uint32_t* q = reinterpret_cast<const uint32_t*>(a0 + c * RNS_PLANE + kh * RNS_PITCH);
+            const uint32_t w = __builtin_amdgcn_alignbyte(q[1], q[0], (uint32_t)sh);   // bytes b0 .. b0+3 of this row
+            acc[(kh * 3 + 0) * 4 + c] = fmaf(gv, (float)(w & 255u), acc[(kh * 3 + 0) * 4 + c]);
+            acc[(kh * 3 + 1) * 4 + c] = fmaf(gv, (float)((w >> 8) & 255u), acc[(kh * 3 + 1) * 4 + c]);
+            acc[(kh * 3 + 2) * 4 + c] = fmaf(gv, (float)((w >> 16) & 255u), acc[(kh * 3 + 2) * 4 + c]);
+          }
+      }
+      p = pnext; ow += 16;
+      if (ow >= 42) { ow -= 42; oh += 1; }
+    }
+  }
+  // block partial: slots of a wave (xor 16, 32), then the four waves in order
+#pragma unroll
+  for (int k = 0; k < 36; ++k) { acc[k] += __shfl_xor(acc[k], 16, 64); acc[k] += __shfl_xor(acc[k], 32, 64); }
+  bacc += __shfl_xor(bacc, 16, 64); bacc += __shfl_xor(bacc, 32, 64);
+  if (slot == 0) {
+#pragma unroll
+    for (int k = 0; k < 36; ++k) red[wave][k][co] = acc[k];
+    red[wave][36][co] = bacc;
+  }
+  __syncthreads();
+  const float inv255 = 1.0f / 255.0f;
+  for (int v = tid; v < 37 * 16; v += 256) {
+    const int k = v >> 4, n = v & 15;
+    const float sum = ((red[0][k][n] + red[1][k][n]) + red[2][k][n]) + red[3][k][n];
+    if (k < 36) part[((size_t)blockIdx.x * 36 + k) * 16 + n] = sum * inv255;
+    else bpart[blockIdx.x * 16 + n] = sum;
+  }
+}
+static int rn_wgrad0_sparse_launch(const uint8_t* obs, const int32_t* idx, const float* g, const uint8_t* pidx, float* part, float* bpart, int B, int max_blocks,
+                                   hipStream_t st) {
+  const int nb = B < max_blocks ? B : max_blocks;
+  hipLaunchKernelGGL(rn_wgrad0_sparse_kernel, dim3(nb), dim3(256), 0, st, obs, idx, g, pidx, part, bpart, B);
   return nb;
 }
