@@ -105,6 +105,10 @@ int conv3_wgrad_frames_splits(int S);
 int conv3_wgrad_frames_splits_bound(int maxS);
 void launch_conv3_wgrad_frames(const float* act2, const float* dypad, float* part, float* bpart, int S, hipStream_t st);
 
+// load-unit fed weight gradient of the dense layer (dense_wgrad.hip): partials part[z][X][Y], bpart[z][Y]; slices = 0: batch not handled (use the igemm)
+int dense_wgrad_dma_slices(int F);
+void launch_dense_wgrad_dma(const float* act, const float* dhid, float* part, float* bpart, int F, int X, int Y, int nz, hipStream_t st);
+
 // ---- pointwise / scan kernels -----------------------------------------------------------
 void launch_sample(const float* logits, int B, int A, uint32_t sk0, uint32_t sk1, int32_t* actions, float* logprobs,
                    const float* value_in, float* value_out, float* logits_out, hipStream_t st);

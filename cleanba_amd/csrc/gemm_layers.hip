@@ -1146,12 +1146,14 @@ void nature_backward(const NatureLayout& L, const float* P, const uint8_t* obs, 
     DenseDgrad<T128x128k16> pd{ws.dhid, P + L.w[3], ws.act3, ws.dact3pad, B, ws.mask3};
     plaunch_bwd(ws, K_DENSE_DGRAD, pd, 1, st);
     // split-bf16 mode: the staging of a tile is the bottleneck, so it wants the bigger 128x64 tile (and more splits to fill the chip)
-    const int nz = ws.bwd_split == 2 ? (B >= 2048 ? 4 : 1) : dense_wgrad_splits(B);
+    const int nz = ws.bwd_split == 2 ? (B >= 2048 ? 4 : 1) : (dense_wgrad_dma_slices(B) ? dense_wgrad_dma_slices(B) : dense_wgrad_splits(B));
     const int rps = round_up(ceil_div(B, nz), 32);
     fits(1, nz);
     if (ws.bwd_split == 2) {
       MatWgrad<T128x64> pw{ws.act3, ws.dhid, wp + rg.w[1], bp + rg.b[1], B, 3136, 512, 512, rps};
       plaunch_bwd(ws, K_DENSE_WGRAD, pw, nz, st);
+    } else if (dense_wgrad_dma_slices(B)) {   // learner minibatches: both operands straight from the load unit (dense_wgrad.hip)
+      prof_launch(ws, K_DENSE_WGRAD, st, "dense_wgrad_dma_kernel", "", [&] { launch_dense_wgrad_dma(ws.act3, ws.dhid, wp + rg.w[1], bp + rg.b[1], B, 3136, 512, nz, st); });
     } else {
       MatWgrad<T128x256k16> pw{ws.act3, ws.dhid, wp + rg.w[1], bp + rg.b[1], B, 3136, 512, 512, rps};
       plaunch(ws, K_DENSE_WGRAD, pw, nz, st);

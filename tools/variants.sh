@@ -8,6 +8,6 @@ while [ $# -ge 2 ]; do
   name=$1; defs=$2; shift; shift
   d=/tmp/abl_$name; mkdir -p $d
   for f in gemm_layers conv1 wgrad_frames; do /opt/rocm/bin/hipcc $F $defs -c $f.hip -o $d/$f.o & done; wait
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC api.o comm.o pointwise.o env.o $d/gemm_layers.o $d/conv1.o $d/wgrad_frames.o -ldl -o ../abl_$name.so
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC api.o comm.o pointwise.o env.o dense_wgrad.o $d/gemm_layers.o $d/conv1.o $d/wgrad_frames.o -ldl -o ../abl_$name.so
   echo built abl_$name.so "($defs)"
 done
