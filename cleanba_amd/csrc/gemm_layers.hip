@@ -899,7 +899,9 @@ static const int RPS_C2 = 1280, RPS_HEADS = 128;   // (RPS_C2: the im2col conv2 
 // dense weight gradient: 128x256 tiles (2x4 accumulators per wave): 50 tiles x 10 reduction slices, 133 -> 124 us isolated (128x128 x 5: 133;
 // 64x64 x 2: 170; 5 / 8 / 15 slices of the 128x256 tile: 143 / 148 / 160)
 static const int DENSE_WGRAD_NZ = 10;
-static int dense_wgrad_splits(int B) { return B >= 2048 ? DENSE_WGRAD_NZ : 1; }
+// (smaller batches: one slice per 128 frames — IMPALA's default 21 x 30 minibatch ran the 50 tiles of the 3136 x 512 gradient as 50 blocks, 116 us,
+// the longest kernel of its update)
+static int dense_wgrad_splits(int B) { return B >= 2048 ? DENSE_WGRAD_NZ : std::max(1, std::min(DENSE_WGRAD_NZ, ceil_div(B, 128))); }
 
 // offsets (floats) of the per-layer partial regions inside ws.wg_part / ws.bias_part.  Built ONCE from the workspace's maxB and used for every
 // batch B <= maxB: nz[i] is an upper bound of the slices any such B produces.  The frame-split counts are NOT monotone in B (they saturate at

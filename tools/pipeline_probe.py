@@ -6,12 +6,16 @@ import cleanba_amd.lib as L
 import cleanba_amd.model as M
 import cleanba_amd.prng as prng
 E, T, A, EPOCHS, NMB = 120, 128, 18, 4, 4
+NET = os.environ.get("NET", "nature")
 cfg = L.default_config(L.ALGO_PPO)
+if NET != "nature":
+    cfg.network = L.NET_IMPALA_RESNET
+    cfg.actor_dense_ksplit = 11
 cfg.local_num_envs, cfg.num_actor_slots, cfg.num_steps, cfg.num_actions = E, 1, T, A
 ctx = L.Context(cfg)
 key = prng.prng_key(1)
 key, nk, ak, ck = prng.split(key, 4)
-ctx.set_params(M.init_nature_params(A, nk, ak, ck))
+ctx.set_params(M.init_params(NET if NET == "nature" else "impala_resnet", A, nk, ak, ck))
 ctx.actor_set_key(0, key)
 ctx.actor_env_reset_device(0, 1)
 lkey = key.copy()

@@ -1,0 +1,36 @@
+#!/bin/bash
+# usage (GPU box, repo root): GIT_REV=<rev> tools/r03_artifacts.sh <tag>   -> gpurun_out/<tag>/*: everything profiles/r03_* is copied from
+#   bench_line.json            python bench.py (the driver's command)
+#   bench_kernel_stats.md      rocprofv3 --kernel-trace --stats over bench.py; pmc_summary.md / pmc_traffic.json: four separate --pmc passes (Nature minibatch)
+#   resnet_kernel_stats.md     rocprofv3 --kernel-trace over one isolated ResNet learner minibatch x 8 + rollout (tools/rn_microbench.py); resnet_pmc_summary.md
+#   impala_*                   rocprofv3 --kernel-trace over tools/impala_probe.py (T = 128 fp32 / bf16, T = 20) + the probe's own lines
+#   readme_table.txt           tools/readme_table.py (secondary workloads through the product trainer)
+tag=$1; R=$PWD; out=$R/gpurun_out/$tag; mkdir -p $out
+export TMPDIR=/tmp PYTHONPATH=$R
+timeout 600 python bench.py > $out/bench_line.json 2> $out/bench.err
+bash tools/pmc_collect.sh $tag > $out/pmc_collect.log 2>&1
+mv $out/kernel_stats.md $out/bench_kernel_stats.md
+prof() { # name, command...
+  local n=$1; shift
+  cd /tmp; timeout 400 rocprofv3 --kernel-trace --stats -d $out/tr_$n -o t -- "$@" > $out/$n.log 2>&1; cd $R
+  python tools/rocprof_summary.py $(find $out/tr_$n -name "*.db" | head -1) > $out/${n}_kernel_stats.md 2>&1; rm -rf $out/tr_$n
+}
+prof resnet python $R/tools/rn_microbench.py 8
+pmc() { cd /tmp; timeout 400 rocprofv3 --pmc $2 --kernel-trace -d $out/rp_$1 -o p -- python $R/tools/rn_microbench.py 2 > $out/rp_$1.log 2>&1; cd $R; }
+pmc sq "SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU"
+pmc lds "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD"
+pmc fetch "FETCH_SIZE"
+pmc write "WRITE_SIZE"
+db() { find $out/rp_$1 -name "*.db" | head -1; }
+python tools/pmc_report.py $(db sq) $(db lds) $(db fetch) $(db write) 2>&1 | sed 's#tools/microbench.py 3 --plain#tools/rn_microbench.py 2#; s#learner kernels of one 3840-frame PPO minibatch, isolated#IMPALA-ResNet: one 128-step rollout + three 3840-frame PPO minibatches#' > $out/resnet_pmc_summary.md
+rm -rf $out/rp_sq $out/rp_lds $out/rp_fetch $out/rp_write
+prof impala_t128 python $R/tools/impala_probe.py
+BF16=1 prof impala_t128_bf16 python $R/tools/impala_probe.py
+T=20 prof impala_t20 python $R/tools/impala_probe.py
+( python tools/impala_probe.py; BF16=1 python tools/impala_probe.py; T=20 python tools/impala_probe.py; T=20 BF16=1 python tools/impala_probe.py ) 2>&1 | grep -v amdgpu > $out/impala_probe.txt
+python tools/readme_table.py 2>&1 | grep -v amdgpu > $out/readme_table.txt
+python tools/host_loop_probe.py 1 2>&1 | grep -v amdgpu > $out/host_loop_probe.txt
+NET=resnet python tools/pipeline_probe.py 2>&1 | grep -v amdgpu > $out/resnet_pipeline_probe.txt
+python tools/pipeline_probe.py 2>&1 | grep -v amdgpu > $out/nature_pipeline_probe.txt
+timeout 200 tools/ubench/gemm2 0 > $out/ubench_gemm2.txt 2>&1
+ls $out
