@@ -120,8 +120,8 @@ def parse_args(argv=None, algo="ppo"):
 def finalize(args, world_size=1, rank=0):
     """Derived fields and the reference's assertions (ppo:411-430)."""
     n_actor_dev, n_learner = len(args.actor_device_ids), len(args.learner_device_ids)
-    # --channels / --hiddens (ppo:92-95) travel in cbm_config; cbm_ctx_create rejects widths the HIP ResNet torso is not built for, with the
-    # same message for a C host as for this CLI (trainer.make_config)
+    # --channels / --hiddens (ppo:92-95) travel in cbm_config; cbm_ctx_create takes --hiddens H (one layer, 64..512 step 64) and the default
+    # --channels only, and rejects other widths with the same message for a C host as for this CLI (trainer.make_config)
     if getattr(args, "async_batch_size", 0):
         # the legacy async script (naturecnn:102-105): one actor thread on one actor device, host envs, PPO, learner on the same GPU
         if args.local_num_envs % args.async_batch_size:

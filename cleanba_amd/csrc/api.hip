@@ -60,6 +60,10 @@ extern "C" int cbm_default_config(int32_t algo, cbm_config* cfg) {
 
 extern "C" int32_t cbm_config_size(void) { return (int32_t)sizeof(cbm_config); }
 
+extern "C" int64_t cbm_param_count_hidden(int32_t network, int32_t num_actions, int32_t hidden) {
+  if (network != CBM_NET_NATURE && network != CBM_NET_IMPALA_RESNET) return -1;
+  return net_layout(network, num_actions, network == CBM_NET_IMPALA_RESNET ? hidden : 0).total;
+}
 extern "C" int64_t cbm_param_count(int32_t network, int32_t num_actions) {
   if (network != CBM_NET_NATURE && network != CBM_NET_IMPALA_RESNET) return -1;
   return net_layout(network, num_actions).total;
@@ -81,12 +85,17 @@ static int ctx_create_impl(const cbm_config* cfg, cbm_ctx** out, cbm_ctx** parti
   if (cfg->algo == CBM_ALGO_IMPALA && cfg->num_steps + 1 > 2000) { cbm_set_error("IMPALA num_steps must be <= 1999 (the V-trace kernel keeps 8 floats per step in LDS)"); return -1; }
   if (cfg->backward_split != 0 && cfg->backward_split != 2 && cfg->backward_split != 3) { cbm_set_error("backward_split must be 0, 2 or 3"); return -1; }
   if (cfg->backward_split && cfg->network != CBM_NET_NATURE) { cbm_set_error("backward_split is built for the Nature-CNN torso only"); return -1; }
-  if (cfg->network == CBM_NET_IMPALA_RESNET &&
-      !(cfg->num_channels == 3 && cfg->channels[0] == 16 && cfg->channels[1] == 32 && cfg->channels[2] == 32 && cfg->num_hiddens == 1 &&
-        cfg->hiddens[0] == 256)) {
-    // the slab-convolution geometries, the dense tiles and the parameter layout are compiled for these widths (ppo:92-95 defaults)
-    cbm_set_error("--channels/--hiddens: only the reference defaults [16, 32, 32] / [256] are built into the HIP ResNet torso");
-    return -1;
+  if (cfg->network == CBM_NET_IMPALA_RESNET) {
+    // the slab-convolution geometries are compiled for the reference's channel widths (ppo:92-93); the hidden layer (ppo:94) may be any multiple of
+    // 64 up to 512 (the dense / heads kernels take its width at run time), one layer
+    if (!(cfg->num_channels == 3 && cfg->channels[0] == 16 && cfg->channels[1] == 32 && cfg->channels[2] == 32)) {
+      cbm_set_error("--channels: only the reference default [16, 32, 32] is built into the HIP ResNet torso");
+      return -1;
+    }
+    if (!(cfg->num_hiddens == 1 && cfg->hiddens[0] >= 64 && cfg->hiddens[0] <= 512 && cfg->hiddens[0] % 64 == 0)) {
+      cbm_set_error("--hiddens: the HIP ResNet torso takes ONE hidden layer of 64, 128, ... 512 units (reference default [256])");
+      return -1;
+    }
   }
   if (cfg->forward_bf16 && cfg->network != CBM_NET_NATURE) { cbm_set_error("forward_bf16 is built for the Nature-CNN torso only"); return -1; }
   int ndev = 0;
@@ -115,7 +124,7 @@ static int ctx_create_impl(const cbm_config* cfg, cbm_ctx** out, cbm_ctx** parti
     cbm_set_error("the batch does not split into num_minibatches*gradient_accumulation_steps = %d micro-batches", c->nmicro); return -1;
   }
   c->MB = is_ppo(c) ? (c->T * c->Bdev) / c->nmicro : c->T1 * (c->Bdev / c->nmicro);
-  c->L = net_layout(cfg->network, c->A);
+  c->L = net_layout(cfg->network, c->A, cfg->network == CBM_NET_IMPALA_RESNET ? cfg->hiddens[0] : 0);
   if (c->L.flat % cfg->actor_dense_ksplit || (c->L.flat / cfg->actor_dense_ksplit) % 32) {
     cbm_set_error("actor_dense_ksplit must cut the %d-wide flatten into multiples of 32 (Nature: 14, ResNet: 11)", c->L.flat); return -1;
   }

@@ -17,7 +17,7 @@ struct NatureLayout {
   int64_t total;
 };
 NatureLayout nature_layout(int A);
-NatureLayout net_layout(int kind, int A);
+NatureLayout net_layout(int kind, int A, int hid = 0);   // hid: width of the hidden layer (0 = the network's default: 512 / 256)
 
 // ---- optional per-kernel HIP-event timing (bench.py roofline): events bracket every launch of the
 // selected kernel id on the stream it is launched on.

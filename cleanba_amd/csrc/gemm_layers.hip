@@ -557,8 +557,16 @@ void launch_ppo_heads_fused(const NatureLayout& L, const float* P, NatureWs& ws,
 
 static void launch_heads_dgrad(const float* dzv, const float* Wa, const float* Wc, const float* hid, int B, int A, int HD, float* dhid, hipStream_t st) {
   const int nb = (B + HG_FR - 1) / HG_FR;
-  if (HD == 512) hipLaunchKernelGGL(heads_dgrad_kernel<512>, dim3(nb), dim3(512), 0, st, dzv, Wa, Wc, hid, B, A, dhid);
-  else hipLaunchKernelGGL(heads_dgrad_kernel<256>, dim3(nb), dim3(256), 0, st, dzv, Wa, Wc, hid, B, A, dhid);
+  switch (HD) {   // one thread per hidden unit: the widths a context can be created with (`--hiddens`, multiples of 64 up to 512)
+    case 512: hipLaunchKernelGGL(heads_dgrad_kernel<512>, dim3(nb), dim3(512), 0, st, dzv, Wa, Wc, hid, B, A, dhid); break;
+    case 448: hipLaunchKernelGGL(heads_dgrad_kernel<448>, dim3(nb), dim3(448), 0, st, dzv, Wa, Wc, hid, B, A, dhid); break;
+    case 384: hipLaunchKernelGGL(heads_dgrad_kernel<384>, dim3(nb), dim3(384), 0, st, dzv, Wa, Wc, hid, B, A, dhid); break;
+    case 320: hipLaunchKernelGGL(heads_dgrad_kernel<320>, dim3(nb), dim3(320), 0, st, dzv, Wa, Wc, hid, B, A, dhid); break;
+    case 256: hipLaunchKernelGGL(heads_dgrad_kernel<256>, dim3(nb), dim3(256), 0, st, dzv, Wa, Wc, hid, B, A, dhid); break;
+    case 192: hipLaunchKernelGGL(heads_dgrad_kernel<192>, dim3(nb), dim3(192), 0, st, dzv, Wa, Wc, hid, B, A, dhid); break;
+    case 128: hipLaunchKernelGGL(heads_dgrad_kernel<128>, dim3(nb), dim3(128), 0, st, dzv, Wa, Wc, hid, B, A, dhid); break;
+    default: hipLaunchKernelGGL(heads_dgrad_kernel<64>, dim3(nb), dim3(64), 0, st, dzv, Wa, Wc, hid, B, A, dhid); break;
+  }
 }
 
 // dense dgrad: dact3[m][j] = sum_n dhid[m][n] * Wd[j][n]; stored masked into the zero-bordered

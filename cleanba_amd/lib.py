@@ -42,7 +42,7 @@ class EnvState(C.Structure):
 
 # every symbol include/cleanba_mi.h declares (checked by tests/test_abi.py against the header text)
 SYMBOLS = [
-    "cbm_default_config", "cbm_config_size", "cbm_ctx_create", "cbm_ctx_destroy", "cbm_last_error", "cbm_build_info", "cbm_param_count",
+    "cbm_default_config", "cbm_config_size", "cbm_ctx_create", "cbm_ctx_destroy", "cbm_last_error", "cbm_build_info", "cbm_param_count", "cbm_param_count_hidden",
     "cbm_params_set", "cbm_params_get", "cbm_actor_params_get", "cbm_buffer", "cbm_copy_to_host", "cbm_copy_to_device",
     "cbm_dev_alloc", "cbm_dev_free", "cbm_learner_stream", "cbm_sync", "cbm_actor_set_key", "cbm_actor_get_key",
     "cbm_actor_begin_rollout", "cbm_actor_step_host", "cbm_actor_record_host", "cbm_actor_rollout_device",
@@ -111,6 +111,7 @@ def load():
     lib.cbm_last_error.restype = C.c_char_p
     lib.cbm_build_info.restype = C.c_char_p
     lib.cbm_param_count.restype = C.c_int64
+    lib.cbm_param_count_hidden.restype = C.c_int64
     if lib.cbm_config_size() != C.sizeof(Config):
         raise CbmError(f"cbm_config is {lib.cbm_config_size()} bytes in {SO_PATH}, {C.sizeof(Config)} in cleanba_amd/lib.py: rebuild the library")
     lib.cbm_learner_grad_tail_offset.restype = C.c_int64
@@ -142,7 +143,10 @@ def default_config(algo=ALGO_PPO):
     return cfg
 
 
-def param_count(network, A):
+def param_count(network, A, hidden=0):
+    """hidden: width of the IMPALA-ResNet's hidden layer (`--hiddens`, ppo:94); 0 = the network's default."""
+    if hidden:
+        return int(load().cbm_param_count_hidden(int(network), int(A), int(hidden)))
     return int(load().cbm_param_count(int(network), int(A)))
 
 
@@ -186,7 +190,7 @@ class Context:
         _chk(self.lib.cbm_ctx_create(C.byref(cfg), C.byref(h)))
         self.h = h
         self.A = cfg.num_actions
-        self.P = param_count(cfg.network, cfg.num_actions)
+        self.P = param_count(cfg.network, cfg.num_actions, cfg.hiddens[0] if cfg.network == NET_IMPALA_RESNET else 0)
 
     def close(self):
         if self.h:

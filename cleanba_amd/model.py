@@ -108,16 +108,17 @@ _RN_CI, _RN_CO = (4, 16, 32), (16, 32, 32)
 _RN_CONVS = ("Conv_0", "ResidualBlock_0/Conv_0", "ResidualBlock_0/Conv_1", "ResidualBlock_1/Conv_0", "ResidualBlock_1/Conv_1")
 
 
-def resnet_layout(A):
-    """name -> (offset, shape), flax tree order (ConvSequence_s/{Conv_0, ResidualBlock_{0,1}/Conv_{0,1}}, Dense_0, heads)."""
+def resnet_layout(A, hidden=256):
+    """name -> (offset, shape), flax tree order (ConvSequence_s/{Conv_0, ResidualBlock_{0,1}/Conv_{0,1}}, Dense_0, heads).  `hidden` = the one
+    hidden layer's width (Network.hiddens, ppo:94)."""
     out, o = {}, 0
     for s in range(3):
         for j, n in enumerate(_RN_CONVS):
             shp = (3, 3, _RN_CI[s] if j == 0 else _RN_CO[s], _RN_CO[s])
             out[f"ConvSequence_{s}/{n}/kernel"] = (o, shp); o += int(np.prod(shp))
             out[f"ConvSequence_{s}/{n}/bias"] = (o, (_RN_CO[s],)); o += _RN_CO[s]
-    for n, shp in (("Dense_0/kernel", (3872, 256)), ("Dense_0/bias", (256,)), ("actor/kernel", (256, A)), ("actor/bias", (A,)),
-                   ("critic/kernel", (256, 1)), ("critic/bias", (1,))):
+    for n, shp in (("Dense_0/kernel", (3872, hidden)), ("Dense_0/bias", (hidden,)), ("actor/kernel", (hidden, A)), ("actor/bias", (A,)),
+                   ("critic/kernel", (hidden, 1)), ("critic/bias", (1,))):
         out[n] = (o, shp); o += int(np.prod(shp))
     return out, o
 
@@ -134,8 +135,8 @@ def _lecun_normal(rng, shape):
     return (std * x).astype(np.float32)
 
 
-def init_resnet_params(A, network_key, actor_key, critic_key):
-    layout, total = resnet_layout(A)
+def init_resnet_params(A, network_key, actor_key, critic_key, hidden=256):
+    layout, total = resnet_layout(A, hidden)
     p = np.zeros(total, np.float32)
 
     def rng_for(key, i):
@@ -154,14 +155,23 @@ def init_resnet_params(A, network_key, actor_key, critic_key):
     return p
 
 
-def init_params(network, A, network_key, actor_key, critic_key):
+def init_params(network, A, network_key, actor_key, critic_key, hidden=256):
     if network == "nature":
         return init_nature_params(A, network_key, actor_key, critic_key)
-    return init_resnet_params(A, network_key, actor_key, critic_key)
+    return init_resnet_params(A, network_key, actor_key, critic_key, hidden)
+
+
+def resnet_hidden_of(P, A):
+    """Hidden width of a flat ResNet parameter vector of length P (the layout is linear in it)."""
+    _, p0 = resnet_layout(A, 0)
+    h, r = divmod(P - p0, 3872 + 1 + A + 1)
+    if r or h <= 0:
+        raise ValueError(f"{P} parameters is not an IMPALA-ResNet with {A} actions")
+    return h
 
 
 def resnet_params_to_flax_tree(p, A):
-    layout, _ = resnet_layout(A)
+    layout, _ = resnet_layout(A, resnet_hidden_of(len(p), A))
     net = {"params": {}}
     for name, (o, shp) in layout.items():
         parts = name.split("/")
@@ -179,8 +189,8 @@ def resnet_params_to_flax_tree(p, A):
 
 
 def resnet_flax_tree_to_params(tree, A):
-    layout, total = resnet_layout(A)
     net, actor, critic = tree
+    layout, total = resnet_layout(A, int(np.asarray(net["params"]["Dense_0"]["bias"]).shape[0]))
     p = np.zeros(total, np.float32)
     for name, (o, shp) in layout.items():
         parts = name.split("/")

@@ -59,7 +59,7 @@ def make_config(args, algo):
     cfg.num_actions = args.num_actions
     ch, hd = list(getattr(args, "channels", [16, 32, 32])), list(getattr(args, "hiddens", [256]))   # ppo:92-95; cbm_ctx_create checks them
     if len(ch) > 4 or len(hd) > 4:
-        raise SystemExit("--channels/--hiddens: only the reference defaults [16, 32, 32] / [256] are built into the HIP ResNet torso")
+        raise SystemExit("--channels/--hiddens: the HIP ResNet torso is built for channels [16, 32, 32] and one hidden layer of 64..512 units")
     cfg.num_channels, cfg.num_hiddens = len(ch), len(hd)
     for i, v in enumerate(ch):
         cfg.channels[i] = int(v)
@@ -361,7 +361,7 @@ def train(args, algo="ppo", engine_factory=None, on_update=None, rendezvous=None
             cfg.local_num_envs, cfg.num_actor_slots = lay.shard_envs, lay.ports
     engine = engine_factory(cfg) if engine_factory else HipEngine(cfg)
     try:
-        params = M.init_params(args.network, args.num_actions, network_key, actor_key, critic_key)
+        params = M.init_params(args.network, args.num_actions, network_key, actor_key, critic_key, hidden=int(args.hiddens[0]))
         engine.set_params(params)
         if lay is not None:
             return _train_split(args, algo, engine, lay, rdv, writer, key, rank, run_name, on_update)

@@ -66,10 +66,10 @@ typedef struct {
                                  backward GEMMs is split exactly into that many bf16 terms and the products are formed on bf16 MFMA with
                                  fp32 accumulation (2: a1b1+a1b2+a2b1, product error ~2^-16; 3: six products, ~2^-22 = fp32 rounding
                                  noise).  The forward pass, losses, returns and the optimizer are untouched.  Nature-CNN only. */
-  int32_t num_channels;       /* Network(channels, hiddens) of ppo:92-95,175-176 (`--channels`, `--hiddens`): the IMPALA-ResNet torso is built for */
-  int32_t channels[4];        /* the reference defaults channels = (16, 32, 32), hiddens = (256,); cbm_default_config fills them and          */
-  int32_t num_hiddens;        /* cbm_ctx_create REJECTS anything else ("--channels/--hiddens: only the reference defaults ...") rather than   */
-  int32_t hiddens[4];         /* silently training a different network.  Ignored for CBM_NET_NATURE (the legacy script has no such flags).    */
+  int32_t num_channels;       /* Network(channels, hiddens) of ppo:92-95,175-176 (`--channels`, `--hiddens`).  channels: the IMPALA-ResNet torso is  */
+  int32_t channels[4];        /* built for the reference default (16, 32, 32) and cbm_ctx_create REJECTS anything else rather than silently training */
+  int32_t num_hiddens;        /* a different network; hiddens: ONE hidden layer of 64, 128, ... 512 units (default 256; flat parameter layout and    */
+  int32_t hiddens[4];         /* cbm_param_count_hidden follow it).  Both ignored for CBM_NET_NATURE (the legacy script has no such flags).          */
   int32_t reserved[3];
 } cbm_config;
 
@@ -86,6 +86,7 @@ const char* cbm_build_info(void);
  * Replaces network.init/actor.init/critic.init + device_put (ppo:481-502) and the
  * params hand-off to the actors (ppo:721-725). */
 int64_t cbm_param_count(int32_t network, int32_t num_actions);
+int64_t cbm_param_count_hidden(int32_t network, int32_t num_actions, int32_t hidden);   /* IMPALA-ResNet with Network(hiddens=(hidden,)), ppo:94 */
 int cbm_params_set(cbm_ctx* ctx, const float* host_params, int64_t n);      /* learner + actor copy, resets optimizer state */
 int cbm_params_get(cbm_ctx* ctx, float* host_params, int64_t n);            /* learner copy */
 int cbm_actor_params_get(cbm_ctx* ctx, float* host_params, int64_t n);      /* actor copy (policy version behind) */

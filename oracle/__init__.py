@@ -334,6 +334,15 @@ def rmsprop_step(p, g, nu, max_norm, lr, decay=0.99, eps=0.01):
 
 
 # ---------------------------------------------------------------- IMPALA-ResNet torso (ppo:149-189)
+def set_resnet_hidden(h=256):
+    """Width of the torso's one hidden layer (Network.hiddens, ppo:94) for every later resnet_* call; 256 = the reference default."""
+    lib().cbo_resnet_set_hidden(int(h))
+
+
+def resnet_hidden():
+    return int(lib().cbo_resnet_get_hidden())
+
+
 def resnet_param_count(A):
     lib().cbo_resnet_param_count.restype = C.c_int64
     return int(lib().cbo_resnet_param_count(int(A)))
@@ -346,7 +355,7 @@ def resnet_act_floats():
 
 def resnet_layout(A):
     """name -> (offset, shape), flax tree order: ConvSequence_s/{Conv_0, ResidualBlock_{0,1}/Conv_{0,1}}, Dense_0, heads."""
-    ci, co = (4, 16, 32), (16, 32, 32)
+    ci, co, hd = (4, 16, 32), (16, 32, 32), resnet_hidden()
     out, o = {}, 0
     for s in range(3):
         names = ["Conv_0", "ResidualBlock_0.Conv_0", "ResidualBlock_0.Conv_1", "ResidualBlock_1.Conv_0", "ResidualBlock_1.Conv_1"]
@@ -354,7 +363,7 @@ def resnet_layout(A):
             shp = (3, 3, ci[s] if j == 0 else co[s], co[s])
             out[f"seq{s}.{n}.w"] = (o, shp); o += int(np.prod(shp))
             out[f"seq{s}.{n}.b"] = (o, (co[s],)); o += co[s]
-    for n, shp in (("dense.w", (3872, 256)), ("dense.b", (256,)), ("actor.w", (256, A)), ("actor.b", (A,)), ("critic.w", (256, 1)),
+    for n, shp in (("dense.w", (3872, hd)), ("dense.b", (hd,)), ("actor.w", (hd, A)), ("actor.b", (A,)), ("critic.w", (hd, 1)),
                    ("critic.b", (1,))):
         out[n] = (o, shp); o += int(np.prod(shp))
     assert o == resnet_param_count(A)

@@ -745,7 +745,11 @@ EXPORT void cbo_bits_to_uniform_v(const uint32_t* b, float* y, int64_t n) { for 
 #define RN_NSEQ 3
 static const int RN_H[3] = {84, 42, 21}, RN_HP[3] = {42, 21, 11}, RN_CI[3] = {4, 16, 32}, RN_CO[3] = {16, 32, 32}, RN_PLO[3] = {0, 0, 1};
 #define RN_FLAT 3872
-#define RN_HID 256
+#define RN_HID_MAX 512
+static int g_rn_hid = 256;   /* Network(hiddens=(H,)), ppo:94: one hidden layer, the reference default 256 */
+#define RN_HID g_rn_hid
+EXPORT void cbo_resnet_set_hidden(int h) { g_rn_hid = h; }
+EXPORT int cbo_resnet_get_hidden(void) { return g_rn_hid; }
 typedef struct { int A; int64_t cw[3][5], cb[3][5], dw, db, aw, ab, vw, vb, total; } rn_layout;
 static void rn_get_layout(int A, rn_layout* L) {
   int64_t o = 0;
@@ -837,7 +841,7 @@ static void rn_fwd_frame(const float* P, const rn_layout* L, const uint8_t* x, i
   float* hid = act + rn_seq_off(3);
   {
     const float* W = P + L->dw; const float* b = P + L->db;
-    float tot[RN_HID], acc[RN_HID];
+    float tot[RN_HID_MAX], acc[RN_HID_MAX];
     const int seg = RN_FLAT / ksplit;
     for (int s = 0; s < ksplit; ++s) {
       for (int n = 0; n < RN_HID; ++n) acc[n] = 0.0f;
@@ -905,7 +909,7 @@ static void rn_bwd_frame(const float* P, const rn_layout* L, const uint8_t* x, c
                          float* s0, float* s1, float* s2) {
   const int A = L->A;
   const float* hid = act + rn_seq_off(3);
-  float dh[RN_HID];
+  float dh[RN_HID_MAX];
   for (int k = 0; k < RN_HID; ++k) {
     double s = 0.0;
     for (int a = 0; a < A; ++a) { s += (double)dlog[a] * P[L->aw + k * A + a]; G[L->aw + k * A + a] += (double)hid[k] * dlog[a]; }

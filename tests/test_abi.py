@@ -45,19 +45,20 @@ def test_channels_and_hiddens_travel_in_the_config_and_are_checked_by_the_librar
     cfg = L.default_config(L.ALGO_PPO)
     assert (cfg.num_channels, list(cfg.channels)[:3], cfg.num_hiddens, cfg.hiddens[0]) == (3, [16, 32, 32], 1, 256)
     cfg.network = L.NET_IMPALA_RESNET
-    for mutate in (lambda c: c.channels.__setitem__(2, 64), lambda c: setattr(c, "num_channels", 2), lambda c: c.hiddens.__setitem__(0, 512),
-                   lambda c: setattr(c, "num_hiddens", 2)):
+    for mutate, msg in ((lambda c: c.channels.__setitem__(2, 64), "--channels: only"), (lambda c: setattr(c, "num_channels", 2), "--channels: only"),
+                        (lambda c: c.hiddens.__setitem__(0, 100), "--hiddens: the HIP"), (lambda c: c.hiddens.__setitem__(0, 576), "--hiddens: the HIP"),
+                        (lambda c: setattr(c, "num_hiddens", 2), "--hiddens: the HIP")):
         bad = L.default_config(L.ALGO_PPO)
         bad.network = L.NET_IMPALA_RESNET
         mutate(bad)
-        with pytest.raises(L.CbmError, match="--channels/--hiddens: only the reference defaults"):
+        with pytest.raises(L.CbmError, match=msg):
             L.Context(bad)
     from cleanba_amd.args import parse_args
     from cleanba_amd.trainer import make_config
     args = parse_args(["--channels", "16", "32", "64", "--hiddens", "512"], "ppo")
     c2 = make_config(args, "ppo")
     assert list(c2.channels)[:3] == [16, 32, 64] and c2.hiddens[0] == 512
-    with pytest.raises(L.CbmError, match="--channels/--hiddens"):
+    with pytest.raises(L.CbmError, match="--channels: only"):
         L.Context(c2)
 
 

@@ -83,7 +83,7 @@ def impala_loss(logits, value, mu_logits, actions, rewards, dones, firststeps, g
     return pg + vf_coef * bl + ent_coef * ent, (pg, bl, ent)
 
 
-def unpack_resnet(params, A, dtype=torch.float64, requires_grad=False):
+def unpack_resnet(params, A, dtype=torch.float64, requires_grad=False, hid=256):
     ci, co = (4, 16, 32), (16, 32, 32)
     flat = torch.tensor(np.asarray(params), dtype=dtype, requires_grad=requires_grad)
     P, o = {}, 0
@@ -93,7 +93,7 @@ def unpack_resnet(params, A, dtype=torch.float64, requires_grad=False):
     for s in range(3):
         for j in range(5):
             take(f"s{s}c{j}w", (3, 3, ci[s] if j == 0 else co[s], co[s])); take(f"s{s}c{j}b", (co[s],))
-    take("dw", (3872, 256)); take("db", (256,)); take("aw", (256, A)); take("ab", (A,)); take("cw", (256, 1)); take("cb", (1,))
+    take("dw", (3872, hid)); take("db", (hid,)); take("aw", (hid, A)); take("ab", (A,)); take("cw", (hid, 1)); take("cb", (1,))
     assert o == flat.numel()
     return flat, P
 
