@@ -1,0 +1,173 @@
+// conv_regw.hip — learner-size conv3 forward (3x3 stride 1, 64 -> 64 channels, 9x9 -> 7x7; naturecnn:160-166) with the WEIGHTS IN REGISTERS.
+//
+// The im2col GEMM kernels (igemm.h) stage both operands through LDS tile by tile: per 16-wide K chunk a gather, a register -> LDS store, a barrier.
+// Here nothing but the activations ever goes through LDS and nothing but `ds_read_b32` + MFMA is issued inside a step:
+//   * a block is 8 waves; wave (cq, tg) keeps W[0:576][16*cq : 16*cq+16] — its 16 output channels, ALL of K — in 144 VGPRs as the B fragments of
+//     v_mfma_f32_16x16x4_f32 (lane (g4, r16) holds W[4s + g4][16 cq + r16] for step s).  147 KB of weights live in the CU's register file, read once.
+//   * the block owns a contiguous run of frames and walks their 49-position outputs as ONE stream of 16-position tiles (a tile may straddle two
+//     frames: every lane carries its own pixel address), 4 tiles = 64 positions per step; waves tg = 0 / 1 take tiles {0,1} / {2,3} of the step with
+//     two independent accumulators, the four cq waves of a tile read the same A fragments.
+//   * input frames sit in a ring of 7 LDS slots as NHWC pixels of 64 floats at a pitch of 68: lane (g4, r16) reads pixel(r16) * 68 + 4c + g4, bank
+//     4 r16 + g4 (+ const) — conflict-free inside an output row.  A frame is copied by 81 `global_load_lds_dword` (one pixel = 256 B each), issued a
+//     whole step (~10 us) before its first use; one raw s_barrier per step, two thirds into it (see SYNC_TAP); the step's results are stored at the
+//     top of the NEXT step, so the vmcnt(0) in front of the barrier never waits for a store or a copy issued less than half a step ago.
+//   * a step's K loop is 9 taps x 16 channel quads = 144 x (2 ds_read_b32 with immediate offsets + 2 MFMA): k = (kh, kw, ci) ascending in one accumulator, four k
+//     per instruction in ascending order — the same fmaf chain as igemm_kernel / igemm_s16_kernel, so the forward stays bit-exact against the oracle.
+// Epilogue = ConvFwd::store_flag's: relu(acc + bias) and the ReLU bit mask (one uint32 per position and 32 channels; a wave owns 16 of them and writes its
+// half as a uint16).
+#include "cbm_internal.h"
+#include <type_traits>
+
+typedef float f32x4_rw __attribute__((ext_vector_type(4)));
+static __device__ __forceinline__ void rw_glds4(const float* g_lane, float* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g_lane, (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
+}
+
+namespace {
+struct C3G {
+  static constexpr int KH = 3, KW = 3, CI = 64, CO = 64, IH = 9, IW = 9, OH = 7, OW = 7;
+  static constexpr int PIX = IH * IW, NPOS = OH * OW, PP = CI + 4, SLOT = PIX * PP, NS = 7, NSTEP = KH * KW * CI / 4;
+  static constexpr int SYNC_TAP = 6;                          // the step's barrier sits in front of this tap
+  static constexpr int NW = 8, DPW = (PIX + NW - 1) / NW;     // copies per wave and frame
+  static constexpr int LDS_BYTES = NS * SLOT * 4;
+};
+}  // namespace
+
+template <class G>
+__global__ __launch_bounds__(512) void conv_fwd_regw_kernel(const float* __restrict__ in, const float* __restrict__ W, const float* __restrict__ bias,
+                                                            float* __restrict__ out, uint32_t* __restrict__ mask, int B, int fpb) {
+  extern __shared__ __attribute__((aligned(16))) float rw_lds[];
+  const int tid = threadIdx.x, lane = tid & 63, r16 = lane & 15, g4 = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cq = wave & 3, tg = wave >> 2;
+  const int f0 = blockIdx.x * fpb, nf = min(fpb, B - f0);
+  if (nf <= 0) return;
+  const int P = nf * G::NPOS, nsteps = (P + 63) >> 6;
+  const float* src0 = in + (size_t)f0 * (G::PIX * G::CI);
+
+  int issued = 0;
+  auto issue_upto = [&](int lim) __attribute__((always_inline)) {
+    lim = min(lim, nf);
+    for (; issued < lim; ++issued) {
+      const float* src = src0 + (size_t)issued * (G::PIX * G::CI) + lane;
+      float* dst = rw_lds + (issued % G::NS) * G::SLOT;
+#pragma unroll
+      for (int i = 0; i < G::DPW; ++i) {
+        const int p = min(wave * G::DPW + i, G::PIX - 1);      // (the last wave repeats pixel 80: same bytes to the same place)
+        rw_glds4(src + p * G::CI, dst + p * G::PP);
+      }
+    }
+  };
+  issue_upto(G::NS);
+
+  float w[G::NSTEP];
+#pragma unroll
+  for (int s = 0; s < G::NSTEP; ++s) w[s] = W[(size_t)(4 * s + g4) * G::CO + 16 * cq + r16];
+  const float bv = bias[16 * cq + r16];
+  uint16_t* mask16 = reinterpret_cast<uint16_t*>(mask);
+
+  // A step = 64 positions = 4 tiles, two per wave (tg takes tiles 2 tg, 2 tg + 1).  When the LAST step has 32 positions or fewer it runs as a half step:
+  // one tile per wave (tile tg), half the instructions — at 3840 frames a block owns 735 positions = 11.5 steps, and a full twelfth step was 4 % of the kernel.
+  const bool half_last = P - 64 * (nsteps - 1) <= 32;
+  float o[2][4];
+  uint32_t mh[2] = {0u, 0u};
+  auto flush = [&](int t, bool half) __attribute__((always_inline)) {      // results of step t
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      if (half && j) break;
+      const int q0 = 64 * t + (half ? tg : 2 * tg + j) * 16;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int q = q0 + 4 * g4 + e;
+        if (q < P) out[((size_t)f0 * G::NPOS + q) * G::CO + 16 * cq + r16] = o[j][e];
+      }
+      if (mask16 && r16 < 4) {
+        const int q = q0 + 4 * g4 + r16;
+        if (q < P) mask16[((size_t)f0 * G::NPOS + q) * (G::CO / 16) + cq] = (uint16_t)mh[j];
+      }
+    }
+  };
+
+  constexpr int QPT = G::CI / 4, NTAP = G::KH * G::KW;          // channel quads per tap
+  auto step = [&](auto ntc, int t) __attribute__((always_inline)) {
+    constexpr int NT = decltype(ntc)::value;
+    int base[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int q = min(64 * t + (NT == 1 ? tg : 2 * tg + j) * 16 + r16, P - 1);
+      const int fr = q / G::NPOS, p = q - fr * G::NPOS, oy = p / G::OW, ox = p - oy * G::OW;
+      base[j] = (fr % G::NS) * G::SLOT + (oy * G::IW + ox) * G::PP + g4;
+    }
+    f32x4_rw acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[j] = f32x4_rw{0.f, 0.f, 0.f, 0.f};
+    // A fragments of a whole tap (QPT k-steps x NT tiles) are read while the previous tap is multiplied: the reads are a tap (~1000 cycles) ahead
+    float a[2][NT][QPT];
+    auto load_part = [&](int tap, int c0, float (&dst)[NT][QPT]) __attribute__((always_inline)) {   // quads c0 .. c0+3 of a tap
+      const int kh = tap / G::KW, kw = tap - kh * G::KW, off = (kh * G::IW + kw) * G::PP;
+#pragma unroll
+      for (int c = c0; c < c0 + 4; ++c)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) dst[j][c] = rw_lds[base[j] + off + 4 * c];
+    };
+#pragma unroll
+    for (int c0 = 0; c0 < QPT; c0 += 4) load_part(0, c0, a[0]);
+#pragma unroll
+    for (int tap = 0; tap < NTAP; ++tap) {
+      if (tap == G::SYNC_TAP) {
+        // Two thirds into the step: every copy issued at this point of the previous step has had a whole step to land (the wait is free), and past
+        // the barrier every wave has left step t-1, so the frames below lo(t) can be overwritten.  What is issued here is first read after the NEXT
+        // barrier.  Keeping the barrier away from the step boundary lets the two waves of a SIMD drift apart: one wave's stores / address arithmetic /
+        // first LDS round trip run under the other's MFMAs.
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");
+        issue_upto((64 * t) / G::NPOS + G::NS);
+      }
+#pragma unroll
+      for (int c0 = 0; c0 < QPT; c0 += 4) {
+        __builtin_amdgcn_sched_barrier(0);                       // (the scheduler otherwise sinks every read to just before its use)
+        if (tap + 1 < NTAP) load_part(tap + 1, c0, a[(tap + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = c0; c < c0 + 4; ++c)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tap & 1][j][c], w[tap * QPT + c], acc[j], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      uint64_t b[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float pre = acc[j][e] + bv;
+        const float v = pre > 0.0f ? pre : 0.0f;
+        o[j][e] = v;
+        b[e] = __ballot(v > 0.0f);
+      }
+      const uint64_t mine = r16 == 0 ? b[0] : (r16 == 1 ? b[1] : (r16 == 2 ? b[2] : b[3]));   // row 4 g4 + r16 lives in ballot r16, bits [16 g4, +16)
+      mh[j] = (uint32_t)(mine >> (16 * g4)) & 0xffffu;
+    }
+  };
+
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("s_barrier" ::: "memory");                       // the first NS frames are in LDS
+  const int nfull = half_last ? nsteps - 1 : nsteps;
+  for (int t = 0; t < nfull; ++t) {
+    if (t > 0) flush(t - 1, false);
+    step(std::integral_constant<int, 2>{}, t);
+  }
+  if (half_last) {
+    if (nfull > 0) flush(nfull - 1, false);
+    step(std::integral_constant<int, 1>{}, nfull);
+  }
+  flush(nsteps - 1, half_last);
+}
+
+void launch_conv3_fwd_regw(const float* in, const float* W, const float* bias, float* out, uint32_t* mask, int B, hipStream_t st) {
+  static bool attr = false;
+  if (!attr) { hipFuncSetAttribute((const void*)conv_fwd_regw_kernel<C3G>, hipFuncAttributeMaxDynamicSharedMemorySize, C3G::LDS_BYTES); attr = true; }
+  const int fpb = (B + 255) / 256, blocks = (B + fpb - 1) / fpb;
+  hipLaunchKernelGGL(conv_fwd_regw_kernel<C3G>, dim3(blocks), dim3(512), C3G::LDS_BYTES, st, in, W, bias, out, mask, B, fpb);
+}

@@ -1091,7 +1091,7 @@ int nature_forward(const NatureLayout& L, const float* P, const uint8_t* obs, co
     if (!ws.bf16_fwd) plaunch_pf2(ws, K_CONV2_FWD, p2, 1, st);
     else plaunch_fwd(ws, K_CONV2_FWD, p2, 1, st);
     ConvFwd<T128x64, 3, 3, 1, 64, 64, 9, 9, 7, 7> p3{ws.act2, P + L.w[2], P + L.b[2], ws.act3, B * 49, ws.mask3};
-    if (!ws.bf16_fwd) plaunch_pf2(ws, K_CONV3_FWD, p3, 1, st);
+    if (!ws.bf16_fwd) prof_launch(ws, K_CONV3_FWD, st, "conv_fwd_regw_kernel", "", [&] { launch_conv3_fwd_regw(ws.act2, P + L.w[2], P + L.b[2], ws.act3, ws.mask3, B, st); });
     else plaunch_fwd(ws, K_CONV3_FWD, p3, 1, st);
   }
   if (dense_ksplit > 1) {

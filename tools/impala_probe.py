@@ -28,9 +28,11 @@ def update():
     lkey, _ = ctx.learner_update(lkey, lrs, lrs, lrs, want_stats=False)
 
 rollout()
-for _ in range(2): rollout(); update()
+# warm up for >= 0.3 s of GPU work: on a fresh box the first process still loads code objects / ramps clocks after 2-3 short steps, which an
+# 8-step sample at T = 20 (21 ms) then measures instead of the steady state (seen: 8.7 vs 2.67 ms per step)
+for _ in range(max(2, 4000 // T)): rollout(); update()
 ctx.sync(); t0 = time.perf_counter()
-N = 8
+N = max(8, 1024 // T)
 for _ in range(N): rollout(); update()
 ctx.sync(); dt = (time.perf_counter() - t0) / N
 print(f"IMPALA E={E} T={T} bf16={cfg.forward_bf16}: pipelined {dt*1e3:.2f} ms/step = {E*T/dt/1e3:.1f} k env-steps/s")
