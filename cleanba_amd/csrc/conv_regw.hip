@@ -5,7 +5,7 @@
 //   * a block is 8 waves; wave (cq, tg) keeps W[0:576][16*cq : 16*cq+16] — its 16 output channels, ALL of K — in 144 VGPRs as the B fragments of
 //     v_mfma_f32_16x16x4_f32 (lane (g4, r16) holds W[4s + g4][16 cq + r16] for step s).  147 KB of weights live in the CU's register file, read once.
 //   * the block owns a contiguous run of frames and walks their 49-position outputs as ONE stream of 16-position tiles (a tile may straddle two
-//     frames: every lane carries its own pixel address), 4 tiles = 64 positions per step; waves tg = 0 / 1 take tiles {0,1} / {2,3} of the step with
+//     frames: every lane carries its own pixel address), 4 tiles = 64 positions per step; waves tg = 0 / 1 take tiles {0,1} / {2,3} of the step (one tile each in a short last step) with
 //     two independent accumulators, the four cq waves of a tile read the same A fragments.
 //   * input frames sit in a ring of 7 LDS slots as NHWC pixels of 64 floats at a pitch of 68: lane (g4, r16) reads pixel(r16) * 68 + 4c + g4, bank
 //     4 r16 + g4 (+ const) — conflict-free inside an output row.  A frame is copied by 81 `global_load_lds_dword` (one pixel = 256 B each), issued a
@@ -28,13 +28,14 @@ struct C3G {
   static constexpr int KH = 3, KW = 3, CI = 64, CO = 64, IH = 9, IW = 9, OH = 7, OW = 7;
   static constexpr int PIX = IH * IW, NPOS = OH * OW, PP = CI + 4, SLOT = PIX * PP, NS = 7, NSTEP = KH * KW * CI / 4;
   static constexpr int SYNC_TAP = 6;                          // the step's barrier sits in front of this tap
-  static constexpr int NW = 8, DPW = (PIX + NW - 1) / NW;     // copies per wave and frame
+  static constexpr int NTG = 2, NW = 4 * NTG, DPW = (PIX + NW - 1) / NW;     // tile groups (waves per SIMD), waves, copies per wave and frame
+  static constexpr int SP = 32 * NTG;                          // positions per step
   static constexpr int LDS_BYTES = NS * SLOT * 4;
 };
 }  // namespace
 
 template <class G>
-__global__ __launch_bounds__(512) void conv_fwd_regw_kernel(const float* __restrict__ in, const float* __restrict__ W, const float* __restrict__ bias,
+__global__ __launch_bounds__(64 * G::NW) void conv_fwd_regw_kernel(const float* __restrict__ in, const float* __restrict__ W, const float* __restrict__ bias,
                                                             float* __restrict__ out, uint32_t* __restrict__ mask, int B, int fpb) {
   extern __shared__ __attribute__((aligned(16))) float rw_lds[];
   const int tid = threadIdx.x, lane = tid & 63, r16 = lane & 15, g4 = lane >> 4;
@@ -42,7 +43,7 @@ __global__ __launch_bounds__(512) void conv_fwd_regw_kernel(const float* __restr
   const int cq = wave & 3, tg = wave >> 2;
   const int f0 = blockIdx.x * fpb, nf = min(fpb, B - f0);
   if (nf <= 0) return;
-  const int P = nf * G::NPOS, nsteps = (P + 63) >> 6;
+  const int P = nf * G::NPOS, nsteps = (P + G::SP - 1) / G::SP;
   const float* src0 = in + (size_t)f0 * (G::PIX * G::CI);
 
   int issued = 0;
@@ -68,14 +69,14 @@ __global__ __launch_bounds__(512) void conv_fwd_regw_kernel(const float* __restr
 
   // A step = 64 positions = 4 tiles, two per wave (tg takes tiles 2 tg, 2 tg + 1).  When the LAST step has 32 positions or fewer it runs as a half step:
   // one tile per wave (tile tg), half the instructions — at 3840 frames a block owns 735 positions = 11.5 steps, and a full twelfth step was 4 % of the kernel.
-  const bool half_last = P - 64 * (nsteps - 1) <= 32;
+  const bool half_last = P - G::SP * (nsteps - 1) <= G::SP / 2;
   float o[2][4];
   uint32_t mh[2] = {0u, 0u};
   auto flush = [&](int t, bool half) __attribute__((always_inline)) {      // results of step t
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       if (half && j) break;
-      const int q0 = 64 * t + (half ? tg : 2 * tg + j) * 16;
+      const int q0 = G::SP * t + (half ? tg : 2 * tg + j) * 16;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int q = q0 + 4 * g4 + e;
@@ -94,7 +95,7 @@ __global__ __launch_bounds__(512) void conv_fwd_regw_kernel(const float* __restr
     int base[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-      const int q = min(64 * t + (NT == 1 ? tg : 2 * tg + j) * 16 + r16, P - 1);
+      const int q = min(G::SP * t + (NT == 1 ? tg : 2 * tg + j) * 16 + r16, P - 1);
       const int fr = q / G::NPOS, p = q - fr * G::NPOS, oy = p / G::OW, ox = p - oy * G::OW;
       base[j] = (fr % G::NS) * G::SLOT + (oy * G::IW + ox) * G::PP + g4;
     }
@@ -122,7 +123,7 @@ __global__ __launch_bounds__(512) void conv_fwd_regw_kernel(const float* __restr
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_barrier" ::: "memory");
-        issue_upto((64 * t) / G::NPOS + G::NS);
+        issue_upto((G::SP * t) / G::NPOS + G::NS);
       }
 #pragma unroll
       for (int c0 = 0; c0 < QPT; c0 += 4) {
@@ -169,5 +170,5 @@ void launch_conv3_fwd_regw(const float* in, const float* W, const float* bias, f
   static bool attr = false;
   if (!attr) { hipFuncSetAttribute((const void*)conv_fwd_regw_kernel<C3G>, hipFuncAttributeMaxDynamicSharedMemorySize, C3G::LDS_BYTES); attr = true; }
   const int fpb = (B + 255) / 256, blocks = (B + fpb - 1) / fpb;
-  hipLaunchKernelGGL(conv_fwd_regw_kernel<C3G>, dim3(blocks), dim3(512), C3G::LDS_BYTES, st, in, W, bias, out, mask, B, fpb);
+  hipLaunchKernelGGL(conv_fwd_regw_kernel<C3G>, dim3(blocks), dim3(64 * C3G::NW), C3G::LDS_BYTES, st, in, W, bias, out, mask, B, fpb);
 }

@@ -20,13 +20,16 @@ ROWS = [
     ("IMPALA resnet T=128", "impala", ["--network", "impala_resnet", "--env-backend", "device"], 1, T),
     ("PPO nature T=128 two actor threads (240 envs)", "ppo", ["--network", "nature", "--env-backend", "device"], 2, T),
     ("IMPALA nature T=20 two actor threads", "impala", ["--network", "nature", "--env-backend", "device"], 2, 20),
+    ("PPO nature T=128 two actor threads x 60 envs", "ppo", ["--network", "nature", "--env-backend", "device"], 2, T, 60),
+    ("PPO nature T=128 four actor threads x 30 envs", "ppo", ["--network", "nature", "--env-backend", "device"], 4, T, 30),
     ("PPO nature T=128 backward-split 2", "ppo", ["--network", "nature", "--env-backend", "device", "--backward-split", "2"], 1, T),
     ("PPO nature host env 1 thread", "ppo", ["--network", "nature", "--env-backend", "host"], 1, T),
     ("PPO nature Atari57 mix", "ppo", ["--network", "nature", "--env-backend", "device", "--env-id", "Atari57Mix-v5"], 1, T),
 ]
 flt = sys.argv[1] if len(sys.argv) > 1 else ""
 os.chdir(os.environ.get("TMPDIR", "/tmp"))
-for name, algo, extra, threads, t in ROWS:
+for name, algo, extra, threads, t, *rest in ROWS:
+    E = rest[0] if rest else 120
     if flt not in name:
         continue
     warm, n_up = 3, (12 if "resnet" not in name else 6)
