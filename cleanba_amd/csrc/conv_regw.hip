@@ -59,7 +59,9 @@ __global__ __launch_bounds__(64 * G::NW) void conv_fwd_regw_kernel(const float* 
       }
     }
   };
-  issue_upto(G::NS);
+  // Only the frames the first step and a third need (reads before the second barrier touch positions < 2 SP) are requested up front; the rest of the ring
+  // is filled from the first barrier on (all 256 blocks start together: seven frames each are 37 MB wanted at once).
+  issue_upto((2 * G::SP - 1) / G::NPOS + 1);
 
   float w[G::NSTEP];
 #pragma unroll
