@@ -5,6 +5,7 @@
 #   resnet_kernel_stats.md     rocprofv3 --kernel-trace over one isolated ResNet learner minibatch x 8 + rollout (tools/rn_microbench.py); resnet_pmc_summary.md
 #   impala_*                   rocprofv3 --kernel-trace over tools/impala_probe.py (T = 128 fp32 / bf16, T = 20) + the probe's own lines
 #   readme_table.txt           tools/readme_table.py (secondary workloads through the product trainer)
+#   actor_progress.md          tools/actor_progress.py over a kernel trace of tools/pipeline_probe.py (rollout progress rate inside each learner kernel)
 tag=$1; R=$PWD; out=$R/gpurun_out/$tag; mkdir -p $out
 export TMPDIR=/tmp PYTHONPATH=$R
 timeout 600 python bench.py > $out/bench_line.json 2> $out/bench.err
@@ -33,4 +34,7 @@ python tools/host_loop_probe.py 1 2>&1 | grep -v amdgpu > $out/host_loop_probe.t
 NET=resnet python tools/pipeline_probe.py 2>&1 | grep -v amdgpu > $out/resnet_pipeline_probe.txt
 python tools/pipeline_probe.py 2>&1 | grep -v amdgpu > $out/nature_pipeline_probe.txt
 timeout 200 tools/ubench/gemm2 0 > $out/ubench_gemm2.txt 2>&1
+timeout 100 tools/ubench/mfma_shape > $out/ubench_mfma_shape.txt 2>&1
+cd /tmp; timeout 300 rocprofv3 --kernel-trace -d $out/tr_ap -o t -- python $R/tools/pipeline_probe.py > /dev/null 2>&1; cd $R
+python tools/actor_progress.py $(find $out/tr_ap -name "*.db" | head -1) > $out/actor_progress.md 2>&1; rm -rf $out/tr_ap
 ls $out
