@@ -1,0 +1,226 @@
+// rnconv_rw.h — learner-size 3x3 SAME convolutions of the IMPALA-ResNet torso (ppo:149-189) with the WEIGHTS IN REGISTERS and the activations in a
+// load-unit-fed NHWC row ring.  Drop-in for rn_conv_kernel (rnconv.h) at large batches: same arguments, same epilogues (EPI 0-5), same k-ascending
+// v_mfma_f32_16x16x4_f32 chain k = (kh, kw, ci) -> the same bits.
+//
+// rn_conv_kernel stages every strip through registers into channel planes (global load -> relu / select -> four scattered ds_write per float4), reads
+// A and B fragments from LDS and decodes an output index per stored element: 4.3 VALU instructions per MFMA on the 16-channel layers, two block
+// barriers per strip with the matrix pipe idle in between.  Here:
+//   * every wave keeps ALL weights of the layer as B fragments in VGPRs (9 CI / 4 steps x CO / 16 column blocks: 36 ... 144 registers);
+//   * input rows live in LDS as NHWC pixels, copied by global_load_lds_dword in granules of 64 floats (4 pixels at CI = 16, 2 at CI = 32) padded to
+//     68, which makes the fragment read of 16 consecutive pixels conflict-free; a row has RPX >= H + 1 pixel slots, the slots past H stay zero (the
+//     copy masks those lanes) and serve as the right / left halo; the halo ROWS between frames are copied from a zero page, so SAME padding
+//     costs no instruction in the loop;
+//   * rows form a ring of NR slots over the block's VIRTUAL rows (H + 1 per frame: a zero row, then the frame's rows), two mirror rows at the end keep
+//     the three rows of a tap window contiguous; a block walks the H*H positions of its frames as one stream of 16-position tiles, TSP positions per
+//     step; one raw s_barrier per step (in front of tap SYNC_TAP), rows are requested a whole step before their first use;
+//   * the pad breaks the uniform pixel stride, so a lane carries three bases per tile (one per kw); kh and the channel quad are immediates.
+// The relu in front of a residual block's first conv is a v_max on the fragment (the load unit cannot apply it).
+// Measured per 3840-frame minibatch against rn_conv_kernel (us): 32->32 @ 11x11 88-96 vs 127-145; 32->32 @ 21x21 277-313 vs 285-368; 16->32 @ 42x42 599
+// vs 737; 32->16 @ 42x42 (input gradient) 621 vs 612; 16->16 @ 42x42 380-435 vs 370-413 (stays on the slab kernel).  Timing builds of this kernel:
+// no row copies 8 % faster, fragments from registers instead of LDS 3-12 %, no residual / mask loads 6-7 %, no stores 1-2 %, all four 276 / 240 us
+// (16->16 @ 42 / 32->32 @ 21) = the MFMA + address arithmetic + barrier skeleton.
+#pragma once
+#include <type_traits>
+
+__device__ float rn_rw_zero_row[42 * 32];
+
+template <int CI_, int CO_, int H_, int NT_, int NR_>
+struct RnRwGeom {
+  static constexpr int CI = CI_, CO = CO_, H = H_, NT = NT_, NR = NR_;
+  static constexpr int GP = 64 / CI, GF = 68, RPX = (H + 1 + GP - 1) / GP * GP, NG = RPX / GP;
+  static constexpr int NCO = CO / 16, QPT = CI / 4, NSTEP = 9 * QPT;
+  static constexpr int NW = 8, TS = NW * NT, TSP = 16 * TS;     // tiles / positions per step
+  static constexpr int NRP = NR + 2;                             // + two mirror rows
+  static constexpr int LDS_FLOATS = (1 + NRP * NG) * GF;         // (granule 0 = the left halo of physical row 0)
+  static constexpr int ROWF = H * CI, FP = H * H;
+  static constexpr int SYNC_TAP = 6;
+  static_assert(LDS_FLOATS * 4 <= 160 * 1024, "row ring exceeds the 160 KB LDS");
+  static_assert(ROWF <= 42 * 32, "zero page too small");
+  __host__ __device__ static int vc_of(int Gr) { const int f = Gr / H; return f * (H + 1) + (Gr - f * H) + 1; }   // output row -> its virtual row
+  __host__ __device__ static int need_lo(int t, int P) { const int q = TSP * t < P - 1 ? TSP * t : P - 1; return vc_of(q / H) - 1; }
+  __host__ __device__ static int need_hi(int t, int P) { const int q = (TSP * (t + 1) < P ? TSP * (t + 1) : P) - 1; return vc_of(q / H) + 1; }
+  // rows read between the barriers of steps t and t+1 were requested at the barrier of step t-1 or earlier: need_hi(t+1) < need_lo(t-1) + NR
+  static bool ring_ok(int nf) {
+    const int P = nf * FP, ns = (P + TSP - 1) / TSP;
+    if (need_hi(ns > 1 ? 1 : 0, P) + 1 > NR) return false;        // what is requested before the first step fits the ring
+    for (int t = 1; t + 1 < ns; ++t) if (need_hi(t + 1, P) >= need_lo(t - 1, P) + NR) return false;
+    return true;
+  }
+};
+
+static __device__ __forceinline__ void rn_rw_glds4(const float* g_lane, float* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g_lane, (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
+}
+
+template <class G, bool PRE_RELU, int EPI>
+__global__ __launch_bounds__(512) void rn_rw_kernel(const float* __restrict__ in, const float* __restrict__ W, const float* __restrict__ bias,
+                                                    const float* aux, float* out, int B, int fpb) {
+  constexpr int H = G::H, CI = G::CI, CO = G::CO, NT = G::NT, NCO = G::NCO, QPT = G::QPT, NG = G::NG, GF = G::GF, NR = G::NR;
+  constexpr bool AUX = EPI == 1 || EPI == 3 || EPI == 4, BIAS = EPI == 0 || EPI == 1 || EPI == 5;
+  extern __shared__ __attribute__((aligned(16))) float rw_smem[];
+  const int tid = threadIdx.x, lane = tid & 63, r16 = lane & 15, g4 = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int f0 = blockIdx.x * fpb, nf = min(fpb, B - f0);
+  if (nf <= 0) return;
+  const int P = nf * G::FP, nsteps = (P + G::TSP - 1) / G::TSP, NV = nf * (H + 1) + 1;
+  for (int i = tid; i < G::LDS_FLOATS; i += 512) rw_smem[i] = 0.0f;      // halo cells stay zero for the whole kernel
+  __syncthreads();
+
+  int issued = 0;                                                        // virtual rows [0, issued) have been requested
+  // A row is copied by ONE wave as NGD unrolled instructions (uniform row pointer + lane, constant granule offsets): the first version dealt
+  // (row, granule) pairs round robin with a division, a pointer select and a 64-bit per-lane address for every 256-byte copy — ~30 instructions
+  // each, 540 per wave and step against ~700 for the step's arithmetic: 30 % of the kernel (557 -> 396 us on the 16-channel layers without them)
+  constexpr int NGD = (G::ROWF + 63) / 64, LASTN = G::ROWF - 64 * (NGD - 1);   // granules that carry data, valid lanes of the last one
+  auto issue_row = [&](int v) __attribute__((always_inline)) {
+    const int fz = v / (H + 1), yy = v - fz * (H + 1);
+    const float* src = (yy == 0 ? rn_rw_zero_row : in + ((size_t)(f0 + fz) * H + (yy - 1)) * G::ROWF) + lane;
+    const int pr = v % NR;
+    float* dst = rw_smem + (1 + pr * NG) * GF;
+#pragma unroll
+    for (int g = 0; g < NGD; ++g)
+      if (g < NGD - 1 || LASTN == 64 || lane < LASTN) rn_rw_glds4(src + g * 64, dst + g * GF);   // lanes past the row's last pixel: zero halo cells
+    if (pr < 2) {                                                         // mirror copy behind the ring
+      float* dm = dst + NR * NG * GF;
+#pragma unroll
+      for (int g = 0; g < NGD; ++g)
+        if (g < NGD - 1 || LASTN == 64 || lane < LASTN) rn_rw_glds4(src + g * 64, dm + g * GF);
+    }
+  };
+  auto issue_upto = [&](int lim) __attribute__((always_inline)) {
+    lim = min(lim, NV);
+    for (int v = issued + wave; v < lim; v += G::NW) issue_row(v);
+    issued = max(issued, lim);
+  };
+  issue_upto(G::need_hi(nsteps > 1 ? 1 : 0, P) + 1);
+
+  float w[NCO][G::NSTEP];
+#pragma unroll
+  for (int jc = 0; jc < NCO; ++jc)
+#pragma unroll
+    for (int s = 0; s < G::NSTEP; ++s) w[jc][s] = W[(size_t)(4 * s + g4) * CO + 16 * jc + r16];
+  float bz[NCO];
+#pragma unroll
+  for (int jc = 0; jc < NCO; ++jc) bz[jc] = BIAS ? bias[16 * jc + r16] : 0.0f;
+  const size_t Q0 = (size_t)f0 * G::FP;
+
+  auto sync_and_issue = [&](int t) __attribute__((always_inline)) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // everything requested one step ago has landed (for this wave)
+    asm volatile("s_barrier" ::: "memory");                     // ... for every wave; and every wave has left step t-1: rows below need_lo(t) are free
+    issue_upto(G::need_lo(t, P) + NR);
+  };
+
+  auto step = [&](auto ntl_, int t, int ntiles) __attribute__((always_inline)) {
+    constexpr int NTL = decltype(ntl_)::value;
+    // tiles of the step are dealt round robin: tile j of this wave = j * NW + wave (a short last step spreads over the waves)
+    int base[NTL][3];
+#pragma unroll
+    for (int j = 0; j < NTL; ++j) {
+      const int q = min(G::TSP * t + (j * G::NW + wave) * 16 + r16, P - 1);
+      const int Gr = q / H, x = q - Gr * H, f = Gr / H, y = Gr - f * H;
+      const int s = (f * (H + 1) + y) % NR;                             // slot of the window's first row (virtual row vc - 1)
+      const int p0 = G::GP + s * G::RPX + x - 1;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) { const int p = p0 + kw; base[j][kw] = (p / G::GP) * GF + (p % G::GP) * CI + g4; }
+    }
+    float ax[AUX ? NTL : 1][NCO][4], ao[EPI == 4 ? NTL : 1][NCO][4];
+    if constexpr (AUX) {
+#pragma unroll
+      for (int j = 0; j < NTL; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int q = min(G::TSP * t + (j * G::NW + wave) * 16 + 4 * g4 + e, P - 1);
+#pragma unroll
+          for (int jc = 0; jc < NCO; ++jc) {
+            const size_t o = (Q0 + q) * CO + 16 * jc + r16;
+            ax[j][jc][e] = aux[o];
+            if constexpr (EPI == 4) ao[j][jc][e] = out[o];
+          }
+        }
+    }
+    rn_f32x4 acc[NTL][NCO];
+#pragma unroll
+    for (int j = 0; j < NTL; ++j)
+#pragma unroll
+      for (int jc = 0; jc < NCO; ++jc) acc[j][jc] = rn_f32x4{0.f, 0.f, 0.f, 0.f};
+    float a[2][NTL][QPT];
+    auto load_tap = [&](int tap, float (&dst)[NTL][QPT]) __attribute__((always_inline)) {
+      const int kh = tap / 3, kw = tap - 3 * kh;
+#pragma unroll
+      for (int c = 0; c < QPT; ++c)
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) dst[j][c] = rw_smem[base[j][kw] + kh * NG * GF + 4 * c];
+    };
+    load_tap(0, a[0]);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      if (tap == G::SYNC_TAP) {
+        __builtin_amdgcn_sched_barrier(0);
+        sync_and_issue(t);
+      }
+      __builtin_amdgcn_sched_barrier(0);                          // (the scheduler otherwise sinks every read to just before its use)
+      if (tap + 1 < 9) load_tap(tap + 1, a[(tap + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int c = 0; c < QPT; ++c)
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) {
+          float av = a[tap & 1][j][c];
+          if (PRE_RELU) av = fmaxf(av, 0.0f);
+#pragma unroll
+          for (int jc = 0; jc < NCO; ++jc) acc[j][jc] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, w[jc][tap * QPT + c], acc[j][jc], 0, 0, 0);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < NTL; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int q = G::TSP * t + (j * G::NW + wave) * 16 + 4 * g4 + e;
+        if (q >= P) continue;
+#pragma unroll
+        for (int jc = 0; jc < NCO; ++jc) {
+          float v = acc[j][jc][e];
+          if (EPI == 0) v = v + bz[jc];
+          else if (EPI == 5) v = fmaxf(v + bz[jc], 0.0f);
+          else if (EPI == 1) v = (v + bz[jc]) + ax[j][jc][e];
+          else if (EPI == 3) v = ax[j][jc][e] > 0.0f ? v : 0.0f;
+          else if (EPI == 4) v = ao[j][jc][e] + (ax[j][jc][e] > 0.0f ? v : 0.0f);
+          out[(Q0 + q) * CO + 16 * jc + r16] = v;
+        }
+      }
+  };
+
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("s_barrier" ::: "memory");                       // the rows of the first step and a half are in LDS
+  for (int t = 0; t < nsteps; ++t) {
+    const int ntiles = (min(G::TSP, P - G::TSP * t) + 15) >> 4;          // tiles of this step
+    const int mine = max(0, min(NT, (ntiles - wave + G::NW - 1) / G::NW));   // ... of this wave (wave-uniform)
+    if (mine == NT) step(std::integral_constant<int, NT>{}, t, ntiles);
+    else if (NT > 2 && mine > NT / 2) step(std::integral_constant<int, NT>{}, t, ntiles);
+    else if (NT > 2 && mine > 1) step(std::integral_constant<int, (NT > 2 ? NT / 2 : 1)>{}, t, ntiles);
+    else if (mine >= 1) step(std::integral_constant<int, 1>{}, t, ntiles);
+    else sync_and_issue(t);                                       // nothing to multiply in this (last) step, but the barrier is everybody's
+  }
+}
+
+template <class G, bool PRE_RELU, int EPI>
+static void rn_rw_launch(const float* in, const float* W, const float* bias, const float* aux, float* out, int B, hipStream_t st) {
+  constexpr int lds = G::LDS_FLOATS * 4;
+  static bool attr = false;
+  if (!attr) { hipFuncSetAttribute((const void*)rn_rw_kernel<G, PRE_RELU, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
+  const int fpb = (B + 255) / 256, blocks = (B + fpb - 1) / fpb;
+  static int checked_fpb = 0;
+  if (checked_fpb != fpb) {
+    if (!G::ring_ok(fpb)) { fprintf(stderr, "rn_rw_kernel: row ring of %d slots too small for H=%d TSP=%d\n", G::NR, G::H, G::TSP); abort(); }
+    checked_fpb = fpb;
+  }
+  hipLaunchKernelGGL((rn_rw_kernel<G, PRE_RELU, EPI>), dim3(blocks), dim3(512), lds, st, in, W, bias, aux, out, B, fpb);
+}
+
+// geometry per layer shape: tiles per wave and step, ring slots (checked by ring_ok at launch)
+template <int CI, int CO, int H> struct RnRwPick;
+template <> struct RnRwPick<16, 16, 42> { using G = RnRwGeom<16, 16, 42, 4, 44>; };
+template <> struct RnRwPick<16, 32, 42> { using G = RnRwGeom<16, 32, 42, 4, 44>; };
+template <> struct RnRwPick<32, 16, 42> { using G = RnRwGeom<32, 16, 42, 2, 24>; };
+template <> struct RnRwPick<32, 32, 21> { using G = RnRwGeom<32, 32, 21, 2, 44>; };
+template <> struct RnRwPick<32, 32, 11> { using G = RnRwGeom<32, 32, 11, 2, 82>; };
