@@ -109,31 +109,41 @@ __global__ __launch_bounds__(512) void rn_rw_kernel(const float* __restrict__ in
     issue_upto(G::need_lo(t, P) + NR);
   };
 
-  auto step = [&](auto ntl_, int t, int ntiles) __attribute__((always_inline)) {
+  // FULL: every position of the step exists (all steps but the last): no clamps, no store predicates, element offsets are immediates
+  auto step = [&](auto ntl_, auto full_, int t) __attribute__((always_inline)) {
     constexpr int NTL = decltype(ntl_)::value;
+    constexpr bool FULL = decltype(full_)::value;
     // tiles of the step are dealt round robin: tile j of this wave = j * NW + wave (a short last step spreads over the waves)
     int base[NTL][3];
 #pragma unroll
     for (int j = 0; j < NTL; ++j) {
-      const int q = min(G::TSP * t + (j * G::NW + wave) * 16 + r16, P - 1);
-      const int Gr = q / H, x = q - Gr * H, f = Gr / H, y = Gr - f * H;
-      const int s = (f * (H + 1) + y) % NR;                             // slot of the window's first row (virtual row vc - 1)
-      const int p0 = G::GP + s * G::RPX + x - 1;
+      uint32_t q = (uint32_t)(G::TSP * t + (j * G::NW + wave) * 16 + r16);
+      if (!FULL) q = min(q, (uint32_t)(P - 1));
+      const uint32_t Gr = q / H, x = q - Gr * H, f = Gr / H, y = Gr - f * H;   // (unsigned: the divisions by constants are a multiply and a shift)
+      const uint32_t s = (f * (H + 1) + y) % NR;                        // slot of the window's first row (virtual row vc - 1)
+      const uint32_t p0 = G::GP + s * G::RPX + x - 1;
 #pragma unroll
-      for (int kw = 0; kw < 3; ++kw) { const int p = p0 + kw; base[j][kw] = (p / G::GP) * GF + (p % G::GP) * CI + g4; }
+      for (int kw = 0; kw < 3; ++kw) { const uint32_t p = p0 + kw; base[j][kw] = (int)((p / G::GP) * GF + (p % G::GP) * CI + g4); }
     }
+    // element e of tile j sits at 32-bit element offset ob[j] + e * CO + 16 jc: one VGPR per tile, the rest immediates (at most 216 M elements per tensor)
+    uint32_t ob[NTL];
+#pragma unroll
+    for (int j = 0; j < NTL; ++j) ob[j] = ((uint32_t)Q0 + (uint32_t)(G::TSP * t + (j * G::NW + wave) * 16 + 4 * g4)) * CO + r16;
     float ax[AUX ? NTL : 1][NCO][4], ao[EPI == 4 ? NTL : 1][NCO][4];
     if constexpr (AUX) {
 #pragma unroll
       for (int j = 0; j < NTL; ++j)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const int q = min(G::TSP * t + (j * G::NW + wave) * 16 + 4 * g4 + e, P - 1);
+          uint32_t o = ob[j] + e * CO;
+          if (!FULL) {
+            const int q = min(G::TSP * t + (j * G::NW + wave) * 16 + 4 * g4 + e, P - 1);
+            o = ((uint32_t)Q0 + (uint32_t)q) * CO + r16;
+          }
 #pragma unroll
           for (int jc = 0; jc < NCO; ++jc) {
-            const size_t o = (Q0 + q) * CO + 16 * jc + r16;
-            ax[j][jc][e] = aux[o];
-            if constexpr (EPI == 4) ao[j][jc][e] = out[o];
+            ax[j][jc][e] = aux[o + 16 * jc];
+            if constexpr (EPI == 4) ao[j][jc][e] = out[o + 16 * jc];
           }
         }
     }
@@ -142,32 +152,34 @@ __global__ __launch_bounds__(512) void rn_rw_kernel(const float* __restrict__ in
     for (int j = 0; j < NTL; ++j)
 #pragma unroll
       for (int jc = 0; jc < NCO; ++jc) acc[j][jc] = rn_f32x4{0.f, 0.f, 0.f, 0.f};
-    float a[2][NTL][QPT];
-    auto load_tap = [&](int tap, float (&dst)[NTL][QPT]) __attribute__((always_inline)) {
-      const int kh = tap / 3, kw = tap - 3 * kh;
+    // K loop in chunks of 4 channel quads (a tap at CI = 16, half a tap at CI = 32): the fragments of chunk u+1 are read while chunk u is multiplied
+    constexpr int QC = 4, CPT = QPT / QC, NCH = 9 * CPT;
+    float a[2][NTL][QC];
+    auto load_chunk = [&](int u, float (&dst)[NTL][QC]) __attribute__((always_inline)) {
+      const int tap = u / CPT, h = u - tap * CPT, kh = tap / 3, kw = tap - 3 * kh;
 #pragma unroll
-      for (int c = 0; c < QPT; ++c)
+      for (int c = 0; c < QC; ++c)
 #pragma unroll
-        for (int j = 0; j < NTL; ++j) dst[j][c] = rw_smem[base[j][kw] + kh * NG * GF + 4 * c];
+        for (int j = 0; j < NTL; ++j) dst[j][c] = rw_smem[base[j][kw] + kh * NG * GF + 4 * (h * QC + c)];
     };
-    load_tap(0, a[0]);
+    load_chunk(0, a[0]);
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      if (tap == G::SYNC_TAP) {
+    for (int u = 0; u < NCH; ++u) {
+      if (u == G::SYNC_TAP * CPT) {
         __builtin_amdgcn_sched_barrier(0);
         sync_and_issue(t);
       }
       __builtin_amdgcn_sched_barrier(0);                          // (the scheduler otherwise sinks every read to just before its use)
-      if (tap + 1 < 9) load_tap(tap + 1, a[(tap + 1) & 1]);
+      if (u + 1 < NCH) load_chunk(u + 1, a[(u + 1) & 1]);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int c = 0; c < QPT; ++c)
+      for (int c = 0; c < QC; ++c)
 #pragma unroll
         for (int j = 0; j < NTL; ++j) {
-          float av = a[tap & 1][j][c];
+          float av = a[u & 1][j][c];
           if (PRE_RELU) av = fmaxf(av, 0.0f);
 #pragma unroll
-          for (int jc = 0; jc < NCO; ++jc) acc[j][jc] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, w[jc][tap * QPT + c], acc[j][jc], 0, 0, 0);
+          for (int jc = 0; jc < NCO; ++jc) acc[j][jc] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, w[jc][u * QC + c], acc[j][jc], 0, 0, 0);
         }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -175,8 +187,7 @@ __global__ __launch_bounds__(512) void rn_rw_kernel(const float* __restrict__ in
     for (int j = 0; j < NTL; ++j)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const int q = G::TSP * t + (j * G::NW + wave) * 16 + 4 * g4 + e;
-        if (q >= P) continue;
+        if (!FULL && G::TSP * t + (j * G::NW + wave) * 16 + 4 * g4 + e >= P) continue;
 #pragma unroll
         for (int jc = 0; jc < NCO; ++jc) {
           float v = acc[j][jc][e];
@@ -185,7 +196,7 @@ __global__ __launch_bounds__(512) void rn_rw_kernel(const float* __restrict__ in
           else if (EPI == 1) v = (v + bz[jc]) + ax[j][jc][e];
           else if (EPI == 3) v = ax[j][jc][e] > 0.0f ? v : 0.0f;
           else if (EPI == 4) v = ao[j][jc][e] + (ax[j][jc][e] > 0.0f ? v : 0.0f);
-          out[(Q0 + q) * CO + 16 * jc + r16] = v;
+          out[ob[j] + e * CO + 16 * jc] = v;
         }
       }
   };
@@ -193,12 +204,12 @@ __global__ __launch_bounds__(512) void rn_rw_kernel(const float* __restrict__ in
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   asm volatile("s_barrier" ::: "memory");                       // the rows of the first step and a half are in LDS
   for (int t = 0; t < nsteps; ++t) {
-    const int ntiles = (min(G::TSP, P - G::TSP * t) + 15) >> 4;          // tiles of this step
+    if (G::TSP * (t + 1) <= P) { step(std::integral_constant<int, NT>{}, std::true_type{}, t); continue; }
+    const int ntiles = (P - G::TSP * t + 15) >> 4;                        // tiles of the (short) last step
     const int mine = max(0, min(NT, (ntiles - wave + G::NW - 1) / G::NW));   // ... of this wave (wave-uniform)
-    if (mine == NT) step(std::integral_constant<int, NT>{}, t, ntiles);
-    else if (NT > 2 && mine > NT / 2) step(std::integral_constant<int, NT>{}, t, ntiles);
-    else if (NT > 2 && mine > 1) step(std::integral_constant<int, (NT > 2 ? NT / 2 : 1)>{}, t, ntiles);
-    else if (mine >= 1) step(std::integral_constant<int, 1>{}, t, ntiles);
+    if (mine > NT / 2 && NT > 1) step(std::integral_constant<int, NT>{}, std::false_type{}, t);
+    else if (NT > 2 && mine > 1) step(std::integral_constant<int, (NT > 2 ? NT / 2 : 1)>{}, std::false_type{}, t);
+    else if (mine >= 1) step(std::integral_constant<int, 1>{}, std::false_type{}, t);
     else sync_and_issue(t);                                       // nothing to multiply in this (last) step, but the barrier is everybody's
   }
 }

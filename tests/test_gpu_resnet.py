@@ -43,6 +43,27 @@ def test_resnet_forward_bit_exact(rctx, oracle):
         assert (bits(lg) == bits(lo)).all() and (bits(vg) == bits(vo)).all()
 
 
+def test_resnet_actor_batch_forward_bit_exact(oracle):
+    """120 frames (the actor's batch): the 11x11 layers run on the row-ring kernel (rnconv_rw.h) from 64 frames up, the rest on the slab kernel."""
+    cfg = L.default_config(L.ALGO_PPO)
+    cfg.network = L.NET_IMPALA_RESNET
+    cfg.actor_dense_ksplit = 11
+    cfg.local_num_envs, cfg.num_actor_slots, cfg.num_steps = 120, 1, 8
+    ctx = L.Context(cfg)
+    try:
+        P = make_resnet_params(oracle, 11)
+        for B in (120, 77):
+            obs = make_frames(B, 13)
+            dP, dO = L.DevBuf(ctx, P), L.DevBuf(ctx, obs)
+            dL = L.DevBuf(ctx, nbytes=B * A * 4, dtype=np.float32, shape=(B, A))
+            dV = L.DevBuf(ctx, nbytes=B * 4, dtype=np.float32, shape=(B,))
+            L._chk(ctx.lib.cbm_forward(ctx.h, L._p(dP.ptr), L._p(dO.ptr), None, B, 11, L._p(dL.ptr), L._p(dV.ptr)))
+            lo, vo = oracle.resnet_forward(P, A, obs, ksplit=11)
+            assert (bits(dL.download()) == bits(lo)).all() and (bits(dV.download()) == bits(vo)).all()
+    finally:
+        ctx.close()
+
+
 @pytest.mark.parametrize("N", [16, 5, 1])   # 5 / 1: partial frame pairs in the 11x11 layers, fewer strips than persistent wgrad blocks
 def test_resnet_ppo_loss_and_grads(rctx, oracle, N):
     rng = np.random.default_rng(6)
