@@ -110,6 +110,7 @@ __device__ __forceinline__ void rn_stage_u8(float* slab, const uint8_t* obs, con
 //      3 out = aux > 0 ? v : 0     (dgrad through the relu in front of the conv)
 //      4 out += aux > 0 ? v : 0    (dgrad joined with the residual path, in place)
 //      5 out = relu(v + bias)      (forward, for an output that is only ever read through a relu: the first conv of a residual block)
+//      6 out = relu(v + bias + aux) (forward, residual add of the torso's LAST block: only the dense layer — through a relu — and relu masks read it)
 // Blocks are PERSISTENT over strips (grid = what fits on the chip): the global loads of strip s+1 — its input slab and, for EPI 1/3/4, the
 // residual / mask values its epilogue needs — are issued before the MFMA sweep of strip s and land during it; the first build ran one strip
 // per block as stage -> barrier -> multiply -> store, every phase exposed (MFMA phase ~40 % of a block's life, 0.41-0.46 of the peak).
@@ -118,7 +119,7 @@ __global__ __launch_bounds__(G::NTHR, G::MINW) void rn_conv_kernel(const float* 
                                                                   int nstrips) {
   constexpr int H = G::H, CI = G::CI, CO = G::CO, WP = G::WP, TP = G::TP, NTW = G::NTW, NT = G::NT;
   constexpr int NE = G::M16 ? 4 : 16;                                   // accumulator elements per lane per tile
-  constexpr bool AUX = EPI == 1 || EPI == 3 || EPI == 4;
+  constexpr bool AUX = EPI == 1 || EPI == 3 || EPI == 4 || EPI == 6;
   extern __shared__ __attribute__((aligned(16))) float rn_smem[];
   float* slab = rn_smem;
   float* Wl = rn_smem + G::SLAB;
@@ -203,7 +204,7 @@ __global__ __launch_bounds__(G::NTHR, G::MINW) void rn_conv_kernel(const float* 
 
   int s = blockIdx.x, b0 = 0, y0 = 0;
   if (s < nstrips) { where(s, b0, y0); fetch(b0, y0); }
-  const float bz = (EPI == 0 || EPI == 1 || EPI == 5) ? bias[li] : 0.0f;
+  const float bz = (EPI == 0 || EPI == 1 || EPI == 5 || EPI == 6) ? bias[li] : 0.0f;
   for (; s < nstrips; s += gridDim.x) {
     __syncthreads();            // the previous strip's sweep is done with the slab (and the weights / pads are staged)
     commit(b0, y0);
@@ -281,6 +282,7 @@ __global__ __launch_bounds__(G::NTHR, G::MINW) void rn_conv_kernel(const float* 
         if (EPI == 0) v = v + bz;
         else if (EPI == 5) v = fmaxf(v + bz, 0.0f);
         else if (EPI == 1) v = (v + bz) + ax[i][e];
+        else if (EPI == 6) v = fmaxf((v + bz) + ax[i][e], 0.0f);
         else if (EPI == 3) v = ax[i][e] > 0.0f ? v : 0.0f;
         else if (EPI == 4) v = ao[i][e] + (ax[i][e] > 0.0f ? v : 0.0f);
         out[o] = v;

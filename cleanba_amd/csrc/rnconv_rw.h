@@ -56,7 +56,7 @@ template <class G, bool PRE_RELU, int EPI>
 __global__ __launch_bounds__(512) void rn_rw_kernel(const float* __restrict__ in, const float* __restrict__ W, const float* __restrict__ bias,
                                                     const float* aux, float* out, int B, int fpb) {
   constexpr int H = G::H, CI = G::CI, CO = G::CO, NT = G::NT, NCO = G::NCO, QPT = G::QPT, NG = G::NG, GF = G::GF, NR = G::NR;
-  constexpr bool AUX = EPI == 1 || EPI == 3 || EPI == 4, BIAS = EPI == 0 || EPI == 1 || EPI == 5;
+  constexpr bool AUX = EPI == 1 || EPI == 3 || EPI == 4 || EPI == 6, BIAS = EPI == 0 || EPI == 1 || EPI == 5 || EPI == 6;
   extern __shared__ __attribute__((aligned(16))) float rw_smem[];
   const int tid = threadIdx.x, lane = tid & 63, r16 = lane & 15, g4 = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -194,6 +194,7 @@ __global__ __launch_bounds__(512) void rn_rw_kernel(const float* __restrict__ in
           if (EPI == 0) v = v + bz[jc];
           else if (EPI == 5) v = fmaxf(v + bz[jc], 0.0f);
           else if (EPI == 1) v = (v + bz[jc]) + ax[j][jc][e];
+          else if (EPI == 6) v = fmaxf((v + bz[jc]) + ax[j][jc][e], 0.0f);
           else if (EPI == 3) v = ax[j][jc][e] > 0.0f ? v : 0.0f;
           else if (EPI == 4) v = ao[j][jc][e] + (ax[j][jc][e] > 0.0f ? v : 0.0f);
           out[ob[j] + e * CO + 16 * jc] = v;
