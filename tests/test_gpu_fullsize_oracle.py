@@ -223,9 +223,11 @@ def _check_resnet_grads(oracle, g, grads_o, bar=1e-5):
     return worst
 
 
-def test_resnet_ppo_minibatch_3840_of_15360_shuffled(oracle):
+@pytest.mark.parametrize("MBR", [MB, 1031])   # 1031: 5 frames per block on the row-ring conv kernels (rnconv_rw.h), the last block holds one
+def test_resnet_ppo_minibatch_3840_of_15360_shuffled(oracle, MBR):
     from test_oracle_resnet import make_resnet_params
     _all_cores(oracle)
+    MB = MBR
     cfg = L.default_config(L.ALGO_PPO)
     cfg.network = L.NET_IMPALA_RESNET
     cfg.actor_dense_ksplit = 11
