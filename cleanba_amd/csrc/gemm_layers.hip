@@ -333,13 +333,15 @@ __global__ __launch_bounds__(256) void actor_tail_rows_kernel(const float* part,
                        smp.env_firststep_next};
   uint32_t older[7][3];
   if (ea.obs_next) env_step_prefetch(ea, b, older);
-  // all partial slices of this thread's two hidden units are requested at once (S <= 16), then added in slice order
-  float v0[16], v1[16];
+  // all partial slices of this thread's hidden units (HD / 256 of them: k = tid, tid + 256) are requested at once (S <= 16), then added in slice order
+  constexpr int NU = HD / 256;
+  static_assert(HD % 256 == 0 && NU >= 1 && NU <= 2, "hidden width 256 or 512");
+  float vv[NU][16];
 #pragma unroll
   for (int s = 0; s < 16; ++s) {
     const int ss = s < S ? s : 0;
-    v0[s] = part[ss * MN + (size_t)b * HD + tid];
-    v1[s] = part[ss * MN + (size_t)b * HD + tid + 256];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) vv[u][s] = part[ss * MN + (size_t)b * HD + tid + 256 * u];
   }
   // heads on v_mfma_f32_16x16x4_f32 with ONE live row (row 0 = this frame; the instruction's other 15 rows repeat it and are ignored): waves
   // 0 / 1 own output columns 0-15 / 16-31 and take their B fragments (HD/4 floats per lane, L2-resident weights) straight into registers,
@@ -353,12 +355,15 @@ __global__ __launch_bounds__(256) void actor_tail_rows_kernel(const float* part,
 #pragma unroll
     for (int st = 0; st < HD / 4; ++st) bw[st] = on ? wp[(size_t)(4 * st + g4) * wstride] : 0.0f;
   }
-  float t0 = v0[0], t1 = v1[0];
 #pragma unroll
-  for (int s = 1; s < 16; ++s)
-    if (s < S) { t0 = t0 + v0[s]; t1 = t1 + v1[s]; }
-  hsT[(tid & 3) * (HD / 4) + (tid >> 2)] = relu(t0 + bd[tid]);                 // k = tid, tid + 256
-  hsT[(tid & 3) * (HD / 4) + ((tid + 256) >> 2)] = relu(t1 + bd[tid + 256]);
+  for (int u = 0; u < NU; ++u) {
+    float t0 = vv[u][0];
+#pragma unroll
+    for (int s = 1; s < 16; ++s)
+      if (s < S) t0 = t0 + vv[u][s];
+    const int k = tid + 256 * u;
+    hsT[(k & 3) * (HD / 4) + (k >> 2)] = relu(t0 + bd[k]);
+  }
   __syncthreads();
   if (wave < 2) {
     f32x4_mfma acc = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -1043,7 +1048,7 @@ using T64x64k16 = IgemmTile<64, 64, 16, 2, 2>;
 
 int nature_forward(const NatureLayout& L, const float* P, const uint8_t* obs, const int32_t* idx, int B, int dense_ksplit,
                     NatureWs& ws, hipStream_t st, const ActorSample* sample) {
-  if (L.kind == CBM_NET_IMPALA_RESNET) { resnet_forward(L, P, obs, idx, B, dense_ksplit, ws, st); return 0; }
+  if (L.kind == CBM_NET_IMPALA_RESNET) return resnet_forward(L, P, obs, idx, B, dense_ksplit, ws, st, sample);
   const bool small = B <= 512;
   // actor-size forward passes (no ReLU masks wanted) run on the 16x16x4 small-batch kernel (igemm.h igemm_s16_kernel), same bits
   // (forward_bf16 too: at <= 512 frames the bf16 MFMA buys nothing over these latency-bound launches, so the actor's behaviour logits stay fp32)
