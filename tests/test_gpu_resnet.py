@@ -88,3 +88,44 @@ def test_resnet_ppo_loss_and_grads(rctx, oracle, N):
         n = int(np.prod(shp))
         ref = grads_o[o:o + n]
         assert np.abs(g[o:o + n] - ref).max() <= 1e-5 * max(np.abs(ref).max(), 1e-7), (name, np.abs(g[o:o + n] - ref).max(), np.abs(ref).max())
+
+
+def test_resnet_device_rollout_replayed_by_the_oracle(oracle):
+    """A device-env rollout on the IMPALA-ResNet (the actor step ends in actor_tail_rows_kernel<256>: split-K reduce + heads + sampling + env step in
+    one launch) replayed with the host env twin + the oracle policy: frames, actions, rewards, dones, log-probs and values bit for bit (ppo:245-261, 308-353)."""
+    import cleanba_amd.prng as prng
+    E, T = 8, 6
+    cfg = L.default_config(L.ALGO_PPO)
+    cfg.network = L.NET_IMPALA_RESNET
+    cfg.actor_dense_ksplit = 11
+    cfg.local_num_envs, cfg.num_actor_slots, cfg.num_steps = E, 1, T
+    ctx = L.Context(cfg)
+    try:
+        params = make_resnet_params(oracle, 21)
+        key = prng.prng_key(3)
+        ctx.set_params(params)
+        ctx.actor_set_key(0, key)
+        ctx.actor_env_reset_device(0, 9)
+        ctx.actor_begin_rollout(0, False)
+        ctx.actor_rollout_device(0, T)
+        ctx.actor_commit(0)
+        ctx.learner_wait()
+        obs = ctx.read("obs", np.uint8).reshape(T + 1, E, 4, 84, 84)
+        actions = ctx.read("actions", np.int32).reshape(T + 1, E)[:T]
+        logprobs = ctx.read("logprobs", np.float32).reshape(T + 1, E)[:T]
+        values = ctx.read("values", np.float32).reshape(T + 1, E)[:T]
+        rewards = ctx.read("rewards", np.float32).reshape(T + 1, E)[:T]
+        dones = ctx.read("dones", np.uint8).reshape(T + 1, E)
+        st, o = L.synth_env_reset_host(9, E)
+        k = key.copy()
+        for t in range(T):
+            assert (o == obs[t]).all(), f"frames differ at t={t}"
+            logits, value = oracle.resnet_forward(params, A, o, ksplit=cfg.actor_dense_ksplit)
+            a, lp, k = oracle.sample_actions(logits, k)
+            assert (a == actions[t]).all(), f"sampled actions differ at t={t}"
+            assert (bits(lp) == bits(logprobs[t])).all() and (bits(value) == bits(values[t])).all()
+            r, d, _, _ = L.synth_env_step_host(9, st, o, a)
+            assert (r == rewards[t]).all() and (d == dones[t + 1]).all()
+        assert (o == obs[T]).all() and (ctx.actor_get_key(0) == k).all()
+    finally:
+        ctx.close()
