@@ -190,19 +190,26 @@ def test_full_ppo_update_e120_t128_matches_oracle_engine(oracle):
         lkey, stats = ctx.learner_update(key, lrs, b1, b2, True)
         okey, ostats = eng.learner_update(key, lrs, b1, b2, True)
         assert np.array_equal(lkey, okey)
-        np.testing.assert_allclose(stats, ostats, rtol=2e-4, atol=2e-5)     # later steps see parameters that already differ by ~1e-7
+        serr = np.abs(np.asarray(stats) - np.asarray(ostats)) / np.maximum(np.abs(np.asarray(ostats)), 1e-3)
+        print("whole update: loss statistics, worst relative error per column (loss, pg, v, entropy, approx_kl):", serr.max(axis=0),
+              "worst row", int(serr.max(axis=1).argmax()))
+        # north_star's bar is 1e-5; 16 dependent optimizer steps compound the per-step 1e-7 parameter differences, so the LAST rows are the worst.
+        # Measured on MI355X (printed above): loss 5.6e-6, value loss 9e-7, entropy 8e-8, approx_kl 2.7e-6 relative; policy loss 3.8e-8 absolute
+        # (it is ~1e-3 itself).  Bar = 2e-5 relative or 2e-7 absolute, i.e. ~3x what is measured
+        np.testing.assert_allclose(stats, ostats, rtol=2e-5, atol=2e-7)
         p, po = ctx.get_params(), eng.get_params()
         assert np.isfinite(p).all()
         assert np.abs(po - P0).max() > 1e-4                                   # 16 Adam steps moved the parameters
         # Adam's step is lr * m / (sqrt(v) + eps) with eps = 1e-5: for a parameter whose gradients are themselves tiny (|g| <~ eps: rarely lit
         # pixels' conv1 weights, dead units) a gradient difference dg moves the step by lr * dg / eps, i.e. the 1e-5-per-tensor gradient bar
         # (dg ~ 1e-7 where max|g| ~ 1e-2) becomes up to 2.5e-6 per step, 4e-5 after 16 steps, for those few parameters, while the typical
-        # parameter agrees to 1e-7.  Bars: median 1e-6, all but 1 in 10 000 within 3e-5, none further than one learning-rate step
-        # (measured: median 1e-7, 99.99 % quantile 1.3e-5, max 4.6e-5).
+        # parameter agrees to 1e-7.  Measured (printed): median 0, 99.99 % quantile 1.7e-6, max 8.6e-6 absolute = 2.4e-5 of max|p|.
+        # Bars ~3x that: median 1e-7, all but 1 in 10 000 within 5e-6, none further than 3e-5 (a tenth of one learning-rate step).
         d = np.abs(p - po)
-        assert np.median(d) <= 1e-6, np.median(d)
-        assert np.quantile(d, 0.9999) <= 3e-5, np.quantile(d, 0.9999)
-        assert d.max() <= 2.5e-4, d.max()
+        print("whole update: |p - p_oracle| median %.2e, 99.99 %% quantile %.2e, max %.2e; relative to max|p| %.2e" % (np.median(d), np.quantile(d, 0.9999), d.max(), d.max() / np.abs(po).max()))
+        assert np.median(d) <= 1e-7, np.median(d)
+        assert np.quantile(d, 0.9999) <= 5e-6, np.quantile(d, 0.9999)
+        assert d.max() <= 3e-5, d.max()
     finally:
         ctx.close()
         eng.close()
