@@ -831,26 +831,39 @@ __global__ __launch_bounds__(WG::NW * 64, 1) void rn_wgrad2_kernel(const float* 
     if (WG::NF == 1) { b0 = st / WG::STRIPS; y0 = (st - b0 * WG::STRIPS) * WG::R; } else { b0 = st * WG::NF; y0 = 0; }
     constexpr int PX = H * CI / 4, PY = H * CO / 4;                  // 16-byte pieces per image row
     constexpr int IX = (PX + 63) / 64, IY = (PY + 63) / 64;          // wave instructions per row
+    // A row is one work item (dealt round robin over the waves) = IX / IY unrolled copies at constant offsets behind a wave-uniform row pointer:
+    // dealing (row, 64-piece group) pairs cost a division and a 64-bit per-lane address per 1 KB copy
     // X rows: slab row sr holds image row y0 + sr - 1 (NF = 1) / row (sr % (H+1)) - 1 of frame b0 + sr / (H+1)
-    for (int j = wave; j < WG::SROWS * IX; j += NW) {                  // wave-uniform work items: (row, 64-piece group)
-      const int sr = j / IX, grp = j - sr * IX;
-      int f, y;
-      if (WG::NF == 1) { f = b0; y = y0 + sr - 1; } else { f = b0 + sr / (H + 1); y = sr % (H + 1) - 1; }
-      const bool ok = y >= 0 && y < H && f < B;
-      float* drow = Xs + (size_t)(1 + sr * WP) * CI + grp * 256;
-      const int piece = grp * 64 + lane;
-      if (ok) { if (piece < PX) rn_glds16(in + ((size_t)(f * H + y) * H) * CI + (size_t)piece * 4, drow); }
-      else if (piece < PX) *reinterpret_cast<float4*>(drow + lane * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    for (int j = wave; j < WG::OROWS * IY; j += NW) {
-      const int orow = j / IY, grp = j - orow * IY;
-      int f, y;
-      if (WG::NF == 1) { f = b0; y = y0 + orow; } else { f = b0 + orow / (H + 1); y = orow % (H + 1); }
-      const bool ok = y < H && f < B && (WG::NF != 1 || orow < WG::R);
-      float* drow = Ys + (size_t)(orow * WP) * CO + grp * 256;
-      const int piece = grp * 64 + lane;
-      if (ok) { if (piece < PY) rn_glds16(dy + ((size_t)(f * H + y) * H) * CO + (size_t)piece * 4, drow); }
-      else if (piece < PY) *reinterpret_cast<float4*>(drow + lane * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = wave; j < WG::SROWS + WG::OROWS; j += NW) {
+      if (j < WG::SROWS) {
+        const int sr = j;
+        int f, y;
+        if (WG::NF == 1) { f = b0; y = y0 + sr - 1; } else { f = b0 + sr / (H + 1); y = sr % (H + 1) - 1; }
+        const bool ok = y >= 0 && y < H && f < B;
+        float* drow = Xs + (size_t)(1 + sr * WP) * CI;
+        const float* src = in + ((size_t)(f * H + y) * H) * CI + lane * 4;
+#pragma unroll
+        for (int grp = 0; grp < IX; ++grp) {
+          if (grp * 64 + 64 <= PX || lane < PX - grp * 64) {
+            if (ok) rn_glds16(src + grp * 256, drow + grp * 256);
+            else *reinterpret_cast<float4*>(drow + grp * 256 + lane * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+        }
+      } else {
+        const int orow = j - WG::SROWS;
+        int f, y;
+        if (WG::NF == 1) { f = b0; y = y0 + orow; } else { f = b0 + orow / (H + 1); y = orow % (H + 1); }
+        const bool ok = y < H && f < B && (WG::NF != 1 || orow < WG::R);
+        float* drow = Ys + (size_t)(orow * WP) * CO;
+        const float* src = dy + ((size_t)(f * H + y) * H) * CO + lane * 4;
+#pragma unroll
+        for (int grp = 0; grp < IY; ++grp) {
+          if (grp * 64 + 64 <= PY || lane < PY - grp * 64) {
+            if (ok) rn_glds16(src + grp * 256, drow + grp * 256);
+            else *reinterpret_cast<float4*>(drow + grp * 256 + lane * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+        }
+      }
     }
   };
 
