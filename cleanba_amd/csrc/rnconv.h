@@ -53,57 +53,6 @@ struct RnGeom {
   static int blocks(int B) { return NF == 1 ? B * STRIPS : (B + NF - 1) / NF; }
 };
 
-// ---- slab staging: fp32 NHWC activations -> channel planes (optionally relu), zero rows/columns outside the image
-template <class G, bool PRE_RELU>
-__device__ __forceinline__ void rn_stage_f32(float* slab, const float* in, int b0, int y0, int B) {
-  constexpr int H = G::H, CI = G::CI, WP = G::WP, NV = G::SROWS * H * (CI / 4);
-  const int tid = threadIdx.x;
-  for (int v = tid; v < NV; v += G::NTHR) {
-    const int g = v % (CI / 4), pix = v / (CI / 4), c = pix % H, sr = pix / H;
-    int f, y;
-    if (G::NF == 1) { f = b0; y = y0 + sr - 1; }
-    else { f = b0 + sr / (H + 1); y = sr % (H + 1) - 1; }
-    const bool ok = y >= 0 && y < H && f < B;
-    const float4 x = *reinterpret_cast<const float4*>(in + ((size_t)(min(f, B - 1) * H + min(max(y, 0), H - 1)) * H + c) * CI + 4 * g);
-    const int s = 1 + sr * WP + c;
-    float e[4] = {x.x, x.y, x.z, x.w};
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      float val = ok ? e[q] : 0.0f;
-      if (PRE_RELU) val = fmaxf(val, 0.0f);
-      const int p = 4 * g + q;
-      slab[(G::M16 ? (p >> 1) * G::PL + (p & 1) * G::PLH : p * G::PL) + s] = val;
-    }
-  }
-  // pad column of every slab row (index sr*WP + WP) and the leading pad (index 0)
-  for (int v = tid; v < (G::SROWS + 1) * G::NPL; v += G::NTHR) {
-    const int p = v % G::NPL, sr = v / G::NPL;
-    slab[G::poff(p) + sr * WP] = 0.0f;
-  }
-}
-
-// uint8 NCHW frames (4 planes of 84x84) / 255 -> 4 channel planes
-template <class G>
-__device__ __forceinline__ void rn_stage_u8(float* slab, const uint8_t* obs, const int32_t* idx, int b0, int y0) {
-  constexpr int H = G::H, WP = G::WP, NV = G::SROWS * (H / 4) * 4;
-  const int tid = threadIdx.x;
-  const int f = idx ? idx[b0] : b0;
-  const uint8_t* fr = obs + (size_t)f * CBM_FRAME;
-  for (int v = tid; v < NV; v += G::NTHR) {
-    const int cq = v % (H / 4), t = v / (H / 4), sr = t % G::SROWS, p = t / G::SROWS;
-    const int y = y0 + sr - 1;
-    const bool ok = y >= 0 && y < H;
-    const uint32_t w = *reinterpret_cast<const uint32_t*>(fr + (size_t)p * H * H + min(max(y, 0), H - 1) * H + 4 * cq);
-    float* d = slab + G::poff(p) + 1 + sr * WP + 4 * cq;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) d[q] = ok ? cbm_u8_unit((uint8_t)((w >> (8 * q)) & 0xffu)) : 0.0f;
-  }
-  for (int v = tid; v < (G::SROWS + 1) * 4; v += G::NTHR) {
-    const int p = v % 4, sr = v / 4;
-    slab[G::poff(p) + sr * WP] = 0.0f;
-  }
-}
-
 // EPI: 0 out = v + bias            (forward)
 //      1 out = v + bias + aux      (forward, residual add)
 //      2 out = v                   (dgrad)
