@@ -7,8 +7,9 @@
 //   * the block owns a contiguous run of frames and walks their 49-position outputs as ONE stream of 16-position tiles (a tile may straddle two
 //     frames: every lane carries its own pixel address), 4 tiles = 64 positions per step; waves tg = 0 / 1 take tiles {0,1} / {2,3} of the step (one tile each in a short last step) with
 //     two independent accumulators, the four cq waves of a tile read the same A fragments.
-//   * input frames sit in a ring of 7 LDS slots as NHWC pixels of 64 floats at a pitch of 68: lane (g4, r16) reads pixel(r16) * 68 + 4c + g4, bank
-//     4 r16 + g4 (+ const) — conflict-free inside an output row.  A frame is copied by 81 `global_load_lds_dword` (one pixel = 256 B each), issued a
+//   * input frames sit in a ring of 7 LDS slots as NHWC pixels of 64 floats at a pitch of 66: lane (g4, r16) reads pixel(r16) * 66 + 4c + g4.  A
+//     ds_read_b32 is served in two groups of 32 lanes over 32 banks (MI355X_MICROARCH, LDS): lanes 0-31 are g4 = 0 / 1 x 16 pixels, and the pitch
+//     = 2 mod 32 puts them on banks 2 r16 + g4 — conflict-free inside an output row (a pitch of 68 was 2-way: PMC conflict share 67 %, 124.5 -> 122.2 us).  A frame is copied by 81 `global_load_lds_dword` (one pixel = 256 B each), issued a
 //     whole step (~10 us) before its first use; one raw s_barrier per step, two thirds into it (see SYNC_TAP); the step's results are stored at the
 //     top of the NEXT step, so the vmcnt(0) in front of the barrier never waits for a store or a copy issued less than half a step ago.
 //   * a step's K loop is 9 taps x 16 channel quads = 144 x (2 ds_read_b32 with immediate offsets + 2 MFMA): k = (kh, kw, ci) ascending in one accumulator, four k
@@ -26,7 +27,7 @@ static __device__ __forceinline__ void rw_glds4(const float* g_lane, float* lds_
 namespace {
 struct C3G {
   static constexpr int KH = 3, KW = 3, CI = 64, CO = 64, IH = 9, IW = 9, OH = 7, OW = 7;
-  static constexpr int PIX = IH * IW, NPOS = OH * OW, PP = CI + 4, SLOT = PIX * PP, NS = 7, NSTEP = KH * KW * CI / 4;
+  static constexpr int PIX = IH * IW, NPOS = OH * OW, PP = CI + 2, SLOT = PIX * PP, NS = 7, NSTEP = KH * KW * CI / 4;
   static constexpr int SYNC_TAP = 6;                          // the step's barrier sits in front of this tap
   static constexpr int NTG = 2, NW = 4 * NTG, DPW = (PIX + NW - 1) / NW;     // tile groups (waves per SIMD), waves, copies per wave and frame
   static constexpr int SP = 32 * NTG;                          // positions per step

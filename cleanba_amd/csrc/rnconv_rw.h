@@ -7,7 +7,7 @@
 // barriers per strip with the matrix pipe idle in between.  Here:
 //   * every wave keeps ALL weights of the layer as B fragments in VGPRs (9 CI / 4 steps x CO / 16 column blocks: 36 ... 144 registers);
 //   * input rows live in LDS as NHWC pixels, copied by global_load_lds_dword in granules of 64 floats (4 pixels at CI = 16, 2 at CI = 32) padded to
-//     68, which makes the fragment read of 16 consecutive pixels conflict-free; a row has RPX >= H + 1 pixel slots, the slots past H stay zero (the
+//     66; a wave's tiles interleave over its positions so that a fragment read touches one pixel per granule: conflict-free (see the step body); a row has RPX >= H + 1 pixel slots, the slots past H stay zero (the
 //     copy masks those lanes) and serve as the right / left halo; the halo ROWS between frames are copied from a zero page, so SAME padding
 //     costs no instruction in the loop;
 //   * rows form a ring of NR slots over the block's VIRTUAL rows (H + 1 per frame: a zero row, then the frame's rows), two mirror rows at the end keep
@@ -15,10 +15,10 @@
 //     step; one raw s_barrier per step (in front of tap SYNC_TAP), rows are requested a whole step before their first use;
 //   * the pad breaks the uniform pixel stride, so a lane carries three bases per tile (one per kw); kh and the channel quad are immediates.
 // The relu in front of a residual block's first conv is a v_max on the fragment (the load unit cannot apply it).
-// Measured per 3840-frame minibatch against rn_conv_kernel (us): 32->32 @ 11x11 88-96 vs 127-145; 32->32 @ 21x21 277-313 vs 285-368; 16->32 @ 42x42 599
-// vs 737; 32->16 @ 42x42 (input gradient) 621 vs 612; 16->16 @ 42x42 380-435 vs 370-413 (stays on the slab kernel).  Timing builds of this kernel:
-// no row copies 8 % faster, fragments from registers instead of LDS 3-12 %, no residual / mask loads 6-7 %, no stores 1-2 %, all four 276 / 240 us
-// (16->16 @ 42 / 32->32 @ 21) = the MFMA + address arithmetic + barrier skeleton.
+// Measured per 3840-frame minibatch against rn_conv_kernel (us): 32->32 @ 11x11 88-98 vs 127-145; 32->32 @ 21x21 267-308 vs 285-368; 16->32 @ 42x42 559
+// vs 737; 32->16 @ 42x42 (input gradient) 547 vs 612; 16->16 @ 42x42 347-408 vs 370-413.  Timing builds of an earlier version: no row copies 8 %
+// faster, fragments from registers instead of LDS 3-12 %, no residual / mask loads 6-7 %, no stores 1-2 %, all four 276 / 240 us (16->16 @ 42 /
+// 32->32 @ 21) = the MFMA + address arithmetic + barrier skeleton.
 #pragma once
 #include <type_traits>
 
@@ -27,7 +27,7 @@ __device__ float rn_rw_zero_row[42 * 32];
 template <int CI_, int CO_, int H_, int NT_, int NR_>
 struct RnRwGeom {
   static constexpr int CI = CI_, CO = CO_, H = H_, NT = NT_, NR = NR_;
-  static constexpr int GP = 64 / CI, GF = 68, RPX = (H + 1 + GP - 1) / GP * GP, NG = RPX / GP;
+  static constexpr int GP = 64 / CI, GF = 66, RPX = (H + 1 + GP - 1) / GP * GP, NG = RPX / GP;
   static constexpr int NCO = CO / 16, QPT = CI / 4, NSTEP = 9 * QPT;
   static constexpr int NW = 8, TS = NW * NT, TSP = 16 * TS;     // tiles / positions per step
   static constexpr int NRP = NR + 2;                             // + two mirror rows
@@ -113,11 +113,16 @@ __global__ __launch_bounds__(512) void rn_rw_kernel(const float* __restrict__ in
   auto step = [&](auto ntl_, auto full_, int t) __attribute__((always_inline)) {
     constexpr int NTL = decltype(ntl_)::value;
     constexpr bool FULL = decltype(full_)::value;
-    // tiles of the step are dealt round robin: tile j of this wave = j * NW + wave (a short last step spreads over the waves)
+    // A wave owns a span of 16 NT consecutive positions per step; its NT tiles INTERLEAVE over the span (row r of tile j = position NT r + j):
+    // a ds_read_b32 is served in two groups of 32 lanes (g4 = 0 / 1 x 16 rows) over 32 banks, and the pixels of one 64-float copy granule share
+    // their banks (pixel strides of 16 / 32 floats) — with one pixel per granule and tile, and granules at a pitch of 66 = 2 mod 32, the 32 lanes
+    // of a group sit on banks 2 m + g4: conflict-free inside an image row (consecutive positions per tile were 2-way: PMC conflict share 60-67 %)
+    static_assert(NTL == NT, "tiles interleave over the wave's span");
+    const int qspan = G::TSP * t + wave * (16 * NT);
     int base[NTL][3];
 #pragma unroll
     for (int j = 0; j < NTL; ++j) {
-      uint32_t q = (uint32_t)(G::TSP * t + (j * G::NW + wave) * 16 + r16);
+      uint32_t q = (uint32_t)(qspan + NT * r16 + j);
       if (!FULL) q = min(q, (uint32_t)(P - 1));
       const uint32_t Gr = q / H, x = q - Gr * H, f = Gr / H, y = Gr - f * H;   // (unsigned: the divisions by constants are a multiply and a shift)
       const uint32_t s = (f * (H + 1) + y) % NR;                        // slot of the window's first row (virtual row vc - 1)
@@ -128,16 +133,16 @@ __global__ __launch_bounds__(512) void rn_rw_kernel(const float* __restrict__ in
     // element e of tile j sits at 32-bit element offset ob[j] + e * CO + 16 jc: one VGPR per tile, the rest immediates (at most 216 M elements per tensor)
     uint32_t ob[NTL];
 #pragma unroll
-    for (int j = 0; j < NTL; ++j) ob[j] = ((uint32_t)Q0 + (uint32_t)(G::TSP * t + (j * G::NW + wave) * 16 + 4 * g4)) * CO + r16;
+    for (int j = 0; j < NTL; ++j) ob[j] = ((uint32_t)Q0 + (uint32_t)(qspan + NT * 4 * g4 + j)) * CO + r16;   // element e: + e * NT * CO
     float ax[AUX ? NTL : 1][NCO][4], ao[EPI == 4 ? NTL : 1][NCO][4];
     if constexpr (AUX) {
 #pragma unroll
       for (int j = 0; j < NTL; ++j)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          uint32_t o = ob[j] + e * CO;
+          uint32_t o = ob[j] + e * NT * CO;
           if (!FULL) {
-            const int q = min(G::TSP * t + (j * G::NW + wave) * 16 + 4 * g4 + e, P - 1);
+            const int q = min(qspan + NT * (4 * g4 + e) + j, P - 1);
             o = ((uint32_t)Q0 + (uint32_t)q) * CO + r16;
           }
 #pragma unroll
@@ -187,7 +192,7 @@ __global__ __launch_bounds__(512) void rn_rw_kernel(const float* __restrict__ in
     for (int j = 0; j < NTL; ++j)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        if (!FULL && G::TSP * t + (j * G::NW + wave) * 16 + 4 * g4 + e >= P) continue;
+        if (!FULL && qspan + NT * (4 * g4 + e) + j >= P) continue;
 #pragma unroll
         for (int jc = 0; jc < NCO; ++jc) {
           float v = acc[j][jc][e];
@@ -197,7 +202,7 @@ __global__ __launch_bounds__(512) void rn_rw_kernel(const float* __restrict__ in
           else if (EPI == 6) v = fmaxf((v + bz[jc]) + ax[j][jc][e], 0.0f);
           else if (EPI == 3) v = ax[j][jc][e] > 0.0f ? v : 0.0f;
           else if (EPI == 4) v = ao[j][jc][e] + (ax[j][jc][e] > 0.0f ? v : 0.0f);
-          out[ob[j] + e * CO + 16 * jc] = v;
+          out[ob[j] + e * NT * CO + 16 * jc] = v;
         }
       }
   };
@@ -206,11 +211,7 @@ __global__ __launch_bounds__(512) void rn_rw_kernel(const float* __restrict__ in
   asm volatile("s_barrier" ::: "memory");                       // the rows of the first step and a half are in LDS
   for (int t = 0; t < nsteps; ++t) {
     if (G::TSP * (t + 1) <= P) { step(std::integral_constant<int, NT>{}, std::true_type{}, t); continue; }
-    const int ntiles = (P - G::TSP * t + 15) >> 4;                        // tiles of the (short) last step
-    const int mine = max(0, min(NT, (ntiles - wave + G::NW - 1) / G::NW));   // ... of this wave (wave-uniform)
-    if (mine > NT / 2 && NT > 1) step(std::integral_constant<int, NT>{}, std::false_type{}, t);
-    else if (NT > 2 && mine > 1) step(std::integral_constant<int, (NT > 2 ? NT / 2 : 1)>{}, std::false_type{}, t);
-    else if (mine >= 1) step(std::integral_constant<int, 1>{}, std::false_type{}, t);
+    if (G::TSP * t + wave * (16 * NT) < P) step(std::integral_constant<int, NT>{}, std::false_type{}, t);   // short last step: spans that begin inside the block
     else sync_and_issue(t);                                       // nothing to multiply in this (last) step, but the barrier is everybody's
   }
 }

@@ -33,6 +33,8 @@ for name, algo, extra, threads, t, *rest in ROWS:
     if flt not in name:
         continue
     warm, n_up = 3, (12 if "resnet" not in name else 6)
+    if t < 64:
+        warm, n_up = 40, 80     # short updates (4-5 ms): a 3-update warm-up still sits inside the first process's clock ramp / code-object loading
     total = warm + n_up
     marks = {}
 
