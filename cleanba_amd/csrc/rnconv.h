@@ -306,6 +306,18 @@ __global__ __launch_bounds__(256, 2) void rn_conv0_pool_kernel(const uint8_t* ob
   };
   const int li = lane & 15, kq = lane >> 4;
   const float bz = bias[li];
+  // where element e of tile i goes in cv (conv row-major [R][H][CO]), decoded once: 0xffff = pad column / row beyond the strip / tile beyond the strip
+  // (per strip it was a division and two compares per stored value: ~400 VALU instructions per wave against 90 MFMAs)
+  uint32_t cvo[NTW][2];
+#pragma unroll
+  for (int i = 0; i < NTW; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int tile = wave + 4 * i, q = tile * TP + 4 * kq + e, orow = q / WP, c = q - orow * WP;
+      const uint32_t o = (tile < NT && c < H && orow < R) ? (uint32_t)((orow * H + c) * CO + li) : 0xffffu;
+      static_assert(R * H * CO < 0xffff, "cv offsets fit 16 bits");
+      if (e & 1) cvo[i][e >> 1] |= o << 16; else cvo[i][e >> 1] = o;
+    }
   int s = blockIdx.x;
   if (s < nstrips) fetch(s);
   for (; s < nstrips; s += gridDim.x) {
@@ -337,16 +349,12 @@ __global__ __launch_bounds__(256, 2) void rn_conv0_pool_kernel(const uint8_t* ob
         for (int i = 0; i < NTW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[i * 4 * TP], bv, acc[i], 0, 0, 0);
       }
 #pragma unroll
-      for (int i = 0; i < NTW; ++i) {
-        const int tile = wave + 4 * i;
-        if (tile >= NT) continue;
+      for (int i = 0; i < NTW; ++i)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const int q = tile * TP + 4 * kq + e;
-          const int orow = q / WP, c = q - orow * WP;
-          if (c < H && orow < R) cv[(orow * H + c) * CO + li] = acc[i][e] + bz;
+          const uint32_t o = (cvo[i][e >> 1] >> (16 * (e & 1))) & 0xffffu;
+          if (o != 0xffffu) cv[o] = acc[i][e] + bz;
         }
-      }
     }
     __syncthreads();
     // max_pool over the rows held in LDS
@@ -354,16 +362,23 @@ __global__ __launch_bounds__(256, 2) void rn_conv0_pool_kernel(const uint8_t* ob
       const int c4 = i % (CO / 4), ow = (i / (CO / 4)) % HP, ohl = i / ((CO / 4) * HP), oh = p0 + ohl;
       if (oh >= HP) continue;
       float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-      uint32_t bi = 0;
-      for (int kh = 0; kh < 3; ++kh) for (int kw = 0; kw < 3; ++kw) {
-        const int ih = oh * 2 + kh, iw = ow * 2 + kw;
-        if (ih >= H || iw >= H) continue;
-        const float4 v = *reinterpret_cast<const float4*>(cv + ((ih - y0) * H + iw) * CO + 4 * c4);
-        const float e[4] = {v.x, v.y, v.z, v.w};
+      uint32_t bq[4] = {0u, 0u, 0u, 0u};                            // arg-max per channel (packed into bytes at the end: 3 instead of 5 VALU per compare)
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-          if (e[q] > best[q]) { best[q] = e[q]; bi = (bi & ~(0xffu << (8 * q))) | ((uint32_t)(kh * 3 + kw) << (8 * q)); }
-      }
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int ih = oh * 2 + kh, iw = ow * 2 + kw;
+          if (ih >= H || iw >= H) continue;
+          const float4 v = *reinterpret_cast<const float4*>(cv + ((ih - y0) * H + iw) * CO + 4 * c4);
+          const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const bool gt = e[q] > best[q];
+            best[q] = gt ? e[q] : best[q];
+            bq[q] = gt ? (uint32_t)(kh * 3 + kw) : bq[q];
+          }
+        }
+      const uint32_t bi = bq[0] | (bq[1] << 8) | (bq[2] << 16) | (bq[3] << 24);
       const size_t o = (((size_t)(b0 * HP + oh) * HP + ow) * (CO / 4) + c4) * 4;
       *reinterpret_cast<float4*>(pooled + o) = make_float4(best[0], best[1], best[2], best[3]);
       *reinterpret_cast<uint32_t*>(pidx + o) = bi;
