@@ -27,11 +27,18 @@ static __device__ __forceinline__ void rw_glds4(const float* g_lane, float* lds_
 namespace {
 struct C3G {
   static constexpr int KH = 3, KW = 3, CI = 64, CO = 64, IH = 9, IW = 9, OH = 7, OW = 7;
-  static constexpr int PIX = IH * IW, NPOS = OH * OW, PP = CI + 2, SLOT = PIX * PP, NS = 7, NSTEP = KH * KW * CI / 4;
+  static constexpr int PIX = IH * IW, NPOS = OH * OW, PP = CI + 2, NS = 7, NSTEP = KH * KW * CI / 4;
   static constexpr int SYNC_TAP = 6;                          // the step's barrier sits in front of this tap
   static constexpr int NTG = 2, NW = 4 * NTG, DPW = (PIX + NW - 1) / NW;     // tile groups (waves per SIMD), waves, copies per wave and frame
   static constexpr int SP = 32 * NTG;                          // positions per step
+  // bank of a fragment read = (address / 4) mod 32 within a group of 32 lanes (16 positions x k = 4s + {0, 1}): pixel pitch = 2 (mod 32) puts the positions
+  // of one output row on banks 2 ox + k; the input-ROW pitch continues that sequence into the next output row (OW positions later: = 2 OW mod 32) and the
+  // slot pitch into the next frame (= 2 NPOS mod 32), so that any 16 consecutive positions of the stream sit on 32 different banks
+  static constexpr int RP0 = IW * PP, RP = RP0 + ((2 * OW - RP0) % 32 + 32) % 32;
+  static constexpr int SLOT0 = IH * RP, SLOT = SLOT0 + ((2 * NPOS - SLOT0) % 32 + 32) % 32;
+  static_assert(RP % 32 == (2 * OW) % 32 && SLOT % 32 == (2 * NPOS) % 32 && PP % 32 == 2, "bank sequence");
   static constexpr int LDS_BYTES = NS * SLOT * 4;
+  static_assert(LDS_BYTES <= 160 * 1024, "frame ring exceeds the LDS");
 };
 }  // namespace
 
@@ -56,7 +63,7 @@ __global__ __launch_bounds__(64 * G::NW) void conv_fwd_regw_kernel(const float* 
 #pragma unroll
       for (int i = 0; i < G::DPW; ++i) {
         const int p = min(wave * G::DPW + i, G::PIX - 1);      // (the last wave repeats pixel 80: same bytes to the same place)
-        rw_glds4(src + p * G::CI, dst + p * G::PP);
+        rw_glds4(src + p * G::CI, dst + (p / G::IW) * G::RP + (p % G::IW) * G::PP);
       }
     }
   };
@@ -100,7 +107,7 @@ __global__ __launch_bounds__(64 * G::NW) void conv_fwd_regw_kernel(const float* 
     for (int j = 0; j < NT; ++j) {
       const int q = min(G::SP * t + (NT == 1 ? tg : 2 * tg + j) * 16 + r16, P - 1);
       const int fr = q / G::NPOS, p = q - fr * G::NPOS, oy = p / G::OW, ox = p - oy * G::OW;
-      base[j] = (fr % G::NS) * G::SLOT + (oy * G::IW + ox) * G::PP + g4;
+      base[j] = (fr % G::NS) * G::SLOT + oy * G::RP + ox * G::PP + g4;
     }
     f32x4_rw acc[NT];
 #pragma unroll
@@ -108,7 +115,7 @@ __global__ __launch_bounds__(64 * G::NW) void conv_fwd_regw_kernel(const float* 
     // A fragments of a whole tap (QPT k-steps x NT tiles) are read while the previous tap is multiplied: the reads are a tap (~1000 cycles) ahead
     float a[2][NT][QPT];
     auto load_part = [&](int tap, int c0, float (&dst)[NT][QPT]) __attribute__((always_inline)) {   // quads c0 .. c0+3 of a tap
-      const int kh = tap / G::KW, kw = tap - kh * G::KW, off = (kh * G::IW + kw) * G::PP;
+      const int kh = tap / G::KW, kw = tap - kh * G::KW, off = kh * G::RP + kw * G::PP;
 #pragma unroll
       for (int c = c0; c < c0 + 4; ++c)
 #pragma unroll
