@@ -8,8 +8,11 @@
 //     frames: every lane carries its own pixel address), 4 tiles = 64 positions per step; waves tg = 0 / 1 take tiles {0,1} / {2,3} of the step (one tile each in a short last step) with
 //     two independent accumulators, the four cq waves of a tile read the same A fragments.
 //   * input frames sit in a ring of 7 LDS slots as NHWC pixels of 64 floats at a pitch of 66: lane (g4, r16) reads pixel(r16) * 66 + 4c + g4.  A
-//     ds_read_b32 is served in two groups of 32 lanes over 32 banks (MI355X_MICROARCH, LDS): lanes 0-31 are g4 = 0 / 1 x 16 pixels, and the pitch
-//     = 2 mod 32 puts them on banks 2 r16 + g4 — conflict-free inside an output row (a pitch of 68 was 2-way: PMC conflict share 67 %, 124.5 -> 122.2 us).  A frame is copied by 81 `global_load_lds_dword` (one pixel = 256 B each), issued a
+//     ds_read_b32 is served in two groups of 32 lanes over 32 banks (MI355X_MICROARCH, LDS): lanes 0-31 are g4 = 0 / 1 x 16 positions; pixel pitch = 2,
+//     input-row pitch = 2 * 7 and slot pitch = 2 * 49 (mod 32) put ANY 16 consecutive positions of the stream on banks 2 p + g4 — conflict-free
+//     (pixel pitch 68: 2-way, PMC conflict share 67 %, 124.5 us; 66 with plain row / slot pitches: tiles spanning output rows collide, 50 %, 122.2 us;
+//     now 120.2 us).
+//   *  A frame is copied by 81 `global_load_lds_dword` (one pixel = 256 B each), issued a
 //     whole step (~10 us) before its first use; one raw s_barrier per step, two thirds into it (see SYNC_TAP); the step's results are stored at the
 //     top of the NEXT step, so the vmcnt(0) in front of the barrier never waits for a store or a copy issued less than half a step ago.
 //   * a step's K loop is 9 taps x 16 channel quads = 144 x (2 ds_read_b32 with immediate offsets + 2 MFMA): k = (kh, kw, ci) ascending in one accumulator, four k
