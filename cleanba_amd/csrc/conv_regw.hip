@@ -179,6 +179,167 @@ __global__ __launch_bounds__(64 * G::NW) void conv_fwd_regw_kernel(const float* 
   flush(nsteps - 1, half_last);
 }
 
+// ------------------------------------------------------------------------------------------------ conv2 forward (4x4 stride 2, 32 -> 64, 20x20 -> 9x9; naturecnn:152-158)
+// Same recipe; what differs: K = 512 -> 128 weight registers per wave; a frame is 51 KB, so the ring holds input ROWS (20 per frame, 10 copy granules of 2
+// pixels = 64 floats each), three mirror rows behind it keep a lane's four tap rows contiguous; stride 2 means consecutive output positions are one GRANULE
+// apart, so a granule pitch of 66 = 2 (mod 32) puts them on banks 2 p + k, and two input rows (one output row) = 2 * 9 (mod 32) continues the sequence.
+namespace {
+struct C2G {
+  static constexpr int KH = 4, KW = 4, ST = 2, CI = 32, CO = 64, IH = 20, IW = 20, OH = 9, OW = 9;
+  static constexpr int NPOS = OH * OW, NSTEP = KH * KW * CI / 4, QPT = CI / 4;
+  static constexpr int NGR = IW * CI / 64, GF = 66;                       // copy granules per input row, granule pitch
+  static constexpr int RP0 = NGR * GF, RP = RP0 + ((OW - RP0) % 16 + 16) % 16;   // 2 RP = 2 OW (mod 32)
+  static_assert((2 * RP) % 32 == (2 * OW) % 32 && GF % 32 == 2, "bank sequence");
+  static constexpr int NTG = 2, NW = 4 * NTG, SP = 32 * NTG;
+  static constexpr int NR = 54, NRP = NR + 3, LDS_BYTES = NRP * RP * 4;   // (ring_ok: three steps of positions touch up to 54 input rows)
+  static constexpr int SYNC_TAP = 11;                                     // of 16
+  static_assert(LDS_BYTES <= 160 * 1024, "row ring exceeds the LDS");
+  __host__ __device__ static int row_of(int q) { const int f = q / NPOS, p = q - f * NPOS; return f * IH + ST * (p / OW); }   // first input row of position q
+  __host__ __device__ static int need_lo(int t, int P) { const int q = SP * t < P - 1 ? SP * t : P - 1; return row_of(q); }
+  __host__ __device__ static int need_hi(int t, int P) { const int q = (SP * (t + 1) < P ? SP * (t + 1) : P) - 1; return row_of(q) + KH - 1; }
+  static bool ring_ok(int nf) {
+    const int P = nf * NPOS, ns = (P + SP - 1) / SP;
+    if (need_hi(ns > 1 ? 1 : 0, P) + 1 > NR) return false;
+    for (int t = 1; t + 1 < ns; ++t) if (need_hi(t + 1, P) >= need_lo(t - 1, P) + NR) return false;
+    return true;
+  }
+};
+}  // namespace
+
+__global__ __launch_bounds__(512) void conv2_fwd_regw_kernel(const float* __restrict__ in, const float* __restrict__ W, const float* __restrict__ bias,
+                                                             float* __restrict__ out, uint32_t* __restrict__ mask, int B, int fpb) {
+  using G = C2G;
+  extern __shared__ __attribute__((aligned(16))) float rw_lds[];
+  const int tid = threadIdx.x, lane = tid & 63, r16 = lane & 15, g4 = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cq = wave & 3, tg = wave >> 2;
+  const int f0 = blockIdx.x * fpb, nf = min(fpb, B - f0);
+  if (nf <= 0) return;
+  const int P = nf * G::NPOS, nsteps = (P + G::SP - 1) / G::SP, NV = nf * G::IH;
+  const float* src0 = in + (size_t)f0 * (G::IH * G::IW * G::CI) + lane;
+
+  int issued = 0;                                                        // input rows [0, issued) of the block's frames have been requested
+  auto issue_row = [&](int v) __attribute__((always_inline)) {          // one wave copies a row: 10 granules at constant offsets
+    const float* src = src0 + (size_t)v * (G::IW * G::CI);
+    const int pr = v % G::NR;
+    float* dst = rw_lds + pr * G::RP;
+#pragma unroll
+    for (int g = 0; g < G::NGR; ++g) rw_glds4(src + g * 64, dst + g * G::GF);
+    if (pr < 3) {
+      float* dm = dst + G::NR * G::RP;
+#pragma unroll
+      for (int g = 0; g < G::NGR; ++g) rw_glds4(src + g * 64, dm + g * G::GF);
+    }
+  };
+  auto issue_upto = [&](int lim) __attribute__((always_inline)) {
+    lim = min(lim, NV);
+    for (int v = issued + wave; v < lim; v += G::NW) issue_row(v);
+    issued = max(issued, lim);
+  };
+  issue_upto(G::need_hi(nsteps > 1 ? 1 : 0, P) + 1);
+
+  float w[G::NSTEP];
+#pragma unroll
+  for (int s = 0; s < G::NSTEP; ++s) w[s] = W[(size_t)(4 * s + g4) * G::CO + 16 * cq + r16];
+  const float bv = bias[16 * cq + r16];
+  uint16_t* mask16 = reinterpret_cast<uint16_t*>(mask);
+  const size_t Q0 = (size_t)f0 * G::NPOS;
+
+  auto sync_and_issue = [&](int t) __attribute__((always_inline)) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");
+    issue_upto(G::need_lo(t, P) + G::NR);
+  };
+
+  // results of a step are kept in registers and stored at the top of the next one (see conv_fwd_regw_kernel)
+  float o[2][4];
+  uint32_t mh[2] = {0u, 0u};
+  auto flush = [&](int t) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int q0 = G::SP * t + (2 * tg + j) * 16;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int q = q0 + 4 * g4 + e;
+        if (q < P) out[(Q0 + q) * G::CO + 16 * cq + r16] = o[j][e];
+      }
+      if (mask16 && r16 < 4) {
+        const int q = q0 + 4 * g4 + r16;
+        if (q < P) mask16[(Q0 + q) * (G::CO / 16) + cq] = (uint16_t)mh[j];
+      }
+    }
+  };
+
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("s_barrier" ::: "memory");
+  for (int t = 0; t < nsteps; ++t) {
+    if (t > 0) flush(t - 1);
+    int base[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const uint32_t q = min((uint32_t)(G::SP * t + (2 * tg + j) * 16 + r16), (uint32_t)(P - 1));
+      const uint32_t f = q / G::NPOS, p = q - f * G::NPOS, oy = p / G::OW, ox = p - oy * G::OW;
+      const uint32_t sr = (f * G::IH + G::ST * oy) % G::NR;              // ring slot of the window's first row
+      base[j] = (int)(sr * G::RP + ox * G::GF + g4);                    // pixel 2 ox = granule ox
+    }
+    f32x4_rw acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[j] = f32x4_rw{0.f, 0.f, 0.f, 0.f};
+    constexpr int QC = 4, CPT = G::QPT / QC, NCH = G::KH * G::KW * CPT;    // chunks of 4 channel quads: half a tap
+    float a[2][2][QC];
+    auto load_chunk = [&](int u, float (&dst)[2][QC]) __attribute__((always_inline)) {
+      const int tap = u / CPT, h = u - tap * CPT, kh = tap / G::KW, kw = tap - kh * G::KW;
+      const int off = kh * G::RP + (kw >> 1) * G::GF + (kw & 1) * G::CI + 4 * (h * QC);
+#pragma unroll
+      for (int c = 0; c < QC; ++c)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) dst[j][c] = rw_lds[base[j] + off + 4 * c];
+    };
+    load_chunk(0, a[0]);
+#pragma unroll
+    for (int u = 0; u < NCH; ++u) {
+      if (u == G::SYNC_TAP * CPT) {
+        __builtin_amdgcn_sched_barrier(0);
+        sync_and_issue(t);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (u + 1 < NCH) load_chunk(u + 1, a[(u + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int c = 0; c < QC; ++c)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u & 1][j][c], w[u * QC + c], acc[j], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      uint64_t b[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float pre = acc[j][e] + bv;
+        const float v = pre > 0.0f ? pre : 0.0f;
+        o[j][e] = v;
+        b[e] = __ballot(v > 0.0f);
+      }
+      const uint64_t mine = r16 == 0 ? b[0] : (r16 == 1 ? b[1] : (r16 == 2 ? b[2] : b[3]));
+      mh[j] = (uint32_t)(mine >> (16 * g4)) & 0xffffu;
+    }
+  }
+  flush(nsteps - 1);
+}
+
+void launch_conv2_fwd_regw(const float* in, const float* W, const float* bias, float* out, uint32_t* mask, int B, hipStream_t st) {
+  static bool attr = false;
+  if (!attr) { hipFuncSetAttribute((const void*)conv2_fwd_regw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, C2G::LDS_BYTES); attr = true; }
+  const int fpb = (B + 255) / 256, blocks = (B + fpb - 1) / fpb;
+  static int checked = 0;
+  if (checked != fpb) {
+    if (!C2G::ring_ok(fpb)) { fprintf(stderr, "conv2_fwd_regw_kernel: row ring of %d slots too small\n", C2G::NR); abort(); }
+    checked = fpb;
+  }
+  hipLaunchKernelGGL(conv2_fwd_regw_kernel, dim3(blocks), dim3(512), C2G::LDS_BYTES, st, in, W, bias, out, mask, B, fpb);
+}
+
 void launch_conv3_fwd_regw(const float* in, const float* W, const float* bias, float* out, uint32_t* mask, int B, hipStream_t st) {
   static bool attr = false;
   if (!attr) { hipFuncSetAttribute((const void*)conv_fwd_regw_kernel<C3G>, hipFuncAttributeMaxDynamicSharedMemorySize, C3G::LDS_BYTES); attr = true; }
