@@ -107,7 +107,7 @@ void launch_conv3_wgrad_frames(const float* act2, const float* dypad, float* par
 
 // load-unit fed weight gradient of the dense layer (dense_wgrad.hip): partials part[z][X][Y], bpart[z][Y]; slices = 0: batch not handled (use the igemm)
 int dense_wgrad_dma_slices(int F);
-// conv_regw.hip: learner-size conv3 forward with the weights in registers (bit-identical to ConvFwd on igemm_kernel)
+// conv_regw.hip: learner-size conv2 / conv3 forward with the weights in registers (bit-identical to ConvFwd on igemm_kernel)
 void launch_conv3_fwd_regw(const float* in, const float* W, const float* bias, float* out, uint32_t* mask, int B, hipStream_t st);
 void launch_conv2_fwd_regw(const float* in, const float* W, const float* bias, float* out, uint32_t* mask, int B, hipStream_t st);
 void launch_dense_wgrad_dma(const float* act, const float* dhid, float* part, float* bpart, int F, int X, int Y, int nz, hipStream_t st);

@@ -1,4 +1,4 @@
-// conv_regw.hip — learner-size conv3 forward (3x3 stride 1, 64 -> 64 channels, 9x9 -> 7x7; naturecnn:160-166) with the WEIGHTS IN REGISTERS.
+// conv_regw.hip — learner-size conv3 forward (3x3 stride 1, 64 -> 64 channels, 9x9 -> 7x7; naturecnn:160-166) and conv2 forward (further down) with the WEIGHTS IN REGISTERS.
 //
 // The im2col GEMM kernels (igemm.h) stage both operands through LDS tile by tile: per 16-wide K chunk a gather, a register -> LDS store, a barrier.
 // Here nothing but the activations ever goes through LDS and nothing but `ds_read_b32` + MFMA is issued inside a step:

@@ -1093,7 +1093,7 @@ int nature_forward(const NatureLayout& L, const float* P, const uint8_t* obs, co
     plaunch_fwd(ws, K_CONV3_FWD, p3, 1, st);
   } else {   // learner-size conv2 / conv3 forward on the two-chunk prefetch kernel (bit-identical to igemm_kernel)
     ConvFwd<T64x64, 4, 4, 2, 32, 64, 20, 20, 9, 9> p2{ws.act1, P + L.w[1], P + L.b[1], ws.act2, B * 81, ws.mask2};
-    static const bool c2rw = [] { const char* e = getenv("CBM_C2_RW"); return !(e && e[0] == '0'); }();
+    static const bool c2rw = [] { const char* e = getenv("CBM_C2_RW"); return !(e && e[0] == '0'); }();   // (=0: the im2col kernel, A/B timing)
     if (!ws.bf16_fwd && c2rw) prof_launch(ws, K_CONV2_FWD, st, "conv2_fwd_regw_kernel", "", [&] { launch_conv2_fwd_regw(ws.act1, P + L.w[1], P + L.b[1], ws.act2, ws.mask2, B, st); });
     else if (!ws.bf16_fwd) plaunch_pf2(ws, K_CONV2_FWD, p2, 1, st);
     else plaunch_fwd(ws, K_CONV2_FWD, p2, 1, st);
