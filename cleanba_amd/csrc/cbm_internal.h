@@ -63,6 +63,7 @@ struct NatureWs {
   int kind = 0;
   float* rn_t[3][6] = {};
   uint8_t* rn_pidx[3] = {};
+  void* rn_m[3][5] = {};   // relu bit masks (value > 0, C bits per position) of rn_t[s][1..4], written by the forward at learner sizes (learner workspaces only)
   float* rn_g[2] = {};
   float* rn_wT = nullptr;  // flipped/transposed conv weights for the dgrad convs (rebuilt per backward)
 };

@@ -271,7 +271,7 @@ struct RnPool0Geom {
 // Blocks are persistent over strips: the bytes of the next strip (3 uint32 per thread) are requested before the sweep of the current one.
 template <int PR>
 __global__ __launch_bounds__(256, 2) void rn_conv0_pool_kernel(const uint8_t* obs, const int32_t* idx, const float* W, const float* bias, float* pooled,
-                                                               uint8_t* pidx, int B, int nstrips) {
+                                                               uint8_t* pidx, int B, int nstrips, uint16_t* mask) {   // mask: null, or 16 bits per pooled position (value > 0)
   using PG = RnPool0Geom<PR>;
   using G = typename PG::G;
   constexpr int H = 84, HP = 42, CO = 16, WP = G::WP, TP = G::TP, NTW = G::NTW, NT = G::NT, R = PG::R;
@@ -382,12 +382,18 @@ __global__ __launch_bounds__(256, 2) void rn_conv0_pool_kernel(const uint8_t* ob
       const size_t o = (((size_t)(b0 * HP + oh) * HP + ow) * (CO / 4) + c4) * 4;
       *reinterpret_cast<float4*>(pooled + o) = make_float4(best[0], best[1], best[2], best[3]);
       *reinterpret_cast<uint32_t*>(pidx + o) = bi;
+      if (mask) {   // the four lanes of a position are consecutive and take the `continue` above together
+        uint32_t wv = ((best[0] > 0.0f ? 1u : 0u) | (best[1] > 0.0f ? 2u : 0u) | (best[2] > 0.0f ? 4u : 0u) | (best[3] > 0.0f ? 8u : 0u)) << (4 * c4);
+        wv |= __shfl_xor(wv, 1);
+        wv |= __shfl_xor(wv, 2);
+        if (c4 == 0) mask[o / 16] = (uint16_t)wv;
+      }
     }
   }
 }
 template <int PR>
 static void rn_conv0_pool_launch(const uint8_t* obs, const int32_t* idx, const float* W, const float* bias, float* pooled, uint8_t* pidx, int B,
-                                 hipStream_t st) {
+                                 hipStream_t st, uint16_t* mask = nullptr) {
   using PG = RnPool0Geom<PR>;
   constexpr size_t lds = (size_t)PG::LDS_FLOATS * sizeof(float);
   static_assert(lds <= 160 * 1024, "conv0+pool strip exceeds LDS");
@@ -396,7 +402,7 @@ static void rn_conv0_pool_launch(const uint8_t* obs, const int32_t* idx, const f
   const int nstrips = B * PG::STRIPS;
   const int per_cu = (int)(160 * 1024 / lds) < 1 ? 1 : (int)(160 * 1024 / lds);
   const int nb = nstrips < 256 * per_cu ? nstrips : 256 * per_cu;
-  hipLaunchKernelGGL((rn_conv0_pool_kernel<PR>), dim3(nb), dim3(256), lds, st, obs, idx, W, bias, pooled, pidx, B, nstrips);
+  hipLaunchKernelGGL((rn_conv0_pool_kernel<PR>), dim3(nb), dim3(256), lds, st, obs, idx, W, bias, pooled, pidx, B, nstrips, mask);
 }
 
 // dgrad as a forward conv: Wt[(jh,jw)][co][ci] = W[(2-jh,2-jw)][ci][co]   (all 14 convs that need a dgrad, one launch)

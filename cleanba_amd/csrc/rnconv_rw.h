@@ -52,11 +52,16 @@ static __device__ __forceinline__ void rn_rw_glds4(const float* g_lane, float* l
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g_lane, (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
 }
 
-template <class G, bool PRE_RELU, int EPI>
+// MASKIN (EPI 3 / 4): the relu mask comes as ONE BIT per element (mask_in: a uint16 / uint32 of CO bits per position, written by the forward kernel
+// that produced the masked tensor) instead of re-reading the tensor itself — the 16-channel input gradients move 1.2-1.7 GB per launch and sit at
+// 3.6-4.0 TB/s; a third / a quarter of that was the mask source.  mask_out (EPI 1 / 5 / 6, may be null): emit that mask for this kernel's output.
+template <class G, bool PRE_RELU, int EPI, bool MASKIN>
 __global__ __launch_bounds__(512) void rn_rw_kernel(const float* __restrict__ in, const float* __restrict__ W, const float* __restrict__ bias,
-                                                    const float* aux, float* out, int B, int fpb) {
+                                                    const float* aux, float* out, int B, int fpb, const void* __restrict__ mask_in, void* __restrict__ mask_out) {
   constexpr int H = G::H, CI = G::CI, CO = G::CO, NT = G::NT, NCO = G::NCO, QPT = G::QPT, NG = G::NG, GF = G::GF, NR = G::NR;
   constexpr bool AUX = EPI == 1 || EPI == 3 || EPI == 4 || EPI == 6, BIAS = EPI == 0 || EPI == 1 || EPI == 5 || EPI == 6;
+  constexpr bool MIN = MASKIN && (EPI == 3 || EPI == 4), MOUT = EPI == 1 || EPI == 5 || EPI == 6;
+  using MW = typename std::conditional<G::CO == 16, uint16_t, uint32_t>::type;   // CO mask bits of one position
   extern __shared__ __attribute__((aligned(16))) float rw_smem[];
   const int tid = threadIdx.x, lane = tid & 63, r16 = lane & 15, g4 = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -134,20 +139,24 @@ __global__ __launch_bounds__(512) void rn_rw_kernel(const float* __restrict__ in
     uint32_t ob[NTL];
 #pragma unroll
     for (int j = 0; j < NTL; ++j) ob[j] = ((uint32_t)Q0 + (uint32_t)(qspan + NT * 4 * g4 + j)) * CO + r16;   // element e: + e * NT * CO
-    float ax[AUX ? NTL : 1][NCO][4], ao[EPI == 4 ? NTL : 1][NCO][4];
+    float ax[AUX && !MIN ? NTL : 1][NCO][4], ao[EPI == 4 ? NTL : 1][NCO][4];
+    uint32_t mw[MIN ? NTL : 1][4];
     if constexpr (AUX) {
+      const uint32_t qb = (uint32_t)Q0 + (uint32_t)(qspan + NT * 4 * g4);
 #pragma unroll
       for (int j = 0; j < NTL; ++j)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          uint32_t o = ob[j] + e * NT * CO;
+          uint32_t o = ob[j] + e * NT * CO, qi = qb + j + e * NT;
           if (!FULL) {
             const int q = min(qspan + NT * (4 * g4 + e) + j, P - 1);
             o = ((uint32_t)Q0 + (uint32_t)q) * CO + r16;
+            qi = (uint32_t)Q0 + (uint32_t)q;
           }
+          if constexpr (MIN) mw[j][e] = (uint32_t)reinterpret_cast<const MW*>(mask_in)[qi];
 #pragma unroll
           for (int jc = 0; jc < NCO; ++jc) {
-            ax[j][jc][e] = aux[o + 16 * jc];
+            if constexpr (!MIN) ax[j][jc][e] = aux[o + 16 * jc];
             if constexpr (EPI == 4) ao[j][jc][e] = out[o + 16 * jc];
           }
         }
@@ -191,18 +200,33 @@ __global__ __launch_bounds__(512) void rn_rw_kernel(const float* __restrict__ in
 #pragma unroll
     for (int j = 0; j < NTL; ++j)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        if (!FULL && qspan + NT * (4 * g4 + e) + j >= P) continue;
+      for (int jc = 0; jc < NCO; ++jc) {
+        uint64_t pos[4];                                              // (MOUT) which lanes hold a positive value in element e
 #pragma unroll
-        for (int jc = 0; jc < NCO; ++jc) {
+        for (int e = 0; e < 4; ++e) {
+          const bool valid = FULL || qspan + NT * (4 * g4 + e) + j < P;
+          bool on = true;
+          if constexpr (EPI == 3 || EPI == 4) {
+            if constexpr (MIN) on = ((mw[j][e] >> (16 * jc + r16)) & 1u) != 0u;
+            else on = ax[j][jc][e] > 0.0f;
+          }
           float v = acc[j][jc][e];
           if (EPI == 0) v = v + bz[jc];
           else if (EPI == 5) v = fmaxf(v + bz[jc], 0.0f);
           else if (EPI == 1) v = (v + bz[jc]) + ax[j][jc][e];
           else if (EPI == 6) v = fmaxf((v + bz[jc]) + ax[j][jc][e], 0.0f);
-          else if (EPI == 3) v = ax[j][jc][e] > 0.0f ? v : 0.0f;
-          else if (EPI == 4) v = ao[j][jc][e] + (ax[j][jc][e] > 0.0f ? v : 0.0f);
-          out[ob[j] + e * NT * CO + 16 * jc] = v;
+          else if (EPI == 3) v = on ? v : 0.0f;
+          else if (EPI == 4) v = ao[j][jc][e] + (on ? v : 0.0f);
+          if (valid) out[ob[j] + e * NT * CO + 16 * jc] = v;
+          if constexpr (MOUT) pos[e] = __ballot(valid && v > 0.0f);
+        }
+        if constexpr (MOUT) {
+          if (mask_out) {                                             // row 4 g4 + e of the tile: bits [16 g4, +16) of ballot e; lane r16 = e stores it
+            const uint64_t mine = r16 == 0 ? pos[0] : (r16 == 1 ? pos[1] : (r16 == 2 ? pos[2] : pos[3]));
+            const int q = qspan + NT * (4 * g4 + r16) + j;
+            if (r16 < 4 && (FULL || q < P))
+              reinterpret_cast<uint16_t*>(mask_out)[(Q0 + (size_t)q) * NCO + jc] = (uint16_t)((mine >> (16 * g4)) & 0xffffu);
+          }
         }
       }
   };
@@ -216,18 +240,19 @@ __global__ __launch_bounds__(512) void rn_rw_kernel(const float* __restrict__ in
   }
 }
 
-template <class G, bool PRE_RELU, int EPI>
-static void rn_rw_launch(const float* in, const float* W, const float* bias, const float* aux, float* out, int B, hipStream_t st) {
+template <class G, bool PRE_RELU, int EPI, bool MASKIN = false>
+static void rn_rw_launch(const float* in, const float* W, const float* bias, const float* aux, float* out, int B, hipStream_t st,
+                         const void* mask_in = nullptr, void* mask_out = nullptr) {
   constexpr int lds = G::LDS_FLOATS * 4;
   static bool attr = false;
-  if (!attr) { hipFuncSetAttribute((const void*)rn_rw_kernel<G, PRE_RELU, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
+  if (!attr) { hipFuncSetAttribute((const void*)rn_rw_kernel<G, PRE_RELU, EPI, MASKIN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
   const int fpb = (B + 255) / 256, blocks = (B + fpb - 1) / fpb;
   static int checked_fpb = 0;
   if (checked_fpb != fpb) {
     if (!G::ring_ok(fpb)) { fprintf(stderr, "rn_rw_kernel: row ring of %d slots too small for H=%d TSP=%d\n", G::NR, G::H, G::TSP); abort(); }
     checked_fpb = fpb;
   }
-  hipLaunchKernelGGL((rn_rw_kernel<G, PRE_RELU, EPI>), dim3(blocks), dim3(512), lds, st, in, W, bias, aux, out, B, fpb);
+  hipLaunchKernelGGL((rn_rw_kernel<G, PRE_RELU, EPI, MASKIN>), dim3(blocks), dim3(512), lds, st, in, W, bias, aux, out, B, fpb, mask_in, mask_out);
 }
 
 // geometry per layer shape: tiles per wave and step, ring slots (checked by ring_ok at launch)
