@@ -1,22 +1,24 @@
 // rnconv_rw.h — learner-size 3x3 SAME convolutions of the IMPALA-ResNet torso (ppo:149-189) with the WEIGHTS IN REGISTERS and the activations in a
-// load-unit-fed NHWC row ring.  Drop-in for rn_conv_kernel (rnconv.h) at large batches: same arguments, same epilogues (EPI 0-5), same k-ascending
+// load-unit-fed NHWC row ring.  Drop-in for rn_conv_kernel (rnconv.h) at large batches: same arguments, same epilogues (EPI 0-6), same k-ascending
 // v_mfma_f32_16x16x4_f32 chain k = (kh, kw, ci) -> the same bits.
 //
 // rn_conv_kernel stages every strip through registers into channel planes (global load -> relu / select -> four scattered ds_write per float4), reads
 // A and B fragments from LDS and decodes an output index per stored element: 4.3 VALU instructions per MFMA on the 16-channel layers, two block
 // barriers per strip with the matrix pipe idle in between.  Here:
 //   * every wave keeps ALL weights of the layer as B fragments in VGPRs (9 CI / 4 steps x CO / 16 column blocks: 36 ... 144 registers);
-//   * input rows live in LDS as NHWC pixels, copied by global_load_lds_dword in granules of 64 floats (4 pixels at CI = 16, 2 at CI = 32) padded to
-//     66; a wave's tiles interleave over its positions so that a fragment read touches one pixel per granule: conflict-free (see the step body); a row has RPX >= H + 1 pixel slots, the slots past H stay zero (the
-//     copy masks those lanes) and serve as the right / left halo; the halo ROWS between frames are copied from a zero page, so SAME padding
-//     costs no instruction in the loop;
+//   * input rows live in LDS as NHWC pixels, copied by global_load_lds_dword in granules of 64 floats (4 pixels at CI = 16, 2 at CI = 32) at a
+//     pitch of 66; a wave's tiles interleave over its positions so that a fragment read touches one pixel per granule (bank rule: see the step
+//     body).  A row has RPX >= H + 1 pixel slots; the slots past H stay zero (the copy masks those lanes) and serve as the right / left halo; the
+//     halo ROWS between frames are copied from a zero page, so SAME padding costs no instruction in the loop;
 //   * rows form a ring of NR slots over the block's VIRTUAL rows (H + 1 per frame: a zero row, then the frame's rows), two mirror rows at the end keep
 //     the three rows of a tap window contiguous; a block walks the H*H positions of its frames as one stream of 16-position tiles, TSP positions per
 //     step; one raw s_barrier per step (in front of tap SYNC_TAP), rows are requested a whole step before their first use;
-//   * the pad breaks the uniform pixel stride, so a lane carries three bases per tile (one per kw); kh and the channel quad are immediates.
+//   * the granule pad breaks the uniform pixel stride, so a lane carries three bases per tile (one per kw); kh, the channel quad, the four output
+//     elements of a lane and the column block are immediates on 32-bit element offsets;
+//   * the relu masks of the input gradients travel as one bit per element (MASKIN / mask_out below).
 // The relu in front of a residual block's first conv is a v_max on the fragment (the load unit cannot apply it).
-// Measured per 3840-frame minibatch against rn_conv_kernel (us): 32->32 @ 11x11 88-98 vs 127-145; 32->32 @ 21x21 267-308 vs 285-368; 16->32 @ 42x42 559
-// vs 737; 32->16 @ 42x42 (input gradient) 547 vs 612; 16->16 @ 42x42 347-408 vs 370-413.  Timing builds of an earlier version: no row copies 8 %
+// Measured per 3840-frame minibatch against rn_conv_kernel (us): 32->32 @ 11x11 88-98 vs 127-145; 32->32 @ 21x21 267-312 vs 285-368; 16->32 @ 42x42 557
+// vs 737; 32->16 @ 42x42 (input gradient) 548 vs 612; 16->16 @ 42x42 325-394 vs 370-413.  Timing builds of an earlier version: no row copies 8 %
 // faster, fragments from registers instead of LDS 3-12 %, no residual / mask loads 6-7 %, no stores 1-2 %, all four 276 / 240 us (16->16 @ 42 /
 // 32->32 @ 21) = the MFMA + address arithmetic + barrier skeleton.
 #pragma once
