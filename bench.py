@@ -64,12 +64,12 @@ def _free_port():
 
 
 # --------------------------------------------------------------------------------------------- CPU baseline (same harness)
-def cpu_baseline(n_envs=16, n_steps=32, updates=3, full_updates=1):
+def cpu_baseline(n_envs=16, n_steps=32, updates=3, full_updates=3):
     """The CPU restatement (oracle/, kind "port") driven by the SAME host program as the GPU run — cleanba_amd.trainer.train with the
     oracle-backed engine (tests/oracle_engine.py) in place of the HIP library: same actor thread, same ring hand-off, same counters — on a
     bounded sample of the workload: Nature-CNN PPO, 4 epochs x 4 minibatches, A=18, host synthetic env, `n_envs` envs x `n_steps` steps per
     rollout (the full 120 x 128 rollout would take ~2 minutes per update on these cores), `updates` updates, env-steps/s = the MEDIAN over
-    updates of local_batch_size / (time between consecutive update completions).  Two rows: the oracle's OpenMP over frames on all cores it
+    updates of local_batch_size / (time between consecutive update completions) — three full-size intervals for `value`.  Two rows: the oracle's OpenMP over frames on all cores it
     can use, and one intra-op thread per role like the reference pins XLA-CPU (ppo:28)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle
@@ -106,6 +106,25 @@ def cpu_baseline(n_envs=16, n_steps=32, updates=3, full_updates=1):
     cores = max(1, min(ncpu, 32, (n_envs * n_steps // NMB) // 6))   # OpenMP over frames: more threads than frames/6 only adds reduction cost
     sps, dts = run(cores)
     sps1, dts1 = run(1)
+    # full-size estimate of the one-thread-per-role row: one thread's time for a PPO minibatch (forward + loss + backward) is linear in the
+    # frames, so a 192-frame slice of a 3840-frame minibatch is timed on ONE thread and scaled; the actor's share is the 120-frame forward.
+    oracle.set_threads(1)
+    rng = np.random.default_rng(7)
+    nf = 192
+    P1 = M.init_nature_params(A, *prng.split(prng.prng_key(1), 4)[1:])
+    fr = rng.integers(0, 256, (nf, 4, 84, 84), dtype=np.uint8)
+    acts_, olp, adv_, tgt_ = rng.integers(0, A, nf).astype(np.int32), np.full(nf, -np.log(A), np.float32), rng.normal(size=nf).astype(np.float32), \
+        rng.normal(size=nf).astype(np.float32)
+    oracle.ppo_loss_grad(P1, A, fr[:8], None, acts_[:8], olp[:8], adv_[:8], tgt_[:8])          # warm the code / pages
+    t0 = time.perf_counter()
+    oracle.ppo_loss_grad(P1, A, fr, None, acts_, olp, adv_, tgt_)
+    t_mb = (time.perf_counter() - t0) * MB / nf                                                   # one 3840-frame minibatch, one thread
+    t0 = time.perf_counter()
+    oracle.nature_forward(P1, A, fr[:E], ksplit=14)
+    t_act = time.perf_counter() - t0                                                              # one 120-env actor forward, one thread
+    t_update, t_rollout = EPOCHS * NMB * t_mb, T * t_act
+    sps1_full = E * T / max(t_update, t_rollout)                                                   # --concurrency: the two threads overlap
+    oracle.set_threads(cores_full)
     return {"value": round(sps_full, 2), "unit": "env-steps/s", "cores": cores_full + 1, "kind": "port", "estimate": False,
             "sample": f"the benchmark's configuration itself: same harness as the GPU run (cleanba_amd.trainer.train, actor thread + learner thread, "
                       f"--concurrency) on the oracle engine, PPO Nature-CNN fp32, {E} envs x {T} steps per rollout, 4 epochs x 4 minibatches of {MB} frames, "
@@ -114,6 +133,11 @@ def cpu_baseline(n_envs=16, n_steps=32, updates=3, full_updates=1):
             "reduced_sample": {"value": round(sps, 2), "cores": cores + 1, "estimate": True,
                                "note": f"{n_envs} envs x {n_steps} steps per rollout (128-frame minibatches cap OpenMP at {cores} threads): median of {updates} "
                                        f"update intervals {dts} s — small batches depress CPU efficiency; NOT the benchmark's configuration"},
+            "reference_threading_full_size": {"value": round(sps1_full, 2), "cores": 2, "estimate": True,
+                                              "note": f"ESTIMATE for the benchmark's own configuration with one intra-op thread per role (ppo:28): a {nf}-frame PPO "
+                                                      f"minibatch (forward + loss + backward) timed on one thread and scaled by {MB}/{nf} = {t_mb:.1f} s per "
+                                                      f"3840-frame minibatch x 16 = {t_update:.0f} s per update; the actor thread's 128 x 120-frame forwards "
+                                                      f"{t_rollout:.1f} s overlap it"},
             "reference_threading": {"value": round(sps1, 2), "cores": 2, "estimate": True,
                                     "note": f"one intra-op thread per role like the reference pins XLA-CPU (ppo:28): one actor thread + one learner thread, on the "
                                             f"reduced sample ({n_envs} x {n_steps}); intervals {dts1} s"}}

@@ -27,6 +27,24 @@ void cbm_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* cbm_last_error(void) { return g_err; }
+static std::mutex g_launch_mu;
+static char g_launch_err[512] = "";
+static std::atomic<bool> g_launch_failed{false};
+void cbm_launch_fail(const char* fmt, ...) {
+  std::lock_guard<std::mutex> lk(g_launch_mu);
+  if (g_launch_failed.load()) return;   // keep the first one
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_launch_err, sizeof(g_launch_err), fmt, ap);
+  va_end(ap);
+  g_launch_failed.store(true, std::memory_order_release);
+}
+int cbm_launch_check(void) {
+  if (!g_launch_failed.load(std::memory_order_acquire)) return 0;
+  std::lock_guard<std::mutex> lk(g_launch_mu);
+  cbm_set_error("%s", g_launch_err);
+  return -1;
+}
 extern "C" const char* cbm_build_info(void) { return "cleanba-mi gfx950 f32-mfma abi=2 built " __DATE__ " " __TIME__; }
 
 static bool is_ppo(const cbm_ctx* c) { return c->cfg.algo == CBM_ALGO_PPO; }
@@ -412,7 +430,7 @@ extern "C" int cbm_actor_step_host(cbm_ctx* c, int32_t s, const uint8_t* obs, co
   CBM_HIP(hipStreamSynchronize(sl.stream));  // the per-step D2H sync of ppo:317
   memcpy(actions_out, pa, E * 4);
   sl.t += 1;
-  return 0;
+  return cbm_launch_check();
 }
 // Async host-env step (naturecnn:346-367): the batch envpool.recv() returned — observations of `async_batch_size` envs, the reward /
 // done that arrived WITH them and their env ids — goes into ring row t; get_action_and_value runs on it; actions come back for
@@ -496,7 +514,7 @@ extern "C" int cbm_actor_rollout_device(cbm_ctx* c, int32_t s, int32_t nsteps) {
       sl.t += 1;
     }
   }
-  return 0;
+  return cbm_launch_check();
 }
 
 extern "C" int cbm_actor_commit(cbm_ctx* c, int32_t s, const uint8_t* next_obs, const uint8_t* next_done) {
@@ -647,7 +665,7 @@ extern "C" int cbm_learner_minibatch_grad(cbm_ctx* c, int32_t epoch, int32_t mb)
                        c->cfg.gamma, c->cfg.vf_coef, c->cfg.ent_coef, c->lws.dzv, c->loss_partials, stats, c->lstream);
     nature_backward(c->L, c->params, R.obs, idx, c->MB, c->lws, c->grads, c->lstream);
   }
-  return 0;
+  return cbm_launch_check();
 }
 
 // Overlapping pmean(grads) (ppo:628) with the backward pass.  The flat gradient is laid out conv1 | conv2 | conv3 | dense | actor | critic and
@@ -797,7 +815,7 @@ extern "C" int cbm_forward(cbm_ctx* c, const float* params, const uint8_t* obs, 
   if (logits) CBM_HIP(hipMemcpyAsync(logits, c->lws.logits, (size_t)B * c->A * 4, hipMemcpyDeviceToDevice, c->lstream));
   if (value) CBM_HIP(hipMemcpyAsync(value, c->lws.value, (size_t)B * 4, hipMemcpyDeviceToDevice, c->lstream));
   CBM_HIP(hipStreamSynchronize(c->lstream));
-  return 0;
+  return cbm_launch_check();
 }
 extern "C" int cbm_sample(cbm_ctx* c, const float* logits, int32_t B, const uint32_t sub[2], int32_t* actions, float* logprobs) {
   CBM_HIP(hipSetDevice(c->cfg.device));
@@ -866,7 +884,7 @@ extern "C" int cbm_ppo_loss_grad(cbm_ctx* c, const float* params, const uint8_t*
   if (logits_out) CBM_HIP(hipMemcpyAsync(logits_out, c->lws.logits, (size_t)N * c->A * 4, hipMemcpyDeviceToDevice, c->lstream));
   if (value_out) CBM_HIP(hipMemcpyAsync(value_out, c->lws.value, (size_t)N * 4, hipMemcpyDeviceToDevice, c->lstream));
   CBM_HIP(hipStreamSynchronize(c->lstream));
-  return 0;
+  return cbm_launch_check();
 }
 extern "C" int cbm_impala_loss_grad(cbm_ctx* c, const float* params, const uint8_t* obs, const int32_t* idx, int32_t T1, int32_t Bm,
                                     const float* mu_logits, const int32_t* actions, const float* rewards, const uint8_t* dones,
@@ -882,7 +900,7 @@ extern "C" int cbm_impala_loss_grad(cbm_ctx* c, const float* params, const uint8
   if (grads) nature_backward(c->L, params, obs, idx, N, c->lws, grads, c->lstream);
   CBM_HIP(hipStreamSynchronize(c->lstream));
   hipFree(partials);
-  return 0;
+  return cbm_launch_check();
 }
 extern "C" int cbm_adam_step(cbm_ctx* c, float* p, const float* g, float* m, float* v, int64_t n, float max_norm, float lr, float bc1, float bc2,
                              float grad_div) {

@@ -39,7 +39,7 @@ struct Slot {
   // hipMemcpyAsync of 120-480 bytes costs the host ~8 us each (runtime staging + bookkeeping), from page-locked memory it is a plain enqueue
   uint8_t* pin = nullptr;
   size_t pin_stride = 0;
-  int pin_cur = 0;
+  uint32_t pin_cur = 0;   // unsigned: the ring index stays in range after the counter wraps
 };
 #define CBM_PIN_RING 8   // staging entries per slot: an entry is reused 8 enqueues later, long after its copy ran (every step ends in a stream sync)
 struct cbm_ctx {

@@ -159,6 +159,11 @@ void launch_env_stats(const cbm_env_state* st_dev, int E, float* out2, hipStream
 
 // error plumbing
 void cbm_set_error(const char* fmt, ...);
+// A launch helper found an internal invariant violated (a ring / partial-region geometry that does not cover the batch it was handed): the
+// launch is skipped, the message is kept process-wide, and the C-ABI entry point that drove the pass returns -1 with it (cbm_launch_check) —
+// the host gets a cbm error instead of an abort().
+void cbm_launch_fail(const char* fmt, ...);
+int cbm_launch_check(void);   // 0 = no launch helper has failed; -1 = one has, cbm_last_error() carries its message
 #define CBM_HIP(call)                                                                      \
   do {                                                                                     \
     hipError_t e_ = (call);                                                                \

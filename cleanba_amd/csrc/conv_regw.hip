@@ -334,7 +334,7 @@ void launch_conv2_fwd_regw(const float* in, const float* W, const float* bias, f
   const int fpb = (B + 255) / 256, blocks = (B + fpb - 1) / fpb;
   static int checked = 0;
   if (checked != fpb) {
-    if (!C2G::ring_ok(fpb)) { fprintf(stderr, "conv2_fwd_regw_kernel: row ring of %d slots too small\n", C2G::NR); abort(); }
+    if (!C2G::ring_ok(fpb)) { cbm_launch_fail("conv2_fwd_regw_kernel: row ring of %d slots too small at %d frames per block", C2G::NR, fpb); return; }
     checked = fpb;
   }
   hipLaunchKernelGGL(conv2_fwd_regw_kernel, dim3(blocks), dim3(512), C2G::LDS_BYTES, st, in, W, bias, out, mask, B, fpb);

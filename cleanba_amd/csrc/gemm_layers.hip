@@ -1145,7 +1145,11 @@ void nature_backward(const NatureLayout& L, const float* P, const uint8_t* obs, 
   if (L.kind == CBM_NET_IMPALA_RESNET) { resnet_backward(L, P, obs, idx, B, ws, grads, st); return; }
   const int A = L.A;
   const WgRegions rg(ws.maxB);   // the layout the workspace was allocated with; every slice count below is checked against it
-  auto fits = [&](int layer, int nz) { if (nz > rg.nz[layer]) { fprintf(stderr, "cleanba_mi: wgrad partial region %d: %d slices > %d allocated\n", layer, nz, rg.nz[layer]); abort(); } };
+  auto fits = [&](int layer, int nz) {
+    if (nz <= rg.nz[layer]) return true;
+    cbm_launch_fail("wgrad partial region %d: %d slices > %d allocated (workspace sized for %d frames, batch %d)", layer, nz, rg.nz[layer], ws.maxB, B);
+    return false;
+  };
   float* const wp = ws.wg_part;
   float* const bp = ws.bias_part;
   RedBatch tail_red(A), conv_red(A);
@@ -1153,7 +1157,7 @@ void nature_backward(const NatureLayout& L, const float* P, const uint8_t* obs, 
   if (!ws.skip_heads) launch_heads_dgrad(ws.dzv, P + L.w[4], P + L.w[5], ws.hid, B, A, 512, ws.dhid, st);
   {
     const int nz = ceil_div(B, RPS_HEADS);
-    fits(0, nz);
+    if (!fits(0, nz)) return;
     MatWgrad<T128x32> p{ws.hid, ws.dzv, wp + rg.w[0], bp + rg.b[0], B, 512, 32, 32, RPS_HEADS};
     plaunch(ws, K_HEADS_WGRAD, p, nz, st);   // (fp32 also in split mode: 9 vs 15 us)
     tail_red.add(wp + rg.w[0], nz, 512 * 32, 32, 2, grads + L.w[4], grads + L.w[5]);
@@ -1166,7 +1170,7 @@ void nature_backward(const NatureLayout& L, const float* P, const uint8_t* obs, 
     // split-bf16 mode: the staging of a tile is the bottleneck, so it wants the bigger 128x64 tile (and more splits to fill the chip)
     const int nz = ws.bwd_split == 2 ? (B >= 2048 ? 4 : 1) : (dense_wgrad_dma_slices(B) ? dense_wgrad_dma_slices(B) : dense_wgrad_splits(B));
     const int rps = round_up(ceil_div(B, nz), 32);
-    fits(1, nz);
+    if (!fits(1, nz)) return;
     if (ws.bwd_split == 2) {
       MatWgrad<T128x64> pw{ws.act3, ws.dhid, wp + rg.w[1], bp + rg.b[1], B, 3136, 512, 512, rps};
       plaunch_bwd(ws, K_DENSE_WGRAD, pw, nz, st);
@@ -1189,7 +1193,7 @@ void nature_backward(const NatureLayout& L, const float* P, const uint8_t* obs, 
     // frame-resident kernel (wgrad_frames.hip): the whole 576x64 gradient in the block's accumulators, act2 / dY frames copied once into LDS
     // (fp32 MFMA also in split mode: the split weight-gradient kernel measured slower than the im2col fp32 one already)
     const int nz = conv3_wgrad_frames_splits(B);
-    fits(2, nz);
+    if (!fits(2, nz)) return;
     prof_launch(ws, K_CONV3_WGRAD, st, "conv3_wgrad_frames_kernel", "", [&] { launch_conv3_wgrad_frames(ws.act2, ws.dact3pad, wp + rg.w[2], bp + rg.b[2], B, st); });
     conv_red.add(wp + rg.w[2], nz, 576 * 64, 64, 0, grads + L.w[2], nullptr);
     conv_red.add(bp + rg.b[2], nz, 64, 64, 0, grads + L.b[2], nullptr);
@@ -1200,13 +1204,13 @@ void nature_backward(const NatureLayout& L, const float* P, const uint8_t* obs, 
     plaunch_bwd(ws, K_CONV2_DGRAD, pd, 1, st);
     if (ws.bwd_split != 2) {   // frame-resident kernel
       const int nz = conv2_wgrad_frames_splits(B);
-      fits(3, nz);
+      if (!fits(3, nz)) return;
       prof_launch(ws, K_CONV2_WGRAD, st, "conv2_wgrad_frames_kernel", "", [&] { launch_conv2_wgrad_frames(ws.act1, ws.dact2pad, wp + rg.w[3], bp + rg.b[3], B, st); });
       conv_red.add(wp + rg.w[3], nz, 512 * 64, 64, 0, grads + L.w[1], nullptr);
       conv_red.add(bp + rg.b[3], nz, 64, 64, 0, grads + L.b[1], nullptr);
     } else {                   // split-bf16: im2col GEMM; the split kernel wants the bigger tile (staging-bound)
       const int M = B * 81, nz = ceil_div(M, RPS_C2);
-      fits(3, nz);
+      if (!fits(3, nz)) return;
       ConvWgrad<T128x64, 4, 4, 2, 32, 64, 20, 20, 9, 9, 1> pw{ws.act1, ws.dact2pad, wp + rg.w[3], bp + rg.b[3], M, RPS_C2};
       plaunch_bwd(ws, K_CONV2_WGRAD, pw, nz, st);
       conv_red.add(wp + rg.w[3], nz, 512 * 64, 64, 0, grads + L.w[1], nullptr);
@@ -1216,7 +1220,7 @@ void nature_backward(const NatureLayout& L, const float* P, const uint8_t* obs, 
   // conv1: wgrad only (frames need no gradient); frame-resident kernel, pixels as integers, 1/255 in the reduce
   {
     const int nz = conv1_wgrad_frames_splits(B);
-    fits(4, nz);
+    if (!fits(4, nz)) return;
     prof_launch(ws, K_CONV1_WGRAD, st, ws.bwd_split == 2 ? "conv1_wgrad_frames_split_kernel" : "conv1_wgrad_frames_kernel", "",
                 [&] { launch_conv1_wgrad_frames(obs, idx, ws.dact1, wp + rg.w[4], bp + rg.b[4], B, st, ws.bwd_split == 2); });
     conv_red.add(wp + rg.w[4], nz, 256 * 32, 32, 1, grads + L.w[0], nullptr, 1.0f / 255.0f);

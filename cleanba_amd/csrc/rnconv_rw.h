@@ -251,7 +251,7 @@ static void rn_rw_launch(const float* in, const float* W, const float* bias, con
   const int fpb = (B + 255) / 256, blocks = (B + fpb - 1) / fpb;
   static int checked_fpb = 0;
   if (checked_fpb != fpb) {
-    if (!G::ring_ok(fpb)) { fprintf(stderr, "rn_rw_kernel: row ring of %d slots too small for H=%d TSP=%d\n", G::NR, G::H, G::TSP); abort(); }
+    if (!G::ring_ok(fpb)) { cbm_launch_fail("rn_rw_kernel: row ring of %d slots too small for H=%d TSP=%d at %d frames per block", G::NR, G::H, G::TSP, fpb); return; }
     checked_fpb = fpb;
   }
   hipLaunchKernelGGL((rn_rw_kernel<G, PRE_RELU, EPI, MASKIN>), dim3(blocks), dim3(512), lds, st, in, W, bias, aux, out, B, fpb, mask_in, mask_out);

@@ -8,6 +8,7 @@ Same contract: load a `.cleanrl_model`, one environment, SAMPLED actions through
 import numpy as np
 
 from . import lib as L
+from . import model as M
 from . import prng
 from .checkpoint import load_cleanrl_model
 
@@ -27,7 +28,12 @@ def evaluate(model_path, make_env, env_id, eval_episodes, run_name=None, Model=N
     cfg.num_actions, cfg.local_num_envs, cfg.num_actor_slots = num_actions, 1, 1
     cfg.num_steps, cfg.num_minibatches, cfg.update_epochs = 8, 1, 1
     ksplit = cfg.actor_dense_ksplit = 14 if network == "nature" else 11   # the actor's numerics
+    if network != "nature":   # --hiddens H (ppo:94): the width is a property of the saved parameter vector
+        cfg.num_hiddens, cfg.hiddens[0] = 1, M.resnet_hidden_of(len(params), num_actions)
     ctx = L.Context(cfg)
+    if len(params) != ctx.P:
+        ctx.close()
+        raise ValueError(f"{model_path}: {len(params)} parameters, the {network} layout with {num_actions} actions has {ctx.P}")
     d_params = L.DevBuf(ctx, np.ascontiguousarray(params, np.float32))
     d_obs = L.DevBuf(ctx, nbytes=L.FRAME, dtype=np.uint8)
     d_logits = L.DevBuf(ctx, nbytes=num_actions * 4, dtype=np.float32)

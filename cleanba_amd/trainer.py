@@ -192,6 +192,22 @@ def _rollout(key, args, algo, engine, writer, slot, world_size, process_index, s
     rollout_queue_put_time = deque(maxlen=10)
     actions = np.empty(E, np.int32)
     first_rollout = True
+    # an env that hands back the SAME observation buffer every step (a pool that steps in place) gets that buffer page-locked once, so the per-step
+    # 3.39 MB upload is a plain DMA instead of a pageable copy (cbm_host_register); fresh arrays per step (envpool's contract, the synthetic twin)
+    # never repeat an address twice in a row and are left alone
+    pinned, last_ptr = {}, [0]
+    register = getattr(engine, "host_register", None)
+
+    def maybe_pin(obs):
+        ptr = obs.ctypes.data
+        if register is not None and ptr == last_ptr[0] and ptr not in pinned and obs.flags.c_contiguous:
+            try:
+                register(obs)
+                pinned[ptr] = obs          # keeps the array alive while it is registered
+            except RuntimeError:
+                pinned[ptr] = None         # not registrable (e.g. a read-only mapping): do not retry every step
+        last_ptr[0] = ptr
+
     if not device_env:
         if algo == "ppo":
             next_obs = envs.reset()
@@ -223,6 +239,7 @@ def _rollout(key, args, algo, engine, writer, slot, world_size, process_index, s
                 global_step += step_inc
                 if algo == "ppo":
                     t1 = time.time()
+                    maybe_pin(next_obs)
                     engine.actor_step_host(slot, next_obs, next_done, None, None, actions)
                     inference_time += time.time() - t1
                     t1 = time.time()
@@ -235,6 +252,7 @@ def _rollout(key, args, algo, engine, writer, slot, world_size, process_index, s
                     next_obs, next_reward, next_done, info = envs.recv()
                     env_recv_time += time.time() - t1
                     t1 = time.time()
+                    maybe_pin(next_obs)
                     engine.actor_step_host(slot, next_obs, next_done, info["elapsed_step"] == 0, next_reward, actions)
                     inference_time += time.time() - t1
                     t1 = time.time()

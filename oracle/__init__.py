@@ -336,7 +336,8 @@ def rmsprop_step(p, g, nu, max_norm, lr, decay=0.99, eps=0.01):
 # ---------------------------------------------------------------- IMPALA-ResNet torso (ppo:149-189)
 def set_resnet_hidden(h=256):
     """Width of the torso's one hidden layer (Network.hiddens, ppo:94) for every later resnet_* call; 256 = the reference default."""
-    lib().cbo_resnet_set_hidden(int(h))
+    if lib().cbo_resnet_set_hidden(int(h)) != 0:
+        raise ValueError(f"oracle: hidden width {h} outside [1, 512]")
 
 
 def resnet_hidden():

@@ -748,7 +748,8 @@ static const int RN_H[3] = {84, 42, 21}, RN_HP[3] = {42, 21, 11}, RN_CI[3] = {4,
 #define RN_HID_MAX 512
 static int g_rn_hid = 256;   /* Network(hiddens=(H,)), ppo:94: one hidden layer, the reference default 256 */
 #define RN_HID g_rn_hid
-EXPORT void cbo_resnet_set_hidden(int h) { g_rn_hid = h; }
+/* the per-frame scratch rows are RN_HID_MAX wide: a width outside [1, RN_HID_MAX] is refused (returns -1, width unchanged) */
+EXPORT int cbo_resnet_set_hidden(int h) { if (h < 1 || h > RN_HID_MAX) return -1; g_rn_hid = h; return 0; }
 EXPORT int cbo_resnet_get_hidden(void) { return g_rn_hid; }
 typedef struct { int A; int64_t cw[3][5], cb[3][5], dw, db, aw, ab, vw, vb, total; } rn_layout;
 static void rn_get_layout(int A, rn_layout* L) {

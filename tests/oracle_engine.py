@@ -60,6 +60,7 @@ class _Shm:
 class OracleEngine:
     def __init__(self, cfg):
         self.cfg = cfg
+        assert int(getattr(cfg, "network", 0)) == 0, "OracleEngine restates the Nature-CNN trainer (the ResNet torso is checked per call: oracle.resnet_*)"
         self.ppo = cfg.algo == 0
         self.A, self.E, self.S = cfg.num_actions, cfg.local_num_envs, cfg.num_actor_slots
         self.T = cfg.num_steps

@@ -34,14 +34,30 @@ def _all_cores(oracle):
     oracle.set_threads(max(1, min(os.cpu_count() or 1, 64)))
 
 
-def _check_grads(oracle, g, grads_o, bar=1e-5):
-    worst = {}
-    for name, (o, shp) in oracle.nature_layout(A).items():
+def _elementwise(g, ref):
+    """Element-wise view of a gradient tensor next to the per-tensor bar: worst |g - ref| / |ref| over the elements that carry signal
+    (|ref| >= 1e-3 * max|ref|: below that an fp32 sum of thousands of terms has no relative meaning), and the share of ALL elements within
+    1e-5 relative or 1e-5 * max|ref| absolute."""
+    mx = max(float(np.abs(ref).max()), 1e-30)
+    d = np.abs(g - ref)
+    big = np.abs(ref) >= 1e-3 * mx
+    worst_rel = float((d[big] / np.abs(ref[big])).max()) if big.any() else 0.0
+    share = float(((d <= 1e-5 * np.abs(ref)) | (d <= 1e-5 * mx)).mean())
+    return worst_rel, share
+
+
+def _check_grads(oracle, g, grads_o, bar=1e-5, layout=None):
+    """Per tensor: max|g - ref| <= bar * max|ref| (asserted).  Returns {name: per-tensor error}; prints the element-wise figures beside it."""
+    worst, elem = {}, {}
+    for name, (o, shp) in (layout or oracle.nature_layout(A)).items():
         n = int(np.prod(shp))
         ref = grads_o[o:o + n]
         err = np.abs(g[o:o + n] - ref).max() / max(np.abs(ref).max(), 1e-7)
         worst[name] = err
+        elem[name] = _elementwise(g[o:o + n], ref)
         assert np.isfinite(g[o:o + n]).all() and err <= bar, (name, err)
+    print("  element-wise (worst relative error over elements >= 1e-3 of the tensor's max, share of all elements within 1e-5):",
+          {k: f"{v[0]:.1e} / {100 * v[1]:.2f}%" for k, v in elem.items()})
     return worst
 
 
@@ -195,8 +211,8 @@ def test_full_ppo_update_e120_t128_matches_oracle_engine(oracle):
               "worst row", int(serr.max(axis=1).argmax()))
         # north_star's bar is 1e-5; 16 dependent optimizer steps compound the per-step 1e-7 parameter differences, so the LAST rows are the worst.
         # Measured on MI355X (printed above): loss 5.6e-6, value loss 9e-7, entropy 8e-8, approx_kl 2.7e-6 relative; policy loss 3.8e-8 absolute
-        # (it is ~1e-3 itself).  Bar = 2e-5 relative or 2e-7 absolute, i.e. ~3x what is measured
-        np.testing.assert_allclose(stats, ostats, rtol=2e-5, atol=2e-7)
+        # (it is ~1e-3 itself).  Bar = north_star's 1e-5 relative, or 1e-7 absolute for the columns that are ~1e-3 themselves (policy loss, approx_kl)
+        np.testing.assert_allclose(stats, ostats, rtol=1e-5, atol=1e-7)
         p, po = ctx.get_params(), eng.get_params()
         assert np.isfinite(p).all()
         assert np.abs(po - P0).max() > 1e-4                                   # 16 Adam steps moved the parameters
@@ -204,12 +220,12 @@ def test_full_ppo_update_e120_t128_matches_oracle_engine(oracle):
         # pixels' conv1 weights, dead units) a gradient difference dg moves the step by lr * dg / eps, i.e. the 1e-5-per-tensor gradient bar
         # (dg ~ 1e-7 where max|g| ~ 1e-2) becomes up to 2.5e-6 per step, 4e-5 after 16 steps, for those few parameters, while the typical
         # parameter agrees to 1e-7.  Measured (printed): median 0, 99.99 % quantile 1.7e-6, max 8.6e-6 absolute = 2.4e-5 of max|p|.
-        # Bars ~3x that: median 1e-7, all but 1 in 10 000 within 5e-6, none further than 3e-5 (a tenth of one learning-rate step).
+        # Bars: median 1e-7, all but 1 in 10 000 within 5e-6, none further than north_star's 1e-5.
         d = np.abs(p - po)
         print("whole update: |p - p_oracle| median %.2e, 99.99 %% quantile %.2e, max %.2e; relative to max|p| %.2e" % (np.median(d), np.quantile(d, 0.9999), d.max(), d.max() / np.abs(po).max()))
         assert np.median(d) <= 1e-7, np.median(d)
         assert np.quantile(d, 0.9999) <= 5e-6, np.quantile(d, 0.9999)
-        assert d.max() <= 3e-5, d.max()
+        assert d.max() <= 1e-5, d.max()
     finally:
         ctx.close()
         eng.close()
@@ -220,14 +236,7 @@ def test_full_ppo_update_e120_t128_matches_oracle_engine(oracle):
 # geometries, the fused conv0 + max-pool, the persistent weight-gradient blocks and the pool backward folded into the conv0 weight gradient
 # only take their learner-size paths (thousands of strips, every persistent block busy) at minibatch scale.
 def _check_resnet_grads(oracle, g, grads_o, bar=1e-5):
-    worst = {}
-    for name, (o, shp) in oracle.resnet_layout(A).items():
-        n = int(np.prod(shp))
-        ref = grads_o[o:o + n]
-        err = np.abs(g[o:o + n] - ref).max() / max(np.abs(ref).max(), 1e-7)
-        worst[name] = err
-        assert np.isfinite(g[o:o + n]).all() and err <= bar, (name, err)
-    return worst
+    return _check_grads(oracle, g, grads_o, bar, layout=oracle.resnet_layout(A))
 
 
 @pytest.mark.parametrize("MBR", [MB, 1031])   # 1031: 5 frames per block on the row-ring conv kernels (rnconv_rw.h), the last block holds one

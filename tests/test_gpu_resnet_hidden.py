@@ -103,3 +103,45 @@ def test_cli_hiddens_trains_and_saves(tmp_path):
     save_cleanrl_model(str(tmp_path / "m.cleanrl_model"), args, p, A, network="impala_resnet")
     _, q = load_cleanrl_model(str(tmp_path / "m.cleanrl_model"), A, network="impala_resnet")
     assert (bits(p) == bits(q)).all()
+
+
+def test_cli_hiddens_save_model_then_evaluate(tmp_path, hidden_oracle):
+    """`--hiddens 128 --save-model` (ppo:94, 753-785): the evaluation loop after training sizes its context from the SAVED vector's width
+    (it used the default 256 and indexed the 128-wide vector with the 256-wide layout); replayed by the oracle at that width."""
+    import os
+    import cleanba_amd.prng as prng
+    from cleanba_amd.args import parse_args
+    from cleanba_amd.checkpoint import load_cleanrl_model
+    from cleanba_amd.envs import make_env
+    from cleanba_amd.evals import evaluate
+    from cleanba_amd.trainer import train
+    oracle = hidden_oracle
+    os.chdir(str(tmp_path))
+    args = parse_args(["--local-num-envs", "8", "--num-actor-threads", "1", "--num-steps", "8", "--env-backend", "device", "--network",
+                       "impala_resnet", "--hiddens", "128", "--total-timesteps", "128", "--save-model", "--eval-episodes", "2",
+                       "--eval-max-episode-steps", "24"], "ppo")
+    res = train(args, "ppo")
+    assert os.path.exists(res["model_path"]) and len(res["eval_returns"]) == 2
+    _, params = load_cleanrl_model(res["model_path"], A, "impala_resnet")
+    assert params.size == M.resnet_layout(A, 128)[1] and np.array_equal(params, res["params"])
+    oracle.set_resnet_hidden(128)
+    envs = make_env(args.env_id, 1, 1, backend="host")()
+    key = prng.split(prng.prng_key(1), 4)[0]
+    want = []
+    for ep in range(2):
+        obs, ret = envs.reset(), 0.0
+        for _ in range(24):
+            logits, _ = oracle.resnet_forward(params, A, obs, ksplit=11)
+            a, _, key = oracle.sample_actions(logits, key)
+            obs, _, _, info = envs.step(a)
+            ret += float(info["reward"][0])
+            if int(info["terminated"].sum()) + int(info["TimeLimit.truncated"].sum()) >= 1:
+                break
+        want.append(ret)
+    assert res["eval_returns"] == want
+    # a vector whose length is no layout at all is refused before anything is launched
+    with open(res["model_path"], "rb") as f:
+        blob = f.read()
+    with pytest.raises(Exception):
+        evaluate(res["model_path"], lambda e, s, n: make_env(e, s, n, backend="host"), args.env_id, 1, network="nature")
+    assert blob
