@@ -273,7 +273,7 @@ extern "C" int cbm_params_get(cbm_ctx* c, float* h, int64_t n) {
   if (n != c->P) { cbm_set_error("param count mismatch"); return -1; }
   CBM_HIP(hipStreamSynchronize(c->lstream));
   CBM_HIP(hipMemcpy(h, c->params, (size_t)n * 4, hipMemcpyDeviceToHost));
-  return 0;
+  return cbm_comm_check_native(c);
 }
 extern "C" int cbm_actor_params_get(cbm_ctx* c, float* h, int64_t n) {
   if (n != c->P) { cbm_set_error("param count mismatch"); return -1; }
@@ -320,7 +320,7 @@ extern "C" int cbm_copy_to_device(cbm_ctx* c, void* dst, const void* src, int64_
 extern "C" int cbm_dev_alloc(int64_t nbytes, void** p) { CBM_HIP(hipMalloc(p, (size_t)nbytes)); return 0; }
 extern "C" int cbm_dev_free(void* p) { CBM_HIP(hipFree(p)); return 0; }
 extern "C" void* cbm_learner_stream(cbm_ctx* c) { return (void*)c->lstream; }
-extern "C" int cbm_sync(cbm_ctx* c) { CBM_HIP(hipSetDevice(c->cfg.device)); CBM_HIP(hipDeviceSynchronize()); return 0; }
+extern "C" int cbm_sync(cbm_ctx* c) { CBM_HIP(hipSetDevice(c->cfg.device)); CBM_HIP(hipDeviceSynchronize()); return cbm_comm_check_native(c); }
 
 // ------------------------------------------------------------------------------------------ actor
 extern "C" int cbm_actor_set_key(cbm_ctx* c, int32_t s, const uint32_t key[2]) { c->slots[s].key[0] = key[0]; c->slots[s].key[1] = key[1]; return 0; }
@@ -706,6 +706,7 @@ extern "C" int cbm_learner_finish(cbm_ctx* c, float* stats_out) {
     std::vector<float> h((size_t)c->stat_rows * 8);
     CBM_HIP(hipMemcpyAsync(h.data(), c->stats_dev, h.size() * 4, hipMemcpyDeviceToHost, c->lstream));
     CBM_HIP(hipStreamSynchronize(c->lstream));
+    if (cbm_comm_check_native(c)) return -1;
     for (int r = 0; r < c->stat_rows; ++r) for (int q = 0; q < w; ++q) stats_out[r * w + q] = h[(size_t)r * 8 + q] * inv;
   }
   cbm_publish(c, c->updates_done, v);

@@ -11,10 +11,19 @@
 #define CBM_COMM_SCRATCH 16
 #define CBM_COMM_PROF_MAX 1024
 
+#define CBM_NATIVE_BUFS 4          // grads | loss statistics | f64 scratch | signal block  (cbm_comm_native_export order)
 struct CbmComm {
   void* comm = nullptr;   // ncclComm_t
   int nranks = 0, rank = -1;
   bool loopback = false;  // self-test: nranks identical ranks, all-reduce(SUM) = scale by nranks
+  // native backend (comm.hip, "native xGMI all-reduce"): every rank's gradient / statistics / scratch buffers and signal block mapped into this
+  // process (HIP IPC, or the plain pointer when the peer context lives in this process); one kernel per collective, flags in the signal blocks
+  bool native = false;
+  void* nat_peer[CBM_NATIVE_BUFS][CBM_NATIVE_MAX_RANKS] = {};
+  bool nat_mapped[CBM_NATIVE_BUFS][CBM_NATIVE_MAX_RANKS] = {};   // opened with hipIpcOpenMemHandle (closed on destroy)
+  uint32_t nat_seq = 0;          // collective sequence number: the flag value of the next call
+  void* nat_sig_local = nullptr; // this rank's signal block (owned)
+  int* nat_err = nullptr;        // page-locked host word: a flag wait timed out (a peer died) — checked when the host next synchronises
 };
 
 struct RingEntry {
@@ -100,4 +109,5 @@ static inline bool cbm_wait(cbm_ctx* c, Pred pred) {
 int cbm_learner_allreduce_grads_impl(cbm_ctx* c, float* grad_div);
 int cbm_learner_allreduce_stats_impl(cbm_ctx* c);
 int cbm_comm_destroy_all(cbm_ctx* c);
+int cbm_comm_check_native(cbm_ctx* c);   // -1 (with the error set) when a native collective's flag wait timed out
 

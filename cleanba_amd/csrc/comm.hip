@@ -15,6 +15,7 @@
 #include <rccl/rccl.h>
 #include <string.h>
 #include <string>
+#include <unistd.h>
 
 // ------------------------------------------------------------------------------------------ RCCL binding
 namespace {
@@ -74,12 +75,161 @@ __global__ void comm_scale_f32_kernel(float* x, int64_t n, float f) {
 __global__ void comm_scale_f64_kernel(double* x, int n, double f) {
   if ((int)threadIdx.x < n) x[threadIdx.x] *= f;
 }
-// all-reduce(SUM) of fp32 data on `st`: RCCL, or the self-test communicator's "n identical ranks"
-static int comm_allreduce_f32(CbmComm& k, float* buf, int64_t n, hipStream_t st) {
+// ------------------------------------------------------------------------------------------ native all-reduce (no RCCL)
+// One kernel per collective, working on the peers' buffers through their IPC mappings (or plain pointers when the peer context lives in this
+// process).  Synchronisation = flag words in per-rank signal blocks: block b of rank r announces phase p of collective #seq by storing seq
+// into sig[peer][p][b][r] of EVERY peer (system-scope release store) and waits until its own sig[r][p][b][*] all carry >= seq.  Flags only
+// grow, so nothing is ever reset; block b only ever talks to block b of the peers, and a kernel has NAT_BLOCKS (<< what the chip holds) blocks, so
+// the waiting kernels of several ranks that share ONE GPU are co-resident and cannot starve each other.
+//   two-shot (flat gradient, in place):  [start] everybody's input is final -> rank r sums slice r of all peers in rank order 0..n-1 (PEER READS) and
+//       stores the sum into slice r of all peers (PEER WRITES; only rank r ever touches slice r between the two barriers) -> [end] all slices landed.
+//   one-shot (statistics, f64 scratch): [start] -> every rank reads all peers, keeps the result in registers -> [end] everybody has read -> write own.
+// Deterministic by construction: one fixed summation order per element, independent of timing (ppo:30 asks XLA for the same).
+#define NAT_BLOCKS 64
+#define NAT_THREADS 512
+#define NAT_SMALL_MAX 4096
+#define NAT_SIG_WORDS (2 * NAT_BLOCKS * CBM_NATIVE_MAX_RANKS)
+struct NatArgs {
+  void* data[CBM_NATIVE_MAX_RANKS];
+  uint32_t* sig[CBM_NATIVE_MAX_RANKS];
+  int nranks, rank;
+  int64_t off, n;                     // element range of this collective inside the registered buffer
+  uint32_t seq;
+  int* err;                           // page-locked host word: 1 / 2 = the start / end wait timed out
+  unsigned long long timeout_ticks;   // wall_clock64() ticks (100 MHz)
+};
+struct NatBlob {   // what a rank publishes (CBM_NATIVE_BLOB_BYTES): IPC handles for other processes, plain pointers for contexts of the same process
+  uint8_t ipc[CBM_NATIVE_BUFS][CBM_IPC_HANDLE_BYTES];
+  uint64_t ptr[CBM_NATIVE_BUFS];
+  uint32_t pid, device;
+};
+static_assert(sizeof(NatBlob) <= CBM_NATIVE_BLOB_BYTES, "blob size");
+
+static __device__ __forceinline__ void nat_signal_and_wait(const NatArgs& a, int phase) {
+  __syncthreads();
+  const int t = threadIdx.x;
+  if (t < a.nranks) {
+    const size_t row = ((size_t)phase * NAT_BLOCKS + blockIdx.x) * CBM_NATIVE_MAX_RANKS;
+    __hip_atomic_store(a.sig[t] + row + a.rank, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    uint32_t* mine = a.sig[a.rank] + row + t;
+    const unsigned long long t0 = wall_clock64();
+    while ((int32_t)(__hip_atomic_load(mine, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - a.seq) < 0) {
+      __builtin_amdgcn_s_sleep(16);
+      if (wall_clock64() - t0 > a.timeout_ticks) { *(volatile int*)a.err = 1 + phase; break; }
+    }
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(NAT_THREADS) void nat_allreduce_f32_kernel(const NatArgs a) {
+  __threadfence_system();
+  nat_signal_and_wait(a, 0);
+  __threadfence_system();               // acquire for every thread: no load below may be served by anything fetched before the peers signalled
+  const int N = a.nranks;
+  const int64_t chunk = (((a.n + N - 1) / N) + 3) & ~(int64_t)3;
+  const int64_t lo = chunk * a.rank < a.n ? chunk * a.rank : a.n;
+  const int64_t hi = lo + chunk < a.n ? lo + chunk : a.n;
+  const int64_t tid = (int64_t)blockIdx.x * NAT_THREADS + threadIdx.x, nth = (int64_t)NAT_BLOCKS * NAT_THREADS;
+  const int64_t nvec = (a.off & 3) == 0 ? (hi - lo) >> 2 : 0;   // slices start at multiples of 4 floats: vector path when the range does too
+  for (int64_t i = tid; i < nvec; i += nth) {
+    const int64_t e = a.off + lo + 4 * i;
+    float4 sum = *reinterpret_cast<const float4*>((const float*)a.data[0] + e);
+    for (int r = 1; r < N; ++r) {
+      const float4 v = *reinterpret_cast<const float4*>((const float*)a.data[r] + e);
+      sum.x = sum.x + v.x; sum.y = sum.y + v.y; sum.z = sum.z + v.z; sum.w = sum.w + v.w;
+    }
+    for (int r = 0; r < N; ++r) *reinterpret_cast<float4*>((float*)a.data[r] + e) = sum;
+  }
+  for (int64_t i = lo + 4 * nvec + tid; i < hi; i += nth) {
+    const int64_t e = a.off + i;
+    float sum = ((const float*)a.data[0])[e];
+    for (int r = 1; r < N; ++r) sum = sum + ((const float*)a.data[r])[e];
+    for (int r = 0; r < N; ++r) ((float*)a.data[r])[e] = sum;
+  }
+  __threadfence_system();               // release: the peer writes above are out before the flag is
+  nat_signal_and_wait(a, 1);
+}
+
+template <class Tv, int OP>   // OP: 0 sum, 1 max, 2 min; one block, n <= NAT_SMALL_MAX
+__global__ __launch_bounds__(1024) void nat_allreduce_small_kernel(const NatArgs a) {
+  __threadfence_system();
+  nat_signal_and_wait(a, 0);
+  __threadfence_system();
+  Tv keep[NAT_SMALL_MAX / 1024];
+#pragma unroll
+  for (int j = 0; j < NAT_SMALL_MAX / 1024; ++j) {
+    const int64_t i = threadIdx.x + 1024 * j;
+    Tv sum = 0;
+    if (i < a.n) {
+      sum = ((const Tv*)a.data[0])[a.off + i];
+      for (int r = 1; r < a.nranks; ++r) {
+        const Tv v = ((const Tv*)a.data[r])[a.off + i];
+        sum = OP == 0 ? sum + v : (OP == 1 ? (v > sum ? v : sum) : (v < sum ? v : sum));
+      }
+    }
+    keep[j] = sum;
+  }
+  __threadfence_system();
+  nat_signal_and_wait(a, 1);            // every rank has read every input: the in-place results may go out
+#pragma unroll
+  for (int j = 0; j < NAT_SMALL_MAX / 1024; ++j) {
+    const int64_t i = threadIdx.x + 1024 * j;
+    if (i < a.n) ((Tv*)a.data[a.rank])[a.off + i] = keep[j];
+  }
+}
+
+static unsigned long long nat_timeout_ticks() {
+  const char* e = getenv("CBM_NATIVE_TIMEOUT_S");
+  const double sec = e && atof(e) > 0 ? atof(e) : 120.0;
+  return (unsigned long long)(sec * 1e8);
+}
+// which registered buffer does [buf, buf + n*elt) live in?  0 grads, 1 statistics, 2 f64 scratch
+static int nat_locate(cbm_ctx* c, const void* buf, int64_t nbytes, int* which_buf, int64_t* off_bytes) {
+  const struct { const void* base; int64_t bytes; } reg[3] = {{c->grads, c->P * 4}, {c->stats_dev, (int64_t)c->stat_rows * 8 * 4}, {c->comm_scratch, CBM_COMM_SCRATCH * 8}};
+  for (int b = 0; b < 3; ++b) {
+    const int64_t d = (const char*)buf - (const char*)reg[b].base;
+    if (d >= 0 && d + nbytes <= reg[b].bytes) { *which_buf = b; *off_bytes = d; return 0; }
+  }
+  cbm_set_error("native all-reduce: the buffer is not one of the registered ones (gradients, statistics, scratch)");
+  return -1;
+}
+static NatArgs nat_args(CbmComm& k, int b, int64_t off, int64_t n) {
+  NatArgs a;
+  memset(&a, 0, sizeof(a));
+  for (int r = 0; r < k.nranks; ++r) { a.data[r] = k.nat_peer[b][r]; a.sig[r] = (uint32_t*)k.nat_peer[3][r]; }
+  a.nranks = k.nranks; a.rank = k.rank; a.off = off; a.n = n; a.seq = ++k.nat_seq; a.err = k.nat_err; a.timeout_ticks = nat_timeout_ticks();
+  return a;
+}
+static int nat_allreduce_f32(cbm_ctx* c, CbmComm& k, float* buf, int64_t n, hipStream_t st) {
+  if (n <= 0) return 0;
+  int b = 0; int64_t offb = 0;
+  if (nat_locate(c, buf, n * 4, &b, &offb)) return -1;
+  const NatArgs a = nat_args(k, b, offb / 4, n);
+  if (n <= NAT_SMALL_MAX) hipLaunchKernelGGL((nat_allreduce_small_kernel<float, 0>), dim3(1), dim3(1024), 0, st, a);
+  else hipLaunchKernelGGL(nat_allreduce_f32_kernel, dim3(NAT_BLOCKS), dim3(NAT_THREADS), 0, st, a);
+  CBM_HIP(hipGetLastError());
+  return 0;
+}
+// a flag wait timed out inside a native collective (a peer died or never joined): reported by the next call that synchronises with the device
+int cbm_comm_check_native(cbm_ctx* c) {
+  for (int i = 0; i < CBM_COMM_SLOTS; ++i) {
+    CbmComm& k = c->comms[i];
+    if (k.native && k.nat_err && *(volatile int*)k.nat_err) {
+      cbm_set_error("native all-reduce (communicator %d, rank %d of %d): the %s wait timed out — a peer rank died or never reached collective #%u",
+                    i, k.rank, k.nranks, *(volatile int*)k.nat_err == 1 ? "start" : "end", k.nat_seq);
+      return -1;
+    }
+  }
+  return 0;
+}
+
+// all-reduce(SUM) of fp32 data on `st`: RCCL, the native kernels, or the self-test communicator's "n identical ranks"
+static int comm_allreduce_f32(cbm_ctx* c, CbmComm& k, float* buf, int64_t n, hipStream_t st) {
   if (k.loopback) {
     if (n > 0) comm_scale_f32_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(buf, n, (float)k.nranks);
     return 0;
   }
+  if (k.native) return nat_allreduce_f32(c, k, buf, n, st);
   CBM_NCCL(g_rccl.AllReduce(buf, buf, (size_t)n, ncclFloat32, ncclSum, (ncclComm_t)k.comm, st));
   return 0;
 }
@@ -126,14 +276,93 @@ extern "C" int cbm_comm_init_loopback(cbm_ctx* c, int32_t which, int32_t nranks)
   return 0;
 }
 
+extern "C" int cbm_comm_native_export(cbm_ctx* c, int32_t which, uint8_t blob[CBM_NATIVE_BLOB_BYTES]) {
+  if (which < 0 || which >= CBM_COMM_SLOTS) { cbm_set_error("communicator slot %d outside [0,%d)", which, CBM_COMM_SLOTS); return -1; }
+  CBM_HIP(hipSetDevice(c->cfg.device));
+  CbmComm& k = c->comms[which];
+  if (!k.nat_sig_local) {
+    // the signal block: uncached device memory when the runtime offers it (flags are polled by other GPUs), plain device memory otherwise
+    // (the flag accesses are system-scope atomics either way)
+    void* p = nullptr;
+    if (hipExtMallocWithFlags(&p, NAT_SIG_WORDS * 4, hipDeviceMallocUncached) != hipSuccess) { (void)hipGetLastError(); CBM_HIP(hipMalloc(&p, NAT_SIG_WORDS * 4)); }
+    CBM_HIP(hipMemset(p, 0, NAT_SIG_WORDS * 4));
+    CBM_HIP(hipDeviceSynchronize());
+    k.nat_sig_local = p;
+    CBM_HIP(hipHostMalloc((void**)&k.nat_err, 64, hipHostMallocDefault));
+    *k.nat_err = 0;
+  }
+  NatBlob b;
+  memset(&b, 0, sizeof(b));
+  void* const bufs[CBM_NATIVE_BUFS] = {c->grads, c->stats_dev, c->comm_scratch, k.nat_sig_local};
+  for (int i = 0; i < CBM_NATIVE_BUFS; ++i) {
+    hipIpcMemHandle_t h;
+    CBM_HIP(hipIpcGetMemHandle(&h, bufs[i]));
+    memcpy(b.ipc[i], &h, sizeof(h));
+    b.ptr[i] = (uint64_t)(uintptr_t)bufs[i];
+  }
+  b.pid = (uint32_t)getpid();
+  b.device = (uint32_t)c->cfg.device;
+  memset(blob, 0, CBM_NATIVE_BLOB_BYTES);
+  memcpy(blob, &b, sizeof(b));
+  return 0;
+}
+
+extern "C" int cbm_comm_native_init(cbm_ctx* c, int32_t which, int32_t nranks, int32_t rank, const uint8_t* blobs) {
+  if (which < 0 || which >= CBM_COMM_SLOTS) { cbm_set_error("communicator slot %d outside [0,%d)", which, CBM_COMM_SLOTS); return -1; }
+  if (nranks < 1 || nranks > CBM_NATIVE_MAX_RANKS || rank < 0 || rank >= nranks) { cbm_set_error("native communicator: rank %d of %d (at most %d ranks)", rank, nranks, CBM_NATIVE_MAX_RANKS); return -1; }
+  CbmComm& k = c->comms[which];
+  if (k.nranks) { cbm_set_error("communicator %d already initialised", which); return -1; }
+  if (!k.nat_sig_local) { cbm_set_error("cbm_comm_native_export must be called on this context first"); return -1; }
+  CBM_HIP(hipSetDevice(c->cfg.device));
+  void* const own[CBM_NATIVE_BUFS] = {c->grads, c->stats_dev, c->comm_scratch, k.nat_sig_local};
+  for (int r = 0; r < nranks; ++r) {
+    NatBlob b;
+    memcpy(&b, blobs + (size_t)r * CBM_NATIVE_BLOB_BYTES, sizeof(b));
+    for (int i = 0; i < CBM_NATIVE_BUFS; ++i) {
+      if (r == rank) { k.nat_peer[i][r] = own[i]; continue; }
+      if (b.pid == (uint32_t)getpid()) { k.nat_peer[i][r] = (void*)(uintptr_t)b.ptr[i]; continue; }   // a context of this process: no IPC needed (nor possible)
+      hipIpcMemHandle_t h;
+      memcpy(&h, b.ipc[i], sizeof(h));
+      void* p = nullptr;
+      const hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+      if (e != hipSuccess) {
+        cbm_set_error("native communicator: hipIpcOpenMemHandle of rank %d's buffer %d (GPU %u) failed on GPU %d: %s (needs HSA_ENABLE_IPC_MODE_LEGACY=0 in "
+                      "every process and a peer path between the GPUs)", r, i, b.device, c->cfg.device, hipGetErrorString(e));
+        return -1;
+      }
+      k.nat_peer[i][r] = p;
+      k.nat_mapped[i][r] = true;
+    }
+  }
+  k.native = true;
+  k.nranks = nranks;
+  k.rank = rank;
+  k.nat_seq = 0;
+  return 0;
+}
+
+extern "C" const char* cbm_comm_backend(cbm_ctx* c, int32_t which) {
+  if (which < 0 || which >= CBM_COMM_SLOTS || !c->comms[which].nranks) return "";
+  return c->comms[which].loopback ? "loopback" : (c->comms[which].native ? "native" : "rccl");
+}
+
 extern "C" int cbm_comm_size(cbm_ctx* c, int32_t which) {
   if (which < 0 || which >= CBM_COMM_SLOTS) return 0;
   return c->comms[which].nranks;
 }
 
 int cbm_comm_destroy_all(cbm_ctx* c) {
-  for (int i = 0; i < CBM_COMM_SLOTS; ++i)
-    if (c->comms[i].comm) { g_rccl.CommDestroy((ncclComm_t)c->comms[i].comm); c->comms[i].comm = nullptr; c->comms[i].nranks = 0; }
+  for (int i = 0; i < CBM_COMM_SLOTS; ++i) {
+    CbmComm& k = c->comms[i];
+    if (k.comm) { g_rccl.CommDestroy((ncclComm_t)k.comm); k.comm = nullptr; }
+    for (int b = 0; b < CBM_NATIVE_BUFS; ++b)
+      for (int r = 0; r < CBM_NATIVE_MAX_RANKS; ++r)
+        if (k.nat_mapped[b][r]) { (void)hipIpcCloseMemHandle(k.nat_peer[b][r]); k.nat_mapped[b][r] = false; }
+    if (k.nat_sig_local) { (void)hipFree(k.nat_sig_local); k.nat_sig_local = nullptr; }
+    if (k.nat_err) { (void)hipHostFree(k.nat_err); k.nat_err = nullptr; }
+    k.native = false;
+    k.nranks = 0;
+  }
   return 0;
 }
 
@@ -146,13 +375,18 @@ extern "C" int cbm_comm_allreduce_f64(cbm_ctx* c, int32_t which, double* host_in
   CBM_HIP(hipMemcpyAsync(c->comm_scratch, host_inout, (size_t)n * 8, hipMemcpyHostToDevice, c->cstream));
   if (c->comms[which].loopback) {
     if (op == 0) comm_scale_f64_kernel<<<dim3(1), dim3(64), 0, c->cstream>>>(c->comm_scratch, n, (double)c->comms[which].nranks);
+  } else if (c->comms[which].native) {
+    const NatArgs a = nat_args(c->comms[which], 2, 0, n);
+    if (op == 1) hipLaunchKernelGGL((nat_allreduce_small_kernel<double, 1>), dim3(1), dim3(1024), 0, c->cstream, a);
+    else if (op == 2) hipLaunchKernelGGL((nat_allreduce_small_kernel<double, 2>), dim3(1), dim3(1024), 0, c->cstream, a);
+    else hipLaunchKernelGGL((nat_allreduce_small_kernel<double, 0>), dim3(1), dim3(1024), 0, c->cstream, a);
   } else {
     CBM_NCCL(g_rccl.AllReduce(c->comm_scratch, c->comm_scratch, (size_t)n, ncclFloat64, op == 1 ? ncclMax : (op == 2 ? ncclMin : ncclSum),
                               (ncclComm_t)c->comms[which].comm, c->cstream));
   }
   CBM_HIP(hipMemcpyAsync(host_inout, c->comm_scratch, (size_t)n * 8, hipMemcpyDeviceToHost, c->cstream));
   CBM_HIP(hipStreamSynchronize(c->cstream));
-  return 0;
+  return cbm_comm_check_native(c);
 }
 
 extern "C" int cbm_comm_barrier(cbm_ctx* c, int32_t which) {
@@ -175,18 +409,18 @@ int cbm_learner_allreduce_grads_impl(cbm_ctx* c, float* grad_div) {
   if (c->comm_overlap) {
     CBM_HIP(hipStreamWaitEvent(c->cstream, c->tail_ev, 0));
     if (timed) CBM_HIP(hipEventRecord(ev[0], c->cstream));
-    if (comm_allreduce_f32(k, c->grads + tail, c->P - tail, c->cstream)) return -1;
+    if (comm_allreduce_f32(c, k, c->grads + tail, c->P - tail, c->cstream)) return -1;
     if (timed) CBM_HIP(hipEventRecord(ev[1], c->cstream));
     CBM_HIP(hipEventRecord(c->bwd_ev, c->lstream));          // the backward pass is complete on the learner stream here
     if (timed) CBM_HIP(hipEventRecord(ev[2], c->lstream));
     CBM_HIP(hipStreamWaitEvent(c->cstream, c->bwd_ev, 0));
-    if (comm_allreduce_f32(k, c->grads, tail, c->cstream)) return -1;
+    if (comm_allreduce_f32(c, k, c->grads, tail, c->cstream)) return -1;
   } else {
     CBM_HIP(hipEventRecord(c->bwd_ev, c->lstream));
     if (timed) CBM_HIP(hipEventRecord(ev[2], c->lstream));
     CBM_HIP(hipStreamWaitEvent(c->cstream, c->bwd_ev, 0));
     if (timed) CBM_HIP(hipEventRecord(ev[0], c->cstream));
-    if (comm_allreduce_f32(k, c->grads, c->P, c->cstream)) return -1;
+    if (comm_allreduce_f32(c, k, c->grads, c->P, c->cstream)) return -1;
     if (timed) CBM_HIP(hipEventRecord(ev[1], c->cstream));
   }
   CBM_HIP(hipEventRecord(c->ext_ev, c->cstream));
@@ -205,7 +439,7 @@ int cbm_learner_allreduce_stats_impl(cbm_ctx* c) {
   if (!k.nranks) return 0;
   CBM_HIP(hipEventRecord(c->bwd_ev, c->lstream));
   CBM_HIP(hipStreamWaitEvent(c->cstream, c->bwd_ev, 0));
-  if (comm_allreduce_f32(k, c->stats_dev, (int64_t)c->stat_rows * 8, c->cstream)) return -1;
+  if (comm_allreduce_f32(c, k, c->stats_dev, (int64_t)c->stat_rows * 8, c->cstream)) return -1;
   CBM_HIP(hipEventRecord(c->ext_ev, c->cstream));
   CBM_HIP(hipStreamWaitEvent(c->lstream, c->ext_ev, 0));
   return 0;

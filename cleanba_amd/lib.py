@@ -56,10 +56,12 @@ SYMBOLS = [
     "cbm_comm_load", "cbm_comm_unique_id", "cbm_comm_init", "cbm_comm_size", "cbm_comm_allreduce_f64", "cbm_comm_barrier",
     "cbm_learner_allreduce_grads", "cbm_comm_profile", "cbm_comm_profile_read", "cbm_ipc_export", "cbm_ipc_open", "cbm_ipc_close",
     "cbm_host_register", "cbm_host_unregister", "cbm_actor_ship_shard", "cbm_io_sync", "cbm_params_push", "cbm_params_mark_published", "cbm_ctx_abort", "cbm_profile_read_all", "cbm_profile_kernel_name",
+    "cbm_comm_native_export", "cbm_comm_native_init", "cbm_comm_backend",
 ]
 
 COMM_LEARNERS, COMM_WORLD = 0, 1
 COMM_ID_BYTES, IPC_HANDLE_BYTES = 128, 64
+NATIVE_BLOB_BYTES, NATIVE_MAX_RANKS = 320, 16
 RING_FIELDS = ("obs", "actions", "logprobs", "values", "rewards", "dones", "firststeps", "logits")
 
 
@@ -120,6 +122,7 @@ def load():
     lib.cbm_actor_stream.restype = C.c_void_p
     lib.cbm_actor_stream.argtypes = [C.c_void_p, C.c_int32]
     lib.cbm_comm_load.argtypes = [C.c_char_p]
+    lib.cbm_comm_backend.restype = C.c_char_p
     _lib = lib
     return lib
 
@@ -349,6 +352,21 @@ class Context:
 
     def comm_init_loopback(self, nranks, which=COMM_LEARNERS):
         _chk(self.lib.cbm_comm_init_loopback(self.h, int(which), int(nranks)))
+
+    # native backend (no RCCL): kernels working on the peers' buffers through IPC mappings; ranks may share one GPU
+    def comm_native_export(self, which=COMM_LEARNERS):
+        blob = (C.c_uint8 * NATIVE_BLOB_BYTES)()
+        _chk(self.lib.cbm_comm_native_export(self.h, int(which), blob))
+        return bytes(blob)
+
+    def comm_native_init(self, blobs, rank, which=COMM_LEARNERS):
+        """blobs: every rank's comm_native_export(), in rank order."""
+        assert all(len(b) == NATIVE_BLOB_BYTES for b in blobs)
+        table = (C.c_uint8 * (NATIVE_BLOB_BYTES * len(blobs))).from_buffer_copy(b"".join(blobs))
+        _chk(self.lib.cbm_comm_native_init(self.h, int(which), len(blobs), int(rank), table))
+
+    def comm_backend(self, which=COMM_LEARNERS):
+        return self.lib.cbm_comm_backend(self.h, int(which)).decode()
 
     def comm_size(self, which=COMM_LEARNERS):
         return int(self.lib.cbm_comm_size(self.h, int(which)))

@@ -133,6 +133,15 @@ class Rendezvous:
         return self.get(key)
 
 
+def comm_backend(nranks=2):
+    """CBM_COMM=native|rccl.  Default: RCCL — except when several ranks were told to share one GPU (CBM_FORCE_DEVICE, the one-GPU test shape),
+    where RCCL refuses two ranks per device and the library's native all-reduce is the only backend that can run."""
+    v = os.environ.get("CBM_COMM", "").lower()
+    if v in ("native", "rccl"):
+        return v
+    return "native" if os.environ.get("CBM_FORCE_DEVICE") is not None and nranks > 1 else "rccl"
+
+
 def setup_learner_comm(engine, rdv, ranks, rank, tag="learners"):
     """The communicator of the gradient / statistics all-reduce over `ranks` (pmap's device list, ppo:435-439,656-660)."""
     if len(ranks) < 2 and not engine.wants_comm_at_world_one():
@@ -142,6 +151,17 @@ def setup_learner_comm(engine, rdv, ranks, rank, tag="learners"):
         # rendezvous, one result line — can run with several ranks on a ONE-GPU box, where RCCL refuses two ranks per device
         rdv.barrier(f"comm/{tag}") if rdv is not None else None
         engine.comm_init_loopback(len(ranks))
+        return
+    if comm_backend(len(ranks)) == "native" and hasattr(engine, "comm_native_export"):
+        # the library's own all-reduce kernels over IPC-mapped peer buffers (csrc/comm.hip): every rank publishes its blob, reads everybody's
+        me = ranks.index(rank)
+        blob = engine.comm_native_export()
+        if rdv is not None:
+            rdv.put(f"comm/{tag}/native/{me}", blob)
+            blobs = [blob if i == me else bytes(rdv.get(f"comm/{tag}/native/{i}")) for i in range(len(ranks))]
+        else:
+            blobs = [blob]
+        engine.comm_native_init(blobs, me)
         return
     uid = rdv.share(f"comm/{tag}/uid", engine.comm_unique_id, ranks[0]) if len(ranks) > 1 else engine.comm_unique_id()
     engine.comm_init(uid, len(ranks), ranks.index(rank))

@@ -159,6 +159,20 @@ int cbm_comm_init(cbm_ctx* ctx, int32_t which, const uint8_t id[CBM_COMM_ID_BYTE
 /* Self-test communicator: behaves like `nranks` ranks holding IDENTICAL data (all-reduce(SUM) = multiply by nranks, on the same streams and
  * behind the same events as the RCCL path), so stream-ordering bugs of the overlapped all-reduce show up as changed bits on one GPU. */
 int cbm_comm_init_loopback(cbm_ctx* ctx, int32_t which, int32_t nranks);
+/* Native backend ("the native design"): the same collectives WITHOUT RCCL — one HIP kernel per all-reduce working straight
+ * on the peers' buffers through HIP IPC mappings.  Two-shot for the flat gradient: rank r reduces slice r of every peer's buffer by PEER READS,
+ * summing in rank order 0..n-1 (deterministic: ppo:30's XLA_FLAGS asks the same of the reference), and writes the result into slice r of every
+ * peer's buffer by PEER WRITES; arrival / completion flags live in a per-rank signal block the peers store to with system-scope atomics.
+ * One-shot (every rank reads all, keeps the result in registers until all have read) for the statistics and the f64 scratch.  Ranks may be
+ * processes on DIFFERENT GPUs of an xGMI node or several processes on ONE GPU (which RCCL refuses) — the way BASELINE configs[3] is tested on
+ * a one-GPU box.  Set-up: every rank exports its blob, the host carries all blobs to every rank (any transport), every rank inits with the table.
+ * A flag wait that exceeds $CBM_NATIVE_TIMEOUT_S (default 120) — a dead peer — makes the next host-synchronising call return an error. */
+#define CBM_NATIVE_MAX_RANKS 16
+#define CBM_NATIVE_BLOB_BYTES 320
+int cbm_comm_native_export(cbm_ctx* ctx, int32_t which, uint8_t blob[CBM_NATIVE_BLOB_BYTES]);
+int cbm_comm_native_init(cbm_ctx* ctx, int32_t which, int32_t nranks, int32_t rank, const uint8_t* blobs /* [nranks][CBM_NATIVE_BLOB_BYTES] */);
+/* "rccl" | "native" | "loopback" | "" (slot not initialised) */
+const char* cbm_comm_backend(cbm_ctx* ctx, int32_t which);
 int cbm_comm_size(cbm_ctx* ctx, int32_t which);              /* ranks of an initialised communicator, 0 otherwise */
 int cbm_comm_allreduce_f64(cbm_ctx* ctx, int32_t which, double* host_inout, int32_t n, int32_t op);   /* op: 0 sum, 1 max, 2 min; blocking */
 int cbm_comm_barrier(cbm_ctx* ctx, int32_t which);

@@ -1,0 +1,164 @@
+"""The library's own all-reduce (csrc/comm.hip, "native": kernels over IPC-mapped / same-process peer buffers, no RCCL) — the backend that lets
+several learner ranks share ONE GPU, which RCCL refuses.  Replaces jax.lax.pmean over the learner devices (ppo:628,649-653).
+
+(1) three contexts of one process: DIFFERENT gradients per rank, result == ((g0 + g1) + g2) bit for bit on every rank (the fixed rank order is
+    the determinism ppo:30 asks of XLA), for the overlapped tail / head pair and for the f64 sum / max / min used by barriers and timing;
+(2) a dead peer: the flag wait times out and the next synchronising call returns an error instead of hanging the GPU;
+(3) BASELINE configs[3] for real on one GPU: `a0-l1,2,3` as four ROLE PROCESSES on GPU 0 at E = 120, T = 128 — every learner holds a different
+    40-env shard, the gradients that are summed differ — against the same topology on the CPU oracle engine over gloo."""
+import os
+import socket
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+
+import cleanba_amd.lib as L
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def _contexts(n):
+    ctxs = []
+    for _ in range(n):
+        cfg = L.default_config(L.ALGO_PPO)
+        cfg.local_num_envs, cfg.num_actor_slots, cfg.num_steps = 8, 1, 8
+        ctxs.append(L.Context(cfg))
+    blobs = [c.comm_native_export() for c in ctxs]
+    for r, c in enumerate(ctxs):
+        c.comm_native_init(blobs, r)
+        assert c.comm_backend() == "native" and c.comm_size() == n
+    return ctxs
+
+
+@pytest.mark.parametrize("n", [2, 3, 5])
+def test_native_allreduce_is_the_rank_ordered_sum(n):
+    ctxs = _contexts(n)
+    try:
+        P = ctxs[0].P
+        rng = np.random.default_rng(n)
+        g = [(rng.normal(size=P) * 10.0 ** rng.integers(-6, 2, P)).astype(np.float32) for _ in range(n)]
+        want = g[0].copy()
+        for r in range(1, n):
+            want = want + g[r]
+        for rep in range(3):       # the flags only grow: repeated collectives on the same signal blocks
+            for c, x in zip(ctxs, g):
+                c.write("grads", x)
+            divs = [c.learner_allreduce_grads() for c in ctxs]      # enqueues tail + head on each context's communication stream
+            for c in ctxs:
+                c.sync()
+            assert divs == [float(n)] * n
+            for r, c in enumerate(ctxs):
+                got = c.read("grads", np.float32)
+                assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (rep, r, np.abs(got - want).max())
+        # the small one-shot form: sum / max / min of host doubles (blocking per rank: one thread per rank)
+        vals = [rng.normal(size=5) for _ in range(n)]
+        with ThreadPoolExecutor(n) as pool:
+            for op, ref in (("sum", np.sum), ("max", np.max), ("min", np.min)):
+                outs = list(pool.map(lambda rc: rc[1].comm_allreduce_f64(vals[rc[0]], op), enumerate(ctxs)))
+                if op == "sum":
+                    w = vals[0].copy()
+                    for r in range(1, n):
+                        w = w + vals[r]
+                else:
+                    w = ref(np.stack(vals), axis=0)
+                for o in outs:
+                    assert np.array_equal(o, w), (op, o, w)
+            list(pool.map(lambda c: c.comm_barrier(), ctxs))
+    finally:
+        for c in ctxs:
+            c.close()
+
+
+def test_native_allreduce_dead_peer_times_out_with_an_error():
+    """Run in a child process: CBM_NATIVE_TIMEOUT_S is read per launch, and a timed-out communicator is not reusable."""
+    code = r'''
+import os, sys, time
+sys.path.insert(0, %r)
+os.environ["CBM_NATIVE_TIMEOUT_S"] = "1.5"
+import numpy as np
+import cleanba_amd.lib as L
+ctxs = []
+for _ in range(2):
+    cfg = L.default_config(L.ALGO_PPO)
+    cfg.local_num_envs, cfg.num_actor_slots, cfg.num_steps = 8, 1, 8
+    ctxs.append(L.Context(cfg))
+blobs = [c.comm_native_export() for c in ctxs]
+for r, c in enumerate(ctxs):
+    c.comm_native_init(blobs, r)
+t0 = time.time()
+ctxs[0].learner_allreduce_grads()        # rank 1 never joins
+try:
+    ctxs[0].sync()
+except RuntimeError as e:
+    assert "timed out" in str(e), e
+    assert 1.0 < time.time() - t0 < 30.0, time.time() - t0
+    print("TIMEOUT-REPORTED")
+else:
+    raise SystemExit("a collective without its peer completed")
+os._exit(0)
+''' % os.path.dirname(HERE)
+    p = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    assert p.returncode == 0 and b"TIMEOUT-REPORTED" in p.stdout, p.stdout.decode()[-3000:]
+
+
+def _run_topology(engine, tmp, tag, E, T, updates, ids, epochs, omp=None):
+    aids, lids = ids.split(":")
+    world = len(aids.split(",")) + len(lids.split(","))
+    port = _free_port()
+    env = dict(os.environ, CBM_TEST_TMP=str(tmp), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if omp:
+        env["OMP_NUM_THREADS"] = str(omp)
+    outs, procs = [], []
+    for r in range(world):
+        out = os.path.join(str(tmp), f"{tag}_{r}.npz")
+        outs.append(out)
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "topo_worker.py"), str(r), str(world), str(port), out, "ppo", engine, str(E), str(T),
+                                       str(updates), ids, str(epochs)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    logs = [p.communicate(timeout=1500)[0].decode() for p in procs]
+    for p in procs:
+        assert p.returncode == 0, "\n=====\n".join(lg[-2500:] for lg in logs)
+    return [np.load(o) for o in outs], logs
+
+
+def test_a0_l123_small_native_equals_oracle_topology(tmp_path):
+    """The same four role processes at a size that runs in seconds (E = 12, T = 8, two updates): learners agree bit for bit with each other, and
+    with the CPU oracle topology within the backward tolerance after the FIRST update (the second one starts from different bits)."""
+    (a, l0, l1, l2), logs = _run_topology("hip", tmp_path, "hip", 12, 8, 1, "0:1,2,3", 2)
+    assert "allreduce.backend: native" in "".join(logs)
+    assert np.array_equal(l0["params"], l1["params"]) and np.array_equal(l0["params"], l2["params"])
+    assert np.array_equal(a["params"], l0["params"])
+    (_, o0, _, _), _ = _run_topology("oracle", tmp_path, "cpu", 12, 8, 1, "0:1,2,3", 2, omp=4)
+    d = np.abs(l0["params"] - o0["params"])
+    print("a0-l1,2,3 small: |p - p_oracle| max %.2e" % d.max())
+    assert np.abs(o0["params"] - o0["p0"]).max() > 1e-4 and d.max() <= 1e-5
+    np.testing.assert_allclose(l0["stats"], o0["stats"], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.slow
+def test_configs3_a0_l123_full_size_on_one_gpu(tmp_path):
+    """BASELINE configs[3] (README.md:62: `--actor-device-ids 0 --learner-device-ids 1 2 3`) at E = 120, T = 128 as four role processes on GPU 0:
+    B_dev = 40 per learner, 1280-frame minibatches, a REAL reduction of three different gradients per minibatch (the native all-reduce), shards
+    written by IPC peer copies.  One whole update against the same topology on the CPU oracle engine (gloo all-reduce) at the whole-update bars."""
+    (a, l0, l1, l2), logs = _run_topology("hip", tmp_path, "hip", 120, 128, 1, "0:1,2,3", 4)
+    assert "allreduce.backend: native" in "".join(logs)
+    assert np.array_equal(l0["params"], l1["params"]) and np.array_equal(l0["params"], l2["params"])
+    assert np.array_equal(a["params"], l0["params"])
+    (_, o0, o1, _), _ = _run_topology("oracle", tmp_path, "cpu", 120, 128, 1, "0:1,2,3", 4, omp=max(4, (os.cpu_count() or 16) // 4))
+    assert np.array_equal(o0["params"], o1["params"])
+    d = np.abs(l0["params"] - o0["params"])
+    serr = np.abs(l0["stats"] - o0["stats"]) / np.maximum(np.abs(o0["stats"]), 1e-3)
+    print("configs[3] on one GPU: |p - p_oracle| median %.2e, 99.99 %% quantile %.2e, max %.2e; statistics worst relative error per column %s"
+          % (np.median(d), np.quantile(d, 0.9999), d.max(), serr.max(axis=0)))
+    assert np.abs(o0["params"] - o0["p0"]).max() > 1e-4
+    np.testing.assert_allclose(l0["stats"], o0["stats"], rtol=1e-5, atol=1e-7)
+    assert np.median(d) <= 1e-7 and np.quantile(d, 0.9999) <= 5e-6 and d.max() <= 1e-5, (np.median(d), np.quantile(d, 0.9999), d.max())
