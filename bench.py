@@ -251,7 +251,9 @@ def run_dp(a, world, rank, local_rank):
         if comm:
             tail_ms, exposed_ms, n = ctx.comm_profile_read()
             P = ctx.P
-            line["allreduce"] = {"backend": "loopback self-test communicator (CBM_COMM_LOOPBACK, not RCCL)" if os.environ.get("CBM_COMM_LOOPBACK") == "1" else "rccl",
+            be = ctx.comm_backend()
+            line["allreduce"] = {"backend": {"loopback": "loopback self-test communicator (CBM_COMM_LOOPBACK, not RCCL)", "native": "native",
+                                             "rccl": "rccl"}.get(be, be),
                                  "ranks": world, "bytes_per_minibatch": int(P * 4), "minibatches": n,
                                  "tail_bytes": int((P - ctx.grad_tail_offset()) * 4),
                                  "tail_allreduce_us_avg": round(tail_ms / max(n, 1) * 1e3, 1),
@@ -358,6 +360,136 @@ def host_env_value(a, params):
     return out
 
 
+def secondary_values():
+    """Secondary workloads under the same clock: 3 warm + 5 timed updates each through the product trainer
+    (cleanba_amd.trainer.train, device env, --concurrency), two device syncs per run.  Not the headline."""
+    from cleanba_amd.args import parse_args
+    from cleanba_amd.trainer import train
+    rows = [("impala_bf16_configs2", "impala", ["--network", "nature", "--bf16-forward"], T, 3, 5,
+             "BASELINE configs[2]: IMPALA a0-l0-d1, V-trace, Nature-CNN bf16-MFMA forward / fp32 returns, 120 envs x 128 steps"),
+            ("impala_fp32_t128", "impala", ["--network", "nature"], T, 3, 5, "IMPALA a0-l0-d1 fp32, 120 envs x 128 steps"),
+            ("impala_fp32_t20", "impala", ["--network", "nature"], 20, 40, 40, "IMPALA a0-l0-d1 fp32 at the script's default num_steps = 20 (40 warm + 40 timed updates of ~2.7 ms)"),
+            ("ppo_resnet", "ppo", ["--network", "impala_resnet"], T, 2, 5, "PPO a0-l0-d1 with the IMPALA-ResNet torso (the CLI's default network, ppo:149-189), 120 envs x 128 steps")]
+    out = {}
+    for name, algo, extra, t, warm, n_up, what in rows:
+        marks = {}
+
+        def on_update(v, st, e, marks=marks, warm=warm, last=warm + n_up):
+            if v == warm or v == last:
+                e.sync()
+                marks[v] = time.perf_counter()
+
+        argv = ["--local-num-envs", str(E), "--num-actor-threads", "1", "--num-steps", str(t), "--env-backend", "device", "--total-timesteps",
+                str((warm + n_up) * E * t), "--log-frequency", "100000", "--concurrency"] + extra
+        cwd = os.getcwd()
+        os.chdir(os.environ.get("TMPDIR", "/tmp"))
+        so = sys.stdout
+        sys.stdout = open(os.devnull, "w")
+        try:
+            train(parse_args(argv, algo), algo, on_update=on_update)
+            dt = (marks[warm + n_up] - marks[warm]) / n_up
+            out[name] = {"value": round(E * t / dt, 1), "unit": "env-steps/s", "ms_per_update": round(dt * 1e3, 3), "updates_timed": n_up, "workload": what}
+        except BaseException as e:  # noqa: BLE001
+            out[name] = {"value": None, "error": f"{type(e).__name__}: {e}", "workload": what}
+        finally:
+            sys.stdout = so
+            os.chdir(cwd)
+    r = out.get("ppo_resnet", {})
+    if r.get("value"):
+        # executed flops per env-step of the ResNet PPO step (rollout forward + 4 epochs x (forward + input gradients except conv0's + weight gradients))
+        r["executed_mflop_per_env_step"] = RESNET_EXEC_MFLOP_PER_ENV_STEP
+        r["executed_frac_of_fp32_mfma_peak"] = round(r["value"] * RESNET_EXEC_MFLOP_PER_ENV_STEP * 1e6 / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)
+        r["per_kernel"] = "profiles/r04_resnet_kernel_stats.md (rocprofv3 --kernel-trace of tools/rn_microbench.py)"
+    return out
+
+
+def _resnet_exec_mflop():
+    """Executed MFLOP per env-step of PPO on the IMPALA-ResNet torso (15 convs 3x3 SAME, dense 3872 -> 256, heads): one rollout forward + 4 epochs
+    x (forward + input gradient of every conv but the first + weight gradient of every conv) + dense / heads forward, dgrad, wgrad."""
+    convs = []   # (H, CI, CO)
+    h, ci = 84, 4
+    for co in (16, 32, 32):
+        convs.append((h, ci, co))
+        h = (h + 1) // 2
+        convs += [(h, co, co)] * 4
+        ci = co
+    fwd = sum(2.0 * hh * hh * 9 * a_ * b_ for hh, a_, b_ in convs)
+    dgrad = sum(2.0 * hh * hh * 9 * a_ * b_ for hh, a_, b_ in convs[1:])
+    dense = 2.0 * 3872 * 256 + 2.0 * 256 * (A + 1)
+    per_frame_fwd = fwd + dense
+    per_frame_bwd = dgrad + fwd + 2 * dense
+    return round((per_frame_fwd + EPOCHS * (per_frame_fwd + per_frame_bwd)) / 1e6, 1)
+
+
+RESNET_EXEC_MFLOP_PER_ENV_STEP = _resnet_exec_mflop()
+
+
+def baseline_topology_on_one_gpu(a):
+    """BASELINE configs[3] (`a0-l1,2,3`: one actor + three learner role processes, README.md:62) with every role on THIS GPU: what a one-GPU box can
+    run of it — real shards by IPC peer copies, a real reduction of three different gradients per minibatch through the library's native
+    all-reduce (RCCL refuses two ranks per device).  A functional measurement: four processes share one GPU."""
+    env = dict(os.environ, CBM_FORCE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    try:
+        p = subprocess.run([sys.executable, os.path.abspath(__file__), "--topology", "a0-l1,2,3", "--steps", "4", "--warmup", "2"], env=env,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240)
+        d = json.loads(p.stdout.decode().strip().splitlines()[-1])
+        return {"config": "BASELINE configs[3] PPO a0-l1,2,3-d1, all four role processes on one GPU (CBM_FORCE_DEVICE=0)", "value": d.get("value"),
+                "unit": "env-steps/s", "ms_per_step": d.get("ms_per_step"), "steps": d.get("steps"), "allreduce": d.get("allreduce"),
+                "note": "functional: the roles time-share one MI355X; the multi-GPU number comes from `bench.py --gpus 4` (key baseline_config)"}
+    except BaseException as e:  # noqa: BLE001
+        return {"config": "BASELINE configs[3] on one GPU", "value": None, "error": f"{type(e).__name__}: {e}"}
+
+
+def baseline_config_phase(a, world, rank):
+    """`bench.py --gpus 4` / `--gpus 8` (the driver's SCALE command) measures the weak-scaling a0_l0_dN line; BASELINE.json's multi-GPU configs
+    are split topologies — configs[3] `a0-l1,2,3` on 4 GPUs, configs[4] `2x(a0-l1,2,3)` + Atari-57 mix on 8.  With exactly 4 / 8 ranks the SAME
+    processes run that topology afterwards (own rendezvous prefix) and its line rides along as `baseline_config`.  Guarded by a watchdog: the
+    headline line is never lost to a failure here."""
+    import copy
+    import threading
+    from cleanba_amd import topology
+    a2 = copy.copy(a)
+    a2.topology, a2.env_id = ("a0-l1,2,3", "Breakout-v5") if world == 4 else ("2x(a0-l1,2,3)", "Atari57Mix-v5")
+    a2.steps, a2.warmup, a2.actor_threads = min(a.steps, 8), 2, 1
+    os.environ["CBM_RDV_PREFIX"] = "cbm-topo"
+    rdv = topology.Rendezvous(world, rank, os.environ.get("MASTER_ADDR", "127.0.0.1"), os.environ.get("MASTER_PORT", "29500"), prefix="cbm-topo-line")
+    box = {}
+
+    def work():
+        try:
+            box["line"] = run_topology(a2, world, rank)
+        except BaseException as e:  # noqa: BLE001
+            box["error"] = f"{type(e).__name__}: {e}"
+
+    th = threading.Thread(target=work, daemon=True)
+    th.start()
+    th.join(300.0)
+    if th.is_alive():
+        box["error"] = "timeout after 300 s"
+    if box.get("line") is not None and rank != 0:
+        rdv.put("line", json.dumps(box["line"]).encode())
+    elif box.get("error") and rank != 0:
+        try:
+            rdv.put(f"error/{rank}", box["error"].encode())
+        except Exception:  # noqa: BLE001
+            pass
+    if rank != 0:
+        return None
+    if box.get("error"):
+        return {"config": a2.topology, "value": None, "error": box["error"]}
+    t0 = time.time()
+    while time.time() - t0 < 30.0:
+        if rdv.store.check(["line"]):
+            d = json.loads(bytes(rdv.store.get("line")).decode())
+            return {"config": f"BASELINE configs[{3 if world == 4 else 4}] PPO {a2.topology}" + (" , Atari-57 synthetic frame mix" if world == 8 else ""),
+                    "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"], "n_gpus": d["n_gpus"],
+                    "scaling": d["scaling"], "allreduce": d.get("allreduce"), "workload": d["config"]["workload"]}
+        time.sleep(0.05)
+    return {"config": a2.topology, "value": None, "error": "no line from learner 0 within 30 s"}
+
+
 # --------------------------------------------------------------------------------------------- split-topology bench
 def parse_topology(spec):
     """'a0-l1,2,3' -> (groups=1, [0], [1,2,3]);  '2x(a0-l1,2,3)' -> (2, [0], [1,2,3]);  'a0,1-l2,3' -> (1, [0,1], [2,3])."""
@@ -385,12 +517,13 @@ def run_topology(a, world, rank):
     args = parse_args(argv, "ppo")
     lay = topology.Layout(args, world, rank)
     os.environ["LOCAL_RANK"] = str(lay.device_id)
-    marks = {}
+    marks, seen = {}, {}
 
     def on_update(v, stats, engine):
         if v == a.warmup or v == a.warmup + a.steps:
             engine.sync()
             marks[v] = time.perf_counter()
+            seen["backend"], seen["ranks"] = engine.comm_backend(), engine.comm_size()
 
     cwd = os.getcwd()
     os.chdir(os.environ.get("TMPDIR", "/tmp"))
@@ -413,7 +546,9 @@ def run_topology(a, world, rank):
                                    f"{len(aids)} actor + {len(lids)} learner role processes",
                        "global_batch": E * T * a.actor_threads * len(aids) * groups, "parallelism": f"{groups}x(actor{len(aids)}+dp{len(lids)})"},
             "roofline": None, "role_processes": world, "timed_on": "learner 0 of group 0 (update completions, device-synchronised)",
-            "updates": int(res["updates"])}
+            "allreduce": {"backend": seen.get("backend") or "none (one learner)", "ranks": seen.get("ranks", 0),
+                          "note": "native = the library's own two-shot all-reduce over IPC-mapped peer buffers (csrc/comm.hip); rccl = RCCL over xGMI"},
+            "all_roles_on_gpu": os.environ.get("CBM_FORCE_DEVICE"), "updates": int(res["updates"])}
 
 
 # --------------------------------------------------------------------------------------------- launcher
@@ -442,6 +577,8 @@ def main():
     ap.add_argument("--prof-kernel", type=int, default=-2, help="-2: HIP events around every GEMM launch (ids 0-11, default); k: only kernel k; -1: off")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-env", action="store_true", help="skip the secondary envpool-API measurement")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary workloads (IMPALA configs[2], IMPALA fp32, PPO-ResNet) and the configs[3]-on-one-GPU row")
+    ap.add_argument("--no-baseline-config", action="store_true", help="with 4 / 8 ranks: skip the BASELINE configs[3] / configs[4] topology line after the dp line")
     ap.add_argument("--bwd-split", type=int, default=0, choices=[0, 2, 3],
                     help="build-only extension (NOT the headline): backward GEMMs on split-bf16 MFMA, see cbm_config.backward_split")
     a = ap.parse_args()
@@ -469,12 +606,21 @@ def main():
             _emit(json.dumps({"error": f"{type(e).__name__}: {e}", "n_gpus": world, "topology": a.topology, "rank": rank,
                               "metric": "env-steps/sec (whole node), Breakout-v5 84x84x4, num_envs=120", "value": None}))
         raise
+    if world in (4, 8) and a.topology == "dp" and not a.no_baseline_config:
+        bc = baseline_config_phase(a, world, rank)
+        if rank == 0:
+            line["baseline_config"] = bc
     if rank == 0:
         if world == 1 and not a.no_host_env:
             line["host_env"] = host_env_value(a, params)
+        if world == 1 and not a.no_secondary:
+            line["secondary"] = secondary_values()
+            line["secondary"]["configs3_on_one_gpu"] = baseline_topology_on_one_gpu(a)
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         _emit(json.dumps(line))
+    if world in (4, 8):
+        os._exit(0)   # (daemon threads of a timed-out topology phase must not keep the rank alive)
 
 
 _REAL_STDOUT = None

@@ -51,11 +51,12 @@ __global__ __launch_bounds__(256) void env_step_kernel(uint32_t seed, int E, int
                                                         const uint8_t* obs_prev, uint8_t* obs_next, float* reward, uint8_t* done_next,
                                                         uint8_t* firststep_next) {
   const EnvStepArgs a{seed, max_steps, st, obs_prev, obs_next, reward, done_next, firststep_next};
-  const int e = blockIdx.x;
-  // all of a thread's plane-shift loads are issued before its first store (one L2 round trip instead of seven on the critical path)
-  uint32_t older[7][3];
-  env_step_prefetch(a, e, older);
-  env_step_block(a, e, actions[e], older);
+  const int e = blockIdx.x, tid = threadIdx.x;
+  __shared__ EnvShared sh;
+  if (tid < 3) env_step_candidates(a, e, sh, tid, st[e]);
+  __syncthreads();
+  env_step_early(a, e, sh, tid, 256);
+  env_step_finish(a, e, sh, actions[e], tid, 256);
 }
 void launch_env_step(uint32_t seed, int E, int max_episode_steps, const int32_t* actions, cbm_env_state* st_dev, const uint8_t* obs_prev,
                      uint8_t* obs_next, float* reward, uint8_t* done_next, uint8_t* firststep_next, hipStream_t st) {
@@ -197,6 +198,10 @@ extern "C" int cbm_synth_env_step_host(uint32_t seed, int32_t n, int32_t max_epi
 // layered painter (layered = 1); tests/test_env.py compares the two over random states of every game preset
 extern "C" int cbm_synth_env_render_host(const cbm_env_state* st, int32_t layered, uint8_t* plane) {
   const EnvGame gm = env_game(st->game);
+  if (layered == 2) {   // the device kernels' word painter (env_word)
+    for (int i = 0; i < 1764; ++i) { const uint32_t w = env_word(st, gm, i); memcpy(plane + 4 * i, &w, 4); }
+    return 0;
+  }
   if (layered) { host_render_plane(st, gm, plane); return 0; }
   for (int i = 0; i < 7056; ++i) plane[i] = env_pixel(st, gm, i / 84, i % 84);
   return 0;

@@ -128,48 +128,122 @@ CBM_HD EnvOut env_transition(cbm_env_state* s, uint32_t seed, uint32_t env_id, i
 }
 
 
-// ---- one env's step by one 256-thread block, in two parts so that a caller can put work between them:
-//   env_step_prefetch  the three older frame planes of the stack (they do not depend on the action) -> registers
-//   env_step_block     transition (thread 0), then every thread paints its words of the new plane and writes the shifted stack
+// the four pixels x .. x+3 of word i of the 84x84 plane (21 words per row, pixel x in byte x % 4): env_pixel's bytes, decided per REGION
+// instead of per pixel — empty rows, top bar, side walls and brick rows directly, only the words that touch the paddle rows, the ball or a
+// scenery rectangle through the per-pixel function (tests/test_env.py holds it to env_pixel over random states of all 57 presets)
+CBM_HD uint32_t env_word(const cbm_env_state* s, const EnvGame& gm, int i) {
+  const int y = i / 21, x = 4 * (i - 21 * y);
+  if (y < 10) return 0u;
+  if (y >= 17 && y < 35) {
+    const int row = (y - 17) / 3, ry = (y - 17) - 3 * row;
+    if (ry == 2 || !((gm.rows_mask >> row) & 1)) return 0u;
+    const uint32_t val = (uint32_t)(200 - 24 * row);
+    uint32_t w = 0u;
+    for (int p = 0; p < 4; ++p) {
+      const int xx = x + p, col = xx / 6, rx = xx - 6 * col, k = row * 14 + col;
+      if (rx < 5 && ((s->bricks[k / 28] >> (k % 28)) & 1u)) w |= val << (8 * p);
+    }
+    return w;
+  }
+  bool slow = (y >= 78 && y < 80) || (y >= s->ball_y && y < s->ball_y + 2 && x + 3 >= s->ball_x && x < s->ball_x + 2);
+  for (int r = 0; r < gm.n_rects; ++r) {
+    const uint32_t k = gm.rect_key * 2654435761u + (uint32_t)r * 0x9E3779B9u;
+    const int ry0 = 36 + (int)(k % 32u), rh = 2 + (int)((k >> 11) % 6u);
+    slow = slow || (y >= ry0 && y < ry0 + rh);
+  }
+  if (slow)
+    return (uint32_t)env_pixel(s, gm, y, x) | ((uint32_t)env_pixel(s, gm, y, x + 1) << 8) | ((uint32_t)env_pixel(s, gm, y, x + 2) << 16) |
+           ((uint32_t)env_pixel(s, gm, y, x + 3) << 24);
+  if (y < 12) return 0x8E8E8E8Eu;                                  // top bar (142)
+  return (x == 0 ? 142u : 0u) | (x == 80 ? 142u << 24 : 0u);       // side walls at x = 0 and x = 83
+}
+
+// ---- one env's step by one 256-thread block, split so that almost all of it runs BEFORE the action exists (the per-frame actor tail samples
+// the action at the very end of its block):
+//   env_step_candidates  three threads: the action acts on the env only through the paddle direction (action % n_actions) % 3, so the three
+//                        possible transitions (state, reward, done, ...) are computed up front                      [needs a barrier after]
+//   env_step_early       `nt` threads: the stack shift (three older planes; four copies of the new plane after a reset) and the new plane
+//                        except its two paddle rows, painted from candidate 0 with the pre-step bricks — ball, scenery and walls do not
+//                        depend on the action, and a brick changes only on a reward (2 % of the steps)
+//   env_step_finish      after the action: pick the candidate, publish state / reward / done, paint the 42 words of the paddle rows, repaint
+//                        the brick rows if a brick went.  Same bytes as painting everything afterwards (tests/test_env.py, test_gpu_e2e.py)
 struct EnvStepArgs {
   uint32_t seed; int32_t max_steps; cbm_env_state* st; const uint8_t* obs_prev; uint8_t* obs_next; float* reward; uint8_t* done_next;
   uint8_t* firststep_next;   // obs_next == nullptr: no env step
 };
+struct EnvCand { cbm_env_state s; EnvOut out; };
+struct EnvShared { EnvCand cand[3]; cbm_env_state pre; EnvGame gm; int32_t reset; };   // lives in LDS: the brick words are indexed dynamically
 #if defined(__HIPCC__)
-static __device__ __forceinline__ void env_step_prefetch(const EnvStepArgs& a, int e, uint32_t (&older)[7][3]) {
-  const uint32_t* p32 = reinterpret_cast<const uint32_t*>(a.obs_prev + (size_t)e * CBM_FRAME);   // 1764 words per plane
-#pragma unroll
-  for (int j = 0; j < 7; ++j) {
-    const int i = min((int)threadIdx.x + 256 * j, 1763);
-    older[j][0] = p32[1764 + i]; older[j][1] = p32[2 * 1764 + i]; older[j][2] = p32[3 * 1764 + i];
+#define ENV_PLANE_WORDS 1764
+// (s = a.st[e], loaded by the caller: the actor tail requests it before its other loads so that this arithmetic runs under their latency)
+static __device__ __forceinline__ void env_step_candidates(const EnvStepArgs& a, int e, EnvShared& sh, int t, const cbm_env_state& s) {
+  cbm_env_state* c = &sh.cand[t].s;
+  *c = s;
+  sh.cand[t].out = env_transition(c, a.seed, (uint32_t)e, t, a.max_steps);   // action = t: every preset has >= 4 actions, so its direction is t
+  if (t == 0) {
+    sh.gm = env_game(s.game);
+    sh.reset = s.needs_reset;
+    // what the early paint shows: candidate 0's ball / episode (the same in all three), and the bricks as they stand BEFORE the step — a reset
+    // starts from the new episode's full wall, otherwise nothing has gone yet
+    sh.pre = *c;
+    if (!s.needs_reset) { sh.pre.bricks[0] = s.bricks[0]; sh.pre.bricks[1] = s.bricks[1]; sh.pre.bricks[2] = s.bricks[2]; }
   }
 }
-static __device__ __forceinline__ void env_step_block(const EnvStepArgs& a, int e, int32_t action, const uint32_t (&older)[7][3]) {
-  __shared__ cbm_env_state s;
-  __shared__ EnvOut out;
-  __shared__ EnvGame gm;
-  if (threadIdx.x == 0) {
-    s = a.st[e];
-    gm = env_game(s.game);
-    out = env_transition(&s, a.seed, (uint32_t)e, action, a.max_steps);
-    a.st[e] = s;
+static __device__ __forceinline__ void env_step_early(const EnvStepArgs& a, int e, const EnvShared& sh, int t, int nt) {
+  const cbm_env_state* pre = &sh.pre;
+  const EnvGame gm = sh.gm;
+  const bool rs = sh.reset != 0;
+  const uint32_t* p32 = reinterpret_cast<const uint32_t*>(a.obs_prev + (size_t)e * CBM_FRAME);
+  uint32_t* o32 = reinterpret_cast<uint32_t*>(a.obs_next + (size_t)e * CBM_FRAME);
+  for (int i0 = t; i0 < ENV_PLANE_WORDS; i0 += 7 * nt) {       // seven words per thread and pass: their 21 loads are in flight together
+    uint32_t older[7][3];
+    if (!rs) {
+#pragma unroll
+      for (int j = 0; j < 7; ++j) {
+        const int i = min(i0 + j * nt, ENV_PLANE_WORDS - 1);
+        older[j][0] = p32[ENV_PLANE_WORDS + i]; older[j][1] = p32[2 * ENV_PLANE_WORDS + i]; older[j][2] = p32[3 * ENV_PLANE_WORDS + i];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      const int i = i0 + j * nt;
+      if (i < ENV_PLANE_WORDS) {
+        const bool paddle_row = i >= 78 * 21 && i < 80 * 21;
+        const uint32_t nw = paddle_row ? 0u : env_word(pre, gm, i);
+        if (rs) {
+          if (!paddle_row) { o32[i] = nw; o32[ENV_PLANE_WORDS + i] = nw; o32[2 * ENV_PLANE_WORDS + i] = nw; }
+        } else {
+          o32[i] = older[j][0]; o32[ENV_PLANE_WORDS + i] = older[j][1]; o32[2 * ENV_PLANE_WORDS + i] = older[j][2];
+        }
+        if (!paddle_row) o32[3 * ENV_PLANE_WORDS + i] = nw;
+      }
+    }
+  }
+}
+// t / nt: the SAME thread numbering env_step_early ran with (a word is re-stored by the thread that stored it first: program order, no fence);
+// the paddle rows, which nobody has stored yet, go to the first 42 of those threads
+static __device__ __forceinline__ void env_step_finish(const EnvStepArgs& a, int e, const EnvShared& sh, int32_t action, int t, int nt) {
+  const EnvGame gm = sh.gm;
+  const int dir = (action % gm.n_actions) % 3;
+  const cbm_env_state* s = &sh.cand[dir].s;
+  const bool rs = sh.reset != 0;
+  if (t == 0) {
+    const EnvOut out = sh.cand[dir].out;
+    a.st[e] = *s;
     a.reward[e] = out.reward;
     a.done_next[e] = out.done;
     if (a.firststep_next) a.firststep_next[e] = out.firststep;
   }
-  __syncthreads();
   uint32_t* o32 = reinterpret_cast<uint32_t*>(a.obs_next + (size_t)e * CBM_FRAME);
-  const bool rs = out.was_reset;
-#pragma unroll
-  for (int j = 0; j < 7; ++j) {
-    const int i = threadIdx.x + 256 * j;
-    if (i >= 1764) break;
-    const int y = (4 * i) / 84, x = (4 * i) % 84;
-    const uint32_t nw = (uint32_t)env_pixel(&s, gm, y, x) | ((uint32_t)env_pixel(&s, gm, y, x + 1) << 8) |
-                        ((uint32_t)env_pixel(&s, gm, y, x + 2) << 16) | ((uint32_t)env_pixel(&s, gm, y, x + 3) << 24);
-    if (rs) { o32[i] = nw; o32[1764 + i] = nw; o32[2 * 1764 + i] = nw; }
-    else { o32[i] = older[j][0]; o32[1764 + i] = older[j][1]; o32[2 * 1764 + i] = older[j][2]; }
-    o32[3 * 1764 + i] = nw;
+  if (t < 42) {
+    const int i = 78 * 21 + t;
+    const uint32_t nw = env_word(s, gm, i);
+    if (rs) { o32[i] = nw; o32[ENV_PLANE_WORDS + i] = nw; o32[2 * ENV_PLANE_WORDS + i] = nw; }
+    o32[3 * ENV_PLANE_WORDS + i] = nw;
+  }
+  if (s->bricks[0] != sh.pre.bricks[0] || s->bricks[1] != sh.pre.bricks[1] || s->bricks[2] != sh.pre.bricks[2]) {   // block-uniform
+    for (int i = t; i < 35 * 21; i += nt)
+      if (i >= 17 * 21) o32[3 * ENV_PLANE_WORDS + i] = env_word(s, gm, i);
   }
 }
 #endif

@@ -324,15 +324,19 @@ __global__ __launch_bounds__(256) void actor_tail_rows_kernel(const float* part,
                                                               const float* bc, int B, int A, ActorSample smp) {
   __builtin_amdgcn_s_setprio(3);   // (see igemm_s16_kernel)
   __shared__ int act_s;
+  __shared__ EnvShared env_sh;
   __shared__ __attribute__((aligned(16))) float hsT[HD];      // hid of this frame, stored as [k % 4][k / 4]: lane group g4 of a 16x16x4 MFMA reads its k = 4*st + g4 as consecutive floats
   __shared__ float lg[32];
   const int tid = threadIdx.x, b = blockIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, g4 = lane >> 4;
   const size_t MN = (size_t)B * HD;
-  // device env: this block also steps env b with the action it samples; the stack's older planes are requested now
+  // device env: this block also steps env b with the action it samples.  Almost all of that step does not need the action (env_model.h): waves 2 / 3,
+  // idle while waves 0 / 1 run the heads' MFMA chain and the sampling, shift the frame stack and paint the new plane meanwhile; what is left
+  // after the action is the choice among three precomputed transitions and the 42 words of the paddle rows
   const EnvStepArgs ea{smp.env_seed, smp.env_max_steps, smp.env_st, smp.env_obs_prev, smp.env_obs_next, smp.env_reward, smp.env_done_next,
                        smp.env_firststep_next};
-  uint32_t older[7][3];
-  if (ea.obs_next) env_step_prefetch(ea, b, older);
+  const bool env_cand = ea.obs_next && tid >= 128 && tid < 131;
+  cbm_env_state env_s0;
+  if (env_cand) env_s0 = ea.st[b];
   // all partial slices of this thread's hidden units (HD / 256 of them: k = tid, tid + 256) are requested at once (S <= 16), then added in slice order
   constexpr int NU = HD / 256;
   static_assert(HD % 256 == 0 && NU >= 1 && NU <= 2, "hidden width 256 or 512");
@@ -355,6 +359,7 @@ __global__ __launch_bounds__(256) void actor_tail_rows_kernel(const float* part,
 #pragma unroll
     for (int st = 0; st < HD / 4; ++st) bw[st] = on ? wp[(size_t)(4 * st + g4) * wstride] : 0.0f;
   }
+  if (env_cand) env_step_candidates(ea, b, env_sh, tid - 128, env_s0);   // (arithmetic on the first load issued: runs while the partials arrive)
 #pragma unroll
   for (int u = 0; u < NU; ++u) {
     float t0 = vv[u][0];
@@ -376,6 +381,8 @@ __global__ __launch_bounds__(256) void actor_tail_rows_kernel(const float* part,
       acc = __builtin_amdgcn_mfma_f32_16x16x4f32(h4.w, bw[4 * q + 3], acc, 0, 0, 0);
     }
     if (g4 == 0 && n <= A) lg[n] = acc[0] + (n < A ? ba[n] : bc[0]);   // D: lane (g4 = 0, r16) element 0 = row 0, column r16
+  } else if (ea.obs_next) {
+    env_step_early(ea, b, env_sh, tid - 128, 128);
   }
   __syncthreads();
   if (tid < 32) {
@@ -410,7 +417,7 @@ __global__ __launch_bounds__(256) void actor_tail_rows_kernel(const float* part,
   }
   if (ea.obs_next) {
     __syncthreads();
-    env_step_block(ea, b, act_s, older);
+    if (tid >= 128) env_step_finish(ea, b, env_sh, act_s, tid - 128, 128);
   }
 }
 static void launch_heads_fwd(const float* hid, const float* Wa, const float* ba, const float* Wc, const float* bc, int B, int A, int HD,

@@ -485,7 +485,7 @@ def synth_env_step_host(seed, st, obs, actions, max_episode_steps=27000):
 
 def synth_env_render_host(state, layered):
     plane = np.empty((84, 84), np.uint8)
-    _chk(load().cbm_synth_env_render_host(C.byref(state), int(bool(layered)), _p(plane)))
+    _chk(load().cbm_synth_env_render_host(C.byref(state), int(layered), _p(plane)))   # 0 per pixel, 1 the host's layers, 2 the kernels' word painter
     return plane
 
 

@@ -71,14 +71,19 @@ class Rendezvous:
     the RCCL unique id, the IPC handles and the 'landed' notifications.  `get` polls so that a failed peer (which posts 'abort') or a
     vanished server ends the wait instead of hanging it."""
 
-    def __init__(self, world, rank, addr, port, timeout_s=1800.0):
+    _base = {}   # (addr, port, world, rank) -> TCPStore: one connection (and, on rank 0, one server) per process, whatever the number of runs
+
+    def __init__(self, world, rank, addr, port, timeout_s=1800.0, prefix=None):
         from torch.distributed import TCPStore
         self.world, self.rank, self.timeout_s = world, rank, timeout_s
         # rank 0 hosts the server — unless torchrun's agent already does on this port (TORCHELASTIC_USE_AGENT_STORE: TCPStore then joins
-        # that one); every key carries a prefix so the job's keys never meet the launcher's
+        # that one); every key carries a prefix so the job's keys never meet the launcher's, and a process that makes several runs in a row
+        # (bench.py: the data-parallel line, then the BASELINE topology line) gives each run its own prefix (CBM_RDV_PREFIX)
         from torch.distributed import PrefixStore
-        self.store = PrefixStore("cbm", TCPStore(addr, int(port), world, rank == 0, timeout=datetime.timedelta(seconds=timeout_s),
-                                                 wait_for_workers=False))
+        k = (addr, int(port), world, rank)
+        if k not in Rendezvous._base:
+            Rendezvous._base[k] = TCPStore(addr, int(port), world, rank == 0, timeout=datetime.timedelta(seconds=timeout_s), wait_for_workers=False)
+        self.store = PrefixStore(prefix or os.environ.get("CBM_RDV_PREFIX", "cbm"), Rendezvous._base[k])
 
     def put(self, key, value=b"1"):
         self.store.set(key, value)

@@ -1,0 +1,45 @@
+"""One rank of tests/test_gpu_native_comm.py::test_native_allreduce_is_the_rank_ordered_sum: its own process and context on GPU 0 (ranks of one
+process would share the runtime's few hardware queues, and a kernel that waits for a peer queued BEHIND it on the same queue can never see it).
+Usage: python native_comm_worker.py <rank> <nranks> <port> <out.npz>"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+rank, n, port, out = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+
+import cleanba_amd.lib as L  # noqa: E402
+from cleanba_amd import topology  # noqa: E402
+
+cfg = L.default_config(L.ALGO_PPO)
+cfg.local_num_envs, cfg.num_actor_slots, cfg.num_steps = 8, 1, 8
+ctx = L.Context(cfg)
+rdv = topology.Rendezvous(n, rank, "127.0.0.1", port, timeout_s=120.0)
+blob = ctx.comm_native_export()
+rdv.put(f"blob/{rank}", blob)
+ctx.comm_native_init([blob if r == rank else bytes(rdv.get(f"blob/{r}")) for r in range(n)], rank)
+assert ctx.comm_backend() == "native" and ctx.comm_size() == n
+
+
+def grads_of(r, rep):
+    rng = np.random.default_rng(1000 * rep + r)
+    return (rng.normal(size=ctx.P) * 10.0 ** rng.integers(-6, 2, ctx.P)).astype(np.float32)
+
+
+res = {}
+for rep in range(3):                     # the flags only grow: repeated collectives on the same signal blocks
+    ctx.write("grads", grads_of(rank, rep))
+    ctx.sync()
+    assert ctx.learner_allreduce_grads() == float(n)     # tail + head on the communication stream, learner stream joined
+    ctx.sync()
+    res[f"g{rep}"] = ctx.read("grads", np.float32)
+vals = np.random.default_rng(77 + rank).normal(size=5)
+for op in ("sum", "max", "min"):
+    res[op] = ctx.comm_allreduce_f64(vals, op)
+ctx.comm_barrier()
+rdv.barrier("done")                      # nobody unmaps while a peer may still be inside a collective
+np.savez(out, **res)
+ctx.close()
+print("rank", rank, "ok", flush=True)

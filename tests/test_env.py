@@ -123,3 +123,19 @@ def test_layered_host_painter_equals_the_per_pixel_function_and_out_of_place_ste
                 slow, fast = L.synth_env_render_host(st_a[e], 0), L.synth_env_render_host(st_a[e], 1)
                 assert (slow == fast).all(), (t, e)
                 assert (fast == obs_a[e, 3]).all()
+                assert (L.synth_env_render_host(st_a[e], 2) == slow).all(), (t, e)   # env_word: what the device kernels paint with
+
+
+def test_word_painter_equals_the_per_pixel_function_on_random_states():
+    """env_word (the device kernels' painter: regions decided per 4-pixel word) against env_pixel on states the dynamics rarely reach: every ball
+    position incl. the brick rows and the walls, paddles at both stops, sparse brick walls, all 57 presets."""
+    rng = np.random.default_rng(5)
+    st, _ = L.synth_env_reset_host(3, 57, atari57_mix=True)
+    for rep in range(40):
+        for e in range(57):
+            s = st[e]
+            s.ball_x, s.ball_y = int(rng.integers(1, 82)), int(rng.integers(12, 76))
+            s.paddle_x = int(rng.choice([1, 36, 83 - 22, 83 - 8, int(rng.integers(1, 60))]))
+            for w in range(3):
+                s.bricks[w] = int(rng.integers(0, 1 << 28)) if rep % 3 else 0x0FFFFFFF
+            assert (L.synth_env_render_host(s, 2) == L.synth_env_render_host(s, 0)).all(), (rep, e)

@@ -14,8 +14,12 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _bench(*args):
-    env = dict(os.environ, CBM_FORCE_DEVICE="0", CBM_COMM_LOOPBACK="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+def _bench(*args, loopback=True):
+    env = dict(os.environ, CBM_FORCE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if loopback:
+        env["CBM_COMM_LOOPBACK"] = "1"
+    else:
+        env.pop("CBM_COMM_LOOPBACK", None)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args, "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-host-env"],
@@ -39,3 +43,15 @@ def test_bench_topology_a0_l1_emits_one_line():
     d = _bench("--gpus", "2", "--topology", "a0-l1")
     assert d["role_processes"] == 2 and d["updates"] == 3 and d["value"] > 0 and "error" not in d
     assert d["config"]["parallelism"] == "1x(actor1+dp1)"
+
+
+def test_bench_gpus_4_native_allreduce_then_the_configs3_topology_line():
+    """The SCALE command at N = 4 with every rank on GPU 0 and NO loopback: the data-parallel line runs on the library's native all-reduce (four
+    ranks, four different gradients — RCCL cannot put two ranks on one device), then the same four processes run BASELINE configs[3]
+    (`a0-l1,2,3`) and its line rides along as `baseline_config`."""
+    d = _bench("--gpus", "4", loopback=False)
+    assert d["n_gpus"] == 4 and "error" not in d and d["value"] > 0
+    assert d["allreduce"]["backend"] == "native" and d["allreduce"]["ranks"] == 4
+    bc = d["baseline_config"]
+    assert bc.get("value") and bc["value"] > 0, bc
+    assert "a0-l1,2,3" in bc["config"] and bc["allreduce"]["backend"] == "native" and bc["allreduce"]["ranks"] == 3

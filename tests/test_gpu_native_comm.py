@@ -1,7 +1,7 @@
 """The library's own all-reduce (csrc/comm.hip, "native": kernels over IPC-mapped / same-process peer buffers, no RCCL) — the backend that lets
 several learner ranks share ONE GPU, which RCCL refuses.  Replaces jax.lax.pmean over the learner devices (ppo:628,649-653).
 
-(1) three contexts of one process: DIFFERENT gradients per rank, result == ((g0 + g1) + g2) bit for bit on every rank (the fixed rank order is
+(1) n rank processes on GPU 0: DIFFERENT gradients per rank, result == ((g0 + g1) + g2) bit for bit on every rank (the fixed rank order is
     the determinism ppo:30 asks of XLA), for the overlapped tail / head pair and for the f64 sum / max / min used by barriers and timing;
 (2) a dead peer: the flag wait times out and the next synchronising call returns an error instead of hanging the GPU;
 (3) BASELINE configs[3] for real on one GPU: `a0-l1,2,3` as four ROLE PROCESSES on GPU 0 at E = 120, T = 128 — every learner holds a different
@@ -10,7 +10,6 @@ import os
 import socket
 import subprocess
 import sys
-from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 import pytest
@@ -27,56 +26,34 @@ def _free_port():
         return sk.getsockname()[1]
 
 
-def _contexts(n):
-    ctxs = []
-    for _ in range(n):
-        cfg = L.default_config(L.ALGO_PPO)
-        cfg.local_num_envs, cfg.num_actor_slots, cfg.num_steps = 8, 1, 8
-        ctxs.append(L.Context(cfg))
-    blobs = [c.comm_native_export() for c in ctxs]
-    for r, c in enumerate(ctxs):
-        c.comm_native_init(blobs, r)
-        assert c.comm_backend() == "native" and c.comm_size() == n
-    return ctxs
-
-
 @pytest.mark.parametrize("n", [2, 3, 5])
-def test_native_allreduce_is_the_rank_ordered_sum(n):
-    ctxs = _contexts(n)
-    try:
-        P = ctxs[0].P
-        rng = np.random.default_rng(n)
-        g = [(rng.normal(size=P) * 10.0 ** rng.integers(-6, 2, P)).astype(np.float32) for _ in range(n)]
-        want = g[0].copy()
-        for r in range(1, n):
-            want = want + g[r]
-        for rep in range(3):       # the flags only grow: repeated collectives on the same signal blocks
-            for c, x in zip(ctxs, g):
-                c.write("grads", x)
-            divs = [c.learner_allreduce_grads() for c in ctxs]      # enqueues tail + head on each context's communication stream
-            for c in ctxs:
-                c.sync()
-            assert divs == [float(n)] * n
-            for r, c in enumerate(ctxs):
-                got = c.read("grads", np.float32)
-                assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (rep, r, np.abs(got - want).max())
-        # the small one-shot form: sum / max / min of host doubles (blocking per rank: one thread per rank)
-        vals = [rng.normal(size=5) for _ in range(n)]
-        with ThreadPoolExecutor(n) as pool:
-            for op, ref in (("sum", np.sum), ("max", np.max), ("min", np.min)):
-                outs = list(pool.map(lambda rc: rc[1].comm_allreduce_f64(vals[rc[0]], op), enumerate(ctxs)))
-                if op == "sum":
-                    w = vals[0].copy()
-                    for r in range(1, n):
-                        w = w + vals[r]
-                else:
-                    w = ref(np.stack(vals), axis=0)
-                for o in outs:
-                    assert np.array_equal(o, w), (op, o, w)
-            list(pool.map(lambda c: c.comm_barrier(), ctxs))
-    finally:
-        for c in ctxs:
-            c.close()
+def test_native_allreduce_is_the_rank_ordered_sum(tmp_path, n):
+    """n rank processes on GPU 0 with DIFFERENT data: after the overlapped tail / head pair every rank holds ((g0 + g1) + g2) ... bit for bit."""
+    port = _free_port()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", CBM_NATIVE_TIMEOUT_S="60")
+    outs = [os.path.join(str(tmp_path), f"r{r}.npz") for r in range(n)]
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "native_comm_worker.py"), str(r), str(n), str(port), outs[r]], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(n)]
+    logs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    for p in procs:
+        assert p.returncode == 0, "\n=====\n".join(lg[-2000:] for lg in logs)
+    got = [np.load(o) for o in outs]
+    P = got[0]["g0"].size
+    for rep in range(3):
+        want = None
+        for r in range(n):
+            rng = np.random.default_rng(1000 * rep + r)
+            g = (rng.normal(size=P) * 10.0 ** rng.integers(-6, 2, P)).astype(np.float32)
+            want = g if want is None else want + g
+        for r in range(n):
+            assert np.array_equal(got[r][f"g{rep}"].view(np.uint32), want.view(np.uint32)), (rep, r, np.abs(got[r][f"g{rep}"] - want).max())
+    vals = [np.random.default_rng(77 + r).normal(size=5) for r in range(n)]
+    wsum = vals[0].copy()
+    for r in range(1, n):
+        wsum = wsum + vals[r]
+    for r in range(n):
+        assert np.array_equal(got[r]["sum"], wsum)
+        assert np.array_equal(got[r]["max"], np.max(np.stack(vals), axis=0)) and np.array_equal(got[r]["min"], np.min(np.stack(vals), axis=0))
 
 
 def test_native_allreduce_dead_peer_times_out_with_an_error():
