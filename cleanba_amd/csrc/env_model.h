@@ -158,23 +158,32 @@ CBM_HD uint32_t env_word(const cbm_env_state* s, const EnvGame& gm, int i) {
   return (x == 0 ? 142u : 0u) | (x == 80 ? 142u << 24 : 0u);       // side walls at x = 0 and x = 83
 }
 
-// ---- one env's step by one 256-thread block, split so that almost all of it runs BEFORE the action exists (the per-frame actor tail samples
-// the action at the very end of its block):
+// ---- one env's step by one 256-thread block, arranged so that almost nothing is left to do once the action exists (the per-frame actor tail
+// samples the action at the very end of its block):
+//   env_step_prefetch    every thread requests its seven words of the three planes that survive the shift (they do not depend on anything)
 //   env_step_candidates  three threads: the action acts on the env only through the paddle direction (action % n_actions) % 3, so the three
 //                        possible transitions (state, reward, done, ...) are computed up front                      [needs a barrier after]
-//   env_step_early       `nt` threads: the stack shift (three older planes; four copies of the new plane after a reset) and the new plane
-//                        except its two paddle rows, painted from candidate 0 with the pre-step bricks — ball, scenery and walls do not
-//                        depend on the action, and a brick changes only on a reward (2 % of the steps)
+//   env_step_early       the shifted stack is stored, and the NEW plane is the previous newest plane with the ball moved: only the words under
+//                        the old and the new 2x2 ball are repainted (env_word); scenery, walls and top bar never change, the paddle rows are
+//                        left to the finish, and a brick goes only on a reward (2 % of the steps).  After a reset: four copies of a full repaint
 //   env_step_finish      after the action: pick the candidate, publish state / reward / done, paint the 42 words of the paddle rows, repaint
-//                        the brick rows if a brick went.  Same bytes as painting everything afterwards (tests/test_env.py, test_gpu_e2e.py)
+//                        the brick rows if a brick went.  Same bytes as painting every pixel afterwards (tests/test_env.py, test_gpu_e2e.py)
 struct EnvStepArgs {
   uint32_t seed; int32_t max_steps; cbm_env_state* st; const uint8_t* obs_prev; uint8_t* obs_next; float* reward; uint8_t* done_next;
   uint8_t* firststep_next;   // obs_next == nullptr: no env step
 };
 struct EnvCand { cbm_env_state s; EnvOut out; };
-struct EnvShared { EnvCand cand[3]; cbm_env_state pre; EnvGame gm; int32_t reset; };   // lives in LDS: the brick words are indexed dynamically
+struct EnvShared { EnvCand cand[3]; cbm_env_state pre; EnvGame gm; int32_t reset, old_ball_x, old_ball_y; };   // lives in LDS: the brick words are indexed dynamically
 #if defined(__HIPCC__)
 #define ENV_PLANE_WORDS 1764
+static __device__ __forceinline__ void env_step_prefetch(const EnvStepArgs& a, int e, int t, int nt, uint32_t (&older)[7][3]) {
+  const uint32_t* p32 = reinterpret_cast<const uint32_t*>(a.obs_prev + (size_t)e * CBM_FRAME);
+#pragma unroll
+  for (int j = 0; j < 7; ++j) {
+    const int i = min(t + nt * j, ENV_PLANE_WORDS - 1);
+    older[j][0] = p32[ENV_PLANE_WORDS + i]; older[j][1] = p32[2 * ENV_PLANE_WORDS + i]; older[j][2] = p32[3 * ENV_PLANE_WORDS + i];
+  }
+}
 // (s = a.st[e], loaded by the caller: the actor tail requests it before its other loads so that this arithmetic runs under their latency)
 static __device__ __forceinline__ void env_step_candidates(const EnvStepArgs& a, int e, EnvShared& sh, int t, const cbm_env_state& s) {
   cbm_env_state* c = &sh.cand[t].s;
@@ -183,41 +192,40 @@ static __device__ __forceinline__ void env_step_candidates(const EnvStepArgs& a,
   if (t == 0) {
     sh.gm = env_game(s.game);
     sh.reset = s.needs_reset;
+    sh.old_ball_x = s.ball_x; sh.old_ball_y = s.ball_y;
     // what the early paint shows: candidate 0's ball / episode (the same in all three), and the bricks as they stand BEFORE the step — a reset
     // starts from the new episode's full wall, otherwise nothing has gone yet
     sh.pre = *c;
     if (!s.needs_reset) { sh.pre.bricks[0] = s.bricks[0]; sh.pre.bricks[1] = s.bricks[1]; sh.pre.bricks[2] = s.bricks[2]; }
   }
 }
-static __device__ __forceinline__ void env_step_early(const EnvStepArgs& a, int e, const EnvShared& sh, int t, int nt) {
+static __device__ __forceinline__ void env_step_early(const EnvStepArgs& a, int e, const EnvShared& sh, int t, int nt, const uint32_t (&older)[7][3]) {
   const cbm_env_state* pre = &sh.pre;
   const EnvGame gm = sh.gm;
-  const bool rs = sh.reset != 0;
-  const uint32_t* p32 = reinterpret_cast<const uint32_t*>(a.obs_prev + (size_t)e * CBM_FRAME);
   uint32_t* o32 = reinterpret_cast<uint32_t*>(a.obs_next + (size_t)e * CBM_FRAME);
-  for (int i0 = t; i0 < ENV_PLANE_WORDS; i0 += 7 * nt) {       // seven words per thread and pass: their 21 loads are in flight together
-    uint32_t older[7][3];
-    if (!rs) {
-#pragma unroll
-      for (int j = 0; j < 7; ++j) {
-        const int i = min(i0 + j * nt, ENV_PLANE_WORDS - 1);
-        older[j][0] = p32[ENV_PLANE_WORDS + i]; older[j][1] = p32[2 * ENV_PLANE_WORDS + i]; older[j][2] = p32[3 * ENV_PLANE_WORDS + i];
-      }
+  if (sh.reset) {   // new episode (about one step in 800): the stack is four copies of the first frame; its paddle rows come from the finish
+#pragma unroll 1
+    for (int i = t; i < ENV_PLANE_WORDS; i += nt) {
+      if (i >= 78 * 21 && i < 80 * 21) continue;
+      const uint32_t nw = env_word(pre, gm, i);
+      o32[i] = nw; o32[ENV_PLANE_WORDS + i] = nw; o32[2 * ENV_PLANE_WORDS + i] = nw; o32[3 * ENV_PLANE_WORDS + i] = nw;
     }
+    return;
+  }
 #pragma unroll
-    for (int j = 0; j < 7; ++j) {
-      const int i = i0 + j * nt;
-      if (i < ENV_PLANE_WORDS) {
-        const bool paddle_row = i >= 78 * 21 && i < 80 * 21;
-        const uint32_t nw = paddle_row ? 0u : env_word(pre, gm, i);
-        if (rs) {
-          if (!paddle_row) { o32[i] = nw; o32[ENV_PLANE_WORDS + i] = nw; o32[2 * ENV_PLANE_WORDS + i] = nw; }
-        } else {
-          o32[i] = older[j][0]; o32[ENV_PLANE_WORDS + i] = older[j][1]; o32[2 * ENV_PLANE_WORDS + i] = older[j][2];
-        }
-        if (!paddle_row) o32[3 * ENV_PLANE_WORDS + i] = nw;
-      }
+  for (int j = 0; j < 7; ++j) {
+    const int i = t + nt * j;
+    if (i < ENV_PLANE_WORDS) {
+      o32[i] = older[j][0]; o32[ENV_PLANE_WORDS + i] = older[j][1]; o32[2 * ENV_PLANE_WORDS + i] = older[j][2];
+      if (!(i >= 78 * 21 && i < 80 * 21)) o32[3 * ENV_PLANE_WORDS + i] = older[j][2];     // the new plane starts as the previous newest one ...
     }
+  }
+  // ... and the (at most eight) words under the old and the new 2x2 ball are repainted, each by the thread that stored it above (program order)
+#pragma unroll 1
+  for (int k = 0; k < 8; ++k) {
+    const int bx = k < 4 ? sh.old_ball_x : pre->ball_x, by = k < 4 ? sh.old_ball_y : pre->ball_y;
+    const int r = by + ((k >> 1) & 1), wx = (bx >> 2) + (k & 1), i = r * 21 + wx;
+    if (r < 84 && wx < 21 && wx <= ((bx + 1) >> 2) && !(r >= 78 && r < 80) && i % nt == t) o32[3 * ENV_PLANE_WORDS + i] = env_word(pre, gm, i);
   }
 }
 // t / nt: the SAME thread numbering env_step_early ran with (a word is re-stored by the thread that stored it first: program order, no fence);

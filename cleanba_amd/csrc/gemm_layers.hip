@@ -329,14 +329,17 @@ __global__ __launch_bounds__(256) void actor_tail_rows_kernel(const float* part,
   __shared__ float lg[32];
   const int tid = threadIdx.x, b = blockIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, g4 = lane >> 4;
   const size_t MN = (size_t)B * HD;
-  // device env: this block also steps env b with the action it samples.  Almost all of that step does not need the action (env_model.h): waves 2 / 3,
-  // idle while waves 0 / 1 run the heads' MFMA chain and the sampling, shift the frame stack and paint the new plane meanwhile; what is left
-  // after the action is the choice among three precomputed transitions and the 42 words of the paddle rows
+  // device env: this block also steps env b with the action it samples.  Almost all of that step does not need the action (env_model.h): the planes
+  // that survive the shift are requested now, the three transitions an action can cause are computed under the load latency, the shifted stack
+  // and the new plane (= the previous newest plane with the ball moved) are stored before the heads' MFMA chain; what is left after the action is
+  // the choice among the three transitions and the 42 words of the paddle rows
   const EnvStepArgs ea{smp.env_seed, smp.env_max_steps, smp.env_st, smp.env_obs_prev, smp.env_obs_next, smp.env_reward, smp.env_done_next,
                        smp.env_firststep_next};
   const bool env_cand = ea.obs_next && tid >= 128 && tid < 131;
   cbm_env_state env_s0;
   if (env_cand) env_s0 = ea.st[b];
+  uint32_t older[7][3];
+  if (ea.obs_next) env_step_prefetch(ea, b, tid, 256, older);
   // all partial slices of this thread's hidden units (HD / 256 of them: k = tid, tid + 256) are requested at once (S <= 16), then added in slice order
   constexpr int NU = HD / 256;
   static_assert(HD % 256 == 0 && NU >= 1 && NU <= 2, "hidden width 256 or 512");
@@ -370,6 +373,7 @@ __global__ __launch_bounds__(256) void actor_tail_rows_kernel(const float* part,
     hsT[(k & 3) * (HD / 4) + (k >> 2)] = relu(t0 + bd[k]);
   }
   __syncthreads();
+  if (ea.obs_next) env_step_early(ea, b, env_sh, tid, 256, older);
   if (wave < 2) {
     f32x4_mfma acc = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
@@ -381,8 +385,6 @@ __global__ __launch_bounds__(256) void actor_tail_rows_kernel(const float* part,
       acc = __builtin_amdgcn_mfma_f32_16x16x4f32(h4.w, bw[4 * q + 3], acc, 0, 0, 0);
     }
     if (g4 == 0 && n <= A) lg[n] = acc[0] + (n < A ? ba[n] : bc[0]);   // D: lane (g4 = 0, r16) element 0 = row 0, column r16
-  } else if (ea.obs_next) {
-    env_step_early(ea, b, env_sh, tid - 128, 128);
   }
   __syncthreads();
   if (tid < 32) {
@@ -417,7 +419,7 @@ __global__ __launch_bounds__(256) void actor_tail_rows_kernel(const float* part,
   }
   if (ea.obs_next) {
     __syncthreads();
-    if (tid >= 128) env_step_finish(ea, b, env_sh, act_s, tid - 128, 128);
+    env_step_finish(ea, b, env_sh, act_s, tid, 256);
   }
 }
 static void launch_heads_fwd(const float* hid, const float* Wa, const float* ba, const float* Wc, const float* bc, int B, int A, int HD,

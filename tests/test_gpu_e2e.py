@@ -245,6 +245,44 @@ def test_atari57_mix_device_env_matches_host_twin():
     ctx.close()
 
 
+@pytest.mark.parametrize("ksplit", [14, 49])
+def test_device_env_long_rollout_matches_host_twin_through_rewards_and_resets(ksplit):
+    """The device env steps in pieces around the action (env_model.h: three precomputed transitions, the new plane = the previous one with the ball
+    moved, paddle rows and changed bricks after the action).  300 steps of 114 envs (two of each preset) see dozens of rewards, brick changes and
+    episode resets; every byte of every stack must equal the host twin's, which paints whole planes.  ksplit = 14: the env step fused into the
+    per-frame actor tail; 49: the stand-alone env_step_kernel."""
+    E, T = 114, 300
+    cfg = L.default_config(L.ALGO_PPO)
+    cfg.local_num_envs, cfg.num_actor_slots, cfg.num_steps, cfg.num_minibatches, cfg.ring_depth, cfg.actor_dense_ksplit = E, 1, T, 6, 2, ksplit
+    ctx = L.Context(cfg)
+    try:
+        key, params = _init(5)
+        ctx.set_params(params)
+        ctx.actor_set_key(0, key)
+        ctx.actor_env_reset_device(0, 23, atari57_mix=True)
+        ctx.actor_begin_rollout(0, False)
+        ctx.actor_rollout_device(0, T)
+        ctx.actor_commit(0)
+        ctx.learner_wait()
+        obs = ctx.read("obs", np.uint8).reshape(T + 1, E, 4, 84, 84)
+        actions = ctx.read("actions", np.int32).reshape(T + 1, E)[:T]
+        rewards = ctx.read("rewards", np.float32).reshape(T + 1, E)[:T]
+        dones = ctx.read("dones", np.uint8).reshape(T + 1, E)
+        st, o = L.synth_env_reset_host(23, E, atari57_mix=True)
+        n_done = n_reward = 0
+        for t in range(T):
+            assert (o == obs[t]).all(), f"frames differ at t={t}: envs {np.nonzero((o != obs[t]).reshape(E, -1).any(axis=1))[0][:8]}"
+            r, d, _, _ = L.synth_env_step_host(23, st, o, actions[t])
+            assert (r == rewards[t]).all() and (d == dones[t + 1]).all(), t
+            n_done += int(d.sum())
+            n_reward += int((r > 0).sum())
+        assert (o == obs[T]).all()
+        print(f"device env vs host twin: {n_reward} rewards, {n_done} episode ends in {E * T} env-steps")
+        assert n_done >= 5 and n_reward >= 100
+    finally:
+        ctx.close()
+
+
 @pytest.mark.parametrize("algo", ["ppo", "impala"])
 def test_gradient_accumulation_update_matches_oracle(oracle, algo):
     # optax.MultiSteps(every_k_schedule=2): the library's fused update vs the oracle-backed engine replaying the same ring

@@ -79,7 +79,7 @@ try:
 except RuntimeError as e:
     assert "timed out" in str(e), e
     assert 1.0 < time.time() - t0 < 30.0, time.time() - t0
-    print("TIMEOUT-REPORTED")
+    print("TIMEOUT-REPORTED", flush=True)
 else:
     raise SystemExit("a collective without its peer completed")
 os._exit(0)
