@@ -53,12 +53,16 @@ __global__ __launch_bounds__(256) void env_step_kernel(uint32_t seed, int E, int
   const EnvStepArgs a{seed, max_steps, st, obs_prev, obs_next, reward, done_next, firststep_next};
   const int e = blockIdx.x, tid = threadIdx.x;
   __shared__ EnvShared sh;
-  uint32_t older[7][3];
-  env_step_prefetch(a, e, tid, 256, older);
-  if (tid < 3) env_step_candidates(a, e, sh, tid, st[e]);
+  EnvPieces<256> pc;
+  env_step_prefetch<256>(a, e, tid, pc);
+  if (tid < 3) {
+    uint32_t sw[ENV_STATE_WORDS];
+    env_state_load_words(st, e, sw);
+    env_step_candidates(a, e, sh, tid, sw);
+  }
   __syncthreads();
-  env_step_early(a, e, sh, tid, 256, older);
-  env_step_finish(a, e, sh, actions[e], tid, 256);
+  env_step_early<256>(a, e, sh, tid, pc);
+  env_step_finish<256>(a, e, sh, env_action_dir(sh, actions[e]), tid, pc);
 }
 void launch_env_step(uint32_t seed, int E, int max_episode_steps, const int32_t* actions, cbm_env_state* st_dev, const uint8_t* obs_prev,
                      uint8_t* obs_next, float* reward, uint8_t* done_next, uint8_t* firststep_next, hipStream_t st) {

@@ -176,82 +176,164 @@ struct EnvCand { cbm_env_state s; EnvOut out; };
 struct EnvShared { EnvCand cand[3]; cbm_env_state pre; EnvGame gm; int32_t reset, old_ball_x, old_ball_y; };   // lives in LDS: the brick words are indexed dynamically
 #if defined(__HIPCC__)
 #define ENV_PLANE_WORDS 1764
-static __device__ __forceinline__ void env_step_prefetch(const EnvStepArgs& a, int e, int t, int nt, uint32_t (&older)[7][3]) {
-  const uint32_t* p32 = reinterpret_cast<const uint32_t*>(a.obs_prev + (size_t)e * CBM_FRAME);
+// (a native vector type: HIP's uint4 is a struct whose copies between memory spaces are memcpys through a private array the compiler then
+// moves to LDS — see env_step_candidates)
+typedef unsigned int env_u32x4 __attribute__((ext_vector_type(4)));
+#define ENV_PLANE_Q 441        // 16-byte pieces of a plane (a frame stack is 4 x 441 of them, 16-byte aligned in the ring)
+// NT threads work on the planes; thread t owns pieces t, t + NT, ... of every plane (NJ = ceil(441 / NT) of them)
+template <int NT> struct EnvPieces { static constexpr int NJ = (ENV_PLANE_Q + NT - 1) / NT; env_u32x4 older[NJ][3], nw[NJ]; };
+template <int NT>
+static __device__ __forceinline__ void env_step_prefetch(const EnvStepArgs& a, int e, int t, EnvPieces<NT>& pc) {
+  const env_u32x4* p = reinterpret_cast<const env_u32x4*>(a.obs_prev + (size_t)e * CBM_FRAME);
 #pragma unroll
-  for (int j = 0; j < 7; ++j) {
-    const int i = min(t + nt * j, ENV_PLANE_WORDS - 1);
-    older[j][0] = p32[ENV_PLANE_WORDS + i]; older[j][1] = p32[2 * ENV_PLANE_WORDS + i]; older[j][2] = p32[3 * ENV_PLANE_WORDS + i];
+  for (int j = 0; j < EnvPieces<NT>::NJ; ++j) {
+    const int i = min(t + NT * j, ENV_PLANE_Q - 1);
+    pc.older[j][0] = p[ENV_PLANE_Q + i]; pc.older[j][1] = p[2 * ENV_PLANE_Q + i]; pc.older[j][2] = p[3 * ENV_PLANE_Q + i];
   }
 }
-// (s = a.st[e], loaded by the caller: the actor tail requests it before its other loads so that this arithmetic runs under their latency)
-static __device__ __forceinline__ void env_step_candidates(const EnvStepArgs& a, int e, EnvShared& sh, int t, const cbm_env_state& s) {
+static __device__ __forceinline__ void env_q_set(env_u32x4& v, int c, uint32_t x) {
+  v.x = c == 0 ? x : v.x; v.y = c == 1 ? x : v.y; v.z = c == 2 ? x : v.z; v.w = c == 3 ? x : v.w;
+}
+static __device__ __forceinline__ bool env_paddle_word(int i) { return i >= 78 * 21 && i < 80 * 21; }
+// a word of the two paddle rows (y = 78, 79): nothing but the paddle and the side walls can be there (the ball stays above row 77, the scenery
+// above row 76) — env_pixel's bytes without its case analysis
+static __device__ __forceinline__ uint32_t env_paddle_row_word(int paddle_x, int paddle_w, int i) {
+  const int y = i / 21, x = 4 * (i - 21 * y);
+  uint32_t w = 0u;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int xx = x + p;
+    const uint32_t v = (xx >= paddle_x && xx < paddle_x + paddle_w) ? 200u : ((xx == 0 || xx == 83) ? 142u : 0u);
+    w |= v << (8 * p);
+  }
+  return w;
+}
+// The state travels as 16 plain words (sw = the words of a.st[e], loaded by the caller: the actor tail requests them before its other loads so that
+// this arithmetic runs under their latency).  No struct lives in a thread's private memory here — the brick words are indexed dynamically, and a
+// private array with dynamic indices is moved to LDS by the compiler, which then reads the dispatch packet for the block shape at kernel entry
+// (a host-memory round trip: 9 us per launch when it was measured)
+#define ENV_STATE_WORDS 16
+static_assert(sizeof(cbm_env_state) == 4 * ENV_STATE_WORDS, "cbm_env_state is 16 words");
+static __device__ __forceinline__ void env_state_load_words(const cbm_env_state* st, int e, uint32_t (&sw)[ENV_STATE_WORDS]) {
+  const env_u32x4* p = reinterpret_cast<const env_u32x4*>(st + e);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { const env_u32x4 v = p[q]; sw[4 * q] = v.x; sw[4 * q + 1] = v.y; sw[4 * q + 2] = v.z; sw[4 * q + 3] = v.w; }
+}
+static __device__ __forceinline__ void env_step_candidates(const EnvStepArgs& a, int e, EnvShared& sh, int t, const uint32_t (&sw)[ENV_STATE_WORDS]) {
   cbm_env_state* c = &sh.cand[t].s;
-  *c = s;
+  uint32_t* cw = reinterpret_cast<uint32_t*>(c);
+#pragma unroll
+  for (int i = 0; i < ENV_STATE_WORDS; ++i) cw[i] = sw[i];
+  const int was_reset = c->needs_reset, obx = c->ball_x, oby = c->ball_y;
+  const uint32_t b0 = c->bricks[0], b1 = c->bricks[1], b2 = c->bricks[2];
+  if (t == 0) sh.gm = env_game(c->game);
   sh.cand[t].out = env_transition(c, a.seed, (uint32_t)e, t, a.max_steps);   // action = t: every preset has >= 4 actions, so its direction is t
   if (t == 0) {
-    sh.gm = env_game(s.game);
-    sh.reset = s.needs_reset;
-    sh.old_ball_x = s.ball_x; sh.old_ball_y = s.ball_y;
+    sh.reset = was_reset;
+    sh.old_ball_x = obx; sh.old_ball_y = oby;
     // what the early paint shows: candidate 0's ball / episode (the same in all three), and the bricks as they stand BEFORE the step — a reset
     // starts from the new episode's full wall, otherwise nothing has gone yet
-    sh.pre = *c;
-    if (!s.needs_reset) { sh.pre.bricks[0] = s.bricks[0]; sh.pre.bricks[1] = s.bricks[1]; sh.pre.bricks[2] = s.bricks[2]; }
+    uint32_t* pw = reinterpret_cast<uint32_t*>(&sh.pre);
+#pragma unroll
+    for (int i = 0; i < ENV_STATE_WORDS; ++i) pw[i] = cw[i];
+    if (!was_reset) { sh.pre.bricks[0] = b0; sh.pre.bricks[1] = b1; sh.pre.bricks[2] = b2; }
   }
 }
-static __device__ __forceinline__ void env_step_early(const EnvStepArgs& a, int e, const EnvShared& sh, int t, int nt, const uint32_t (&older)[7][3]) {
+// The new plane's pieces stay in registers (pc.nw) for the finish: a piece is re-stored by the thread that stored it first (program order, no fence).
+template <int NT>
+static __device__ __forceinline__ void env_step_early(const EnvStepArgs& a, int e, const EnvShared& sh, int t, EnvPieces<NT>& pc) {
+  constexpr int NJ = EnvPieces<NT>::NJ;
   const cbm_env_state* pre = &sh.pre;
-  const EnvGame gm = sh.gm;
-  uint32_t* o32 = reinterpret_cast<uint32_t*>(a.obs_next + (size_t)e * CBM_FRAME);
+  const EnvGame& gm = sh.gm;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) pc.nw[j] = pc.older[j][2];      // the new plane starts as the previous newest one ...
   if (sh.reset) {   // new episode (about one step in 800): the stack is four copies of the first frame; its paddle rows come from the finish
+    uint32_t* o32 = reinterpret_cast<uint32_t*>(a.obs_next + (size_t)e * CBM_FRAME);
 #pragma unroll 1
-    for (int i = t; i < ENV_PLANE_WORDS; i += nt) {
-      if (i >= 78 * 21 && i < 80 * 21) continue;
-      const uint32_t nw = env_word(pre, gm, i);
-      o32[i] = nw; o32[ENV_PLANE_WORDS + i] = nw; o32[2 * ENV_PLANE_WORDS + i] = nw; o32[3 * ENV_PLANE_WORDS + i] = nw;
+    for (int i = t; i < ENV_PLANE_WORDS; i += NT) {
+      if (env_paddle_word(i)) continue;
+      const uint32_t w = env_word(pre, gm, i);
+      o32[i] = w; o32[ENV_PLANE_WORDS + i] = w; o32[2 * ENV_PLANE_WORDS + i] = w; o32[3 * ENV_PLANE_WORDS + i] = w;
     }
     return;
   }
+  env_u32x4* o4 = reinterpret_cast<env_u32x4*>(a.obs_next + (size_t)e * CBM_FRAME);
 #pragma unroll
-  for (int j = 0; j < 7; ++j) {
-    const int i = t + nt * j;
-    if (i < ENV_PLANE_WORDS) {
-      o32[i] = older[j][0]; o32[ENV_PLANE_WORDS + i] = older[j][1]; o32[2 * ENV_PLANE_WORDS + i] = older[j][2];
-      if (!(i >= 78 * 21 && i < 80 * 21)) o32[3 * ENV_PLANE_WORDS + i] = older[j][2];     // the new plane starts as the previous newest one ...
-    }
+  for (int j = 0; j < NJ; ++j) {
+    const int i4 = t + NT * j;
+    if (i4 < ENV_PLANE_Q) { o4[i4] = pc.older[j][0]; o4[ENV_PLANE_Q + i4] = pc.older[j][1]; o4[2 * ENV_PLANE_Q + i4] = pc.older[j][2]; }
   }
-  // ... and the (at most eight) words under the old and the new 2x2 ball are repainted, each by the thread that stored it above (program order)
+  // ... with the (at most eight) words under the old and the new 2x2 ball repainted
+  const int obx = sh.old_ball_x, oby = sh.old_ball_y, nbx = pre->ball_x, nby = pre->ball_y;
 #pragma unroll 1
   for (int k = 0; k < 8; ++k) {
-    const int bx = k < 4 ? sh.old_ball_x : pre->ball_x, by = k < 4 ? sh.old_ball_y : pre->ball_y;
-    const int r = by + ((k >> 1) & 1), wx = (bx >> 2) + (k & 1), i = r * 21 + wx;
-    if (r < 84 && wx < 21 && wx <= ((bx + 1) >> 2) && !(r >= 78 && r < 80) && i % nt == t) o32[3 * ENV_PLANE_WORDS + i] = env_word(pre, gm, i);
+    const int bx = k < 4 ? obx : nbx, by = k < 4 ? oby : nby;
+    const int r = by + ((k >> 1) & 1), wx = (bx >> 2) + (k & 1), i = r * 21 + wx, i4 = i >> 2;
+    if (r < 84 && wx < 21 && wx <= ((bx + 1) >> 2) && !env_paddle_word(i)) {
+      bool mine = false;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) mine = mine || i4 == t + NT * j;
+      if (mine) {
+        const uint32_t w = env_word(pre, gm, i);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+          if (i4 == t + NT * j) env_q_set(pc.nw[j], i & 3, w);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int i4 = t + NT * j;
+    if (i4 < ENV_PLANE_Q) o4[3 * ENV_PLANE_Q + i4] = pc.nw[j];   // (paddle-row words are still the previous step's: the finish re-stores those pieces)
   }
 }
-// t / nt: the SAME thread numbering env_step_early ran with (a word is re-stored by the thread that stored it first: program order, no fence);
-// the paddle rows, which nobody has stored yet, go to the first 42 of those threads
-static __device__ __forceinline__ void env_step_finish(const EnvStepArgs& a, int e, const EnvShared& sh, int32_t action, int t, int nt) {
-  const EnvGame gm = sh.gm;
-  const int dir = (action % gm.n_actions) % 3;
+// the paddle direction of an action (the only way it acts on the env): what indexes the three candidates
+static __device__ __forceinline__ int env_action_dir(const EnvShared& sh, int32_t action) { return (action % sh.gm.n_actions) % 3; }
+template <int NT>
+static __device__ __forceinline__ void env_step_finish(const EnvStepArgs& a, int e, const EnvShared& sh, int dir, int t, EnvPieces<NT>& pc) {
+  constexpr int NJ = EnvPieces<NT>::NJ;
+  const EnvGame& gm = sh.gm;
   const cbm_env_state* s = &sh.cand[dir].s;
-  const bool rs = sh.reset != 0;
   if (t == 0) {
     const EnvOut out = sh.cand[dir].out;
-    a.st[e] = *s;
+    const env_u32x4* sw4 = reinterpret_cast<const env_u32x4*>(s);
+    env_u32x4* dst4 = reinterpret_cast<env_u32x4*>(a.st + e);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dst4[q] = sw4[q];
     a.reward[e] = out.reward;
     a.done_next[e] = out.done;
     if (a.firststep_next) a.firststep_next[e] = out.firststep;
   }
-  uint32_t* o32 = reinterpret_cast<uint32_t*>(a.obs_next + (size_t)e * CBM_FRAME);
-  if (t < 42) {
-    const int i = 78 * 21 + t;
-    const uint32_t nw = env_word(s, gm, i);
-    if (rs) { o32[i] = nw; o32[ENV_PLANE_WORDS + i] = nw; o32[2 * ENV_PLANE_WORDS + i] = nw; }
-    o32[3 * ENV_PLANE_WORDS + i] = nw;
+  if (sh.reset) {   // the paddle rows of all four copies (nothing else can have changed: a reset step ignores the action)
+    uint32_t* o32 = reinterpret_cast<uint32_t*>(a.obs_next + (size_t)e * CBM_FRAME);
+    if (t < 42) {
+      const int i = 78 * 21 + t;
+      const uint32_t w = env_paddle_row_word(s->paddle_x, gm.paddle_w, i);
+      o32[i] = w; o32[ENV_PLANE_WORDS + i] = w; o32[2 * ENV_PLANE_WORDS + i] = w; o32[3 * ENV_PLANE_WORDS + i] = w;
+    }
+    return;
   }
-  if (s->bricks[0] != sh.pre.bricks[0] || s->bricks[1] != sh.pre.bricks[1] || s->bricks[2] != sh.pre.bricks[2]) {   // block-uniform
-    for (int i = t; i < 35 * 21; i += nt)
-      if (i >= 17 * 21) o32[3 * ENV_PLANE_WORDS + i] = env_word(s, gm, i);
+  const bool bricks = s->bricks[0] != sh.pre.bricks[0] || s->bricks[1] != sh.pre.bricks[1] || s->bricks[2] != sh.pre.bricks[2];   // block-uniform
+  env_u32x4* o4 = reinterpret_cast<env_u32x4*>(a.obs_next + (size_t)e * CBM_FRAME);
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int i4 = t + NT * j, lo = 4 * i4;
+    if (i4 >= ENV_PLANE_Q) continue;
+    bool hit = false;
+    if (lo + 3 >= 78 * 21 && lo < 80 * 21) {                       // pieces 409 .. 419
+      hit = true;
+      const int px = s->paddle_x, pw = gm.paddle_w;
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (env_paddle_word(lo + c)) env_q_set(pc.nw[j], c, env_paddle_row_word(px, pw, lo + c));
+    }
+    if (bricks && lo + 3 >= 17 * 21 && lo < 35 * 21) {            // a reward took a brick (2 % of the steps): the brick rows again
+      hit = true;
+#pragma unroll 1
+      for (int c = 0; c < 4; ++c)
+        if (lo + c >= 17 * 21 && lo + c < 35 * 21) env_q_set(pc.nw[j], c, env_word(s, gm, lo + c));
+    }
+    if (hit) o4[3 * ENV_PLANE_Q + i4] = pc.nw[j];
   }
 }
 #endif

@@ -319,27 +319,41 @@ __global__ __launch_bounds__(256) void actor_tail_kernel(const float* hid, const
 // sums its two hidden units over the S partial slices in slice order (dense_reduce_kernel's chain), the A + 1 head outputs are 512-long
 // k-ascending fmaf chains on A + 1 lanes (bitwise the MFMA's chain: DESIGN 3) fed from LDS, and the frame's 32 sampling lanes run
 // sample_kernel's code.  hid never reaches HBM.
+// timing build only (tools/variants.sh tailtrace "-DCBM_TAIL_TRACE"): shader-clock stamps of block 0's four waves at the phase boundaries of the tail
+#ifdef CBM_TAIL_TRACE
+__device__ unsigned long long cbm_tail_trace[4][16];
+extern "C" int cbm_debug_tail_trace(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(cbm_tail_trace), sizeof(cbm_tail_trace)) == hipSuccess ? 0 : -1; }
+#define TT(k) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) cbm_tail_trace[threadIdx.x >> 6][k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define TT(k) do { } while (0)
+#endif
 template <int HD>
 __global__ __launch_bounds__(256) void actor_tail_rows_kernel(const float* part, const float* bd, int S, const float* Wa, const float* ba, const float* Wc,
                                                               const float* bc, int B, int A, ActorSample smp) {
   __builtin_amdgcn_s_setprio(3);   // (see igemm_s16_kernel)
+  TT(0);
   __shared__ int act_s;
   __shared__ EnvShared env_sh;
   __shared__ __attribute__((aligned(16))) float hsT[HD];      // hid of this frame, stored as [k % 4][k / 4]: lane group g4 of a 16x16x4 MFMA reads its k = 4*st + g4 as consecutive floats
-  __shared__ float lg[32];
-  const int tid = threadIdx.x, b = blockIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, g4 = lane >> 4;
+  __shared__ __attribute__((aligned(16))) float wl[HD * 28];  // actor weights [HD][A] as they lie in memory (A <= 28)
+  __shared__ float wcl[HD];                                   // critic weights
+  __shared__ float lg[32], gum[32];
+  const int tid = threadIdx.x, b = blockIdx.x, lane = tid & 63, r16 = lane & 15, g4 = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const size_t MN = (size_t)B * HD;
-  // device env: this block also steps env b with the action it samples.  Almost all of that step does not need the action (env_model.h): the planes
-  // that survive the shift are requested now, the three transitions an action can cause are computed under the load latency, the shifted stack
-  // and the new plane (= the previous newest plane with the ball moved) are stored before the heads' MFMA chain; what is left after the action is
-  // the choice among the three transitions and the 42 words of the paddle rows
+  // device env: this block also steps env b with the action it samples.  Almost all of that step does not need the action (env_model.h) and runs on
+  // the waves the heads leave idle: the planes that survive the shift are requested now by waves 1-3 (16 bytes per load); wave 2 computes the three
+  // transitions an action can cause while waves 0 / 1 run the heads' MFMA chain; waves 1-3 store the shifted stack and the new plane (= the previous
+  // newest plane with the ball moved) while wave 0 samples; what is left after the action is the choice among the three transitions and the eleven
+  // pieces that hold the paddle rows
   const EnvStepArgs ea{smp.env_seed, smp.env_max_steps, smp.env_st, smp.env_obs_prev, smp.env_obs_next, smp.env_reward, smp.env_done_next,
                        smp.env_firststep_next};
   const bool env_cand = ea.obs_next && tid >= 128 && tid < 131;
-  cbm_env_state env_s0;
-  if (env_cand) env_s0 = ea.st[b];
-  uint32_t older[7][3];
-  if (ea.obs_next) env_step_prefetch(ea, b, tid, 256, older);
+  uint32_t env_s0[ENV_STATE_WORDS];
+  if (env_cand) env_state_load_words(ea.st, b, env_s0);
+  EnvPieces<192> env_pc;
+  if (ea.obs_next && wave >= 1) env_step_prefetch<192>(ea, b, tid - 64, env_pc);
+  TT(11);
   // all partial slices of this thread's hidden units (HD / 256 of them: k = tid, tid + 256) are requested at once (S <= 16), then added in slice order
   constexpr int NU = HD / 256;
   static_assert(HD % 256 == 0 && NU >= 1 && NU <= 2, "hidden width 256 or 512");
@@ -350,19 +364,22 @@ __global__ __launch_bounds__(256) void actor_tail_rows_kernel(const float* part,
 #pragma unroll
     for (int u = 0; u < NU; ++u) vv[u][s] = part[ss * MN + (size_t)b * HD + tid + 256 * u];
   }
-  // heads on v_mfma_f32_16x16x4_f32 with ONE live row (row 0 = this frame; the instruction's other 15 rows repeat it and are ignored): waves
-  // 0 / 1 own output columns 0-15 / 16-31 and take their B fragments (HD/4 floats per lane, L2-resident weights) straight into registers,
-  // requested together with the partial slices
-  const int n = wave * 16 + r16;
-  const bool on = wave < 2 && n <= A;
-  const float* wp = n < A ? Wa + n : Wc;
-  const int wstride = n < A ? A : 1;
-  float bw[HD / 4];
-  if (wave < 2) {
-#pragma unroll
-    for (int st = 0; st < HD / 4; ++st) bw[st] = on ? wp[(size_t)(4 * st + g4) * wstride] : 0.0f;
+  TT(12);
+  // head weights -> LDS by the load unit (global_load_lds: 1 KB per wave instruction, no registers): [HD][A] is HD / 256 * A instructions of 64 x 16 bytes,
+  // the critic column HD / 64 of 64 x 4 bytes.  (Held in registers as B fragments — 128 strided loads per lane on waves 0 / 1 — their ISSUE alone took
+  // 3.2 us of the block's 5 us load phase: in-kernel clock stamps, tools/tail_trace.py.)
+  {
+    const bool al16 = ((uintptr_t)Wa & 15) == 0;
+    if (al16) {
+      for (int q = wave; q < NU * A; q += 4) ig_glds16(Wa + (size_t)(64 * q + lane) * 4, wl + 64 * q * 4);
+    } else {
+      for (int i = tid; i < HD * A; i += 256) wl[i] = Wa[i];
+    }
+    for (int q = wave; q < HD / 64; q += 4)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Wc + 64 * q + lane), (__attribute__((address_space(3))) void*)(wcl + 64 * q), 4, 0, 0);
   }
-  if (env_cand) env_step_candidates(ea, b, env_sh, tid - 128, env_s0);   // (arithmetic on the first load issued: runs while the partials arrive)
+  TT(1);
+  TT(2);
 #pragma unroll
   for (int u = 0; u < NU; ++u) {
     float t0 = vv[u][0];
@@ -372,30 +389,57 @@ __global__ __launch_bounds__(256) void actor_tail_rows_kernel(const float* part,
     const int k = tid + 256 * u;
     hsT[(k & 3) * (HD / 4) + (k >> 2)] = relu(t0 + bd[k]);
   }
+  TT(3);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the load unit's LDS writes have landed (this wave's; the barrier makes it everybody's)
   __syncthreads();
-  if (ea.obs_next) env_step_early(ea, b, env_sh, tid, 256, older);
+  TT(4);
   if (wave < 2) {
+    // heads on v_mfma_f32_16x16x4_f32 with ONE live row (row 0 = this frame; the instruction's other 15 rows repeat it and are ignored): waves
+    // 0 / 1 own output columns 0-15 / 16-31; column n <= A is a 512-long k-ascending chain (bitwise the 16-row tail's and heads_fwd's: DESIGN 3).
+    // The B fragments come out of LDS in one sweep BEFORE the chain (read inside it, each MFMA waited for its own LDS round trip: 5.0 us against 2.4)
+    const int n = wave * 16 + r16;
+    // columns past A + 1 multiply whatever the critic column holds: their results are never read, and no lane needs a predicate around its reads
+    const float* wq = (n < A ? wl + n : wcl) + g4 * (n < A ? A : 1);
+    const int wstep = 4 * (n < A ? A : 1);
+    float bw[HD / 4];
+    float4 hq[HD / 16];
+    {
+      const float* wr = wq;      // (a running pointer: wq[st * wstep] is a quarter-rate v_mul_lo_u32 per read — 2 us for the 128 of them)
+#pragma unroll
+      for (int st = 0; st < HD / 4; ++st) { bw[st] = *wr; wr += wstep; }
+    }
+    TT(13);
+#pragma unroll
+    for (int q = 0; q < HD / 16; ++q) hq[q] = *reinterpret_cast<const float4*>(hsT + g4 * (HD / 4) + 4 * q);   // k = 4*(4q + i) + g4, i = 0..3
+    __builtin_amdgcn_sched_barrier(0);     // (every fragment is requested before the first MFMA: inside the chain each group of eight waited for its own LDS round trip)
+    TT(14);
     f32x4_mfma acc = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
     for (int q = 0; q < HD / 16; ++q) {
-      const float4 h4 = *reinterpret_cast<const float4*>(hsT + g4 * (HD / 4) + 4 * q);   // k = 4*(4q + i) + g4, i = 0..3
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(h4.x, bw[4 * q], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(h4.y, bw[4 * q + 1], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(h4.z, bw[4 * q + 2], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(h4.w, bw[4 * q + 3], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(hq[q].x, bw[4 * q], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(hq[q].y, bw[4 * q + 1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(hq[q].z, bw[4 * q + 2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(hq[q].w, bw[4 * q + 3], acc, 0, 0, 0);
     }
     if (g4 == 0 && n <= A) lg[n] = acc[0] + (n < A ? ba[n] : bc[0]);   // D: lane (g4 = 0, r16) element 0 = row 0, column r16
+    TT(6);
+  } else if (wave == 2) {
+    if (env_cand) env_step_candidates(ea, b, env_sh, tid - 128, env_s0);   // the three transitions an action can cause
+  } else if (lane < 32) {
+    // the Gumbel perturbation of every action: it depends on the key and the frame, not on the logits
+    const int aa = lane < A ? lane : A - 1;
+    const float u = cbm_bits_to_uniform(cbm_random_bits_at(smp.sk0, smp.sk1, (uint32_t)(B * A), (uint32_t)(b * A + aa)));
+    gum[lane] = cbm_logf(-cbm_logf(u));
   }
+  TT(5);
   __syncthreads();
+  TT(7);
   if (tid < 32) {
     const int a = tid;
     const bool live = a < A;
     const int aa = live ? a : A - 1;
-    const uint32_t nn = (uint32_t)(B * A);
-    const int bg = b;
     const float z = lg[aa];
-    const float u = cbm_bits_to_uniform(cbm_random_bits_at(smp.sk0, smp.sk1, nn, (uint32_t)(bg * A + aa)));
-    float g = live ? z - cbm_logf(-cbm_logf(u)) : -INFINITY;
+    float g = live ? z - gum[a] : -INFINITY;      // z - log(-log(u)): jax.random.categorical's Gumbel arg-max (ppo:256-259)
     if (live && smp.logits_out) smp.logits_out[(size_t)b * A + a] = z;
     int bi = a;
     float bv = g, mx = live ? z : -INFINITY;
@@ -408,19 +452,31 @@ __global__ __launch_bounds__(256) void actor_tail_rows_kernel(const float* part,
     }
     const float e = live ? cbm_expf(z - mx) : 0.0f;
     const float zb = __shfl(z, bi, 32);
+    float ej[28];
+#pragma unroll
+    for (int j = 0; j < 28; ++j) ej[j] = __shfl(e, j, 32);      // (all requested before the first add: one LDS-crossbar latency instead of A)
     float ssum = 0.0f;
-    for (int j = 0; j < A; ++j) ssum += __shfl(e, j, 32);
+#pragma unroll
+    for (int j = 0; j < 28; ++j)
+      if (j < A) ssum += ej[j];
     if (a == 0) {
       smp.actions[b] = bi;
-      act_s = bi;
+      if (ea.obs_next) act_s = env_action_dir(env_sh, bi);      // what the env's finish needs of the action: the paddle direction
       if (smp.logprobs) smp.logprobs[b] = (zb - mx) - cbm_logf(ssum);
       if (smp.value_out) smp.value_out[b] = lg[A];
     }
+  } else if (ea.obs_next && wave >= 1) {
+    env_step_early<192>(ea, b, env_sh, tid - 64, env_pc);     // under wave 0's sampling
   }
+  TT(8);
   if (ea.obs_next) {
-    __syncthreads();
-    env_step_finish(ea, b, env_sh, act_s, tid, 256);
+    // (a raw barrier: the action travels through LDS, and the early part's stores need not have landed — a piece the finish stores again is stored
+    // by the thread that stored it before; __syncthreads() also waits for vmcnt(0), 1.2 us of store latency on the block's critical path)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    TT(9);
+    if (wave >= 1) env_step_finish<192>(ea, b, env_sh, act_s, tid - 64, env_pc);
   }
+  TT(10);
 }
 static void launch_heads_fwd(const float* hid, const float* Wa, const float* ba, const float* Wc, const float* bc, int B, int A, int HD,
                              float* logits, float* value, hipStream_t st) {
