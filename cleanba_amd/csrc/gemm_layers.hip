@@ -536,36 +536,54 @@ __global__ __launch_bounds__(256) void ppo_heads_fused_kernel(const float* hid, 
   __shared__ float red[16][4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, g4 = lane >> 4;
   const int m0 = blockIdx.x * 16;
-  // (A) hid rows and both weight matrices -> LDS.  (Head weights held in registers, as in the actor tail, did not survive here: with the
-  // dgrad fragments also live the compiler sank the loads next to their MFMAs — 128 L2 round trips in the chain, 21 us.)
-  for (int i = tid; i < 16 * HD / 4; i += 256) {
-    const int row = i / (HD / 4), c4 = (i % (HD / 4)) * 4;
-    *reinterpret_cast<float4*>(hs + row * PH + c4) = *reinterpret_cast<const float4*>(hid + (size_t)min(m0 + row, B - 1) * HD + c4);
+  // (A) hid rows and both weight matrices -> LDS by the load unit (global_load_lds: 1 KB per wave instruction, no staging registers, no ds_write):
+  // a hid row is two such copies behind its padded row base, the actor matrix HD / 256 * A of them as it lies in memory, the critic column HD / 64
+  // 256-byte ones.  (Through registers this phase and the chain below were 31 us for a block that owns a CU alone — the same pattern the actor tail
+  // had: DESIGN 4.1.)
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  for (int q = wave_u; q < 16 * (HD / 256); q += 4) {
+    const int row = q / (HD / 256), part = q % (HD / 256);
+    ig_glds16(hid + (size_t)min(m0 + row, B - 1) * HD + part * 256 + lane * 4, hs + row * PH + part * 256);
   }
-  for (int i = tid; i < HD * A / 4; i += 256) reinterpret_cast<float4*>(wl)[i] = reinterpret_cast<const float4*>(Wa)[i];
-  for (int i = tid; i < HD; i += 256) wc[i] = Wc[i];
+  if (((uintptr_t)Wa & 15) == 0) {
+    for (int q = wave_u; q < (HD / 256) * A; q += 4) ig_glds16(Wa + (size_t)(64 * q + lane) * 4, wl + 64 * q * 4);
+  } else {
+    for (int i = tid; i < HD * A; i += 256) wl[i] = Wa[i];
+  }
+  for (int q = wave_u; q < HD / 64; q += 4)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Wc + 64 * q + lane), (__attribute__((address_space(3))) void*)(wc + 64 * q), 4, 0, 0);
   __shared__ int s_act[16];
   __shared__ float s_olp[16], s_adv[16], s_tgt[16];
   if (tid < 16) {   // the samples' scalars (a gather through idx: two dependent round trips) are fetched under the staging, not inside the loss phase
     const int ii = min(m0 + tid, B - 1), n = idx ? idx[ii] : ii;
     s_act[tid] = actions[n]; s_olp[tid] = old_logprob[n]; s_adv[tid] = adv[n]; s_tgt[tid] = target[n];
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   {
     const int n = wave * 16 + r16;
     if (wave < 2) {
-      const float* wp = n < A ? wl + n : wc;
-      const int wstride = n < A ? A : 1;
-      const bool on = n <= A;
-      f32x4_mfma acc = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll 16
-      for (int st = 0; st < HD / 4; ++st) {
-        const float bv = on ? wp[(4 * st + g4) * wstride] : 0.0f;
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(hs[r16 * PH + 4 * st + g4], bv, acc, 0, 0, 0);
-      }
-      const float bias = n < A ? ba[n] : (n == A ? bc[0] : 0.0f);
+      // every fragment of the 128-step chain comes out of LDS BEFORE the first MFMA, through running pointers (read inside the chain each group of
+      // MFMAs waits for its own LDS round trip; indexed as base[st * stride] each read costs a quarter-rate integer multiply).  Columns past A + 1
+      // multiply whatever the critic column holds: their results are never stored.
+      const float* wq = (n < A ? wl + n : wc) + g4 * (n < A ? A : 1);
+      const int wstep = 4 * (n < A ? A : 1);
+      float bw[HD / 4], av[HD / 4];
+      {
+        const float* wr = wq;
+        const float* ar = hs + r16 * PH + g4;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) lg[4 * g4 + e][n] = acc[e] + bias;
+        for (int st = 0; st < HD / 4; ++st) { bw[st] = *wr; wr += wstep; av[st] = ar[4 * st]; }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      f32x4_mfma acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+      for (int st = 0; st < HD / 4; ++st) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[st], bw[st], acc, 0, 0, 0);
+      const float bias = n < A ? ba[n] : (n == A ? bc[0] : 0.0f);
+      if (n <= A) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) lg[4 * g4 + e][n] = acc[e] + bias;
+      }
     }
   }
   const int nst = (A + 4) / 4;                      // j runs over A logits + the value column

@@ -33,7 +33,9 @@ for rep in range(6):
         assert ctx.lib.cbm_debug_tail_trace(buf) == 0
         t = np.array(buf, np.float64).reshape(4, 16)[:, :15]
         if rep >= 1:
-            acc += (t - t[:, :1].min()) / 2100.0
+            d = (t - t[:, :1].min()) / 2100.0
+            d[t == 0] = np.nan                 # a stamp this wave never takes (only waves 0 / 1 run the heads' chain)
+            acc += d
             n += 1
     ctx.actor_commit(0)
     ctx.params_publish_external(ctx.buffer("params")[0])
@@ -41,5 +43,5 @@ acc /= n
 print("us since the block's first stamp (avg of %d launches; rows = waves 0-3)" % n)
 print("%-14s" % "" + "".join("%9s" % ("w%d" % w) for w in range(4)))
 for k in order:
-    print("%-14s" % names[k] + "".join("%9.2f" % acc[w, k] for w in range(4)))
+    print("%-14s" % names[k] + "".join(("%9.2f" % acc[w, k]) if np.isfinite(acc[w, k]) else "%9s" % "-" for w in range(4)))
 ctx.close()
