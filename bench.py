@@ -299,10 +299,11 @@ def roofline(ctx, a, dt, prof_steps):
            "traffic": r["traffic"], "hbm_gbps": r["hbm_gbps"], "hbm_frac": r["hbm_frac"], "launches": r["launches"], "avg_us": r["avg_us"],
            "flops_per_launch": r["flops_per_launch"], "time_share": r["time_share"],
            "selection": "largest measured time share; source = HIP events on the learner stream around every launch of kernel ids 0-11 during the "
-                        "first %d of the %d timed steps.  rocprofv3 --kernel-trace of the same command (profiles/r03_bench_kernel_stats.md) agrees within ~3 %% "
-                        "for ten of the twelve; conv1_wgrad and conv3_wgrad — the two that leave LDS free for blocks of the concurrent rollout — run longer "
-                        "under the profiler (their per-dispatch minimum there equals the event time), where the two queues interleave differently and the "
-                        "actor kernels stretch to 4x their isolated time; the unprofiled event times are the ones that add up to the measured step" % (prof_steps, a.steps),
+                        "first %d of the %d timed steps.  Without a concurrent rollout the two clocks agree within 1 %% on all twelve (profiles/r04_microbench.txt: "
+                        "events, profiles/r04_learner_only_kernel_stats.md: rocprofv3 --kernel-trace of the same minibatches); under the rollout rocprofv3 "
+                        "(profiles/r04_bench_kernel_stats.md) agrees within ~3 %% for ten and reads conv1_wgrad / dense_fwd / conv3_wgrad — the kernels that leave LDS "
+                        "free for actor blocks — 10-30 %% longer, because under the profiler the two queues interleave differently (actor kernels stretch to 4x "
+                        "their isolated time).  The unprofiled event times are the ones that add up to the measured step, so they are what this object reports" % (prof_steps, a.steps),
            "event_steps": prof_steps,
            "min_frac": min(v["frac"] for k, v in rows.items() if k != 4),   # (id 4, the 32-wide heads wgrad, is 0.2 % of the flops)
            "whole_step": {"executed_flops_per_env_step": round(EXEC_FLOPS_PER_ENV_STEP), "executed_achieved": round(exec_tf, 2),
