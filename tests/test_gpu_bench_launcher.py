@@ -55,3 +55,14 @@ def test_bench_gpus_4_native_allreduce_then_the_configs3_topology_line():
     bc = d["baseline_config"]
     assert bc.get("value") and bc["value"] > 0, bc
     assert "a0-l1,2,3" in bc["config"] and bc["allreduce"]["backend"] == "native" and bc["allreduce"]["ranks"] == 3
+
+
+def test_bench_gpus_8_native_allreduce_then_the_configs4_topology_line():
+    """The SCALE command at N = 8 on one GPU: eight data-parallel ranks on the native all-reduce, then BASELINE configs[4] (`2x(a0-l1,2,3)`, Atari-57
+    synthetic frame mix: two actor + six learner role processes, one six-rank communicator) rides along as `baseline_config`."""
+    d = _bench("--gpus", "8", loopback=False)
+    assert d["n_gpus"] == 8 and "error" not in d and d["value"] > 0
+    assert d["allreduce"]["backend"] == "native" and d["allreduce"]["ranks"] == 8
+    bc = d["baseline_config"]
+    assert bc.get("value") and bc["value"] > 0, bc
+    assert "2x(a0-l1,2,3)" in bc["config"] and "Atari-57" in bc["config"] and bc["allreduce"]["backend"] == "native" and bc["allreduce"]["ranks"] == 6

@@ -88,9 +88,9 @@ os._exit(0)
     assert p.returncode == 0 and b"TIMEOUT-REPORTED" in p.stdout, p.stdout.decode()[-3000:]
 
 
-def _run_topology(engine, tmp, tag, E, T, updates, ids, epochs, omp=None):
+def _run_topology(engine, tmp, tag, E, T, updates, ids, epochs, omp=None, groups=1, env_id="Breakout-v5"):
     aids, lids = ids.split(":")
-    world = len(aids.split(",")) + len(lids.split(","))
+    world = groups * (len(aids.split(",")) + len(lids.split(",")))
     port = _free_port()
     env = dict(os.environ, CBM_TEST_TMP=str(tmp), HSA_ENABLE_IPC_MODE_LEGACY="0")
     if omp:
@@ -100,7 +100,7 @@ def _run_topology(engine, tmp, tag, E, T, updates, ids, epochs, omp=None):
         out = os.path.join(str(tmp), f"{tag}_{r}.npz")
         outs.append(out)
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "topo_worker.py"), str(r), str(world), str(port), out, "ppo", engine, str(E), str(T),
-                                       str(updates), ids, str(epochs)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+                                       str(updates), ids, str(epochs), env_id], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     logs = [p.communicate(timeout=1500)[0].decode() for p in procs]
     for p in procs:
         assert p.returncode == 0, "\n=====\n".join(lg[-2500:] for lg in logs)
@@ -119,6 +119,24 @@ def test_a0_l123_small_native_equals_oracle_topology(tmp_path):
     print("a0-l1,2,3 small: |p - p_oracle| max %.2e" % d.max())
     assert np.abs(o0["params"] - o0["p0"]).max() > 1e-4 and d.max() <= 1e-5
     np.testing.assert_allclose(l0["stats"], o0["stats"], rtol=1e-5, atol=1e-6)
+
+
+def test_configs4_two_groups_atari57_mix_native_equals_oracle_topology(tmp_path):
+    """BASELINE configs[4] (benchmark.sh:80 family: `2x(a0-l1,2,3)`, `--distributed` with a split layout, synthetic Atari-57 frame mix) as EIGHT role
+    processes on GPU 0: two actors with different env seeds and game sets, six learners in ONE communicator (gradients averaged over the learners of
+    BOTH groups through the native all-reduce), each group's learner 0 feeding its own actor.  Small sizes; against the same topology on the CPU oracle
+    engine over gloo after the first update."""
+    outs, logs = _run_topology("hip", tmp_path, "hip8", 12, 8, 1, "0:1,2,3", 2, groups=2, env_id="Atari57Mix-v5")
+    a0, l00, l01, l02, a1, l10, l11, l12 = outs
+    assert "allreduce.backend: native ranks 6" in "".join(logs)
+    for x in (l01, l02, l10, l11, l12):
+        assert np.array_equal(l00["params"], x["params"])
+    assert np.array_equal(a0["params"], l00["params"]) and np.array_equal(a1["params"], l10["params"])
+    o, _ = _run_topology("oracle", tmp_path, "cpu8", 12, 8, 1, "0:1,2,3", 2, omp=2, groups=2, env_id="Atari57Mix-v5")
+    d = np.abs(l00["params"] - o[1]["params"])
+    print("2x(a0-l1,2,3) small, Atari-57 mix: |p - p_oracle| max %.2e" % d.max())
+    assert np.abs(o[1]["params"] - o[1]["p0"]).max() > 1e-4 and d.max() <= 1e-5
+    np.testing.assert_allclose(l00["stats"], o[1]["stats"], rtol=1e-5, atol=1e-6)
 
 
 @pytest.mark.slow

@@ -1,6 +1,6 @@
 """One ROLE process of a split-topology run, on the HIP engine (every role pinned to GPU 0: CBM_FORCE_DEVICE, learner all-reduce = the
 library's native backend) or on the CPU oracle engine (gloo) — same host program, same arguments, so the two can be compared.
-Usage: python topo_worker.py <rank> <world> <port> <out.npz> <algo> <hip|oracle> <E> <T> <updates> <actor_ids:learner_ids> <update_epochs>"""
+Usage: python topo_worker.py <rank> <world> <port> <out.npz> <algo> <hip|oracle> <E> <T> <updates> <actor_ids:learner_ids> <update_epochs> [env_id]"""
 import os
 import sys
 
@@ -14,6 +14,7 @@ rank, world, port, out, algo, engine = int(sys.argv[1]), int(sys.argv[2]), int(s
 E, T, updates = (int(x) for x in sys.argv[7:10])
 aids, lids = (x.split(",") for x in sys.argv[10].split(":"))
 epochs = sys.argv[11]
+env_id = sys.argv[12] if len(sys.argv) > 12 else "Breakout-v5"
 os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
 if engine == "hip":
     os.environ.update(CBM_FORCE_DEVICE="0", LOCAL_RANK="0")
@@ -23,7 +24,8 @@ from cleanba_amd.trainer import train  # noqa: E402
 
 # the device env and the host env are byte-identical twins and actions are bit-exact, so both engines see the same first rollout
 argv = ["--local-num-envs", str(E), "--num-actor-threads", "1", "--num-steps", str(T), "--env-backend", "device" if engine == "hip" else "host",
-        "--network", "nature", "--total-timesteps", str(updates * E * T), "--log-frequency", "1", "--update-epochs", epochs, "--distributed",
+        "--network", "nature", "--env-id", env_id, "--total-timesteps", str(updates * E * T * (world // (len(aids) + len(lids)))), "--log-frequency", "1",
+        "--update-epochs", epochs, "--distributed",
         "--actor-device-ids"] + aids + ["--learner-device-ids"] + lids
 os.chdir(os.environ.get("CBM_TEST_TMP", "/tmp"))
 factory = None
