@@ -362,13 +362,13 @@ def host_env_value(a, params):
 
 
 def secondary_values():
-    """Secondary workloads under the same clock: 3 warm + 5 timed updates each through the product trainer
+    """Secondary workloads under the same clock: a few warm-up + 5 (PPO-ResNet) / 20 (IMPALA T = 128) / 40 (T = 20) timed updates each through the product trainer
     (cleanba_amd.trainer.train, device env, --concurrency), two device syncs per run.  Not the headline."""
     from cleanba_amd.args import parse_args
     from cleanba_amd.trainer import train
-    rows = [("impala_bf16_configs2", "impala", ["--network", "nature", "--bf16-forward"], T, 3, 5,
+    rows = [("impala_bf16_configs2", "impala", ["--network", "nature", "--bf16-forward"], T, 5, 20,
              "BASELINE configs[2]: IMPALA a0-l0-d1, V-trace, Nature-CNN bf16-MFMA forward / fp32 returns, 120 envs x 128 steps"),
-            ("impala_fp32_t128", "impala", ["--network", "nature"], T, 3, 5, "IMPALA a0-l0-d1 fp32, 120 envs x 128 steps"),
+            ("impala_fp32_t128", "impala", ["--network", "nature"], T, 5, 20, "IMPALA a0-l0-d1 fp32, 120 envs x 128 steps"),
             ("impala_fp32_t20", "impala", ["--network", "nature"], 20, 40, 40, "IMPALA a0-l0-d1 fp32 at the script's default num_steps = 20 (40 warm + 40 timed updates of ~2.7 ms)"),
             ("ppo_resnet", "ppo", ["--network", "impala_resnet"], T, 2, 5, "PPO a0-l0-d1 with the IMPALA-ResNet torso (the CLI's default network, ppo:149-189), 120 envs x 128 steps")]
     out = {}
