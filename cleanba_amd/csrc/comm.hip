@@ -121,11 +121,14 @@ static __device__ __forceinline__ void nat_signal_and_wait(const NatArgs& a, int
   __syncthreads();
 }
 
+// NR > 0: the rank count is a compile-time constant — the NR peer loads of an element are all requested before the first add (one fabric round trip
+// per element instead of NR); NR = 0: any count up to CBM_NATIVE_MAX_RANKS, one load after the other
+template <int NR>
 __global__ __launch_bounds__(NAT_THREADS) void nat_allreduce_f32_kernel(const NatArgs a) {
   __threadfence_system();
   nat_signal_and_wait(a, 0);
   __threadfence_system();               // acquire for every thread: no load below may be served by anything fetched before the peers signalled
-  const int N = a.nranks;
+  const int N = NR > 0 ? NR : a.nranks;
   const int64_t chunk = (((a.n + N - 1) / N) + 3) & ~(int64_t)3;
   const int64_t lo = chunk * a.rank < a.n ? chunk * a.rank : a.n;
   const int64_t hi = lo + chunk < a.n ? lo + chunk : a.n;
@@ -133,12 +136,24 @@ __global__ __launch_bounds__(NAT_THREADS) void nat_allreduce_f32_kernel(const Na
   const int64_t nvec = (a.off & 3) == 0 ? (hi - lo) >> 2 : 0;   // slices start at multiples of 4 floats: vector path when the range does too
   for (int64_t i = tid; i < nvec; i += nth) {
     const int64_t e = a.off + lo + 4 * i;
-    float4 sum = *reinterpret_cast<const float4*>((const float*)a.data[0] + e);
-    for (int r = 1; r < N; ++r) {
-      const float4 v = *reinterpret_cast<const float4*>((const float*)a.data[r] + e);
-      sum.x = sum.x + v.x; sum.y = sum.y + v.y; sum.z = sum.z + v.z; sum.w = sum.w + v.w;
+    float4 sum;
+    if constexpr (NR > 0) {
+      float4 v[NR];
+#pragma unroll
+      for (int r = 0; r < NR; ++r) v[r] = *reinterpret_cast<const float4*>((const float*)a.data[r] + e);
+      sum = v[0];
+#pragma unroll
+      for (int r = 1; r < NR; ++r) { sum.x = sum.x + v[r].x; sum.y = sum.y + v[r].y; sum.z = sum.z + v[r].z; sum.w = sum.w + v[r].w; }   // rank order
+#pragma unroll
+      for (int r = 0; r < NR; ++r) *reinterpret_cast<float4*>((float*)a.data[r] + e) = sum;
+    } else {
+      sum = *reinterpret_cast<const float4*>((const float*)a.data[0] + e);
+      for (int r = 1; r < N; ++r) {
+        const float4 v = *reinterpret_cast<const float4*>((const float*)a.data[r] + e);
+        sum.x = sum.x + v.x; sum.y = sum.y + v.y; sum.z = sum.z + v.z; sum.w = sum.w + v.w;
+      }
+      for (int r = 0; r < N; ++r) *reinterpret_cast<float4*>((float*)a.data[r] + e) = sum;
     }
-    for (int r = 0; r < N; ++r) *reinterpret_cast<float4*>((float*)a.data[r] + e) = sum;
   }
   for (int64_t i = lo + 4 * nvec + tid; i < hi; i += nth) {
     const int64_t e = a.off + i;
@@ -206,7 +221,17 @@ static int nat_allreduce_f32(cbm_ctx* c, CbmComm& k, float* buf, int64_t n, hipS
   if (nat_locate(c, buf, n * 4, &b, &offb)) return -1;
   const NatArgs a = nat_args(k, b, offb / 4, n);
   if (n <= NAT_SMALL_MAX) hipLaunchKernelGGL((nat_allreduce_small_kernel<float, 0>), dim3(1), dim3(1024), 0, st, a);
-  else hipLaunchKernelGGL(nat_allreduce_f32_kernel, dim3(NAT_BLOCKS), dim3(NAT_THREADS), 0, st, a);
+  else {
+    const dim3 g(NAT_BLOCKS), t(NAT_THREADS);
+    switch (k.nranks) {
+      case 2: hipLaunchKernelGGL(nat_allreduce_f32_kernel<2>, g, t, 0, st, a); break;
+      case 3: hipLaunchKernelGGL(nat_allreduce_f32_kernel<3>, g, t, 0, st, a); break;
+      case 4: hipLaunchKernelGGL(nat_allreduce_f32_kernel<4>, g, t, 0, st, a); break;
+      case 6: hipLaunchKernelGGL(nat_allreduce_f32_kernel<6>, g, t, 0, st, a); break;
+      case 8: hipLaunchKernelGGL(nat_allreduce_f32_kernel<8>, g, t, 0, st, a); break;
+      default: hipLaunchKernelGGL(nat_allreduce_f32_kernel<0>, g, t, 0, st, a);
+    }
+  }
   CBM_HIP(hipGetLastError());
   return 0;
 }

@@ -39,6 +39,19 @@ vals = np.random.default_rng(77 + rank).normal(size=5)
 for op in ("sum", "max", "min"):
     res[op] = ctx.comm_allreduce_f64(vals, op)
 ctx.comm_barrier()
+if os.environ.get("CBM_NATIVE_BENCH"):      # tools/native_allreduce_bench.py: ranks in lockstep, nothing else on the GPU
+    import time
+    for _ in range(5):
+        ctx.learner_allreduce_grads()
+    ctx.sync()
+    ctx.comm_barrier()
+    t0 = time.perf_counter()
+    iters = 200
+    for _ in range(iters):
+        ctx.learner_allreduce_grads()
+    ctx.sync()
+    res["us_per_allreduce"] = np.float64((time.perf_counter() - t0) / iters * 1e6)
+    res["bytes"] = np.int64(ctx.P * 4)
 rdv.barrier("done")                      # nobody unmaps while a peer may still be inside a collective
 np.savez(out, **res)
 ctx.close()
