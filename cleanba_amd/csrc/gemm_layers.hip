@@ -354,61 +354,64 @@ __global__ __launch_bounds__(256) void actor_tail_rows_kernel(const float* part,
   EnvPieces<192> env_pc;
   if (ea.obs_next && wave >= 1) env_step_prefetch<192>(ea, b, tid - 64, env_pc);
   TT(11);
-  // all partial slices of this thread's hidden units (HD / 256 of them: k = tid, tid + 256) are requested at once (S <= 16), then added in slice order
-  constexpr int NU = HD / 256;
-  static_assert(HD % 256 == 0 && NU >= 1 && NU <= 2, "hidden width 256 or 512");
+  // Division of the load phase: waves 0 / 1 bring the head weights into LDS with the load unit (global_load_lds: 1 KB per wave instruction, no
+  // registers: [HD][A] is HD / 256 * A instructions of 64 x 16 bytes, the critic column HD / 64 of 64 x 4 bytes) and, after a first barrier, lift
+  // their B fragments out of LDS while waves 2 / 3 still wait for the dense layer's partial slices (all S <= 16 slices of a thread's HD / 128 hidden
+  // units are requested at once, then added in slice order).  (Held in registers straight from L2 — 128 strided loads per lane — the fragments' ISSUE
+  // alone took 3.2 us of a 5 us load phase: in-kernel clock stamps, tools/tail_trace.py.)
+  constexpr int NU = HD / 128;
+  static_assert(HD % 256 == 0 && NU >= 2 && NU <= 4, "hidden width 256 or 512");
   float vv[NU][16];
+  if (wave >= 2) {
 #pragma unroll
-  for (int s = 0; s < 16; ++s) {
-    const int ss = s < S ? s : 0;
+    for (int s = 0; s < 16; ++s) {
+      const int ss = s < S ? s : 0;
 #pragma unroll
-    for (int u = 0; u < NU; ++u) vv[u][s] = part[ss * MN + (size_t)b * HD + tid + 256 * u];
+      for (int u = 0; u < NU; ++u) vv[u][s] = part[ss * MN + (size_t)b * HD + (tid - 128) + 128 * u];
+    }
+  } else {
+    if (((uintptr_t)Wa & 15) == 0) {
+      for (int q = wave; q < (HD / 256) * A; q += 2) ig_glds16(Wa + (size_t)(64 * q + lane) * 4, wl + 64 * q * 4);
+    } else {
+      for (int i = tid; i < HD * A; i += 128) wl[i] = Wa[i];
+    }
+    for (int q = wave; q < HD / 64; q += 2)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Wc + 64 * q + lane), (__attribute__((address_space(3))) void*)(wcl + 64 * q), 4, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the weights has landed in LDS
   }
   TT(12);
-  // head weights -> LDS by the load unit (global_load_lds: 1 KB per wave instruction, no registers): [HD][A] is HD / 256 * A instructions of 64 x 16 bytes,
-  // the critic column HD / 64 of 64 x 4 bytes.  (Held in registers as B fragments — 128 strided loads per lane on waves 0 / 1 — their ISSUE alone took
-  // 3.2 us of the block's 5 us load phase: in-kernel clock stamps, tools/tail_trace.py.)
-  {
-    const bool al16 = ((uintptr_t)Wa & 15) == 0;
-    if (al16) {
-      for (int q = wave; q < NU * A; q += 4) ig_glds16(Wa + (size_t)(64 * q + lane) * 4, wl + 64 * q * 4);
-    } else {
-      for (int i = tid; i < HD * A; i += 256) wl[i] = Wa[i];
-    }
-    for (int q = wave; q < HD / 64; q += 4)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Wc + 64 * q + lane), (__attribute__((address_space(3))) void*)(wcl + 64 * q), 4, 0, 0);
-  }
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // (raw: waves 2 / 3 arrive with their loads in flight)
   TT(1);
-  TT(2);
+  const int hn = wave * 16 + r16;                    // waves 0 / 1: this lane's head column
+  float bw[HD / 4];
+  if (wave < 2) {
+    // columns past A + 1 multiply whatever the critic column holds: their results are never read, and no lane needs a predicate around its reads;
+    // a running pointer, because wq[st * wstep] is a quarter-rate v_mul_lo_u32 per read (2 us for the 128 of them)
+    const float* wr = (hn < A ? wl + hn : wcl) + g4 * (hn < A ? A : 1);
+    const int wstep = 4 * (hn < A ? A : 1);
 #pragma unroll
-  for (int u = 0; u < NU; ++u) {
-    float t0 = vv[u][0];
+    for (int st = 0; st < HD / 4; ++st) { bw[st] = *wr; wr += wstep; }
+    TT(13);
+  } else {
 #pragma unroll
-    for (int s = 1; s < 16; ++s)
-      if (s < S) t0 = t0 + vv[u][s];
-    const int k = tid + 256 * u;
-    hsT[(k & 3) * (HD / 4) + (k >> 2)] = relu(t0 + bd[k]);
+    for (int u = 0; u < NU; ++u) {
+      float t0 = vv[u][0];
+#pragma unroll
+      for (int s = 1; s < 16; ++s)
+        if (s < S) t0 = t0 + vv[u][s];
+      const int k = (tid - 128) + 128 * u;
+      hsT[(k & 3) * (HD / 4) + (k >> 2)] = relu(t0 + bd[k]);
+    }
   }
   TT(3);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the load unit's LDS writes have landed (this wave's; the barrier makes it everybody's)
   __syncthreads();
   TT(4);
   if (wave < 2) {
     // heads on v_mfma_f32_16x16x4_f32 with ONE live row (row 0 = this frame; the instruction's other 15 rows repeat it and are ignored): waves
     // 0 / 1 own output columns 0-15 / 16-31; column n <= A is a 512-long k-ascending chain (bitwise the 16-row tail's and heads_fwd's: DESIGN 3).
-    // The B fragments come out of LDS in one sweep BEFORE the chain (read inside it, each MFMA waited for its own LDS round trip: 5.0 us against 2.4)
-    const int n = wave * 16 + r16;
-    // columns past A + 1 multiply whatever the critic column holds: their results are never read, and no lane needs a predicate around its reads
-    const float* wq = (n < A ? wl + n : wcl) + g4 * (n < A ? A : 1);
-    const int wstep = 4 * (n < A ? A : 1);
-    float bw[HD / 4];
+    // Every fragment is in registers before the first MFMA (read inside the chain, each group of MFMAs waited for its own LDS round trip: 5.0 us against 2.4)
+    const int n = hn;
     float4 hq[HD / 16];
-    {
-      const float* wr = wq;      // (a running pointer: wq[st * wstep] is a quarter-rate v_mul_lo_u32 per read — 2 us for the 128 of them)
-#pragma unroll
-      for (int st = 0; st < HD / 4; ++st) { bw[st] = *wr; wr += wstep; }
-    }
-    TT(13);
 #pragma unroll
     for (int q = 0; q < HD / 16; ++q) hq[q] = *reinterpret_cast<const float4*>(hsT + g4 * (HD / 4) + 4 * q);   // k = 4*(4q + i) + g4, i = 0..3
     __builtin_amdgcn_sched_barrier(0);     // (every fragment is requested before the first MFMA: inside the chain each group of eight waited for its own LDS round trip)
