@@ -278,3 +278,43 @@ def test_benchmark_fan_out_matrix_and_slurm_render(tmp_path, monkeypatch):
     assert "--gpus-per-task=4" in out and "--cpus-per-gpu=7" in out and "--ntasks=2" in out and "--array=0-0%0" in out and "#SBATCH --nodes=1" in out
     assert "env_ids=(Breakout-v5)" in out and "seeds=(1)" in out and "{{" not in out
     assert "srun python -m cleanba_amd.cleanba_ppo --distributed --learner-device-ids 1 2 3 --env-id $env_id --seed $seed" in out
+
+
+def test_comm_backend_selection(monkeypatch):
+    """CBM_COMM=native|rccl picks the learner all-reduce's backend; the default is RCCL unless several ranks were told to share one GPU
+    (CBM_FORCE_DEVICE), where RCCL refuses two ranks per device and only the library's native all-reduce can run."""
+    from cleanba_amd import topology
+    for k in ("CBM_COMM", "CBM_FORCE_DEVICE"):
+        monkeypatch.delenv(k, raising=False)
+    assert topology.comm_backend(4) == "rccl"
+    monkeypatch.setenv("CBM_FORCE_DEVICE", "0")
+    assert topology.comm_backend(3) == "native" and topology.comm_backend(1) == "rccl"
+    monkeypatch.setenv("CBM_COMM", "rccl")
+    assert topology.comm_backend(3) == "rccl"
+    monkeypatch.setenv("CBM_COMM", "native")
+    monkeypatch.delenv("CBM_FORCE_DEVICE")
+    assert topology.comm_backend(8) == "native"
+
+
+def test_rendezvous_runs_of_one_process_share_the_store_but_not_their_keys():
+    """bench.py makes two runs in a row in the same rank processes (the data-parallel line, then the BASELINE topology line): one TCP store per
+    process, one key prefix per run."""
+    from cleanba_amd import topology
+    port = _free_port()
+    a = topology.Rendezvous(1, 0, "127.0.0.1", port, timeout_s=10.0, prefix="run-a")
+    b = topology.Rendezvous(1, 0, "127.0.0.1", port, timeout_s=10.0, prefix="run-b")
+    assert len([k for k in topology.Rendezvous._base if k[1] == port]) == 1
+    a.put("comm/learners/uid", b"A")
+    assert not b.store.check(["comm/learners/uid"])
+    b.put("comm/learners/uid", b"B")
+    assert bytes(a.get("comm/learners/uid")) == b"A" and bytes(b.get("comm/learners/uid")) == b"B"
+    a.barrier("done")
+    b.barrier("done")
+
+
+def test_bench_workload_constants():
+    """bench.py's flop accounting: the Nature step's executed flops and the IMPALA-ResNet step's (15 convs 3x3 SAME, dense 3872 -> 256, heads)."""
+    import bench
+    assert round(bench.EXEC_FLOPS_PER_ENV_STEP / 1e6, 1) == 216.9
+    assert bench.RESNET_EXEC_MFLOP_PER_ENV_STEP == 1377.4
+    assert bench.parse_topology("2x(a0-l1,2,3)") == (2, [0], [1, 2, 3]) and bench.parse_topology("a0,1-l2,3") == (1, [0, 1], [2, 3])
