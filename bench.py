@@ -400,7 +400,7 @@ def secondary_values():
         # executed flops per env-step of the ResNet PPO step (rollout forward + 4 epochs x (forward + input gradients except conv0's + weight gradients))
         r["executed_mflop_per_env_step"] = RESNET_EXEC_MFLOP_PER_ENV_STEP
         r["executed_frac_of_fp32_mfma_peak"] = round(r["value"] * RESNET_EXEC_MFLOP_PER_ENV_STEP * 1e6 / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)
-        r["per_kernel"] = "profiles/r04_resnet_kernel_stats.md (rocprofv3 --kernel-trace of tools/rn_microbench.py)"
+        r["per_kernel"] = "profiles/r04_resnet_roofline.md (tools/resnet_roofline.py over the rocprofv3 --kernel-trace of tools/rn_microbench.py: executed flops per launch from each kernel's geometry)"
     return out
 
 

@@ -539,6 +539,7 @@ __global__ __launch_bounds__(256) void ppo_heads_fused_kernel(const float* hid, 
   __shared__ float red[16][4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, g4 = lane >> 4;
   const int m0 = blockIdx.x * 16;
+  TT(0);
   // (A) hid rows and both weight matrices -> LDS by the load unit (global_load_lds: 1 KB per wave instruction, no staging registers, no ds_write):
   // a hid row is two such copies behind its padded row base, the actor matrix HD / 256 * A of them as it lies in memory, the critic column HD / 64
   // 256-byte ones.  (Through registers this phase and the chain below were 31 us for a block that owns a CU alone — the same pattern the actor tail
@@ -561,8 +562,10 @@ __global__ __launch_bounds__(256) void ppo_heads_fused_kernel(const float* hid, 
     const int ii = min(m0 + tid, B - 1), n = idx ? idx[ii] : ii;
     s_act[tid] = actions[n]; s_olp[tid] = old_logprob[n]; s_adv[tid] = adv[n]; s_tgt[tid] = target[n];
   }
+  TT(1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  TT(2);
   {
     const int n = wave * 16 + r16;
     if (wave < 2) {
@@ -579,9 +582,11 @@ __global__ __launch_bounds__(256) void ppo_heads_fused_kernel(const float* hid, 
         for (int st = 0; st < HD / 4; ++st) { bw[st] = *wr; wr += wstep; av[st] = ar[4 * st]; }
       }
       __builtin_amdgcn_sched_barrier(0);
+      TT(3);
       f32x4_mfma acc = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
       for (int st = 0; st < HD / 4; ++st) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[st], bw[st], acc, 0, 0, 0);
+      TT(4);
       const float bias = n < A ? ba[n] : (n == A ? bc[0] : 0.0f);
       if (n <= A) {
 #pragma unroll
@@ -591,6 +596,7 @@ __global__ __launch_bounds__(256) void ppo_heads_fused_kernel(const float* hid, 
   }
   const int nst = (A + 4) / 4;                      // j runs over A logits + the value column
   __syncthreads();
+  TT(5);
   const float invN = 1.0f / (float)B;
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
@@ -608,7 +614,9 @@ __global__ __launch_bounds__(256) void ppo_heads_fused_kernel(const float* hid, 
     }
     if (j == 0) { red[row][0] = live ? ss.pg : 0.0f; red[row][1] = live ? ss.dv2 : 0.0f; red[row][2] = live ? ss.ent : 0.0f; red[row][3] = live ? ss.kl : 0.0f; }
   }
+  TT(6);
   __syncthreads();
+  TT(7);
   if (tid < 4) {
     float v = 0.0f;
     for (int q = 0; q < 16; ++q) v += red[q][tid];
@@ -631,6 +639,7 @@ __global__ __launch_bounds__(256) void ppo_heads_fused_kernel(const float* hid, 
       if (m < B) dhid[(size_t)m * HD + k] = hs[row * PH + k] > 0.0f ? acc[e] : 0.0f;
     }
   }
+  TT(8);
 }
 bool ppo_heads_fusable(const NatureLayout& L) { return L.A + 1 <= 32 && (L.hid == 512 || L.hid == 256); }
 void launch_ppo_heads_fused(const NatureLayout& L, const float* P, NatureWs& ws, int B, const int32_t* idx, const int32_t* actions,
