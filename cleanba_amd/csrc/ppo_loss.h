@@ -1,20 +1,31 @@
 // ppo_loss.h — the PPO loss head of one sample on its 32 lanes (ppo:516-577), shared by ppo_loss_kernel (pointwise.hip) and the fused
 // heads + loss + heads-dgrad kernel (gemm_layers.hip).  Lane j holds the logit of action j (lanes >= A idle); the exponentials run in parallel,
-// the softmax sums are taken in ascending action order by a shuffle walk (the same order, hence the same bits, as a serial loop and as the
-// oracle).  Returns this lane's dL/d(logit j) (lane A: dL/dvalue, other lanes 0); lane 0's `st` holds the sample's four statistics.
+// the softmax sums are taken in ascending action order (the same order, hence the same bits, as a serial loop and as the oracle): every lane
+// fetches all A terms by shuffles that are ALL requested before the first add — as a walk of A dependent shuffle + add pairs the three sums of a
+// sample cost 54 LDS-crossbar round trips (8.8 us of the fused kernel's 23: tools/heads_trace.py).  Returns this lane's dL/d(logit j) (lane A: dL/dvalue, other lanes 0); lane 0's `st` holds the sample's four statistics.
 #pragma once
 #include "cbm_internal.h"
 #include <float.h>
 
 struct PpoSampleStats { float pg, dv2, ent, kl; };
+// sum_{q < A} x_q in ascending q, x_q = lane q's value (A <= 28)
+static __device__ __forceinline__ float ppo_ordered_sum32(float x, int A) {
+  float t[28];
+#pragma unroll
+  for (int q = 0; q < 28; ++q) t[q] = __shfl(x, q, 32);
+  float s = 0.0f;
+#pragma unroll
+  for (int q = 0; q < 28; ++q)
+    if (q < A) s += t[q];
+  return s;
+}
 static __device__ __forceinline__ float ppo_loss_lane(float zj, int j, int A, int a, float value, float old_lp, float ad, float tgt, float clip_coef,
                                                       float ent_coef, float vf_coef, float invN, PpoSampleStats& st) {
   const bool act = j < A;
   float mx = act ? zj : -INFINITY;
   for (int o = 16; o > 0; o >>= 1) { const float t = __shfl_xor(mx, o, 32); mx = t > mx ? t : mx; }
   const float ej = act ? cbm_expf(zj - mx) : 0.0f;
-  float se = 0.0f;
-  for (int q = 0; q < A; ++q) se += __shfl(ej, q, 32);
+  const float se = ppo_ordered_sum32(ej, A);
   const float lse_shift = cbm_logf(se);
   const float za = __shfl(zj, a, 32);
   const float newlp = (za - mx) - lse_shift;
@@ -24,13 +35,10 @@ static __device__ __forceinline__ float ppo_loss_lane(float zj, int j, int A, in
   float mx2 = act ? zn : -INFINITY;
   for (int o = 16; o > 0; o >>= 1) { const float t = __shfl_xor(mx2, o, 32); mx2 = t > mx2 ? t : mx2; }
   const float e2 = act ? cbm_expf(zn - mx2) : 0.0f;
-  float s2 = 0.0f;
-  for (int q = 0; q < A; ++q) s2 += __shfl(e2, q, 32);
+  const float s2 = ppo_ordered_sum32(e2, A);
   const float pj = e2 / s2;
   const float tj = act ? zn * pj : 0.0f;
-  float ent = 0.0f;
-  for (int q = 0; q < A; ++q) ent += __shfl(tj, q, 32);
-  ent = -ent;
+  const float ent = -ppo_ordered_sum32(tj, A);
   const float logratio = newlp - old_lp;
   const float ratio = cbm_expf(logratio);
   const float lo = 1.0f - clip_coef, hi = 1.0f + clip_coef;
