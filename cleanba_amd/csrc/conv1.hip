@@ -17,6 +17,14 @@
 #include "igemm.h"
 
 #define FR 28224
+// timing build only (-DCBM_CONV1_TRACE): shader-clock stamps of block 0's second frame, per wave and phase (tools/conv1_trace.py)
+#ifdef CBM_CONV1_TRACE
+__device__ unsigned long long cbm_conv1_trace[4][32];
+extern "C" int cbm_debug_conv1_trace(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(cbm_conv1_trace), sizeof(cbm_conv1_trace)) == hipSuccess ? 0 : -1; }
+#define C1T(k) do { if (blockIdx.x == 0 && s == s_lo + 1 && (threadIdx.x & 63) == 0) cbm_conv1_trace[threadIdx.x >> 6][k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define C1T(k) do { } while (0)
+#endif
 
 static __device__ __forceinline__ float relu_(float v) { return v > 0.0f ? v : 0.0f; }
 
@@ -94,7 +102,9 @@ __global__ __launch_bounds__(256, 2) void conv1_fwd_planes_kernel(const uint8_t*
     const uint8_t* frame = obs + (size_t)(idx ? idx[s] : s) * FR;
 #pragma unroll 1
     for (int c = 0; c < 4; ++c) {
+      C1T(5 * c);
       __syncthreads();                       // every wave is done with the previous plane (and, for c == 0, with the weights' staging loads)
+      C1T(5 * c + 1);
 #pragma unroll
       for (int j = 0; j < 7; ++j) {
         const int v = tid + 256 * j;
@@ -108,7 +118,9 @@ __global__ __launch_bounds__(256, 2) void conv1_fwd_planes_kernel(const uint8_t*
       }
       if (c < 3) load_plane(frame + (c + 1) * 7056);                                           // lands while this plane is multiplied
       else if (s + 1 < s_hi) load_plane(obs + (size_t)(idx ? idx[s + 1] : s + 1) * FR);
+      C1T(5 * c + 2);
       __syncthreads();
+      C1T(5 * c + 3);
       f32x2_t aa[2][MAXT][2];
       float ta[2][2], wv[2][6];
       auto fetch = [&](int kh, int set) __attribute__((always_inline)) {
@@ -148,10 +160,17 @@ __global__ __launch_bounds__(256, 2) void conv1_fwd_planes_kernel(const uint8_t*
         fma_row(kh & 1);
         __builtin_amdgcn_sched_barrier(0);
       }
+      C1T(5 * c + 4);
     }
+    C1T(20);
+#ifdef CBM_CONV1_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    C1T(22);
+#endif
     float* o = out + (size_t)s * 400 * 32 + li;
 #pragma unroll
     for (int t = 0; t < MAXT; ++t) {
+      C1T(23 + t);
       const int m0 = (first + 4 * t) * 32 + 4 * h;
       uint32_t word = 0;
 #pragma unroll
@@ -165,6 +184,7 @@ __global__ __launch_bounds__(256, 2) void conv1_fwd_planes_kernel(const uint8_t*
       }
       if (mask && lane < 32) mask[(size_t)s * 400 + (first + 4 * t) * 32 + lane] = word;
     }
+    C1T(26);
     if (four) {
       const float bt = bias[16 * tj + r16];
       uint32_t word = 0;
@@ -178,6 +198,7 @@ __global__ __launch_bounds__(256, 2) void conv1_fwd_planes_kernel(const uint8_t*
       }
       if (mask && lane < 16) reinterpret_cast<uint16_t*>(mask + (size_t)s * 400 + 384 + lane)[tj] = (uint16_t)word;
     }
+    C1T(21);
   }
 }
 
