@@ -517,6 +517,8 @@ def run_topology(a, world, rank):
            ["--learner-device-ids"] + [str(i) for i in lids]
     args = parse_args(argv, "ppo")
     lay = topology.Layout(args, world, rank)
+    if groups > 1 and os.environ.get("CBM_FORCE_DEVICE") is None and "CBM_GROUP_DEVICE_STRIDE" not in os.environ:
+        os.environ["CBM_GROUP_DEVICE_STRIDE"] = str(max(aids + lids) + 1)   # one launcher, one visible device set: group g sits on GPUs [g*stride, ...)
     os.environ["LOCAL_RANK"] = str(lay.device_id)
     marks, seen = {}, {}
 

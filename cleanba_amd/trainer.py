@@ -369,7 +369,10 @@ def train(args, algo="ppo", engine_factory=None, on_update=None, rendezvous=None
     cfg = make_config(args, algo)
     if lay is not None:
         if engine_factory is None:
-            cfg.device = lay.device_id
+            # the id lists are relative to the group's visible devices (the reference's recipe gives every group its own HIP_VISIBLE_DEVICES,
+            # README.md:71-72); a launcher that starts ALL groups with one common device set (bench.py --topology "2x(...)" on an 8-GPU node) says
+            # how far apart the groups sit: CBM_GROUP_DEVICE_STRIDE
+            cfg.device = lay.device_id + lay.group * int(os.environ.get("CBM_GROUP_DEVICE_STRIDE", "0") or 0)
     if os.environ.get("CBM_FORCE_DEVICE"):   # testing aid: every role on this GPU (the split path between processes on a one-GPU box)
         cfg.device = int(os.environ["CBM_FORCE_DEVICE"])
     if lay is not None:
