@@ -96,6 +96,9 @@ struct Conv1Fwd {
       if (mask) put_mask_word(mask, (size_t)m, 1, n, o > 0.0f);
     }
   }
+  static constexpr bool BIAS_PRE = true;   // (small-batch kernel: no masks there)
+  __device__ float bias_pre(int n) const { return bias[n]; }
+  __device__ void store_pre(int m, int n, float v, float b) const { if (m < M) out[(size_t)m * 32 + n] = relu(v + b); }
   static constexpr bool MASKOUT = true;   // igemm_kernel epilogue: one mask store per 32x32 tile instead of one per element row
   __device__ bool store_flag(int m, int n, float v, int, int) const {
     const float o = relu(v + bias[n]);
@@ -145,6 +148,9 @@ struct ConvFwd {
       if (mask) put_mask_word(mask, (size_t)m, CO / 32, n, o > 0.0f);
     }
   }
+  static constexpr bool BIAS_PRE = true;   // (small-batch kernel: no masks there)
+  __device__ float bias_pre(int n) const { return bias[n]; }
+  __device__ void store_pre(int m, int n, float v, float b) const { if (m < M) out[(size_t)m * CO + n] = relu(v + b); }
   static constexpr bool MASKOUT = true;
   __device__ bool store_flag(int m, int n, float v, int, int) const {
     const float o = relu(v + bias[n]);
@@ -319,6 +325,12 @@ __global__ __launch_bounds__(256) void actor_tail_kernel(const float* hid, const
 // sums its two hidden units over the S partial slices in slice order (dense_reduce_kernel's chain), the A + 1 head outputs are 512-long
 // k-ascending fmaf chains on A + 1 lanes (bitwise the MFMA's chain: DESIGN 3) fed from LDS, and the frame's 32 sampling lanes run
 // sample_kernel's code.  hid never reaches HBM.
+#ifdef CBM_S16_TRACE
+extern "C" int cbm_debug_s16_trace(int sel_x, unsigned long long* out) {
+  if (sel_x >= 0) return hipMemcpyToSymbol(HIP_SYMBOL(cbm_s16_trace_sel), &sel_x, sizeof(int)) == hipSuccess ? 0 : -1;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(cbm_s16_trace), sizeof(cbm_s16_trace)) == hipSuccess ? 0 : -1;
+}
+#endif
 // timing build only (tools/variants.sh tailtrace "-DCBM_TAIL_TRACE"): shader-clock stamps of block 0's four waves at the phase boundaries of the tail
 #ifdef CBM_TAIL_TRACE
 __device__ unsigned long long cbm_tail_trace[4][16];

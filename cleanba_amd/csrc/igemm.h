@@ -60,6 +60,13 @@ template <class P, class = void>
 struct igemm_rowepi { static constexpr bool value = false; };
 template <class P>
 struct igemm_rowepi<P, decltype((void)P::ROWEPI)> { static constexpr bool value = P::ROWEPI; };
+// P::BIAS_PRE: the epilogue's bias is a function of the output column only — bias_pre(n) fetches it, store_pre(m, n, v, b) stores with it.  The
+// small-batch kernel requests it in its prologue: fetched inside store() at the end, its L2 round trip was the last ~1 us of every block's 7 us life
+// (tools/s16_trace.py).
+template <class P, class = void>
+struct igemm_bias_pre { static constexpr bool value = false; };
+template <class P>
+struct igemm_bias_pre<P, decltype((void)P::BIAS_PRE)> { static constexpr bool value = P::BIAS_PRE; };
 template <class P, class = void>
 struct igemm_rowptr_s16 { static constexpr bool value = false; };
 template <class P>
@@ -539,8 +546,26 @@ static inline void igemm_pf2_launch(const P& p, int nsplit, hipStream_t stream) 
 //   LDS: A[x][r] pitch BR+4 and B[r][y] pitch BY+16 floats: both fragment reads (lane = (g4, r16): A[r16][4s+g4], B[4s+g4][r16]) are
 //   conflict-free and both tiles are filled with 16-byte stores.
 typedef float f32x4_mfma __attribute__((ext_vector_type(4)));
+// timing build only (-DCBM_S16_TRACE; tools/s16_trace.py): clock stamps of the first, the middle and the last block of the launch whose X() equals
+// cbm_s16_trace_sel (wave 0): entry, prologue, first loads issued / landed, every K chunk, end
+#ifdef CBM_S16_TRACE
+__device__ unsigned long long cbm_s16_trace[3][24];
+__device__ int cbm_s16_trace_sel;
+#define S16T(k) do { if (s16_tb >= 0 && (threadIdx.x & 255) == 0) cbm_s16_trace[s16_tb][k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define S16T(k) do { } while (0)
+#endif
 template <class P, int BX, int BY, int BR>
-__global__ __launch_bounds__(256, 2) void igemm_s16_kernel(const P p) {   // (, 2): without it the register allocator aims at 8 waves per SIMD (64 VGPRs) and spills the prefetch sets to scratch — LDS caps these kernels at 3 blocks per CU anyway
+__global__ __launch_bounds__(256, 2) void igemm_s16_kernel(const P p) {
+#ifdef CBM_S16_TRACE
+  int s16_tb = -1;
+  if (p.X() == cbm_s16_trace_sel && blockIdx.y == 0 && blockIdx.z == 0) {
+    const int nb = gridDim.x;
+    s16_tb = blockIdx.x == 0 ? 0 : ((int)blockIdx.x == nb / 2 ? 1 : ((int)blockIdx.x == nb - 1 ? 2 : -1));
+  }
+#endif
+  S16T(0);
+  // (, 2): without it the register allocator aims at 8 waves per SIMD (64 VGPRs) and spills the prefetch sets to scratch — LDS caps these kernels at 3 blocks per CU anyway
   static_assert(BX % 16 == 0 && BY % 16 == 0 && BR % 32 == 0 && (BX / 16) * (BY / 16) % 4 == 0, "tile shape");
   static_assert(!P::A_RX && !P::B_YR && !P::BIAS_GRAD && P::NCLS == 1, "forward-style problems");
   constexpr int NT16 = (BX / 16) * (BY / 16) / 4;          // 16x16 tiles per wave
@@ -626,10 +651,19 @@ __global__ __launch_bounds__(256, 2) void igemm_s16_kernel(const P p) {   // (, 
   };
 
   float4 a0[NVA], b0[NVB], a1[NVA], b1[NVB];
+  float bpre[NT16];
+  if constexpr (igemm_bias_pre<P>::value) {
+#pragma unroll
+    for (int i = 0; i < NT16; ++i) { const int q = wave * NT16 + i, ty = q % (BY / 16); bpre[i] = p.bias_pre(y0 + ty * 16 + r16); }
+  }
+  S16T(1);
   gload(0, a0, b0);
+  S16T(2);
   sstore(0, a0, b0);
+  S16T(3);
   if (nchunk > 1) gload(1, a0, b0);
   __syncthreads();
+  S16T(4);
   int buf = 0, c = 0;
   while (true) {
     if (c + 2 < nchunk) gload(c + 2, a1, b1);        // set 0 holds chunk c+1
@@ -637,12 +671,14 @@ __global__ __launch_bounds__(256, 2) void igemm_s16_kernel(const P p) {   // (, 
     if (c + 1 < nchunk) sstore(buf ^ 1, a0, b0);
     __syncthreads();
     buf ^= 1;
+    S16T(5 + (c < 16 ? c : 16));
     if (++c >= nchunk) break;
     if (c + 2 < nchunk) gload(c + 2, a0, b0);        // set 1 holds chunk c+1
     compute(buf);
     if (c + 1 < nchunk) sstore(buf ^ 1, a1, b1);
     __syncthreads();
     buf ^= 1;
+    S16T(5 + (c < 16 ? c : 16));
     if (++c >= nchunk) break;
   }
   // D layout of the 16x16 tile: lane (g4, r16) holds rows 4*g4 + i, column r16
@@ -650,8 +686,12 @@ __global__ __launch_bounds__(256, 2) void igemm_s16_kernel(const P p) {   // (, 
   for (int i = 0; i < NT16; ++i) {
     const int q = wave * NT16 + i, tx = q / (BY / 16), ty = q % (BY / 16);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) p.store(x0 + tx * 16 + 4 * g4 + e, y0 + ty * 16 + r16, acc[i][e], z, 0);
+    for (int e = 0; e < 4; ++e) {
+      if constexpr (igemm_bias_pre<P>::value) p.store_pre(x0 + tx * 16 + 4 * g4 + e, y0 + ty * 16 + r16, acc[i][e], bpre[i]);
+      else p.store(x0 + tx * 16 + 4 * g4 + e, y0 + ty * 16 + r16, acc[i][e], z, 0);
+    }
   }
+  S16T(22);
 }
 template <int BX, int BY, int BR, class P>
 static inline void igemm_s16_launch(const P& p, int nsplit, hipStream_t stream) {
