@@ -197,6 +197,9 @@ struct DenseFwd {
     if (SPLIT) out[((size_t)z * M + m) * N + n] = v;
     else out[(size_t)m * N + n] = relu(v + bias[n]);
   }
+  static constexpr bool BIAS_PRE = !SPLIT;
+  __device__ float bias_pre(int n) const { return bias[min(n, N - 1)]; }
+  __device__ void store_pre(int m, int n, float v, float b) const { if (m < M && n < N) out[(size_t)m * N + n] = relu(v + b); }
 };
 
 __global__ void dense_reduce_kernel(const float* part, const float* bias, float* out, int M, int N, int S) {

@@ -344,6 +344,7 @@ __global__ __launch_bounds__(256, P::Tile::MINW) void igemm_pf2_kernel(const P p
   if constexpr (KSKIP) { kctx = p.block_ctx(x0, cls); rlo = 0; rhi = p.block_k(kctx); }
   const int nchunk = (rhi - rlo + BR - 1) / BR;
 
+
   f32x16 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
