@@ -318,3 +318,48 @@ def test_bench_workload_constants():
     assert round(bench.EXEC_FLOPS_PER_ENV_STEP / 1e6, 1) == 216.9
     assert bench.RESNET_EXEC_MFLOP_PER_ENV_STEP == 1377.4
     assert bench.parse_topology("2x(a0-l1,2,3)") == (2, [0], [1, 2, 3]) and bench.parse_topology("a0,1-l2,3") == (1, [0, 1], [2, 3])
+
+
+def test_trainer_page_locks_an_observation_buffer_the_env_reuses(monkeypatch, tmp_path):
+    """An env that hands back the SAME observation array every step (a pool that steps in place) gets it page-locked once (cbm_host_register through
+    engine.host_register); the synthetic twin, which returns a fresh array per step like envpool, never triggers it."""
+    sys.path.insert(0, HERE)
+    from oracle_engine import OracleEngine
+    from cleanba_amd import trainer
+    from cleanba_amd.args import parse_args
+    calls = []
+
+    class Eng(OracleEngine):
+        def host_register(self, arr):
+            calls.append(arr.ctypes.data)
+
+    real = trainer.make_env
+
+    def reusing(env_id, seed, n, **kw):
+        thunk = real(env_id, seed, n, **kw)
+
+        def make():
+            e = thunk()
+            buf = np.zeros((n, 4, 84, 84), np.uint8)
+            step0, reset0 = e.step, e.reset
+
+            def step(a):
+                o, r, d, i = step0(a)
+                buf[...] = o
+                return buf, r, d, i
+
+            def reset():
+                buf[...] = reset0()
+                return buf
+            e.step, e.reset = step, reset
+            return e
+        return make
+
+    os.chdir(str(tmp_path))
+    argv = ["--local-num-envs", "4", "--num-actor-threads", "1", "--num-steps", "4", "--env-backend", "host", "--network", "nature",
+            "--total-timesteps", "32", "--log-frequency", "1000", "--update-epochs", "1", "--num-minibatches", "2"]
+    trainer.train(parse_args(argv, "ppo"), "ppo", engine_factory=Eng)
+    assert calls == []                                  # fresh arrays per step: nothing to pin
+    monkeypatch.setattr(trainer, "make_env", reusing)
+    trainer.train(parse_args(argv, "ppo"), "ppo", engine_factory=Eng)
+    assert len(calls) == 1                              # the reused buffer, once
