@@ -977,9 +977,16 @@ __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const RedJobs j
   const int i = (((int)blockIdx.x - J.block0) * ow + o) * 4;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   if (i < XY)
-    for (int z = g; z < nz; z += zg) {
-      const float4 v = *reinterpret_cast<const float4*>(J.part + (size_t)z * XY + i);
-      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    for (int z0 = g; z0 < nz; z0 += 8 * zg) {   // eight slices in flight (one after the other, the 5 slices of the dense layer were 5 HBM round trips per block)
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int z = z0 + u * zg;
+        if (z < nz) v[u] = *reinterpret_cast<const float4*>(J.part + (size_t)z * XY + i);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (z0 + u * zg < nz) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }   // same z order as the scalar form
     }
   red[threadIdx.x] = s;
   __syncthreads();
