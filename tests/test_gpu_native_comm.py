@@ -88,7 +88,7 @@ os._exit(0)
     assert p.returncode == 0 and b"TIMEOUT-REPORTED" in p.stdout, p.stdout.decode()[-3000:]
 
 
-def _run_topology(engine, tmp, tag, E, T, updates, ids, epochs, omp=None, groups=1, env_id="Breakout-v5"):
+def _run_topology(engine, tmp, tag, E, T, updates, ids, epochs, omp=None, groups=1, env_id="Breakout-v5", algo="ppo"):
     aids, lids = ids.split(":")
     world = groups * (len(aids.split(",")) + len(lids.split(",")))
     port = _free_port()
@@ -99,7 +99,7 @@ def _run_topology(engine, tmp, tag, E, T, updates, ids, epochs, omp=None, groups
     for r in range(world):
         out = os.path.join(str(tmp), f"{tag}_{r}.npz")
         outs.append(out)
-        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "topo_worker.py"), str(r), str(world), str(port), out, "ppo", engine, str(E), str(T),
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "topo_worker.py"), str(r), str(world), str(port), out, algo, engine, str(E), str(T),
                                        str(updates), ids, str(epochs), env_id], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     logs = [p.communicate(timeout=1500)[0].decode() for p in procs]
     for p in procs:
@@ -119,6 +119,20 @@ def test_a0_l123_small_native_equals_oracle_topology(tmp_path):
     print("a0-l1,2,3 small: |p - p_oracle| max %.2e" % d.max())
     assert np.abs(o0["params"] - o0["p0"]).max() > 1e-4 and d.max() <= 1e-5
     np.testing.assert_allclose(l0["stats"], o0["stats"], rtol=1e-5, atol=1e-6)
+
+
+def test_a0_l12_impala_native_equals_oracle_topology(tmp_path):
+    """The IMPALA script in a split topology (impala:599-645: V-trace loss, RMSProp, pmean of four statistics): one actor + two learner role processes
+    on GPU 0, each learner a different half of the env columns, gradients and statistics through the native all-reduce; after the first update against
+    the same topology on the CPU oracle engine over gloo."""
+    (a, l0, l1), logs = _run_topology("hip", tmp_path, "ihip", 8, 8, 1, "0:1,2", 1, algo="impala")
+    assert "allreduce.backend: native ranks 2" in "".join(logs)
+    assert np.array_equal(l0["params"], l1["params"]) and np.array_equal(a["params"], l0["params"])
+    (_, o0, _), _ = _run_topology("oracle", tmp_path, "icpu", 8, 8, 1, "0:1,2", 1, omp=4, algo="impala")
+    d = np.abs(l0["params"] - o0["params"])
+    print("impala a0-l1,2 small: |p - p_oracle| max %.2e" % d.max())
+    assert np.abs(o0["params"] - o0["p0"]).max() > 1e-5 and d.max() <= 1e-5
+    np.testing.assert_allclose(l0["stats"], o0["stats"], rtol=1e-5, atol=1e-5)   # (IMPALA's losses are SUMS over T x B, impala:569-597: the bar of tests/test_gpu_parity.py)
 
 
 def test_configs4_two_groups_atari57_mix_native_equals_oracle_topology(tmp_path):
