@@ -322,11 +322,215 @@ void launch_ppo_loss(const float* logits, const float* value, int N, int A, cons
 // ------------------------------------------------------------------------------------------
 // IMPALA loss head impala:569-597 + rlax 0.1.5 V-trace (lambda = 1, rho/c/pg clips = 1).
 // One BLOCK per env column of the minibatch (network outputs are [T1][Bm] rows, t-major; storage fields are [T1][ld] with this
-// minibatch at columns col0..col0+Bm).  The per-step work (two log-softmaxes, entropy, gradients: ~100 transcendental calls) runs
-// t-parallel across the block; only the V-trace recursion itself is a serial scan, fed from LDS.  Every per-element expression
-// and every summation order is the one of the original one-thread-per-column kernel (which spent 3.4 ms per minibatch on 30
-// threads), so results are bit-identical to it.
-__global__ __launch_bounds__(256) void impala_loss_kernel(const float* logits, const float* value, const float* mu_logits, const int32_t* actions,
+// minibatch at columns col0..col0+Bm).  Only Bm = 30 blocks exist, so the kernel is as long as one block's instruction stream: the work is
+// cut into phases that are either ELEMENT-parallel (one thread per (t, action): the 3 x T x A exponentials, the probabilities, the gradients)
+// or STEP-parallel (one thread per t: maxima, the sums over actions in ascending action order, logarithms), every operand in LDS, and the
+// V-trace recursion itself runs on one lane while the other waves take the entropy sums.  No loop bound or guard is a scalar branch: bounds
+// that are uniform (A, T) are compared through a VGPR copy so that the compiler predicates instead — with `if (j < A)` inside unrolled loops
+// the one-step-per-thread form of this kernel spent most of its 40-47 us in s_cbranch (tools/il_trace.py: scan 9.3 us for 128 steps).
+// Every per-element expression and every summation order is the one of impala_loss_column_kernel below (one thread per column, the
+// form the oracle restates), so results are bit-identical to it.
+#ifdef CBM_IL_TRACE   // timing build: phase stamps of block 0, thread 0 (read back by tools/il_trace.py through cbm_debug_il_trace)
+__device__ unsigned long long cbm_il_trace[16];
+extern "C" int cbm_debug_il_trace(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(cbm_il_trace), sizeof(cbm_il_trace)) == hipSuccess ? 0 : -1; }
+#define ILT(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) cbm_il_trace[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define ILT(k) do { } while (0)
+#endif
+#define IL_NT 512
+#define IL_PAD 32          // floats behind each [T][A] array / in front of the scan arrays: unguarded reads and writes land here
+static __device__ __forceinline__ int il_opaque(int x) { asm volatile("" : "+v"(x)); return x; }   // a uniform bound the compiler must treat as per-lane
+// sum of row[0..A) in ascending order; all 28 candidates are read before the first add (row has IL_PAD floats of slack behind the array)
+static __device__ __forceinline__ float il_row_sum(const float* row, int Av) {
+  float v[28];
+#pragma unroll
+  for (int q = 0; q < 28; ++q) v[q] = row[q];
+  float s = 0.0f;
+#pragma unroll
+  for (int q = 0; q < 28; ++q) { const float n = s + v[q]; s = q < Av ? n : s; }
+  return s;
+}
+static __device__ __forceinline__ float il_row_max(const float* row, int Av) {
+  float v[28];
+#pragma unroll
+  for (int q = 0; q < 28; ++q) v[q] = row[q];
+  float mx = v[0];
+#pragma unroll
+  for (int q = 1; q < 28; ++q) mx = (q < Av && v[q] > mx) ? v[q] : mx;
+  return mx;
+}
+size_t impala_loss_lds_bytes(int T1, int A) { return ((size_t)24 * T1 + 3 * IL_PAD + 3 * ((size_t)(T1 - 1) * A + IL_PAD)) * sizeof(float); }
+__global__ __launch_bounds__(IL_NT) void impala_loss_kernel(const float* logits, const float* value, const float* mu_logits, const int32_t* actions,
+                                   const float* rewards, const uint8_t* dones, const uint8_t* firststeps, int T1, int Bm, int A, int col0,
+                                   int ld, float gamma, float vf_coef, float ent_coef, float* dzv, float* partials) {
+  extern __shared__ float ish[];
+  const int b = blockIdx.x, T = T1 - 1, tid = threadIdx.x, TA = T * A;
+  const int Av = il_opaque(A), Tv = il_opaque(T);
+  float* p = ish;
+  auto take = [&](int n) { float* r = p; p += n; return r; };
+  float* s_val = take(T1);                 // value[t][b], t = 0..T
+  int* s_act = (int*)take(T1);
+  float* s_disc = take(T1);                // (1 - done) * gamma
+  float* s_rew = take(T1);
+  float* s_mask = take(T1);                // 1 - firststep
+  float* s_mx = take(2 * T1);              // [0, T): max_j z   [T, 2T): max_j mu
+  float* s_ma = take(T1);                  // mu logit of the action taken
+  float* s_lpa = take(T1);                 // log pi(a)
+  float* s_lma = take(T1);                 // log mu(a)
+  float* s_se = take(T1);                  // sum_j exp(z_j - mx)
+  float* s_lse = take(T1);                 // its logarithm
+  float* s_cr = take(T1);                  // min(1, rho)
+  float* s_H = take(T1);                   // entropy
+  float* s_pg = take(T1);                  // per-t loss terms, summed in t order at the end
+  float* s_bl = take(T1);
+  float* s_en = take(T1);
+  float* s_c1 = take(T1);                  // -pgadv * mask
+  float* s_c2 = take(T1);                  // ent_coef * mask
+  float* s_dv = take(T1);                  // dL/dvalue
+  float* s_td = take(T1 + IL_PAD) + IL_PAD;    // cr * (r + disc*v' - v); the scan reads up to 15 entries below [0]
+  float* s_dc = take(T1 + IL_PAD) + IL_PAD;    // disc * cr
+  float* s_err = take(T1 + IL_PAD) + IL_PAD;   // err recursion
+  float* zs = take(TA + IL_PAD);           // z[t][j]
+  float* ez = take(TA + IL_PAD);           // exp(z - mx)
+  float* ms = take(TA + IL_PAD);           // mu[t][j] -> exp(mu - mm) -> p_j * log p_j
+  ILT(0);
+  // element index e = t*A + j of this thread's k-th element: e = tid + k*IL_NT, walked without a division per element
+  const int t_first = tid / A, j_first = tid - t_first * A, dt = IL_NT / A, dj = IL_NT - dt * A;
+  // phase 0: operands into LDS
+  {
+    int t = t_first, j = j_first;
+    for (int e = tid; e < TA; e += IL_NT) {
+      zs[e] = logits[((size_t)t * Bm + b) * A + j];
+      ms[e] = mu_logits[((size_t)t * ld + col0 + b) * A + j];
+      t += dt; j += dj;
+      const bool wrap = j >= Av; j = wrap ? j - A : j; t = wrap ? t + 1 : t;
+    }
+    for (int t1 = tid; t1 < T1; t1 += IL_NT) {
+      s_val[t1] = value[(size_t)t1 * Bm + b];
+      if (t1 < T) {
+        const size_t sidx = (size_t)t1 * ld + col0 + b;
+        s_act[t1] = actions[sidx];
+        s_disc[t1] = (1.0f - (float)dones[sidx]) * gamma;
+        s_rew[t1] = rewards[sidx];
+        s_mask[t1] = 1.0f - (float)firststeps[sidx];
+      }
+    }
+  }
+  __syncthreads();
+  ILT(1);
+  // phase 1 (one thread per (policy, t)): row maxima; the behaviour policy's side also keeps mu[a] (its row is overwritten in phase 2)
+  for (int u = tid; u < 2 * T; u += IL_NT) {
+    const bool mu = u >= T;
+    const int t = mu ? u - T : u;
+    const float* row = (mu ? ms : zs) + t * A;
+    s_mx[u] = il_row_max(row, Av);
+    if (mu) s_ma[t] = row[s_act[t]];
+  }
+  __syncthreads();
+  ILT(2);
+  // phase 2 (per element): the exponentials of both softmaxes
+  {
+    int t = t_first, j = j_first;
+    for (int e = tid; e < TA; e += IL_NT) {
+      ez[e] = cbm_expf(zs[e] - s_mx[t]);
+      ms[e] = cbm_expf(ms[e] - s_mx[T + t]);
+      t += dt; j += dj;
+      const bool wrap = j >= Av; j = wrap ? j - A : j; t = wrap ? t + 1 : t;
+    }
+  }
+  __syncthreads();
+  ILT(3);
+  // phase 3 (one thread per (policy, t)): sums in ascending action order, logarithms, log pi(a) / log mu(a)
+  for (int u = tid; u < 2 * T; u += IL_NT) {
+    const bool mu = u >= T;
+    const int t = mu ? u - T : u;
+    const float sum = il_row_sum((mu ? ms : ez) + t * A, Av);
+    const float lg = cbm_logf(sum);
+    if (mu) s_lma[t] = (s_ma[t] - s_mx[u]) - lg;
+    else { s_lpa[t] = (zs[t * A + s_act[t]] - s_mx[u]) - lg; s_se[t] = sum; s_lse[t] = lg; }
+  }
+  __syncthreads();
+  ILT(4);
+  // phase 4: the scan's inputs (one thread per t), and p_j * log p_j per element into the freed mu rows
+  for (int t = tid; t < T; t += IL_NT) {
+    const float rho = cbm_expf(s_lpa[t] - s_lma[t]);
+    const float cr = rho < 1.0f ? rho : 1.0f;
+    const float disc = s_disc[t];
+    s_cr[t] = cr;
+    s_td[t] = cr * ((s_rew[t] + disc * s_val[t + 1]) - s_val[t]);
+    s_dc[t] = disc * cr;
+  }
+  {
+    int t = t_first, j = j_first;
+    for (int e = tid; e < TA; e += IL_NT) {
+      const float lp = (zs[e] - s_mx[t]) - s_lse[t];
+      ms[e] = (ez[e] / s_se[t]) * lp;
+      t += dt; j += dj;
+      const bool wrap = j >= Av; j = wrap ? j - A : j; t = wrap ? t + 1 : t;
+    }
+  }
+  __syncthreads();
+  ILT(5);
+  // phase 5: lane 0 runs the recursion err_t = td_t + disc_t*c_t*err_{t+1} in reverse, inputs fetched sixteen steps at a time (the batch that
+  // crosses t = 0 reads and writes the pad in front of the arrays); the other waves take the entropy sums meanwhile
+  if (tid == 0) {
+    float e = 0.0f;
+    for (int t1 = T; t1 > 0; t1 -= 16) {
+      float td[16], dc[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) { td[u] = s_td[t1 - 1 - u]; dc[u] = s_dc[t1 - 1 - u]; }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) { e = td[u] + dc[u] * e; s_err[t1 - 1 - u] = e; }
+    }
+  } else if (tid >= 64) {
+    for (int t = tid - 64; t < T; t += IL_NT - 64) s_H[t] = -il_row_sum(ms + t * A, Av);
+  }
+  __syncthreads();
+  ILT(6);
+  // phase 6 (one thread per t): q values, advantages, the three loss terms, the per-step gradient coefficients
+  for (int t = tid; t < T; t += IL_NT) {
+    const float v = s_val[t], vn = s_val[t + 1], mask = s_mask[t], H = s_H[t];
+    const float errors = (s_err[t] + v) - v;
+    const float en = s_err[t + 1];
+    const float qboot = t == T - 1 ? vn : ((en + vn) - vn) + vn;
+    const float q = s_rew[t] + s_disc[t] * qboot;
+    const float pgadv = s_cr[t] * (q - v);
+    s_pg[t] = -s_lpa[t] * pgadv * mask;
+    s_bl[t] = errors * errors * mask;
+    s_en[t] = -H * mask;
+    s_c1[t] = -pgadv * mask;
+    s_c2[t] = ent_coef * mask;
+    s_dv[t] = vf_coef * (-errors) * mask;
+  }
+  __syncthreads();
+  ILT(7);
+  // phase 7 (one thread per element of dzv's [T][32] rows): gradients; three lanes sum the loss terms in t order first
+  if (tid < 3) {
+    const float* src = tid == 0 ? s_pg : (tid == 1 ? s_bl : s_en);
+    float acc = 0.0f;
+    for (int t0 = 0; t0 < T; t0 += 16) {
+      float v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = src[t0 + u];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) { const float n = acc + v[u]; acc = t0 + u < Tv ? n : acc; }
+    }
+    partials[b * 3 + tid] = acc;
+  }
+  for (int x = tid; x < T * 32; x += IL_NT) {
+    const int t = x >> 5, j = x & 31;
+    const int e = t * A + (j < Av ? j : 0);
+    const float lp = (zs[e] - s_mx[t]) - s_lse[t], pj = ez[e] / s_se[t];
+    const float d = s_c1[t] * ((j == s_act[t] ? 1.0f : 0.0f) - pj) + s_c2[t] * pj * (lp + s_H[t]);
+    dzv[((size_t)t * Bm + b) * 32 + j] = j < Av ? d : (j == Av ? s_dv[t] : 0.0f);
+  }
+  // bootstrap row T: no gradient
+  if (tid < 32) dzv[((size_t)T * Bm + b) * 32 + tid] = 0.0f;
+  ILT(8);
+}
+// One THREAD per time step, serial over the actions: the form this path started from (and the order of operations the phases above keep);
+// used when T x A is too large for the block's LDS.
+__global__ __launch_bounds__(256) void impala_loss_column_kernel(const float* logits, const float* value, const float* mu_logits, const int32_t* actions,
                                    const float* rewards, const uint8_t* dones, const uint8_t* firststeps, int T1, int Bm, int A, int col0,
                                    int ld, float gamma, float vf_coef, float ent_coef, float* dzv, float* partials) {
   extern __shared__ float ish[];
@@ -417,8 +621,13 @@ __global__ void impala_stats_kernel(const float* partials, int Bm, float vf_coef
 void launch_impala_loss(const float* logits, const float* value, const float* mu_logits, const int32_t* actions, const float* rewards,
                         const uint8_t* dones, const uint8_t* firststeps, int T1, int Bm, int A, int col0, int ld, float gamma,
                         float vf_coef, float ent_coef, float* dzv, float* partials, float* stats4, hipStream_t st) {
-  hipLaunchKernelGGL(impala_loss_kernel, dim3(Bm), dim3(T1 - 1 >= 192 ? 256 : 128), (size_t)8 * T1 * sizeof(float), st, logits, value, mu_logits, actions,
-                     rewards, dones, firststeps, T1, Bm, A, col0, ld, gamma, vf_coef, ent_coef, dzv, partials);
+  const size_t lds = impala_loss_lds_bytes(T1, A);
+  if (lds <= 64 * 1024)
+    hipLaunchKernelGGL(impala_loss_kernel, dim3(Bm), dim3(IL_NT), lds, st, logits, value, mu_logits, actions, rewards, dones, firststeps, T1, Bm, A, col0, ld,
+                       gamma, vf_coef, ent_coef, dzv, partials);
+  else
+    hipLaunchKernelGGL(impala_loss_column_kernel, dim3(Bm), dim3(T1 - 1 >= 192 ? 256 : 128), (size_t)8 * T1 * sizeof(float), st, logits, value, mu_logits,
+                       actions, rewards, dones, firststeps, T1, Bm, A, col0, ld, gamma, vf_coef, ent_coef, dzv, partials);
   hipLaunchKernelGGL(impala_stats_kernel, dim3(1), dim3(64), 0, st, partials, Bm, vf_coef, ent_coef, stats4);
 }
 

@@ -1,7 +1,8 @@
 """Per-kernel roofline rows of the IMPALA-ResNet learner from a rocprofv3 kernel-stats table (tools/rocprof_summary.py over tools/rn_microbench.py):
 executed flops of a 3840-frame minibatch per launch from the kernel's own geometry (template arguments CI, CO, H in its name), TFLOP/s and fraction
-of the fp32 MFMA peak (157.3).  Learner-size launches only (the same kernels also run at 120 frames inside the rollout: rows whose avg is far
-below the max are split by the per-launch minimum / maximum, so only kernels with >= 5 % spread are flagged).
+of the fp32 MFMA peak (157.3).  Learner-size launches only: a kernel that also runs at 120 frames inside the rollout (its shortest launch is far
+below its average) is priced at its longest launch, one that only runs at 3840 frames at its average (the first, cold launch of each is 2-3x the rest
+and would otherwise be reported as the kernel's time).
 usage: python tools/resnet_roofline.py profiles/r04_resnet_kernel_stats.md"""
 import re
 import sys
@@ -26,7 +27,7 @@ for ln in open(sys.argv[1]):
         flops = 2.0 * MB * 42 * 42 * 9 * 4 * 16      # executed: one of the four conv outputs under each pooled element carries gradient
     else:
         continue
-    learner_us = mx if (mx - mn) / mx > 0.5 else avg     # mixed 120-frame / 3840-frame launches: the learner-size ones are the long ones
+    learner_us = mx if mn < 0.5 * avg else avg     # mixed 120-frame / 3840-frame launches: the learner-size ones are the long ones
     if learner_us < 60:
         continue
     rows.append((total, name, f"{ci}->{co} @ {h}x{h} {kind}", learner_us, flops))

@@ -7,7 +7,7 @@ F="-O3 -std=c++20 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-math-errno 
 while [ $# -ge 2 ]; do
   name=$1; defs=$2; shift; shift
   d=/tmp/abl_$name; mkdir -p $d
-  for f in gemm_layers conv1 wgrad_frames conv_regw dense_wgrad; do /opt/rocm/bin/hipcc $F $defs -c $f.hip -o $d/$f.o & done; wait
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC api.o comm.o pointwise.o env.o $d/dense_wgrad.o $d/conv_regw.o $d/gemm_layers.o $d/conv1.o $d/wgrad_frames.o -ldl -o ../abl_$name.so
+  for f in gemm_layers conv1 wgrad_frames conv_regw dense_wgrad pointwise; do /opt/rocm/bin/hipcc $F $defs -c $f.hip -o $d/$f.o & done; wait
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC api.o comm.o $d/pointwise.o env.o $d/dense_wgrad.o $d/conv_regw.o $d/gemm_layers.o $d/conv1.o $d/wgrad_frames.o -ldl -o ../abl_$name.so
   echo built abl_$name.so "($defs)"
 done
