@@ -20,7 +20,8 @@ template <int N> static __device__ __forceinline__ void dw_wait_vm() { asm volat
 #define DW_BK 16
 #define DW_ST 3
 // A = act [F][X] (X = 3136 outputs of the gradient's rows), G = dhid [F][Y] (Y = 512); block (bx, by, z): rows [bx*128, +128), columns [by*128, +128),
-// frames [z*fslice, min(F, (z+1)*fslice)) — fslice a multiple of 16
+// frames [z*fslice, min(F, (z+1)*fslice)) — fslice a multiple of 16.  F itself need not be (IMPALA's minibatches are 129 x 30 rows): the last chunk of
+// the last slice then starts at F - 16, and the rows it shares with the chunk before it enter the products as zeros.
 __global__ __launch_bounds__(256, 2) void dense_wgrad_dma_kernel(const float* __restrict__ A, const float* __restrict__ G, float* __restrict__ part,
                                                                  float* __restrict__ bpart, int F, int X, int Y, int fslice) {
   constexpr int ASZ = DW_BM * DW_BK, BSZ = DW_BN * DW_BK, DA = ASZ / 256 / 4, DB = BSZ / 256 / 4, DPW = DA + DB;   // 1 KiB copies per wave and chunk
@@ -40,7 +41,7 @@ __global__ __launch_bounds__(256, 2) void dense_wgrad_dma_kernel(const float* __
   auto dma = [&](int c) __attribute__((always_inline)) {
     float* As = smem + (c % DW_ST) * (ASZ + BSZ);
     float* Bs = As + ASZ;
-    const int k0 = min(f_lo + c * DW_BK, F - DW_BK);   // (F is a multiple of 16 at the call site; a short last slice re-reads rows it masks below)
+    const int k0 = min(f_lo + c * DW_BK, F - DW_BK);   // (a ragged last chunk re-reads rows of its predecessor: masked in compute)
     const float* Ac = A + (size_t)k0 * X;
     const float* Gc = G + (size_t)k0 * Y;
 #pragma unroll
@@ -57,21 +58,22 @@ __global__ __launch_bounds__(256, 2) void dense_wgrad_dma_kernel(const float* __
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
   float bsum = 0.0f;
   const bool do_bias = blockIdx.x == 0;            // the column sums of dhid (bias gradient) come from the B tiles of the first row of blocks
-  auto compute = [&](int c) __attribute__((always_inline)) {
+  // skip > 0 only for a ragged last chunk: its first `skip` k rows were already multiplied by the chunk before
+  auto compute = [&](int c, int skip) __attribute__((always_inline)) {
     const float* As = smem + (c % DW_ST) * (ASZ + BSZ);
     const float* Bs = As + ASZ;
     float fa[DW_BK / 2][2], fb[DW_BK / 2][2];
 #pragma unroll
     for (int s = 0; s < DW_BK / 2; ++s) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) fa[s][i] = As[(2 * s + h) * DW_BM + wx * 64 + i * 32 + li];
+      for (int i = 0; i < 2; ++i) { const float v = As[(2 * s + h) * DW_BM + wx * 64 + i * 32 + li]; fa[s][i] = 2 * s + h >= skip ? v : 0.0f; }
 #pragma unroll
       for (int j = 0; j < 2; ++j) fb[s][j] = Bs[(2 * s + h) * DW_BN + wy * 64 + j * 32 + li];
     }
     if (do_bias) {                                 // thread t: column t % 128, k rows (t / 128) * 8 .. + 8, ascending
       const int n = tid & 127, kh = (tid >> 7) * 8;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) bsum += Bs[(kh + k) * DW_BN + n];
+      for (int k = 0; k < 8; ++k) { const float v = Bs[(kh + k) * DW_BN + n]; bsum += kh + k >= skip ? v : 0.0f; }
     }
 #pragma unroll
     for (int s = 0; s < DW_BK / 2; ++s)
@@ -86,7 +88,8 @@ __global__ __launch_bounds__(256, 2) void dense_wgrad_dma_kernel(const float* __
     if (c + 1 < nc) dw_wait_vm<DPW>(); else dw_wait_vm<0>();   // chunk c has landed; chunk c+1 may still be in flight
     asm volatile("s_barrier" ::: "memory");                    // (not __syncthreads(): its fence would wait for every copy in flight)
     if (c + DW_ST - 1 < nc) dma(c + DW_ST - 1);                // into the buffer chunk c-1 was multiplied from: every wave is past that
-    compute(c);
+    const int over = f_lo + c * DW_BK + DW_BK - F;             // > 0: the chunk was moved back by this many rows to end at F
+    if (over > 0) compute(c, over); else compute(c, 0);
   }
   float* Pz = part + (size_t)z * X * Y;
 #pragma unroll
@@ -108,7 +111,7 @@ __global__ __launch_bounds__(256, 2) void dense_wgrad_dma_kernel(const float* __
   }
 }
 
-int dense_wgrad_dma_slices(int F) { return F >= 2048 && F % 16 == 0 ? 5 : 0; }   // 0: batch not handled here (small / ragged batches stay on igemm_kernel)
+int dense_wgrad_dma_slices(int F) { return F >= 2048 ? 5 : 0; }   // 0: batch not handled here (small batches stay on igemm_kernel)
 void launch_dense_wgrad_dma(const float* act, const float* dhid, float* part, float* bpart, int F, int X, int Y, int nz, hipStream_t st) {
   const int fslice = ((F + nz - 1) / nz + DW_BK - 1) / DW_BK * DW_BK;
   dim3 grid((X + DW_BM - 1) / DW_BM, (Y + DW_BN - 1) / DW_BN, nz);

@@ -33,9 +33,12 @@ rollout()
 for _ in range(max(2, 4000 // T)): rollout(); update()
 ctx.sync(); t0 = time.perf_counter()
 N = max(8, 1024 // T)
-for _ in range(N): rollout(); update()
+hr = hu = 0.0
+for _ in range(N):
+    a = time.perf_counter(); rollout(); b = time.perf_counter(); update(); hr += b - a; hu += time.perf_counter() - b
 ctx.sync(); dt = (time.perf_counter() - t0) / N
 print(f"IMPALA E={E} T={T} bf16={cfg.forward_bf16}: pipelined {dt*1e3:.2f} ms/step = {E*T/dt/1e3:.1f} k env-steps/s")
+print(f"  host time inside the calls: rollout {hr/N*1e3:.2f} ms, update {hu/N*1e3:.2f} ms per step")
 tr = tu = 0.0
 for _ in range(4):
     ctx.sync(); t0 = time.perf_counter(); rollout(); ctx.sync(); tr += time.perf_counter() - t0
