@@ -560,6 +560,10 @@ __global__ __launch_bounds__(256) void ppo_heads_fused_kernel(const float* hid, 
   // 256-byte ones.  (Through registers this phase and the chain below were 31 us for a block that owns a CU alone — the same pattern the actor tail
   // had: DESIGN 4.1.)
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  // the samples' scalars are a gather through idx — two dependent round trips: the index is requested first, the scalars once the staging copies are
+  // on their way (vmcnt retires in order: waiting for the index does not wait for the copies behind it)
+  int n_gather = 0;
+  if (tid < 16) { const int ii = min(m0 + tid, B - 1); n_gather = idx ? idx[ii] : ii; }
   for (int q = wave_u; q < 16 * (HD / 256); q += 4) {
     const int row = q / (HD / 256), part = q % (HD / 256);
     ig_glds16(hid + (size_t)min(m0 + row, B - 1) * HD + part * 256 + lane * 4, hs + row * PH + part * 256);
@@ -573,10 +577,7 @@ __global__ __launch_bounds__(256) void ppo_heads_fused_kernel(const float* hid, 
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Wc + 64 * q + lane), (__attribute__((address_space(3))) void*)(wc + 64 * q), 4, 0, 0);
   __shared__ int s_act[16];
   __shared__ float s_olp[16], s_adv[16], s_tgt[16];
-  if (tid < 16) {   // the samples' scalars (a gather through idx: two dependent round trips) are fetched under the staging, not inside the loss phase
-    const int ii = min(m0 + tid, B - 1), n = idx ? idx[ii] : ii;
-    s_act[tid] = actions[n]; s_olp[tid] = old_logprob[n]; s_adv[tid] = adv[n]; s_tgt[tid] = target[n];
-  }
+  if (tid < 16) { const int n = n_gather; s_act[tid] = actions[n]; s_olp[tid] = old_logprob[n]; s_adv[tid] = adv[n]; s_tgt[tid] = target[n]; }
   TT(1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -633,21 +634,32 @@ __global__ __launch_bounds__(256) void ppo_heads_fused_kernel(const float* hid, 
   __syncthreads();
   TT(7);
   if (tid < 4) {
-    float v = 0.0f;
-    for (int q = 0; q < 16; ++q) v += red[q][tid];
+    float r[16], v = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) r[q] = red[q][tid];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v += r[q];
     partials[blockIdx.x * 4 + tid] = v;
   }
+  // dhid = dz x [Wa | Wc]^T, 16-column tiles.  No guard is a branch: all eight k steps run (A + 1 <= 29 columns; dz is zero past column A, the weight
+  // operand is selected to zero there, and acc + 0 * 0 leaves acc as it is), the weights are read wherever the index lands (inside wl) and selected
+  // afterwards, the dz fragments are read once — guarded per step the compiler serialised 40 branch / LDS read / wait / MFMA groups: 7.9 us of this
+  // kernel's 21.5 (tools/heads_trace.py)
+  (void)nst;
+  const int Av = cbm_opaque_vgpr(A);
+  float az[8];
+#pragma unroll
+  for (int st = 0; st < 8; ++st) az[st] = dz[r16][4 * st + g4];
 #pragma unroll
   for (int ti = 0; ti < NT; ++ti) {
     const int k = (wave * NT + ti) * 16 + r16;
+    const float wck = wc[k];
+    float bv[8];
+#pragma unroll
+    for (int st = 0; st < 8; ++st) { const int jc = 4 * st + g4; const float x = wl[k * A + jc]; bv[st] = jc < Av ? x : (jc == Av ? wck : 0.0f); }
     f32x4_mfma acc = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-    for (int st = 0; st < 8; ++st)
-      if (st < nst) {
-        const int jc = 4 * st + g4;
-        const float bv = jc < A ? wl[k * A + jc] : (jc == A ? wc[k] : 0.0f);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(dz[r16][jc], bv, acc, 0, 0, 0);
-      }
+    for (int st = 0; st < 8; ++st) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(az[st], bv[st], acc, 0, 0, 0);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int row = 4 * g4 + e, m = m0 + row;

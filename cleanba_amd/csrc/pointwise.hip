@@ -339,7 +339,6 @@ extern "C" int cbm_debug_il_trace(unsigned long long* out) { return hipMemcpyFro
 #endif
 #define IL_NT 512
 #define IL_PAD 32          // floats behind each [T][A] array / in front of the scan arrays: unguarded reads and writes land here
-static __device__ __forceinline__ int il_opaque(int x) { asm volatile("" : "+v"(x)); return x; }   // a uniform bound the compiler must treat as per-lane
 // sum of row[0..A) in ascending order; all 28 candidates are read before the first add (row has IL_PAD floats of slack behind the array)
 static __device__ __forceinline__ float il_row_sum(const float* row, int Av) {
   float v[28];
@@ -365,7 +364,7 @@ __global__ __launch_bounds__(IL_NT) void impala_loss_kernel(const float* logits,
                                    int ld, float gamma, float vf_coef, float ent_coef, float* dzv, float* partials) {
   extern __shared__ float ish[];
   const int b = blockIdx.x, T = T1 - 1, tid = threadIdx.x, TA = T * A;
-  const int Av = il_opaque(A), Tv = il_opaque(T);
+  const int Av = cbm_opaque_vgpr(A), Tv = cbm_opaque_vgpr(T);
   float* p = ish;
   auto take = [&](int n) { float* r = p; p += n; return r; };
   float* s_val = take(T1);                 // value[t][b], t = 0..T
