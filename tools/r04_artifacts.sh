@@ -30,7 +30,7 @@ BF16=1 prof impala_t128_bf16 python $R/tools/impala_probe.py
 T=20 prof impala_t20 python $R/tools/impala_probe.py
 ( python tools/impala_probe.py; BF16=1 python tools/impala_probe.py; T=20 python tools/impala_probe.py; T=20 BF16=1 python tools/impala_probe.py ) 2>&1 | grep -v amdgpu > $out/impala_probe.txt
 python tools/readme_table.py 2>&1 | grep -v amdgpu > $out/readme_table.txt
-python tools/host_loop_probe.py 1 2>&1 | grep -v amdgpu > $out/host_loop_probe.txt
+( python tools/host_loop_probe.py 1; echo '# equal stream priorities (CBM_STREAM_PRIO=none)'; CBM_STREAM_PRIO=none python tools/host_loop_probe.py 1 ) 2>&1 | grep -v amdgpu > $out/host_loop_probe.txt
 NET=resnet python tools/pipeline_probe.py 2>&1 | grep -v amdgpu > $out/resnet_pipeline_probe.txt
 python tools/pipeline_probe.py 2>&1 | grep -v amdgpu > $out/nature_pipeline_probe.txt
 timeout 200 tools/ubench/gemm2 0 > $out/ubench_gemm2.txt 2>&1
@@ -39,13 +39,16 @@ cd /tmp; timeout 300 rocprofv3 --kernel-trace -d $out/tr_ap -o t -- python $R/to
 python tools/actor_progress.py $(find $out/tr_ap -name "*.db" | head -1) > $out/actor_progress.md 2>&1; rm -rf $out/tr_ap
 # round 4 additions
 #   actor_probe.txt / actor_kernel_stats.md   the actor step alone (rollout-only context): us per 120-env step, per-kernel averages
-#   tail_trace.txt                            in-kernel clock stamps of the per-frame actor tail (needs cleanba_amd/abl_tailtrace.so: tools/variants.sh tailtrace "-DCBM_TAIL_TRACE")
+#   tail_trace.txt / heads_trace.txt          in-kernel clock stamps of the per-frame actor tail / the fused PPO heads (needs cleanba_amd/abl_tailtrace.so: tools/variants.sh tailtrace "-DCBM_TAIL_TRACE")
+#   il_trace.txt                              phase stamps of impala_loss_kernel (needs cleanba_amd/abl_iltrace.so: tools/variants.sh iltrace "-DCBM_IL_TRACE")
 #   learner_only_kernel_stats.md              rocprofv3 --kernel-trace over tools/microbench.py --plain: the twelve GEMMs WITHOUT a concurrent rollout
 #   bench_line_a0-l1,2,3_one_gpu.json         BASELINE configs[3] as four role processes on this GPU, native all-reduce
 #   bench_line_dp4_one_gpu.json               bench.py --gpus 4 with every rank on this GPU: native 4-rank all-reduce + the configs[3] line as baseline_config
 ( python tools/actor_probe.py 20; ALGO=impala python tools/actor_probe.py 20; NET=resnet python tools/actor_probe.py 5 ) 2>&1 | grep -v amdgpu > $out/actor_probe.txt
 prof actor python $R/tools/actor_probe.py 5
 [ -f cleanba_amd/abl_tailtrace.so ] && CBM_SO=$R/cleanba_amd/abl_tailtrace.so python tools/tail_trace.py 2>&1 | grep -v amdgpu > $out/tail_trace.txt
+[ -f cleanba_amd/abl_tailtrace.so ] && CBM_SO=$R/cleanba_amd/abl_tailtrace.so python tools/heads_trace.py 2>&1 | grep -v amdgpu > $out/heads_trace.txt
+[ -f cleanba_amd/abl_iltrace.so ] && CBM_SO=$R/cleanba_amd/abl_iltrace.so python tools/il_trace.py 2>&1 | grep -v amdgpu > $out/il_trace.txt
 prof learner_only python $R/tools/microbench.py 8 --plain
 python tools/microbench.py 8 2>&1 | grep -v amdgpu > $out/microbench.txt
 CBM_FORCE_DEVICE=0 timeout 300 python bench.py --topology a0-l1,2,3 --steps 6 --warmup 2 > "$out/bench_line_a0-l1,2,3_one_gpu.json" 2>> $out/bench.err
