@@ -62,9 +62,6 @@ class Args:
     backward_split: int = 0  # build-only extension: 0 = backward GEMMs on fp32 MFMA (reference precision); 2 / 3 = fp32 operands split exactly into
                              # 2 / 3 bf16 terms, products on bf16 MFMA, fp32 accumulate (gradient error ~1e-6 / ~1e-7 of the fp32 path's); Nature-CNN
     bf16_forward: bool = False  # build-only extension (reference is fp32): conv2/conv3/dense forward on bf16 MFMA, fp32 accumulate + fp32 returns (Nature-CNN)
-    actor_stream_priority: str = "auto"  # "high": the actor threads' HIP streams on the high-priority queue (their small per-step kernels are dispatched ahead of
-                                         # the learner's pending workgroups); "normal"; "auto" = high exactly when ONE actor thread steps a host-side env
-                                         # (envpool API, per-step sync ppo:317: the rollout is the critical path) — cbm_config.actor_stream_priority
     same_env_seed_all_ranks: bool = False  # testing aid: every process steps identical envs (then dp-N == dp-1 bitwise)
 
     # runtime arguments to be filled in (ppo:105-117)

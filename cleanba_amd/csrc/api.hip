@@ -162,18 +162,14 @@ static int ctx_create_impl(const cbm_config* cfg, cbm_ctx** out, cbm_ctx** parti
     for (int s = 0; s < c->S; ++s) CBM_HIP(hipEventCreateWithFlags(&R.ready[s], hipEventDisableTiming));
     CBM_HIP(hipEventCreateWithFlags(&R.consumed, hipEventDisableTiming));
   }
-  // stream priorities: cbm_config.actor_stream_priority puts the actor streams on the high-priority queue; the experiment knob
-  // CBM_STREAM_PRIO=actor_hi|actor|learner|learner_lo overrides it (actor / learner also push the other side to the LOW queue)
+  // stream priorities (experiment knob, DESIGN.md section 4.1: nothing measurable either way): CBM_STREAM_PRIO=learner|actor|actor_hi|learner_lo
   int prio_lo = 0, prio_hi = 0;
   hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-  int prio_actor = cfg->actor_stream_priority ? prio_hi : 0, prio_learner = 0;
-  if (const char* pe = getenv("CBM_STREAM_PRIO")) {
-    if (!strcmp(pe, "actor")) { prio_actor = prio_hi; prio_learner = prio_lo; }
-    else if (!strcmp(pe, "learner")) { prio_actor = prio_lo; prio_learner = prio_hi; }
-    else if (!strcmp(pe, "actor_hi")) { prio_actor = prio_hi; prio_learner = 0; }
-    else if (!strcmp(pe, "learner_lo")) { prio_actor = 0; prio_learner = prio_lo; }
-    else if (!strcmp(pe, "none")) { prio_actor = prio_learner = 0; }
-  }
+  const char* pe = getenv("CBM_STREAM_PRIO");
+  int prio_actor = pe && !strcmp(pe, "actor") ? prio_hi : (pe && !strcmp(pe, "learner") ? prio_lo : 0);
+  int prio_learner = pe && !strcmp(pe, "learner") ? prio_hi : (pe && !strcmp(pe, "actor") ? prio_lo : 0);
+  if (pe && !strcmp(pe, "actor_hi")) { prio_actor = prio_hi; prio_learner = 0; }      // (actor / learner also push the other side to the LOW queue)
+  if (pe && !strcmp(pe, "learner_lo")) { prio_actor = 0; prio_learner = prio_lo; }
   for (int s = 0; s < c->S; ++s) {
     Slot& sl = c->slots[s];
     CBM_HIP(hipStreamCreateWithPriority(&sl.stream, hipStreamNonBlocking, prio_actor));

@@ -78,20 +78,7 @@ def make_config(args, algo):
     cfg.norm_adv = int(args.norm_adv) if algo == "ppo" else 0
     cfg.gamma, cfg.gae_lambda = args.gamma, args.gae_lambda
     cfg.clip_coef, cfg.ent_coef, cfg.vf_coef, cfg.max_grad_norm = args.clip_coef, args.ent_coef, args.vf_coef, args.max_grad_norm
-    cfg.actor_stream_priority = int(actor_priority_high(args))
     return cfg
-
-
-def actor_priority_high(args):
-    """--actor-stream-priority: with one actor thread stepping a host-side env the rollout is the critical path (128 x ~370 us against a 30 ms
-    update) and its five small kernels per step queue behind the learner's workgroups: dispatch priority buys 6 % env-steps/s.  With two threads
-    actor work is always pending and a higher queue starves the learner (-25 %); the all-device pipeline does not care."""
-    mode = getattr(args, "actor_stream_priority", "auto")
-    if mode not in ("auto", "high", "normal"):
-        raise SystemExit(f"--actor-stream-priority {mode}: expected auto, high or normal")
-    if mode != "auto":
-        return mode == "high"
-    return args.env_backend != "device" and args.num_actor_threads * len(args.actor_device_ids) == 1
 
 
 def rollout(key, args, algo, engine, writer, slot, world_size, process_index, stop_event, errors, on_commit=None, device_thread_id=None,

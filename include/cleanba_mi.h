@@ -70,12 +70,7 @@ typedef struct {
   int32_t channels[4];        /* built for the reference default (16, 32, 32) and cbm_ctx_create REJECTS anything else rather than silently training */
   int32_t num_hiddens;        /* a different network; hiddens: ONE hidden layer of 64, 128, ... 512 units (default 256; flat parameter layout and    */
   int32_t hiddens[4];         /* cbm_param_count_hidden follow it).  Both ignored for CBM_NET_NATURE (the legacy script has no such flags).          */
-  int32_t actor_stream_priority; /* 0: the actor slots' streams and the learner's stream share one dispatch priority.  1: the actor streams are created on
-                                    the HIGH-priority queue (hipStreamCreateWithPriority): workgroups of the small per-step actor kernels are dispatched ahead of
-                                    the learner's pending ones.  Pays when ONE host-stepped actor thread is the critical path (rollout_time > update time,
-                                    ppo:317's per-step sync): +6 % env-steps/s; with two actor threads actor work is always pending and the learner starves
-                                    (-25 %); the all-device pipeline is work-bound and indifferent.  Results are bit-identical either way (ordering only). */
-  int32_t reserved[2];
+  int32_t reserved[3];
 } cbm_config;
 
 /* Fills cfg with the reference defaults for `algo` (ppo:34-118 / impala:34-110). */

@@ -480,21 +480,3 @@ def test_backward_split_training_run_matches_the_oracle_engine(tmp_path, split):
     d = np.abs(gpu["params"] - cpu["params"]).max()
     assert d <= (2e-5 if split == 3 else 1e-4) * max(1.0, np.abs(cpu["params"]).max()), d
     np.testing.assert_allclose(gpu["stats"], cpu["stats"], rtol=5e-4, atol=5e-5)
-
-
-def test_actor_stream_priority_changes_the_schedule_not_the_bits(tmp_path):
-    # `--actor-stream-priority` (cbm_config.actor_stream_priority): one host-stepped actor thread gets the high-priority HIP queue by default
-    # ("auto"); dispatch order is all it may change — a run with it equals the run on equal priorities bit for bit.
-    import os
-    from cleanba_amd.args import parse_args
-    from cleanba_amd.trainer import train, make_config
-    os.chdir(str(tmp_path))
-    updates = 3
-    argv = ["--local-num-envs", "8", "--num-actor-threads", "1", "--num-steps", "8", "--num-minibatches", "2", "--update-epochs", "2", "--network", "nature",
-            "--env-backend", "host", "--total-timesteps", str(updates * 8 * 8), "--log-frequency", "1000", "--concurrency"]
-    assert make_config(parse_args(argv, "ppo"), "ppo").actor_stream_priority == 1
-    assert make_config(parse_args(argv + ["--actor-stream-priority", "normal"], "ppo"), "ppo").actor_stream_priority == 0
-    hi = train(parse_args(argv, "ppo"), "ppo")
-    lo = train(parse_args(argv + ["--actor-stream-priority", "normal"], "ppo"), "ppo")
-    assert hi["updates"] == lo["updates"] == updates
-    assert np.array_equal(hi["params"], lo["params"]) and np.array_equal(hi["stats"], lo["stats"])

@@ -363,17 +363,3 @@ def test_trainer_page_locks_an_observation_buffer_the_env_reuses(monkeypatch, tm
     monkeypatch.setattr(trainer, "make_env", reusing)
     trainer.train(parse_args(argv, "ppo"), "ppo", engine_factory=Eng)
     assert len(calls) == 1                              # the reused buffer, once
-
-
-def test_actor_stream_priority_rule():
-    """--actor-stream-priority auto = high exactly for ONE actor thread stepping a host-side env (trainer.actor_priority_high)."""
-    from cleanba_amd.args import parse_args
-    from cleanba_amd.trainer import actor_priority_high
-    base = ["--network", "nature", "--local-num-envs", "8"]
-    assert actor_priority_high(parse_args(base + ["--env-backend", "host", "--num-actor-threads", "1"], "ppo"))
-    assert not actor_priority_high(parse_args(base + ["--env-backend", "host", "--num-actor-threads", "2"], "ppo"))
-    assert not actor_priority_high(parse_args(base + ["--env-backend", "device", "--num-actor-threads", "1"], "ppo"))
-    assert not actor_priority_high(parse_args(base + ["--env-backend", "host", "--num-actor-threads", "1", "--actor-stream-priority", "normal"], "impala"))
-    assert actor_priority_high(parse_args(base + ["--env-backend", "device", "--num-actor-threads", "2", "--actor-stream-priority", "high"], "ppo"))
-    with pytest.raises(SystemExit):
-        actor_priority_high(parse_args(base + ["--actor-stream-priority", "urgent"], "ppo"))

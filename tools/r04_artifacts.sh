@@ -30,7 +30,7 @@ BF16=1 prof impala_t128_bf16 python $R/tools/impala_probe.py
 T=20 prof impala_t20 python $R/tools/impala_probe.py
 ( python tools/impala_probe.py; BF16=1 python tools/impala_probe.py; T=20 python tools/impala_probe.py; T=20 BF16=1 python tools/impala_probe.py ) 2>&1 | grep -v amdgpu > $out/impala_probe.txt
 python tools/readme_table.py 2>&1 | grep -v amdgpu > $out/readme_table.txt
-( python tools/host_loop_probe.py 1; echo '# equal stream priorities (CBM_STREAM_PRIO=none)'; CBM_STREAM_PRIO=none python tools/host_loop_probe.py 1 ) 2>&1 | grep -v amdgpu > $out/host_loop_probe.txt
+( python tools/host_loop_probe.py 1; echo '# actor streams on the high-priority queue (CBM_STREAM_PRIO=actor_hi)'; CBM_STREAM_PRIO=actor_hi python tools/host_loop_probe.py 1 ) 2>&1 | grep -v amdgpu > $out/host_loop_probe.txt
 NET=resnet python tools/pipeline_probe.py 2>&1 | grep -v amdgpu > $out/resnet_pipeline_probe.txt
 python tools/pipeline_probe.py 2>&1 | grep -v amdgpu > $out/nature_pipeline_probe.txt
 timeout 200 tools/ubench/gemm2 0 > $out/ubench_gemm2.txt 2>&1
