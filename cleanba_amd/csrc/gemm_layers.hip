@@ -1186,9 +1186,9 @@ int nature_forward(const NatureLayout& L, const float* P, const uint8_t* obs, co
     Conv1Fwd<T64x64k16> p1{obs, idx, P + L.w[0], P + L.b[0], ws.act1, B * 400, nullptr};
     igemm_s16_launch<32, 32, 32>(p1, 1, st);
     ConvFwd<T64x64k16, 4, 4, 2, 32, 64, 20, 20, 9, 9> p2{ws.act1, P + L.w[1], P + L.b[1], ws.act2, B * 81, nullptr};
-    igemm_s16_launch<32, 32, 64>(p2, 1, st);
+    igemm_s16_launch<32, 32, 32>(p2, 1, st);   // (K chunks of 32 like conv1 / dense: 21.5 KB of LDS and 65 VGPRs per block instead of 42 KB / 129 —
     ConvFwd<T64x64k16, 3, 3, 1, 64, 64, 9, 9, 7, 7> p3{ws.act2, P + L.w[2], P + L.b[2], ws.act3, B * 49, nullptr};
-    igemm_s16_launch<32, 32, 64>(p3, 1, st);
+    igemm_s16_launch<32, 32, 32>(p3, 1, st);   //  no slower alone, and more of these blocks find room beside the learner's: DESIGN.md section 4.1)
     if (dense_ksplit > 1) {
       DenseFwd<T64x64k16, true> pd{ws.act3, P + L.w[3], P + L.b[3], ws.dense_part, B, 3136, 512, 3136 / dense_ksplit};
       igemm_s16_launch<32, 32, 32>(pd, dense_ksplit, st);

@@ -1,11 +1,12 @@
 #!/bin/bash
 # usage (GPU box, repo root): tools/pmc_collect.sh <tag>
-#   1. rocprofv3 --kernel-trace --stats over `python bench.py` (the driver's command shape)        -> gpurun_out/<tag>/kernel_stats.md
+#   1. rocprofv3 --kernel-trace --stats over `python bench.py` — the headline workload only: the host_env / secondary / cpu_baseline legs
+#      launch the same kernels at other sizes and would mix into the per-kernel averages      -> gpurun_out/<tag>/kernel_stats.md
 #   2. four SEPARATE rocprofv3 --pmc passes over one isolated learner minibatch (tools/microbench.py --plain), as MI355X_MICROARCH.md
 #      prescribes (never --pmc together with the sys/hip/hsa trace domains)                          -> gpurun_out/<tag>/pmc_summary.md, pmc_traffic.json
 tag=$1; R=$PWD; out=$R/gpurun_out/$tag; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp PYTHONPATH=$R
-timeout 400 rocprofv3 --kernel-trace --stats -d $out/trace -o b -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-host-env > $out/trace.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats -d $out/trace -o b -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-host-env --no-secondary --no-baseline-config > $out/trace.log 2>&1
 python $R/tools/rocprof_summary.py $(find $out/trace -name "*.db" | head -1) > $out/kernel_stats.md 2>&1
 pass() { timeout 400 rocprofv3 --pmc $2 --kernel-trace -d $out/pmc_$1 -o p -- python $R/tools/microbench.py 3 --plain > $out/pmc_$1.log 2>&1; }
 pass sq "SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU"
