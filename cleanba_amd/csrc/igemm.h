@@ -544,8 +544,8 @@ static inline void igemm_pf2_launch(const P& p, int nsplit, hipStream_t stream) 
 // ascending order into the accumulator, steps ascend, chunks ascend: the SAME k-ascending fmaf chain as igemm_kernel -> identical bits
 // (tests/test_gpu_parity.py::test_forward_bit_exact runs both).  Row-gather A / row-major B problems (the forward GEMMs), plain
 // p.store epilogue (no ReLU-mask emission: actor workspaces have no masks).
-//   LDS: A[x][r] pitch BR+4 and B[r][y] pitch BY+16 floats: both fragment reads (lane = (g4, r16): A[r16][4s+g4], B[4s+g4][r16]) are
-//   conflict-free and both tiles are filled with 16-byte stores.
+//   LDS: A[x][r] pitch BR+4, B[r][y] unpadded with a column swizzle (see the kernel): both fragment reads (lane = (g4, r16): A[r16][4s+g4],
+//   B[4s+g4][r16]) are conflict-free and both tiles are filled with 16-byte stores.
 typedef float f32x4_mfma __attribute__((ext_vector_type(4)));
 // timing build only (-DCBM_S16_TRACE; tools/s16_trace.py): clock stamps of the first, the middle and the last block of the launch whose X() equals
 // cbm_s16_trace_sel (wave 0): entry, prologue, first loads issued / landed, every K chunk, end
@@ -570,7 +570,12 @@ __global__ __launch_bounds__(256, 2) void igemm_s16_kernel(const P p) {
   static_assert(BX % 16 == 0 && BY % 16 == 0 && BR % 32 == 0 && (BX / 16) * (BY / 16) % 4 == 0, "tile shape");
   static_assert(!P::A_RX && !P::B_YR && !P::BIAS_GRAD && P::NCLS == 1, "forward-style problems");
   constexpr int NT16 = (BX / 16) * (BY / 16) / 4;          // 16x16 tiles per wave
-  constexpr int PA = BR + 4, PB = BY + 16, ASZ = BX * PA, BSZ = BR * PB;
+  // B rows are unpadded and the two halves of a row trade places on rows 1, 2 (mod 4) (XOR 16 on the column): of the four k rows of a fragment
+  // read, g4 = 0 / 1 and g4 = 2 / 3 (the two 32-lane groups a ds_read_b32 is served in) sit on different halves of the 32 banks, like a pitch of
+  // BY + 16 did — at 2/3 of the LDS (17.4 KB per block at BR = 32: a block now also fits beside the learner's conv2 weight-gradient blocks, which
+  // leave 19 KB of a CU's LDS)
+  static_assert(BY == 32, "the column swizzle of the B tile is written for 32-column tiles");
+  constexpr int PA = BR + 4, PB = BY, ASZ = BX * PA, BSZ = BR * PB;
   constexpr int NVA = (BX * BR / 4 + 255) / 256, NVB = (BR * BY / 4 + 255) / 256;
   __shared__ __attribute__((aligned(16))) float smem[2 * ASZ + 2 * BSZ];
   float* As = smem;
@@ -633,7 +638,7 @@ __global__ __launch_bounds__(256, 2) void igemm_s16_kernel(const P p) {
 #pragma unroll
     for (int j = 0; j < NVB; ++j) {
       const int v = tid + 256 * j;
-      if (BR * BY / 4 % 256 == 0 || v < BR * BY / 4) { const int yq = v % (BY / 4), rl = v / (BY / 4); *reinterpret_cast<float4*>(B_ + rl * PB + 4 * yq) = rb[j]; }
+      if (BR * BY / 4 % 256 == 0 || v < BR * BY / 4) { const int yq = v % (BY / 4), rl = v / (BY / 4); *reinterpret_cast<float4*>(B_ + rl * PB + ((4 * yq) ^ (((rl ^ (rl >> 1)) & 1) << 4))) = rb[j]; }
     }
   };
   auto compute = [&](int buf) {
@@ -645,7 +650,7 @@ __global__ __launch_bounds__(256, 2) void igemm_s16_kernel(const P p) {
       for (int i = 0; i < NT16; ++i) {
         const int q = wave * NT16 + i, tx = q / (BY / 16), ty = q % (BY / 16);
         const float a = A_[(tx * 16 + r16) * PA + 4 * st + g4];
-        const float b = B_[(4 * st + g4) * PB + ty * 16 + r16];
+        const float b = B_[(4 * st + g4) * PB + ((ty * 16 + r16) ^ (((g4 ^ (g4 >> 1)) & 1) << 4))];
         acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
       }
     }
