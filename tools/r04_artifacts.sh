@@ -8,7 +8,7 @@
 #   actor_progress.md          tools/actor_progress.py over a kernel trace of tools/pipeline_probe.py (rollout progress rate inside each learner kernel)
 tag=$1; R=$PWD; out=$R/gpurun_out/$tag; mkdir -p $out
 export TMPDIR=/tmp PYTHONPATH=$R
-timeout 600 python bench.py > $out/bench_line.json 2> $out/bench.err
+t0=$(date +%s); timeout 600 python bench.py > $out/bench_line.json 2> $out/bench.err; echo "python bench.py (no flags): $(( $(date +%s) - t0 )) s wall" > $out/bench_wall.txt
 bash tools/pmc_collect.sh $tag > $out/pmc_collect.log 2>&1
 mv $out/kernel_stats.md $out/bench_kernel_stats.md
 prof() { # name, command...
