@@ -665,7 +665,10 @@ extern "C" int cbm_learner_minibatch_grad(cbm_ctx* c, int32_t epoch, int32_t mb)
     nature_forward(c->L, c->params, R.obs, idx, c->MB, learner_ksplit(c), c->lws, c->lstream);
     launch_impala_loss(c->lws.logits, c->lws.value, R.logits, R.actions, R.rewards, R.dones, R.firststeps, c->T1, Bm, c->A, mb * Bm, c->Bdev,
                        c->cfg.gamma, c->cfg.vf_coef, c->cfg.ent_coef, c->lws.dzv, c->loss_partials, stats, c->lstream);
-    nature_backward(c->L, c->params, R.obs, idx, c->MB, c->lws, c->grads, c->lstream);
+    // The bootstrap row (t = T: the minibatch's LAST Bm frames) enters the loss through its value only and receives no gradient (impala:577-590): its
+    // dL/d(logits, value) rows are zeros, so the backward pass runs on the first T * Bm frames — 3840 of 3870 at E = 120, T = 128, which is also
+    // what the frame-resident kernels want (15 frames on each of 256 CUs instead of 16 on 242).
+    nature_backward(c->L, c->params, R.obs, idx, c->MB - Bm, c->lws, c->grads, c->lstream);
   }
   return cbm_launch_check();
 }
@@ -900,7 +903,7 @@ extern "C" int cbm_impala_loss_grad(cbm_ctx* c, const float* params, const uint8
   CBM_HIP(hipMalloc((void**)&partials, (size_t)Bm * 3 * 4 + 64));
   launch_impala_loss(c->lws.logits, c->lws.value, mu_logits, actions, rewards, dones, firststeps, T1, Bm, c->A, 0, Bm, c->cfg.gamma, c->cfg.vf_coef,
                      c->cfg.ent_coef, c->lws.dzv, partials, stats4, c->lstream);
-  if (grads) nature_backward(c->L, params, obs, idx, N, c->lws, grads, c->lstream);
+  if (grads) nature_backward(c->L, params, obs, idx, N - Bm, c->lws, grads, c->lstream);   // (the bootstrap row carries no gradient: see cbm_learner_minibatch_grad)
   CBM_HIP(hipStreamSynchronize(c->lstream));
   hipFree(partials);
   return cbm_launch_check();
