@@ -198,7 +198,7 @@ static int ctx_create_impl(const cbm_config* cfg, cbm_ctx** out, cbm_ctx** parti
   if (c->asyncB && dalloc(&c->advn, T1 * B)) return -1;
   if (dalloc(&c->adv, T1 * B) || dalloc(&c->target, T1 * B) || dalloc(&c->next_value, B) || dalloc(&c->stats_dev, (size_t)c->stat_rows * 8) ||
       dalloc(&c->loss_partials, (size_t)4 * (lmax / 8 + 2) + 3 * B) || dalloc(&c->norm_partials, CBM_NORM_PARTS) ||
-      dalloc(&c->perm, T1 * B) || dalloc(&c->perm_tmp, T1 * B) || dalloc(&c->ckeys, 2 * T1 * B)) return -1;
+      dalloc(&c->perm, T1 * B) || dalloc(&c->perm_tmp, T1 * B) || dalloc(&c->ckeys, permutation_scratch_u64((int)(T1 * B)))) return -1;
   if (!is_ppo(c)) {  // static minibatch index table: contiguous env-column chunks, all T+1 rows (impala:623-634)
     const int Bm = c->Bdev / c->nmicro;
     std::vector<int32_t> h((size_t)c->nmicro * c->MB);
@@ -866,7 +866,7 @@ extern "C" int cbm_permutation(cbm_ctx* c, const uint32_t key[2], int32_t n, int
   CBM_HIP(hipSetDevice(c->cfg.device));
   int32_t* tmp = nullptr; uint64_t* ck = nullptr;
   CBM_HIP(hipMalloc((void**)&tmp, (size_t)n * 4));
-  CBM_HIP(hipMalloc((void**)&ck, (size_t)n * 16));
+  CBM_HIP(hipMalloc((void**)&ck, permutation_scratch_u64(n) * 8));
   launch_permutation(key, n, perm, tmp, ck, c->lstream);
   CBM_HIP(hipStreamSynchronize(c->lstream));
   hipFree(tmp); hipFree(ck);

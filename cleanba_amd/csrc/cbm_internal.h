@@ -131,7 +131,8 @@ void launch_vtrace(const float* v_tm1, const float* v_t, const float* r_t, const
                    float* pg_adv, float* q_est, hipStream_t st);
 void launch_mb_advnorm(const float* adv, const int32_t* idx, int n, float* out, hipStream_t st);
 // perm = jax.random.permutation(key, n): host does the key splits, device the bits + stable sorts.
-void launch_permutation(const uint32_t key[2], int n, int32_t* perm, int32_t* tmp, uint64_t* ckeys, hipStream_t st);
+size_t permutation_scratch_u64(int n);   // uint64 words of scratch launch_permutation needs for n elements
+void launch_permutation(const uint32_t key[2], int n, int32_t* perm, int32_t* tmp, uint64_t* scratch, hipStream_t st);
 void launch_ppo_loss(const float* logits, const float* value, int N, int A, const int32_t* idx, const int32_t* actions,
                      const float* old_logprob, const float* adv, const float* target, float clip_coef, float ent_coef,
                      float vf_coef, float* dzv, float* partials, float* stats5, hipStream_t st);

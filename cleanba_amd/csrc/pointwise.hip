@@ -211,41 +211,64 @@ void launch_mb_advnorm(const float* adv, const int32_t* idx, int n, float* out, 
 }
 
 // ------------------------------------------------------------------------------------------
-// jax.random.permutation (ppo:606): per round, composite key (random_bits << 32 | position) makes the
-// sort stable by construction; rank by counting (n^2 compares, n = 15360: ~20 us) then scatter.
-__global__ void perm_keys_kernel(uint32_t sk0, uint32_t sk1, int n, uint64_t* ckeys) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) ckeys[i] = ((uint64_t)cbm_random_bits_at(sk0, sk1, (uint32_t)n, (uint32_t)i) << 32) | (uint32_t)i;
-}
-// rank[i] = #{j : ckey[j] < ckey[i]}; the j range is split over blockIdx.y and combined with integer atomics
-// (exact, order-independent), then a scatter pass writes out[rank[i]] = in[i].
-#define PERM_JSPLIT 8
-__global__ __launch_bounds__(256) void perm_rank_kernel(const uint64_t* ckeys, int n, int32_t* rank) {
-  __shared__ uint64_t tile[1024];
+// jax.random.permutation (ppo:606): per round, composite key (random_bits << 32 | position) makes the sort stable by construction; an element's
+// place in the sorted order is the number of keys below it.  Counting against all n keys was n^2 = 2.4e8 64-bit compares (32 us per round, two rounds
+// per epoch: 360 us of every update); the keys are uniform, so they are first dealt into PERM_G ranges by their top bits (a block ranks its 256
+// elements per range in LDS and reserves its run in each range's list with ONE global atomic per range: list order is arbitrary, the COUNT below a
+// key is not), and an element is then counted against its own range only — n / 64 keys — plus the sizes of the ranges below.  The same pass
+// writes out[place] = in[position]: no rank array, no separate scatter.  Scratch (uint64 units): PERM_G lists of n keys, then the PERM_G counters.
+#define PERM_G 64
+#define PERM_LOG2G 6
+size_t permutation_scratch_u64(int n) { return (size_t)PERM_G * (size_t)n + 64; }
+__global__ __launch_bounds__(256) void perm_bucket_kernel(uint32_t sk0, uint32_t sk1, int n, uint64_t* lists, int32_t* counts) {
+  __shared__ int32_t hist[PERM_G], base[PERM_G];
   const int i = blockIdx.x * 256 + threadIdx.x;
-  const uint64_t mine = i < n ? ckeys[i] : 0;
-  const int per = ((n + PERM_JSPLIT - 1) / PERM_JSPLIT + 1023) / 1024 * 1024;
-  const int jlo = blockIdx.y * per, jhi = min(n, jlo + per);
-  int r = 0;
-  for (int j0 = jlo; j0 < jhi; j0 += 1024) {
-    __syncthreads();
-    for (int q = threadIdx.x; q < 1024; q += 256) tile[q] = (j0 + q < jhi) ? ckeys[j0 + q] : ~0ull;
-    __syncthreads();
-#pragma unroll 8
-    for (int q = 0; q < 1024; ++q) r += tile[q] < mine ? 1 : 0;
+  if (threadIdx.x < PERM_G) hist[threadIdx.x] = 0;
+  __syncthreads();
+  uint64_t key = 0;
+  int g = 0, local = 0;
+  if (i < n) {
+    const uint32_t bits = cbm_random_bits_at(sk0, sk1, (uint32_t)n, (uint32_t)i);
+    key = ((uint64_t)bits << 32) | (uint32_t)i;
+    g = (int)(bits >> (32 - PERM_LOG2G));
+    local = atomicAdd(&hist[g], 1);
   }
-  if (i < n && r) atomicAdd(&rank[i], r);
+  __syncthreads();
+  if (threadIdx.x < PERM_G) base[threadIdx.x] = hist[threadIdx.x] ? atomicAdd(&counts[threadIdx.x], hist[threadIdx.x]) : 0;
+  __syncthreads();
+  if (i < n) lists[(size_t)g * n + base[g] + local] = key;
 }
-__global__ void perm_scatter_kernel(const int32_t* rank, int n, const int32_t* in_vals, int32_t* out_vals) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out_vals[rank[i]] = in_vals ? in_vals[i] : i;
+// block (x, g): elements [256 x, +256) of range g's list; place = (sizes of the ranges below) + #{keys of the range below mine}
+__global__ __launch_bounds__(256) void perm_place_kernel(const uint64_t* lists, const int32_t* counts, int n, const int32_t* in_vals, int32_t* out_vals) {
+  __shared__ uint64_t tile[512];
+  __shared__ int32_t cs[PERM_G];
+  const int g = blockIdx.y, cnt = counts[g];
+  if ((int)blockIdx.x * 256 >= cnt) return;
+  if (threadIdx.x < PERM_G) cs[threadIdx.x] = threadIdx.x < g ? counts[threadIdx.x] : 0;
+  const uint64_t* list = lists + (size_t)g * n;
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  const uint64_t mine = e < cnt ? list[e] : 0;
+  int r = 0;
+  for (int j0 = 0; j0 < cnt; j0 += 512) {
+    __syncthreads();
+    for (int q = threadIdx.x; q < 512; q += 256) tile[q] = (j0 + q < cnt) ? list[j0 + q] : ~0ull;
+    __syncthreads();
+    const int m = (min(512, cnt - j0) + 7) & ~7;      // (the pad entries compare as "not below")
+    for (int q = 0; q < m; q += 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) r += tile[q + u] < mine ? 1 : 0;
+    }
+  }
+  int below = 0;
+#pragma unroll
+  for (int h = 0; h < PERM_G; ++h) below += cs[h];
+  if (e < cnt) { const int i = (int)(uint32_t)mine; out_vals[below + r] = in_vals ? in_vals[i] : i; }
 }
-void launch_permutation(const uint32_t key_in[2], int n, int32_t* perm, int32_t* tmp, uint64_t* ckeys, hipStream_t st) {
+void launch_permutation(const uint32_t key_in[2], int n, int32_t* perm, int32_t* tmp, uint64_t* scratch, hipStream_t st) {
   uint32_t k0 = key_in[0], k1 = key_in[1];
   const double sz = n > 1 ? (double)n : 1.0;
   const int rounds = (int)ceil(3.0 * log(sz) / log(4294967295.0));
-  // ckeys buffer holds n composite keys followed by n int32 ranks
-  int32_t* rank = reinterpret_cast<int32_t*>(ckeys + n);
+  int32_t* counts = reinterpret_cast<int32_t*>(scratch + (size_t)PERM_G * n);
   int32_t* bufs[2] = {perm, tmp};
   int cur = (rounds % 2 == 1) ? 0 : 1;  // ping-pong so the final round lands in `perm`
   const int32_t* src = nullptr;
@@ -254,10 +277,9 @@ void launch_permutation(const uint32_t key_in[2], int n, int32_t* perm, int32_t*
     cbm_split_at(k0, k1, 2, 0, &n0, &n1);
     cbm_split_at(k0, k1, 2, 1, &s0, &s1);
     k0 = n0; k1 = n1;
-    hipLaunchKernelGGL(perm_keys_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, s0, s1, n, ckeys);
-    hipMemsetAsync(rank, 0, (size_t)n * 4, st);
-    hipLaunchKernelGGL(perm_rank_kernel, dim3(ceil_div(n, 256), PERM_JSPLIT), dim3(256), 0, st, ckeys, n, rank);
-    hipLaunchKernelGGL(perm_scatter_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, rank, n, src, bufs[cur]);
+    hipMemsetAsync(counts, 0, PERM_G * sizeof(int32_t), st);
+    hipLaunchKernelGGL(perm_bucket_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, s0, s1, n, scratch, counts);
+    hipLaunchKernelGGL(perm_place_kernel, dim3(ceil_div(n, 256), PERM_G), dim3(256), 0, st, scratch, counts, n, src, bufs[cur]);
     src = bufs[cur];
     cur ^= 1;
   }
