@@ -59,15 +59,29 @@ __global__ void gae_kernel(const float* rewards, const float* values, const uint
   float a = 0.0f;
   float nv = next_value[b];
   float nd = (float)next_done[b];
-  for (int t = T - 1; t >= 0; --t) {
-    const float v = values[(size_t)t * B + b];
-    const float nnt = 1.0f - nd;
-    const float delta = (rewards[(size_t)t * B + b] + (gamma * nv) * nnt) - v;
-    a = delta + ((gl * nnt) * a);
-    adv[(size_t)t * B + b] = a;
-    target[(size_t)t * B + b] = a + v;
-    nv = v;
-    nd = (float)dones[(size_t)t * B + b];
+  // sixteen steps' operands are requested before the first of them is used: with the loads inside the recursion every step waited for its own
+  // round trip to L2 (50 us for T = 128); the recursion itself is unchanged
+  for (int t1 = T; t1 > 0; t1 -= 16) {
+    float v[16], r[16], d[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int t = max(t1 - 1 - u, 0);
+      v[u] = values[(size_t)t * B + b]; r[u] = rewards[(size_t)t * B + b]; d[u] = (float)dones[(size_t)t * B + b];
+    }
+    const int t1v = cbm_opaque_vgpr(t1);   // (a per-lane copy: the guard below is then a predicate, not a scalar branch per step)
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int t = t1v - 1 - u;
+      if (t >= 0) {
+        const float nnt = 1.0f - nd;
+        const float delta = (r[u] + (gamma * nv) * nnt) - v[u];
+        a = delta + ((gl * nnt) * a);
+        adv[(size_t)t * B + b] = a;
+        target[(size_t)t * B + b] = a + v[u];
+        nv = v[u];
+        nd = d[u];
+      }
+    }
   }
 }
 void launch_gae(const float* rewards, const float* values, const uint8_t* dones, const float* next_value, const uint8_t* next_done,
