@@ -642,6 +642,7 @@ static int learner_epoch_perm(cbm_ctx* c, uint32_t key[2]) {
 static int learner_ksplit(const cbm_ctx* c) { return c->MB <= 1024 ? c->cfg.actor_dense_ksplit : 1; }
 extern "C" int cbm_learner_minibatch_grad(cbm_ctx* c, int32_t epoch, int32_t mb) {
   CBM_HIP(hipSetDevice(c->cfg.device));
+  c->lws.tail_ev = c->comms[CBM_COMM_LEARNERS].nranks ? c->tail_ev : nullptr;   // the gradient tail is finished early only when an all-reduce waits for it
   RingEntry& R = cur_ring(c);
   float* stats = c->stats_dev + (size_t)(epoch * c->nmicro + mb) * 8;
   if (is_ppo(c)) {

@@ -975,7 +975,7 @@ static void launch_reduce(const float* part, int nz, int XY, int Ycols, int mode
 // and the reductions run as TWO launches: {heads, dense} right after the dense weight gradient (their result is the tail the data-parallel
 // all-reduce waits for) and {conv3, conv2, conv1} at the end.  Same per-output summation order as the single launches -> same bits.
 struct RedJob { const float* part; float* gw; float* gw2; int nz, XY, Ycols, mode, zg, block0; float scale; };
-#define RED_MAX_JOBS 32   // Nature: 4 + 6 jobs in two launches; ResNet: 4 (dense + heads) and 30 (15 convs x {weights, bias}) in two launches
+#define RED_MAX_JOBS 36   // Nature: 4 + 6 jobs; ResNet: 4 (dense + heads) + 30 (15 convs x {weights, bias}) — two launches beside an all-reduce, one without
 struct RedJobs { RedJob j[RED_MAX_JOBS]; int n, A; };
 __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const RedJobs jobs) {
   // four consecutive outputs per thread (16-byte loads; every XY is a multiple of 32), same z order per output as the scalar form
@@ -1025,7 +1025,12 @@ struct RedBatch {
     jobs.j[jobs.n++] = RedJob{part, gw, gw2, nz, XY, Ycols, mode, zg, blocks, scale};
     blocks += (XY / 4 + ow - 1) / ow;
   }
-  void launch(hipStream_t st) { hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3(blocks), dim3(256), 0, st, jobs); }
+  void launch(hipStream_t st) { if (jobs.n) hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3(blocks), dim3(256), 0, st, jobs); }
+  // the jobs of `o` join this launch (no all-reduce waits for them: one launch instead of two)
+  void absorb(const RedBatch& o) {
+    for (int k = 0; k < o.jobs.n; ++k) { jobs.j[jobs.n] = o.jobs.j[k]; jobs.j[jobs.n].block0 += blocks; ++jobs.n; }
+    blocks += o.blocks;
+  }
 };
 
 // ------------------------------------------------------------------------------------------ workspace
@@ -1311,7 +1316,7 @@ void nature_backward(const NatureLayout& L, const float* P, const uint8_t* obs, 
     }
     tail_red.add(wp + rg.w[1], nz, 3136 * 512, 512, 0, grads + L.w[3], nullptr);
     tail_red.add(bp + rg.b[1], nz, 512, 512, 0, grads + L.b[3], nullptr);
-    tail_red.launch(st);
+    if (ws.tail_ev) tail_red.launch(st);   // (without a communicator nobody waits for the tail: its reductions ride in the launch at the end)
   }
   if (ws.tail_ev) hipEventRecord(ws.tail_ev, st);   // 95 % of the flat gradient is final here: its all-reduce can overlap the conv backward
   // conv3: dgrad -> dact2pad (position-major with tap skipping), wgrad
@@ -1354,6 +1359,7 @@ void nature_backward(const NatureLayout& L, const float* P, const uint8_t* obs, 
                 [&] { launch_conv1_wgrad_frames(obs, idx, ws.dact1, wp + rg.w[4], bp + rg.b[4], B, st, ws.bwd_split == 2); });
     conv_red.add(wp + rg.w[4], nz, 256 * 32, 32, 1, grads + L.w[0], nullptr, 1.0f / 255.0f);
     conv_red.add(bp + rg.b[4], nz, 32, 32, 0, grads + L.b[0], nullptr);
+    if (!ws.tail_ev) conv_red.absorb(tail_red);
     conv_red.launch(st);
   }
 }
