@@ -22,6 +22,7 @@ import os
 import pickle
 import queue
 import threading
+import sys
 import time
 
 PPO_FIELDS = ("obs", "actions", "logprobs", "values", "rewards", "dones")
@@ -100,7 +101,8 @@ class Rendezvous:
             if since_abort_check >= 1.0:
                 since_abort_check = 0.0
                 if self.store.check(["abort"]):
-                    raise RuntimeError(f"rank {self.rank}: a peer aborted while this rank waited for '{key}'")
+                    why = self.store.get("abort").decode(errors="replace")
+                    raise RuntimeError(f"rank {self.rank}: a peer aborted while this rank waited for '{key}' ({why})")
                 if time.time() - t0 > self.timeout_s:
                     raise TimeoutError(f"rank {self.rank}: '{key}' did not arrive within {self.timeout_s} s")
         v = self.store.get(key)
@@ -108,9 +110,14 @@ class Rendezvous:
             self.store.delete_key(key)
         return v
 
-    def abort(self):
+    def abort(self, reason=None):
+        """Tells every peer blocked in get() to stop; the key carries who failed and with what (the exception being handled, if any): the FIRST
+        failure is what the peers report, later aborts (peers that failed because of it) do not overwrite it."""
         try:
-            self.store.set("abort", b"1")
+            if reason is None:
+                exc = sys.exc_info()[1]
+                reason = repr(exc) if exc is not None else "abort requested"
+            self.store.compare_set("abort", "", f"rank {self.rank}: {reason}"[:500])
         except Exception:  # noqa: BLE001
             pass
 
