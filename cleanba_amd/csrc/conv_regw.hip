@@ -27,13 +27,10 @@ static __device__ __forceinline__ void rw_glds4(const float* g_lane, float* lds_
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g_lane, (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
 }
 
-#ifndef CBM_C3_NS
-#define CBM_C3_NS 7
-#endif
 namespace {
 struct C3G {
   static constexpr int KH = 3, KW = 3, CI = 64, CO = 64, IH = 9, IW = 9, OH = 7, OW = 7;
-  static constexpr int PIX = IH * IW, NPOS = OH * OW, PP = CI + 2, NS = CBM_C3_NS, NSTEP = KH * KW * CI / 4;
+  static constexpr int PIX = IH * IW, NPOS = OH * OW, PP = CI + 2, NS = 7, NSTEP = KH * KW * CI / 4;
   static constexpr int SYNC_TAP = 6;                          // the step's barrier sits in front of this tap
   static constexpr int NTG = 2, NW = 4 * NTG, DPW = (PIX + NW - 1) / NW;     // tile groups (waves per SIMD), waves, copies per wave and frame
   static constexpr int SP = 32 * NTG;                          // positions per step
