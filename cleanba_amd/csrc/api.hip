@@ -616,9 +616,12 @@ extern "C" int cbm_learner_prepare(cbm_ctx* c, uint32_t key[2]) {
   }
   // compute_gae ppo:543-560: bootstrap value with the LEARNER's params on next_obs (row T)
   CbmProf* const pf = c->lws.prof;
+  uint32_t* const m1 = c->lws.mask1;
   c->lws.prof = nullptr;   // the per-kernel timers are for the minibatch-size launches, not for this 1-row bootstrap pass
+  c->lws.mask1 = nullptr;  // no backward follows it either: without ReLU masks wanted a pass of <= 512 frames takes the actor's small-batch kernels (same bits, 110 -> 60 us)
   nature_forward(c->L, c->params, R.obs + (size_t)T * B * CBM_FRAME, nullptr, B, c->cfg.actor_dense_ksplit, c->lws, c->lstream);
   c->lws.prof = pf;
+  c->lws.mask1 = m1;
   CBM_HIP(hipMemcpyAsync(c->next_value, c->lws.value, (size_t)B * 4, hipMemcpyDeviceToDevice, c->lstream));
   launch_gae(R.rewards, R.values, R.dones, c->next_value, R.dones + (size_t)T * B, T, B, c->cfg.gamma, c->cfg.gae_lambda, c->adv, c->target, c->lstream);
   if (c->cfg.norm_adv) launch_advnorm(c->adv, T, B, c->nmb, c->lstream);
