@@ -662,6 +662,7 @@ extern "C" int cbm_learner_minibatch_grad(cbm_ctx* c, int32_t epoch, int32_t mb)
                       c->cfg.vf_coef, c->lws.dzv, c->loss_partials, stats, c->lstream);
     }
     nature_backward(c->L, c->params, R.obs, idx, c->MB, c->lws, c->grads, c->lstream);
+    flush_pending_stats(c->lws, c->lstream);   // (only if the backward pass ended early)
     c->lws.skip_heads = false;
   } else {
     const int Bm = c->Bdev / c->nmicro;
@@ -890,6 +891,7 @@ extern "C" int cbm_ppo_loss_grad(cbm_ctx* c, const float* params, const uint8_t*
     launch_ppo_loss(c->lws.logits, c->lws.value, N, c->A, nullptr, actions, old_logprob, adv, target, c->cfg.clip_coef, c->cfg.ent_coef,
                     c->cfg.vf_coef, c->lws.dzv, c->loss_partials, stats5, c->lstream);
   if (grads) nature_backward(c->L, params, obs, idx, N, c->lws, grads, c->lstream);
+  flush_pending_stats(c->lws, c->lstream);   // no backward pass ran (or it ended early): the statistics take their own launch
   c->lws.skip_heads = false;
   if (logits_out) CBM_HIP(hipMemcpyAsync(logits_out, c->lws.logits, (size_t)N * c->A * 4, hipMemcpyDeviceToDevice, c->lstream));
   if (value_out) CBM_HIP(hipMemcpyAsync(value_out, c->lws.value, (size_t)N * 4, hipMemcpyDeviceToDevice, c->lstream));

@@ -43,7 +43,11 @@ struct CbmProf {
 };
 
 // ---- workspace for running the network on up to maxB frames ----------------------------
+// The fused PPO heads leave their block partials of the loss statistics; the sum rides in the backward pass's reduction launch
+// (gemm_layers.hip: RedBatch::add_stats), or in its own launch when no backward pass follows (flush_pending_stats).
+struct PendingStats { const float* partials = nullptr; float* stats5 = nullptr; int nblk = 0, N = 0; float ent_coef = 0.0f, vf_coef = 0.0f; };
 struct NatureWs {
+  PendingStats pending_stats;
   CbmProf* prof = nullptr;
   int maxB = 0;
   bool with_grad = false;
@@ -138,6 +142,19 @@ void launch_ppo_loss(const float* logits, const float* value, int N, int A, cons
                      float vf_coef, float* dzv, float* partials, float* stats5, hipStream_t st);
 // the block partials of ppo_loss_kernel / the fused heads kernel -> the five statistics of ppo:649-653
 void launch_ppo_stats(const float* partials, int nblk, int N, float ent_coef, float vf_coef, float* stats5, hipStream_t st);
+void flush_pending_stats(NatureWs& ws, hipStream_t st);   // statistics left by launch_ppo_heads_fused when no backward pass consumed them
+// ppo_stats_kernel's arithmetic for one wave (shared with the reduction launch's statistics job: the same order, the same bits)
+__device__ __forceinline__ void ppo_stats_wave(const float* partials, int nblk, int N, float ent_coef, float vf_coef, float* stats5) {
+  const int l = threadIdx.x;
+  float s[4] = {0, 0, 0, 0};
+  for (int b = l; b < nblk; b += 64) for (int q = 0; q < 4; ++q) s[q] += partials[b * 4 + q];
+  for (int q = 0; q < 4; ++q) for (int o = 32; o > 0; o >>= 1) s[q] += __shfl_down(s[q], o, 64);
+  if (l != 0) return;
+  const float n = (float)N;
+  const float pg = s[0] / n, v = 0.5f * (s[1] / n), e = s[2] / n, kl = s[3] / n;
+  stats5[0] = pg - ent_coef * e + v * vf_coef;
+  stats5[1] = pg; stats5[2] = v; stats5[3] = e; stats5[4] = kl;
+}
 // heads forward + PPO loss + heads input gradient of a minibatch in one launch (gemm_layers.hip): hid [B][HD] -> logits / value (ws), dzv [B][32],
 // dhid [B][HD], the five statistics.  Same logits bits as launch_heads_fwd, same loss arithmetic as launch_ppo_loss.
 bool ppo_heads_fusable(const NatureLayout& L);

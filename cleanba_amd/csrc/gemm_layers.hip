@@ -679,7 +679,14 @@ void launch_ppo_heads_fused(const NatureLayout& L, const float* P, NatureWs& ws,
   else
     hipLaunchKernelGGL(ppo_heads_fused_kernel<256>, dim3(nblk), dim3(256), 0, st, ws.hid, P + L.w[4], P + L.b[4], P + L.w[5], P + L.b[5], B, L.A, idx, actions,
                        old_logprob, adv, target, clip_coef, ent_coef, vf_coef, ws.logits, ws.value, ws.dzv, ws.dhid, partials);
-  launch_ppo_stats(partials, nblk, B, ent_coef, vf_coef, stats5, st);
+  // the statistics are summed by the backward pass's reduction launch (RedBatch::add_stats); a caller without a backward pass flushes them itself
+  ws.pending_stats = PendingStats{partials, stats5, nblk, B, ent_coef, vf_coef};
+}
+void flush_pending_stats(NatureWs& ws, hipStream_t st) {
+  const PendingStats ps = ws.pending_stats;
+  if (!ps.partials) return;
+  ws.pending_stats = PendingStats{};
+  launch_ppo_stats(ps.partials, ps.nblk, ps.N, ps.ent_coef, ps.vf_coef, ps.stats5, st);
 }
 
 static void launch_heads_dgrad(const float* dzv, const float* Wa, const float* Wc, const float* hid, int B, int A, int HD, float* dhid, hipStream_t st) {
@@ -976,7 +983,7 @@ static void launch_reduce(const float* part, int nz, int XY, int Ycols, int mode
 // all-reduce waits for) and {conv3, conv2, conv1} at the end.  Same per-output summation order as the single launches -> same bits.
 struct RedJob { const float* part; float* gw; float* gw2; int nz, XY, Ycols, mode, zg, block0; float scale; };
 #define RED_MAX_JOBS 36   // Nature: 4 + 6 jobs; ResNet: 4 (dense + heads) + 30 (15 convs x {weights, bias}) — two launches beside an all-reduce, one without
-struct RedJobs { RedJob j[RED_MAX_JOBS]; int n, A; };
+struct RedJobs { RedJob j[RED_MAX_JOBS]; int n, A; float ent_coef, vf_coef; };
 __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const RedJobs jobs) {
   // four consecutive outputs per thread (16-byte loads; every XY is a multiple of 32), same z order per output as the scalar form
   __shared__ float4 red[256];
@@ -984,6 +991,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const RedJobs j
 #pragma unroll
   for (int k = 1; k < RED_MAX_JOBS; ++k) if (k < jobs.n && (int)blockIdx.x >= jobs.j[k].block0) q = k;
   const RedJob& J = jobs.j[q];
+  if (J.mode == 4) {   // the PPO loss statistics of this minibatch (one block; ppo_stats_kernel's arithmetic in its order, on wave 0): see RedBatch::add_stats
+    if (threadIdx.x < 64) ppo_stats_wave(J.part, J.nz, J.XY, jobs.ent_coef, jobs.vf_coef, J.gw);
+    return;
+  }
   const int zg = J.zg, ow = 256 / zg, nz = J.nz, XY = J.XY;
   const int o = threadIdx.x % ow, g = threadIdx.x / ow;
   const int i = (((int)blockIdx.x - J.block0) * ow + o) * 4;
@@ -1019,11 +1030,18 @@ __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const RedJobs j
 struct RedBatch {
   RedJobs jobs;
   int blocks = 0;
-  explicit RedBatch(int A) { jobs.n = 0; jobs.A = A; }
+  explicit RedBatch(int A) { jobs.n = 0; jobs.A = A; jobs.ent_coef = jobs.vf_coef = 0.0f; }
   void add(const float* part, int nz, int XY, int Ycols, int mode, float* gw, float* gw2, float scale = 1.0f) {
     const int zg = nz >= 64 ? 16 : (nz >= 8 ? 4 : 1), ow = 256 / zg;
     jobs.j[jobs.n++] = RedJob{part, gw, gw2, nz, XY, Ycols, mode, zg, blocks, scale};
     blocks += (XY / 4 + ow - 1) / ow;
+  }
+  // The five loss statistics (ppo:649-653) were a launch of one wave behind the fused heads (4.8 us on the learner stream, nothing downstream
+  // reads them before the update ends): the sum over the heads' block partials rides here as one more block.
+  void add_stats(const PendingStats& ps) {
+    jobs.j[jobs.n++] = RedJob{ps.partials, ps.stats5, nullptr, ps.nblk, ps.N, 1, 4, 1, blocks, 1.0f};
+    jobs.ent_coef = ps.ent_coef; jobs.vf_coef = ps.vf_coef;
+    blocks += 1;
   }
   void launch(hipStream_t st) { if (jobs.n) hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3(blocks), dim3(256), 0, st, jobs); }
   // the jobs of `o` join this launch (no all-reduce waits for them: one launch instead of two)
@@ -1360,6 +1378,7 @@ void nature_backward(const NatureLayout& L, const float* P, const uint8_t* obs, 
     conv_red.add(wp + rg.w[4], nz, 256 * 32, 32, 1, grads + L.w[0], nullptr, 1.0f / 255.0f);
     conv_red.add(bp + rg.b[4], nz, 32, 32, 0, grads + L.b[0], nullptr);
     if (!ws.tail_ev) conv_red.absorb(tail_red);
+    if (ws.pending_stats.partials) { conv_red.add_stats(ws.pending_stats); ws.pending_stats = PendingStats{}; }
     conv_red.launch(st);
   }
 }

@@ -333,15 +333,7 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(const float* logits, cons
 }
 // sum of the block partials: 64 lanes take strided subsets in ascending order, then a fixed shuffle tree
 __global__ void ppo_stats_kernel(const float* partials, int nblk, int N, float ent_coef, float vf_coef, float* stats5) {
-  const int l = threadIdx.x;
-  float s[4] = {0, 0, 0, 0};
-  for (int b = l; b < nblk; b += 64) for (int q = 0; q < 4; ++q) s[q] += partials[b * 4 + q];
-  for (int q = 0; q < 4; ++q) for (int o = 32; o > 0; o >>= 1) s[q] += __shfl_down(s[q], o, 64);
-  if (l != 0) return;
-  const float n = (float)N;
-  const float pg = s[0] / n, v = 0.5f * (s[1] / n), e = s[2] / n, kl = s[3] / n;
-  stats5[0] = pg - ent_coef * e + v * vf_coef;
-  stats5[1] = pg; stats5[2] = v; stats5[3] = e; stats5[4] = kl;
+  ppo_stats_wave(partials, nblk, N, ent_coef, vf_coef, stats5);
 }
 void launch_ppo_stats(const float* partials, int nblk, int N, float ent_coef, float vf_coef, float* stats5, hipStream_t st) {
   hipLaunchKernelGGL(ppo_stats_kernel, dim3(1), dim3(64), 0, st, partials, nblk, N, ent_coef, vf_coef, stats5);
@@ -671,11 +663,22 @@ void launch_impala_loss(const float* logits, const float* value, const float* mu
 // Pass 1: CBM_NORM_PARTS block partials of sum(g^2); pass 2: every block re-reduces the partials in the
 // same fixed order (bit-identical norm everywhere, no atomics) and applies the elementwise update.
 __global__ __launch_bounds__(256) void sqnorm_partials_kernel(const float* g, int64_t n, float grad_div, float* partials) {
+  // A thread's elements (stride gridDim * 256) are requested sixteen at a time and added in ascending order: the order, hence the bits, of the
+  // one-load-per-iteration loop (an element past n enters as +0: s + 0 * 0 == s), without a memory round trip per element.
   __shared__ float red[4];
   float s = 0.0f;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    const float v = grad_div == 1.0f ? g[i] : g[i] / grad_div;
-    s += v * v;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x; i0 < n; i0 += 16 * stride) {
+    float x[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) { const int64_t i = i0 + u * stride; x[u] = i < n ? g[i] : 0.0f; }
+    if (grad_div == 1.0f) {   // uniform: no division computed and discarded per element
+#pragma unroll
+      for (int u = 0; u < 16; ++u) s += x[u] * x[u];
+    } else {
+#pragma unroll
+      for (int u = 0; u < 16; ++u) { const float v = x[u] / grad_div; s += v * v; }
+    }
   }
   for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
@@ -691,32 +694,75 @@ __device__ float norm_from_partials(const float* partials) {
   __syncthreads();
   return sqrtf((red[0] + red[1]) + (red[2] + red[3]));
 }
+// Elementwise updates: one expression per element, shared by the scalar kernels and the four-elements-per-thread ones (16-byte loads / stores
+// when the four vectors are 16-byte aligned — the context's own always are); -ffp-contract=off, so both forms give the same bits.
+__device__ __forceinline__ void adam_elem(float& p, float g, float& m, float& v, bool clip, float gn, float max_norm, float lr, float b1, float b2,
+                                          float eps, float bc1, float bc2, float grad_div) {
+  float gi = grad_div == 1.0f ? g : g / grad_div;
+  if (clip) gi = (gi / gn) * max_norm;
+  const float mi = (1.0f - b1) * gi + b1 * m;
+  const float vi = (1.0f - b2) * (gi * gi) + b2 * v;
+  m = mi; v = vi;
+  const float u = (mi / bc1) / (sqrtf(vi / bc2) + eps);
+  p = p + (-lr) * u;
+}
+__device__ __forceinline__ void rmsprop_elem(float& p, float g, float& nu, bool clip, float gn, float max_norm, float lr, float decay, float eps,
+                                             float grad_div) {
+  float gi = grad_div == 1.0f ? g : g / grad_div;
+  if (clip) gi = (gi / gn) * max_norm;
+  const float ni = (1.0f - decay) * (gi * gi) + decay * nu;
+  nu = ni;
+  p = p + (-lr) * (gi / (sqrtf(ni) + eps));
+}
 __global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, float* m, float* v, int64_t n, float max_norm, float lr,
                                                    float b1, float b2, float eps, float bc1, float bc2, float grad_div,
                                                    const float* partials) {
   const float gn = norm_from_partials(partials);
   const bool clip = !(gn < max_norm);
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    float gi = grad_div == 1.0f ? g[i] : g[i] / grad_div;
-    if (clip) gi = (gi / gn) * max_norm;
-    const float mi = (1.0f - b1) * gi + b1 * m[i];
-    const float vi = (1.0f - b2) * (gi * gi) + b2 * v[i];
-    m[i] = mi; v[i] = vi;
-    const float u = (mi / bc1) / (sqrtf(vi / bc2) + eps);
-    p[i] = p[i] + (-lr) * u;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    adam_elem(p[i], g[i], m[i], v[i], clip, gn, max_norm, lr, b1, b2, eps, bc1, bc2, grad_div);
+}
+__global__ __launch_bounds__(256) void adam_vec4_kernel(float* p, const float* g, float* m, float* v, int64_t n, float max_norm, float lr,
+                                                        float b1, float b2, float eps, float bc1, float bc2, float grad_div,
+                                                        const float* partials) {
+  const float gn = norm_from_partials(partials);
+  const bool clip = !(gn < max_norm);
+  const int64_t n4 = n >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const float4 G = reinterpret_cast<const float4*>(g)[i];
+    float4 Pv = reinterpret_cast<float4*>(p)[i], M = reinterpret_cast<float4*>(m)[i], V = reinterpret_cast<float4*>(v)[i];
+    adam_elem(Pv.x, G.x, M.x, V.x, clip, gn, max_norm, lr, b1, b2, eps, bc1, bc2, grad_div);
+    adam_elem(Pv.y, G.y, M.y, V.y, clip, gn, max_norm, lr, b1, b2, eps, bc1, bc2, grad_div);
+    adam_elem(Pv.z, G.z, M.z, V.z, clip, gn, max_norm, lr, b1, b2, eps, bc1, bc2, grad_div);
+    adam_elem(Pv.w, G.w, M.w, V.w, clip, gn, max_norm, lr, b1, b2, eps, bc1, bc2, grad_div);
+    reinterpret_cast<float4*>(m)[i] = M; reinterpret_cast<float4*>(v)[i] = V; reinterpret_cast<float4*>(p)[i] = Pv;
   }
+  const int64_t it = (n4 << 2) + threadIdx.x;   // the last n % 4 elements
+  if (blockIdx.x == 0 && it < n) adam_elem(p[it], g[it], m[it], v[it], clip, gn, max_norm, lr, b1, b2, eps, bc1, bc2, grad_div);
 }
 __global__ __launch_bounds__(256) void rmsprop_kernel(float* p, const float* g, float* nu, int64_t n, float max_norm, float lr, float decay,
                                                       float eps, float grad_div, const float* partials) {
   const float gn = norm_from_partials(partials);
   const bool clip = !(gn < max_norm);
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    float gi = grad_div == 1.0f ? g[i] : g[i] / grad_div;
-    if (clip) gi = (gi / gn) * max_norm;
-    const float ni = (1.0f - decay) * (gi * gi) + decay * nu[i];
-    nu[i] = ni;
-    p[i] = p[i] + (-lr) * (gi / (sqrtf(ni) + eps));
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    rmsprop_elem(p[i], g[i], nu[i], clip, gn, max_norm, lr, decay, eps, grad_div);
+}
+__global__ __launch_bounds__(256) void rmsprop_vec4_kernel(float* p, const float* g, float* nu, int64_t n, float max_norm, float lr, float decay,
+                                                           float eps, float grad_div, const float* partials) {
+  const float gn = norm_from_partials(partials);
+  const bool clip = !(gn < max_norm);
+  const int64_t n4 = n >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const float4 G = reinterpret_cast<const float4*>(g)[i];
+    float4 Pv = reinterpret_cast<float4*>(p)[i], N = reinterpret_cast<float4*>(nu)[i];
+    rmsprop_elem(Pv.x, G.x, N.x, clip, gn, max_norm, lr, decay, eps, grad_div);
+    rmsprop_elem(Pv.y, G.y, N.y, clip, gn, max_norm, lr, decay, eps, grad_div);
+    rmsprop_elem(Pv.z, G.z, N.z, clip, gn, max_norm, lr, decay, eps, grad_div);
+    rmsprop_elem(Pv.w, G.w, N.w, clip, gn, max_norm, lr, decay, eps, grad_div);
+    reinterpret_cast<float4*>(nu)[i] = N; reinterpret_cast<float4*>(p)[i] = Pv;
   }
+  const int64_t it = (n4 << 2) + threadIdx.x;
+  if (blockIdx.x == 0 && it < n) rmsprop_elem(p[it], g[it], nu[it], clip, gn, max_norm, lr, decay, eps, grad_div);
 }
 __global__ __launch_bounds__(256) void grad_accumulate_kernel(float* g, float* acc, int64_t n, float inv_steps_arg, float steps, int last, float grad_div) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
@@ -728,13 +774,23 @@ __global__ __launch_bounds__(256) void grad_accumulate_kernel(float* g, float* a
 void launch_grad_accumulate(float* g, float* acc, int64_t n, int mini_step, bool last, float grad_div, hipStream_t st) {
   hipLaunchKernelGGL(grad_accumulate_kernel, dim3(1024), dim3(256), 0, st, g, acc, n, 0.0f, (float)(mini_step + 1), last ? 1 : 0, grad_div);
 }
+static bool opt_vec4_ok(const void* a, const void* b, const void* c, const void* d) {
+  return (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)d) & 15) == 0;
+}
+static int opt_vec4_blocks(int64_t n) { const int64_t b = ((n >> 2) + 255) / 256; return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b)); }
 void launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float max_norm, float lr, float b1, float b2, float eps,
                  float bc1, float bc2, float grad_div, float* norm_partials, hipStream_t st) {
   hipLaunchKernelGGL(sqnorm_partials_kernel, dim3(CBM_NORM_PARTS), dim3(256), 0, st, g, n, grad_div, norm_partials);
-  hipLaunchKernelGGL(adam_kernel, dim3(1024), dim3(256), 0, st, p, g, m, v, n, max_norm, lr, b1, b2, eps, bc1, bc2, grad_div, norm_partials);
+  if (opt_vec4_ok(p, g, m, v))
+    hipLaunchKernelGGL(adam_vec4_kernel, dim3(opt_vec4_blocks(n)), dim3(256), 0, st, p, g, m, v, n, max_norm, lr, b1, b2, eps, bc1, bc2, grad_div, norm_partials);
+  else
+    hipLaunchKernelGGL(adam_kernel, dim3(1024), dim3(256), 0, st, p, g, m, v, n, max_norm, lr, b1, b2, eps, bc1, bc2, grad_div, norm_partials);
 }
 void launch_rmsprop(float* p, const float* g, float* nu, int64_t n, float max_norm, float lr, float decay, float eps, float grad_div,
                     float* norm_partials, hipStream_t st) {
   hipLaunchKernelGGL(sqnorm_partials_kernel, dim3(CBM_NORM_PARTS), dim3(256), 0, st, g, n, grad_div, norm_partials);
-  hipLaunchKernelGGL(rmsprop_kernel, dim3(1024), dim3(256), 0, st, p, g, nu, n, max_norm, lr, decay, eps, grad_div, norm_partials);
+  if (opt_vec4_ok(p, g, nu, nu))
+    hipLaunchKernelGGL(rmsprop_vec4_kernel, dim3(opt_vec4_blocks(n)), dim3(256), 0, st, p, g, nu, n, max_norm, lr, decay, eps, grad_div, norm_partials);
+  else
+    hipLaunchKernelGGL(rmsprop_kernel, dim3(1024), dim3(256), 0, st, p, g, nu, n, max_norm, lr, decay, eps, grad_div, norm_partials);
 }
