@@ -198,7 +198,9 @@ static int ctx_create_impl(const cbm_config* cfg, cbm_ctx** out, cbm_ctx** parti
   if (c->asyncB && dalloc(&c->advn, T1 * B)) return -1;
   if (dalloc(&c->adv, T1 * B) || dalloc(&c->target, T1 * B) || dalloc(&c->next_value, B) || dalloc(&c->stats_dev, (size_t)c->stat_rows * 8) ||
       dalloc(&c->loss_partials, (size_t)4 * (lmax / 8 + 2) + 3 * B) || dalloc(&c->norm_partials, CBM_NORM_PARTS) ||
-      dalloc(&c->perm, T1 * B) || dalloc(&c->perm_tmp, T1 * B) || dalloc(&c->ckeys, permutation_scratch_u64((int)(T1 * B)))) return -1;
+      dalloc(&c->perm, (size_t)c->epochs * T1 * B) || dalloc(&c->perm_tmp, (size_t)c->epochs * T1 * B) ||
+      dalloc(&c->ckeys, std::max(permutation_scratch_u64((int)(T1 * B)), permutation_batch_scratch_u64((int)(T1 * B), c->epochs)))) return -1;
+  c->perm_cur = c->perm;
   if (!is_ppo(c)) {  // static minibatch index table: contiguous env-column chunks, all T+1 rows (impala:623-634)
     const int Bm = c->Bdev / c->nmicro;
     std::vector<int32_t> h((size_t)c->nmicro * c->MB);
@@ -636,7 +638,24 @@ static int learner_epoch_perm(cbm_ctx* c, uint32_t key[2]) {
   key[0] = n0; key[1] = n1;
   const uint32_t sub[2] = {s0, s1};
   launch_permutation(sub, c->T * c->Bdev, c->perm, c->perm_tmp, c->ckeys, c->lstream);
+  c->perm_cur = c->perm;
   return 0;
+}
+// The whole-update call knows every epoch's subkey before its first minibatch: all permutations in four launches (pointwise.hip) instead of six
+// per epoch on the learner stream; epoch e then reads rows [e][...] of c->perm.  The key advances exactly as epoch-by-epoch calls advance it.
+static bool learner_all_epoch_perms(cbm_ctx* c, uint32_t key[2]) {
+  if (c->epochs < 2 || c->epochs > CBM_PERM_BATCH_MAX) return false;
+  uint32_t subs[CBM_PERM_BATCH_MAX][2];
+  uint32_t k0 = key[0], k1 = key[1];
+  for (int e = 0; e < c->epochs; ++e) {
+    uint32_t n0, n1;
+    cbm_split_at(k0, k1, 2, 1, &subs[e][0], &subs[e][1]);
+    cbm_split_at(k0, k1, 2, 0, &n0, &n1);
+    k0 = n0; k1 = n1;
+  }
+  if (!launch_permutations_batch(subs, c->epochs, c->T * c->Bdev, c->perm, c->perm_tmp, c->ckeys, c->lstream)) return false;
+  key[0] = k0; key[1] = k1;
+  return true;
 }
 
 // Small minibatches (<= 1024 frames, e.g. IMPALA's default 21 x 30) leave the 3136 -> 512 dense with ~80 blocks and a 98-chunk
@@ -649,7 +668,7 @@ extern "C" int cbm_learner_minibatch_grad(cbm_ctx* c, int32_t epoch, int32_t mb)
   RingEntry& R = cur_ring(c);
   float* stats = c->stats_dev + (size_t)(epoch * c->nmicro + mb) * 8;
   if (is_ppo(c)) {
-    const int32_t* idx = c->perm + (size_t)mb * c->MB;
+    const int32_t* idx = c->perm_cur + (size_t)mb * c->MB;
     c->lws.skip_heads = ppo_heads_fusable(c->L);
     nature_forward(c->L, c->params, R.obs, idx, c->MB, learner_ksplit(c), c->lws, c->lstream);
     const float* adv = c->adv;
@@ -728,8 +747,10 @@ extern "C" int cbm_learner_update(cbm_ctx* c, uint32_t key[2], const float* lrs,
   if (n_opt_steps != c->epochs * c->nmb) { cbm_set_error("n_opt_steps must be epochs*minibatches = %d", c->epochs * c->nmb); return -1; }
   if (cbm_learner_prepare(c, key)) return -1;
   int step = 0;
+  const bool all_perms = is_ppo(c) && learner_all_epoch_perms(c, key);
   for (int e = 0; e < c->epochs; ++e) {
-    if (is_ppo(c)) learner_epoch_perm(c, key);
+    if (all_perms) c->perm_cur = c->perm + (size_t)e * c->T * c->Bdev;
+    else if (is_ppo(c)) learner_epoch_perm(c, key);
     for (int mb = 0; mb < c->nmicro; ++mb) {
       if (cbm_learner_minibatch_grad(c, e, mb)) return -1;
       float grad_div = 1.0f;

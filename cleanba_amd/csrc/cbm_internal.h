@@ -137,6 +137,11 @@ void launch_mb_advnorm(const float* adv, const int32_t* idx, int n, float* out, 
 // perm = jax.random.permutation(key, n): host does the key splits, device the bits + stable sorts.
 size_t permutation_scratch_u64(int n);   // uint64 words of scratch launch_permutation needs for n elements
 void launch_permutation(const uint32_t key[2], int n, int32_t* perm, int32_t* tmp, uint64_t* scratch, hipStream_t st);
+// every epoch's permutation of one update at once (perms / tmps [ne][n], scratch of permutation_batch_scratch_u64(n, ne) words); false = not
+// taken (one epoch, or more than CBM_PERM_BATCH_MAX epoch x round jobs): the caller permutes epoch by epoch
+#define CBM_PERM_BATCH_MAX 16
+size_t permutation_batch_scratch_u64(int n, int ne);
+bool launch_permutations_batch(const uint32_t (*epoch_keys)[2], int ne, int n, int32_t* perms, int32_t* tmps, uint64_t* scratch, hipStream_t st);
 void launch_ppo_loss(const float* logits, const float* value, int N, int A, const int32_t* idx, const int32_t* actions,
                      const float* old_logprob, const float* adv, const float* target, float clip_coef, float ent_coef,
                      float vf_coef, float* dzv, float* partials, float* stats5, hipStream_t st);

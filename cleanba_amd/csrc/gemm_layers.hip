@@ -1060,7 +1060,7 @@ static int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static int round_up(int a, int b) { return ceil_div(a, b) * b; }
 
 // rows of the reduction handled by one split block (multiples of BR = 32)
-static const int RPS_C2 = 1280, RPS_HEADS = 128;   // (RPS_C2: the im2col conv2 weight gradient of the split-bf16 mode)
+static const int RPS_C2 = 1280, RPS_HEADS = 128;   // (heads: 64-row slices are 3 us faster per minibatch, and their summation grouping moves the whole-update statistics from 6e-6 to 5e-5 of the oracle: not taken; RPS_C2: the im2col conv2 weight gradient of the split-bf16 mode)
 // dense weight gradient: 128x256 tiles (2x4 accumulators per wave): 50 tiles x 10 reduction slices, 133 -> 124 us isolated (128x128 x 5: 133;
 // 64x64 x 2: 170; 5 / 8 / 15 slices of the 128x256 tile: 143 / 148 / 160)
 static const int DENSE_WGRAD_NZ = 10;

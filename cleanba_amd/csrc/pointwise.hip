@@ -234,7 +234,7 @@ void launch_mb_advnorm(const float* adv, const int32_t* idx, int n, float* out, 
 #define PERM_G 64
 #define PERM_LOG2G 6
 size_t permutation_scratch_u64(int n) { return (size_t)PERM_G * (size_t)n + 64; }
-__global__ __launch_bounds__(256) void perm_bucket_kernel(uint32_t sk0, uint32_t sk1, int n, uint64_t* lists, int32_t* counts) {
+__device__ __forceinline__ void perm_bucket_body(uint32_t sk0, uint32_t sk1, int n, uint64_t* lists, int32_t* counts) {
   __shared__ int32_t hist[PERM_G], base[PERM_G];
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (threadIdx.x < PERM_G) hist[threadIdx.x] = 0;
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(256) void perm_bucket_kernel(uint32_t sk0, uint32_t
   if (i < n) lists[(size_t)g * n + base[g] + local] = key;
 }
 // block (x, g): elements [256 x, +256) of range g's list; place = (sizes of the ranges below) + #{keys of the range below mine}
-__global__ __launch_bounds__(256) void perm_place_kernel(const uint64_t* lists, const int32_t* counts, int n, const int32_t* in_vals, int32_t* out_vals) {
+__device__ __forceinline__ void perm_place_body(const uint64_t* lists, const int32_t* counts, int n, const int32_t* in_vals, int32_t* out_vals) {
   __shared__ uint64_t tile[512];
   __shared__ int32_t cs[PERM_G];
   const int g = blockIdx.y, cnt = counts[g];
@@ -278,10 +278,19 @@ __global__ __launch_bounds__(256) void perm_place_kernel(const uint64_t* lists, 
   for (int h = 0; h < PERM_G; ++h) below += cs[h];
   if (e < cnt) { const int i = (int)(uint32_t)mine; out_vals[below + r] = in_vals ? in_vals[i] : i; }
 }
+__global__ __launch_bounds__(256) void perm_bucket_kernel(uint32_t sk0, uint32_t sk1, int n, uint64_t* lists, int32_t* counts) {
+  perm_bucket_body(sk0, sk1, n, lists, counts);
+}
+__global__ __launch_bounds__(256) void perm_place_kernel(const uint64_t* lists, const int32_t* counts, int n, const int32_t* in_vals, int32_t* out_vals) {
+  perm_place_body(lists, counts, n, in_vals, out_vals);
+}
+static int perm_rounds(int n) {
+  const double sz = n > 1 ? (double)n : 1.0;
+  return (int)ceil(3.0 * log(sz) / log(4294967295.0));
+}
 void launch_permutation(const uint32_t key_in[2], int n, int32_t* perm, int32_t* tmp, uint64_t* scratch, hipStream_t st) {
   uint32_t k0 = key_in[0], k1 = key_in[1];
-  const double sz = n > 1 ? (double)n : 1.0;
-  const int rounds = (int)ceil(3.0 * log(sz) / log(4294967295.0));
+  const int rounds = perm_rounds(n);
   int32_t* counts = reinterpret_cast<int32_t*>(scratch + (size_t)PERM_G * n);
   int32_t* bufs[2] = {perm, tmp};
   int cur = (rounds % 2 == 1) ? 0 : 1;  // ping-pong so the final round lands in `perm`
@@ -297,6 +306,50 @@ void launch_permutation(const uint32_t key_in[2], int n, int32_t* perm, int32_t*
     src = bufs[cur];
     cur ^= 1;
   }
+}
+// The permutations of ALL epochs of an update (ppo:599-606: one subkey per epoch, known before the first minibatch) in four launches instead of
+// six per epoch: job (epoch e, round r) has its own lists and counters, one bucket pass takes every job (blockIdx.y), one place pass per round
+// takes that round of every epoch (blockIdx.z).  The same kernels' bodies on the same keys: the same permutations.  perms / tmps: [ne][n].
+struct PermKeys { uint32_t k[CBM_PERM_BATCH_MAX][2]; };
+__global__ __launch_bounds__(256) void perm_bucket_batch_kernel(const PermKeys keys, int n, uint64_t* lists, int32_t* counts) {
+  const int job = blockIdx.y;
+  perm_bucket_body(keys.k[job][0], keys.k[job][1], n, lists + (size_t)job * PERM_G * n, counts + job * PERM_G);
+}
+__global__ __launch_bounds__(256) void perm_place_batch_kernel(const uint64_t* lists, const int32_t* counts, int n, int rounds, int r,
+                                                               const int32_t* in_base, int32_t* out_base) {
+  const int e = blockIdx.z, job = e * rounds + r;
+  perm_place_body(lists + (size_t)job * PERM_G * n, counts + job * PERM_G, n, in_base ? in_base + (size_t)e * n : nullptr, out_base + (size_t)e * n);
+}
+size_t permutation_batch_scratch_u64(int n, int ne) {
+  const size_t jobs = (size_t)ne * perm_rounds(n);
+  return jobs * PERM_G * (size_t)n + jobs * PERM_G / 2 + 64;
+}
+bool launch_permutations_batch(const uint32_t (*epoch_keys)[2], int ne, int n, int32_t* perms, int32_t* tmps, uint64_t* scratch, hipStream_t st) {
+  const int rounds = perm_rounds(n), jobs = ne * rounds;
+  if (ne < 2 || rounds < 1 || jobs > CBM_PERM_BATCH_MAX) return false;
+  PermKeys keys;
+  for (int e = 0; e < ne; ++e) {
+    uint32_t k0 = epoch_keys[e][0], k1 = epoch_keys[e][1];
+    for (int r = 0; r < rounds; ++r) {   // launch_permutation's key chain
+      uint32_t n0, n1, s0, s1;
+      cbm_split_at(k0, k1, 2, 0, &n0, &n1);
+      cbm_split_at(k0, k1, 2, 1, &s0, &s1);
+      k0 = n0; k1 = n1;
+      keys.k[e * rounds + r][0] = s0; keys.k[e * rounds + r][1] = s1;
+    }
+  }
+  int32_t* counts = reinterpret_cast<int32_t*>(scratch + (size_t)jobs * PERM_G * n);
+  hipMemsetAsync(counts, 0, (size_t)jobs * PERM_G * sizeof(int32_t), st);
+  hipLaunchKernelGGL(perm_bucket_batch_kernel, dim3(ceil_div(n, 256), jobs), dim3(256), 0, st, keys, n, scratch, counts);
+  int32_t* bufs[2] = {perms, tmps};
+  int cur = (rounds % 2 == 1) ? 0 : 1;
+  const int32_t* src = nullptr;
+  for (int r = 0; r < rounds; ++r) {
+    hipLaunchKernelGGL(perm_place_batch_kernel, dim3(ceil_div(n, 256), PERM_G, ne), dim3(256), 0, st, scratch, counts, n, rounds, r, src, bufs[cur]);
+    src = bufs[cur];
+    cur ^= 1;
+  }
+  return true;
 }
 
 // ------------------------------------------------------------------------------------------
