@@ -1207,7 +1207,10 @@ int nature_forward(const NatureLayout& L, const float* P, const uint8_t* obs, co
   // (forward_bf16 too: at <= 512 frames the bf16 MFMA buys nothing over these latency-bound launches, so the actor's behaviour logits stay fp32)
   if (small && !ws.mask1 && !ws.prof) {
     Conv1Fwd<T64x64k16> p1{obs, idx, P + L.w[0], P + L.b[0], ws.act1, B * 400, nullptr};
-    igemm_s16_launch<32, 32, 32>(p1, 1, st);
+    // conv1 on 64-row tiles (750 blocks instead of 1500): no faster alone (rollout 6.52 -> 6.53 ms), but beside the learner's CU-filling kernels half as
+    // many blocks wait for a slot — pipelined step 33.87 -> 33.64 ms over six A/B pairs, IMPALA and the host-stepped path unchanged; the same 64 rows
+    // for conv2 / conv3 / dense cost the rollout alone 0.1-0.4 ms and IMPALA 2-4 %
+    igemm_s16_launch<64, 32, 32>(p1, 1, st);
     ConvFwd<T64x64k16, 4, 4, 2, 32, 64, 20, 20, 9, 9> p2{ws.act1, P + L.w[1], P + L.b[1], ws.act2, B * 81, nullptr};
     igemm_s16_launch<32, 32, 32>(p2, 1, st);   // (K chunks of 32 like conv1 / dense: 21.5 KB of LDS and 65 VGPRs per block instead of 42 KB / 129 —
     ConvFwd<T64x64k16, 3, 3, 1, 64, 64, 9, 9, 7, 7> p3{ws.act2, P + L.w[2], P + L.b[2], ws.act3, B * 49, nullptr};

@@ -172,3 +172,50 @@ def test_relu_bit_masks_equal_the_activations(big):
                 bad = np.nonzero(want != m[:, w])[0]
                 assert bad.size == 0, (n, name, w, bad[:8])
         dP.free(); dO.free()
+
+
+@pytest.mark.parametrize("epochs,E2,T2", [(4, E, T), (3, 16, 32), (1, 16, 32)])
+def test_whole_update_call_equals_the_per_epoch_calls(epochs, E2, T2):
+    """cbm_learner_update permutes every epoch of the update in one batch of launches (and lets the loss statistics ride in the reduction
+    launch); the split C calls (prepare / epoch_begin / minibatch_grad / optimizer_step / finish, the form a data-parallel host drives)
+    permute epoch by epoch.  Same rollout, same key -> the same key afterwards, the same statistics rows and the same parameters, bit for bit
+    (ppo:599-615: one subkey per epoch)."""
+    def run(split):
+        cfg = L.default_config(L.ALGO_PPO)
+        cfg.local_num_envs, cfg.num_actor_slots, cfg.num_steps, cfg.update_epochs = E2, 1, T2, epochs
+        ctx = L.Context(cfg)
+        key = prng.prng_key(3)
+        key, nk, ak, ck = prng.split(key, 4)
+        ctx.set_params(M.init_nature_params(A, nk, ak, ck))
+        ctx.actor_set_key(0, key)
+        ctx.actor_env_reset_device(0, 5)
+        ctx.actor_begin_rollout(0, False)
+        ctx.actor_rollout_device(0, T2)
+        ctx.actor_commit(0)
+        ctx.learner_wait()
+        nmb = cfg.num_minibatches
+        n_opt = epochs * nmb
+        lrs = np.full(n_opt, 2.5e-4, np.float32)
+        bc = [M.adam_bias_corrections(i + 1) for i in range(n_opt)]
+        b1, b2 = np.array([b[0] for b in bc], np.float32), np.array([b[1] for b in bc], np.float32)
+        if not split:
+            k, stats = ctx.learner_update(key, lrs, b1, b2)
+        else:
+            k = ctx.learner_prepare(key)
+            i = 0
+            for e in range(epochs):
+                k = ctx.learner_epoch_begin(k)
+                for mb in range(nmb):
+                    ctx.learner_minibatch_grad(e, mb)
+                    ctx.learner_optimizer_step(float(lrs[i]), float(b1[i]), float(b2[i]))
+                    i += 1
+            stats = ctx.learner_finish(n_opt)
+        p = ctx.get_params()
+        ctx.close()
+        return np.asarray(k), np.asarray(stats), p
+    k1, s1, p1 = run(False)
+    k2, s2, p2 = run(True)
+    assert np.isfinite(p1).all() and np.isfinite(s1).all()
+    assert np.array_equal(k1, k2)
+    assert np.array_equal(bits(s1), bits(s2))
+    assert np.array_equal(bits(p1), bits(p2))
