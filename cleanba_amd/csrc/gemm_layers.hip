@@ -982,7 +982,7 @@ static void launch_reduce(const float* part, int nz, int XY, int Ycols, int mode
 // and the reductions run as TWO launches: {heads, dense} right after the dense weight gradient (their result is the tail the data-parallel
 // all-reduce waits for) and {conv3, conv2, conv1} at the end.  Same per-output summation order as the single launches -> same bits.
 struct RedJob { const float* part; float* gw; float* gw2; int nz, XY, Ycols, mode, zg, block0; float scale; };
-#define RED_MAX_JOBS 36   // Nature: 4 + 6 jobs; ResNet: 4 (dense + heads) + 30 (15 convs x {weights, bias}) — two launches beside an all-reduce, one without
+#define RED_MAX_JOBS 36   // Nature: 4 + 6 jobs; ResNet: 4 (dense + heads) + 30 (15 convs x {weights, bias}) — two launches beside an all-reduce, one without; + 1: the PPO loss statistics
 struct RedJobs { RedJob j[RED_MAX_JOBS]; int n, A; float ent_coef, vf_coef; };
 __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const RedJobs jobs) {
   // four consecutive outputs per thread (16-byte loads; every XY is a multiple of 32), same z order per output as the scalar form
@@ -1030,15 +1030,23 @@ __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const RedJobs j
 struct RedBatch {
   RedJobs jobs;
   int blocks = 0;
+  // (the job table is a kernel argument of fixed size; a layer list that outgrows it fails the launch check instead of writing past it)
+  bool room(int more) {
+    if (jobs.n + more <= RED_MAX_JOBS) return true;
+    cbm_launch_fail("reduction launch: %d jobs > %d", jobs.n + more, RED_MAX_JOBS);
+    return false;
+  }
   explicit RedBatch(int A) { jobs.n = 0; jobs.A = A; jobs.ent_coef = jobs.vf_coef = 0.0f; }
   void add(const float* part, int nz, int XY, int Ycols, int mode, float* gw, float* gw2, float scale = 1.0f) {
     const int zg = nz >= 64 ? 16 : (nz >= 8 ? 4 : 1), ow = 256 / zg;
+    if (!room(1)) return;
     jobs.j[jobs.n++] = RedJob{part, gw, gw2, nz, XY, Ycols, mode, zg, blocks, scale};
     blocks += (XY / 4 + ow - 1) / ow;
   }
   // The five loss statistics (ppo:649-653) were a launch of one wave behind the fused heads (4.8 us on the learner stream, nothing downstream
   // reads them before the update ends): the sum over the heads' block partials rides here as one more block.
   void add_stats(const PendingStats& ps) {
+    if (!room(1)) return;
     jobs.j[jobs.n++] = RedJob{ps.partials, ps.stats5, nullptr, ps.nblk, ps.N, 1, 4, 1, blocks, 1.0f};
     jobs.ent_coef = ps.ent_coef; jobs.vf_coef = ps.vf_coef;
     blocks += 1;
@@ -1046,6 +1054,7 @@ struct RedBatch {
   void launch(hipStream_t st) { if (jobs.n) hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3(blocks), dim3(256), 0, st, jobs); }
   // the jobs of `o` join this launch (no all-reduce waits for them: one launch instead of two)
   void absorb(const RedBatch& o) {
+    if (!room(o.jobs.n)) return;
     for (int k = 0; k < o.jobs.n; ++k) { jobs.j[jobs.n] = o.jobs.j[k]; jobs.j[jobs.n].block0 += blocks; ++jobs.n; }
     blocks += o.blocks;
   }
