@@ -11,6 +11,8 @@ cfg = L.default_config(L.ALGO_PPO)
 if NET != "nature":
     cfg.network = L.NET_IMPALA_RESNET
     cfg.actor_dense_ksplit = 11
+if os.environ.get("KSPLIT"):   # K segments of the actor's dense launch (Nature: 7 / 14; the numerics spec ships 14)
+    cfg.actor_dense_ksplit = int(os.environ["KSPLIT"])
 cfg.local_num_envs, cfg.num_actor_slots, cfg.num_steps, cfg.num_actions = E, 1, T, A
 ctx = L.Context(cfg)
 key = prng.prng_key(1)
