@@ -260,6 +260,12 @@ def run_dp(a, world, rank, local_rank):
                                  "exposed_us_avg": round(exposed_ms / max(n, 1) * 1e3, 1),
                                  "note": "tail (dense + heads) runs on the communication stream under the conv backward; exposed = end of the "
                                          "backward pass -> optimizer may start on the learner stream (head all-reduce + whatever of the tail was not hidden)"}
+    # teardown of a run whose ranks map each other's buffers (native all-reduce): unmap -> barrier -> free.  An owner that frees a window a peer
+    # still maps leaves the exporting process's IPC state broken for its NEXT export (tools/ipc_stress.py racy: hipIpcGetMemHandle "invalid
+    # argument" / the peers' hipIpcOpenMemHandle "invalid device pointer" one cycle later) — the round-4 failure of the topology phase below.
+    ctx.unmap_peers()
+    if rdv is not None:
+        rdv.barrier("unmapped")
     ctx.close()
     return line, params
 

@@ -148,14 +148,52 @@ static int ctx_create_impl(const cbm_config* cfg, cbm_ctx** out, cbm_ctx** parti
   }
   c->P = c->L.total;
   const size_t P = (size_t)c->P, B = (size_t)c->Bdev, T1 = (size_t)c->T1;
-  if (dalloc(&c->params, P) || dalloc(&c->grads, P) || dalloc(&c->opt_m, P) || dalloc(&c->opt_v, P)) return -1;
-  hipMemset(c->params, 0, P * 4); hipMemset(c->grads, 0, P * 4); hipMemset(c->opt_m, 0, P * 4); hipMemset(c->opt_v, 0, P * 4);
-  for (int i = 0; i < NPV; ++i) { if (dalloc(&c->actor_params[i], P)) return -1; CBM_HIP(hipEventCreateWithFlags(&c->params_ready[i], hipEventDisableTiming)); }
+  c->stat_rows = c->epochs * c->nmicro;
+  // The two export windows (cbm_ctx.h): every buffer a peer process may map is carved from one of them at 4 KB granularity, so a peer maps ONE
+  // allocation per context and purpose (never one of the runtime's sub-allocated fragments) and addresses fields by offset (cbm_ipc_window_offset).
+  {
+    auto carve = [](size_t& off, size_t bytes) { const size_t o = off; off = (off + bytes + 4095) & ~(size_t)4095; return o; };
+    struct RingOff { size_t obs, actions, logprobs, values, rewards, logits, dones, firststeps, env_ids; } ro[MAX_RING];
+    size_t w0 = 0, ap[NPV];
+    for (int i = 0; i < NPV; ++i) ap[i] = carve(w0, P * 4);
+    for (int r = 0; r < cfg->ring_depth; ++r) {
+      ro[r].obs = carve(w0, T1 * B * CBM_FRAME); ro[r].actions = carve(w0, T1 * B * 4); ro[r].logprobs = carve(w0, T1 * B * 4);
+      ro[r].values = carve(w0, T1 * B * 4); ro[r].rewards = carve(w0, T1 * B * 4); ro[r].logits = carve(w0, T1 * B * c->A * 4);
+      ro[r].dones = carve(w0, T1 * B); ro[r].firststeps = carve(w0, T1 * B); ro[r].env_ids = carve(w0, T1 * B * 4);
+    }
+    size_t w1 = 0;
+    const size_t o_grads = carve(w1, P * 4), o_stats = carve(w1, (size_t)c->stat_rows * 8 * 4), o_scr = carve(w1, CBM_COMM_SCRATCH * 8);
+    const size_t min_win = (size_t)4 << 20;
+    c->win_bytes[0] = std::max(w0, min_win);
+    c->win_bytes[1] = std::max(w1, min_win);
+    // window 1 is what the native all-reduce's kernels read and write in PEER memory while they run: across devices that needs fine-grained
+    // memory (coarse-grained memory is only coherent at kernel boundaries).  CBM_NATIVE_FINEGRAINED=1 / 0 forces it; default: fine-grained when the
+    // host asked for the native backend (CBM_COMM=native) without pinning every rank to one device (CBM_FORCE_DEVICE).
+    const char* fg = getenv("CBM_NATIVE_FINEGRAINED");
+    const char* be = getenv("CBM_COMM");
+    c->win_fine[1] = fg ? atoi(fg) != 0 : (be && !strcmp(be, "native") && !getenv("CBM_FORCE_DEVICE") && ndev > 1);
+    for (int w = 0; w < CBM_WINDOWS; ++w) {
+      void* p = nullptr;
+      const hipError_t e = c->win_fine[w] ? hipExtMallocWithFlags(&p, c->win_bytes[w], hipDeviceMallocFinegrained) : hipMalloc(&p, c->win_bytes[w]);
+      if (e != hipSuccess) { cbm_set_error("export window %d: %s of %zu bytes failed: %s", w, c->win_fine[w] ? "fine-grained allocation" : "hipMalloc", c->win_bytes[w], hipGetErrorString(e)); return -1; }
+      c->win[w] = (uint8_t*)p;
+    }
+    CBM_HIP(hipMemset(c->win[1], 0, c->win_bytes[1]));
+    c->grads = (float*)(c->win[1] + o_grads); c->stats_dev = (float*)(c->win[1] + o_stats); c->comm_scratch = (double*)(c->win[1] + o_scr);
+    for (int i = 0; i < NPV; ++i) c->actor_params[i] = (float*)(c->win[0] + ap[i]);
+    for (int r = 0; r < cfg->ring_depth; ++r) {
+      RingEntry& R = c->ring[r];
+      uint8_t* const w = c->win[0];
+      R.obs = w + ro[r].obs; R.actions = (int32_t*)(w + ro[r].actions); R.logprobs = (float*)(w + ro[r].logprobs); R.values = (float*)(w + ro[r].values);
+      R.rewards = (float*)(w + ro[r].rewards); R.logits = (float*)(w + ro[r].logits); R.dones = w + ro[r].dones; R.firststeps = w + ro[r].firststeps;
+      R.env_ids = (int32_t*)(w + ro[r].env_ids);
+    }
+  }
+  if (dalloc(&c->params, P) || dalloc(&c->opt_m, P) || dalloc(&c->opt_v, P)) return -1;
+  hipMemset(c->params, 0, P * 4); hipMemset(c->opt_m, 0, P * 4); hipMemset(c->opt_v, 0, P * 4);
+  for (int i = 0; i < NPV; ++i) { hipMemset(c->actor_params[i], 0, P * 4); CBM_HIP(hipEventCreateWithFlags(&c->params_ready[i], hipEventDisableTiming)); }
   for (int r = 0; r < cfg->ring_depth; ++r) {
     RingEntry& R = c->ring[r];
-    if (dalloc(&R.obs, T1 * B * CBM_FRAME) || dalloc(&R.actions, T1 * B) || dalloc(&R.logprobs, T1 * B) || dalloc(&R.values, T1 * B) ||
-        dalloc(&R.rewards, T1 * B) || dalloc(&R.logits, T1 * B * c->A) || dalloc(&R.dones, T1 * B) || dalloc(&R.firststeps, T1 * B) ||
-        dalloc(&R.env_ids, T1 * B)) return -1;
     hipMemset(R.env_ids, 0, T1 * B * 4); hipMemset(R.actions, 0, T1 * B * 4); hipMemset(R.logprobs, 0, T1 * B * 4); hipMemset(R.values, 0, T1 * B * 4);
     hipMemset(R.logits, 0, T1 * B * c->A * 4);   // rows a rollout never writes (PPO row T) read back as zeros, not as stale HBM
     hipMemset(R.dones, 0, T1 * B); hipMemset(R.firststeps, 0, T1 * B); hipMemset(R.rewards, 0, T1 * B * 4);
@@ -191,12 +229,10 @@ static int ctx_create_impl(const cbm_config* cfg, cbm_ctx** out, cbm_ctx** parti
   c->lws.tail_ev = c->tail_ev;
   CBM_HIP(hipStreamCreateWithFlags(&c->cstream, hipStreamNonBlocking));
   CBM_HIP(hipStreamCreateWithFlags(&c->iostream, hipStreamNonBlocking));
-  if (dalloc(&c->comm_scratch, CBM_COMM_SCRATCH)) return -1;
   { const char* ov = getenv("CBM_ALLREDUCE_OVERLAP"); c->comm_overlap = !(ov && !strcmp(ov, "0")); }
-  c->stat_rows = c->epochs * c->nmicro;
   if (c->accum > 1) { if (dalloc(&c->gacc, P)) return -1; hipMemset(c->gacc, 0, P * 4); }
   if (c->asyncB && dalloc(&c->advn, T1 * B)) return -1;
-  if (dalloc(&c->adv, T1 * B) || dalloc(&c->target, T1 * B) || dalloc(&c->next_value, B) || dalloc(&c->stats_dev, (size_t)c->stat_rows * 8) ||
+  if (dalloc(&c->adv, T1 * B) || dalloc(&c->target, T1 * B) || dalloc(&c->next_value, B) ||
       dalloc(&c->loss_partials, (size_t)4 * (lmax / 8 + 2) + 3 * B) || dalloc(&c->norm_partials, CBM_NORM_PARTS) ||
       dalloc(&c->perm, (size_t)c->epochs * T1 * B) || dalloc(&c->perm_tmp, (size_t)c->epochs * T1 * B) ||
       dalloc(&c->ckeys, std::max(permutation_scratch_u64((int)(T1 * B)), permutation_batch_scratch_u64((int)(T1 * B), c->epochs)))) return -1;
@@ -230,16 +266,15 @@ extern "C" int cbm_ctx_destroy(cbm_ctx* c) {
   if (!c) return 0;
   hipSetDevice(c->cfg.device);
   hipDeviceSynchronize();
-  void* ps[] = {c->params, c->grads, c->opt_m, c->opt_v, c->adv, c->target, c->next_value, c->stats_dev, c->loss_partials, c->norm_partials,
+  cbm_ipc_close_all_impl(c);   // peer mappings first (a host that shares windows calls cbm_ipc_close_all on every peer, then a barrier, then this)
+  void* ps[] = {c->params, c->opt_m, c->opt_v, c->adv, c->target, c->next_value, c->loss_partials, c->norm_partials,
                 c->perm, c->perm_tmp, c->ckeys, c->impala_idx, c->gacc, c->advn};
   for (void* p : ps) if (p) hipFree(p);
-  for (int i = 0; i < NPV; ++i) { if (c->actor_params[i]) hipFree(c->actor_params[i]); hipEventDestroy(c->params_ready[i]); }
+  for (int i = 0; i < NPV; ++i) if (c->params_ready[i]) hipEventDestroy(c->params_ready[i]);
   for (int r = 0; r < c->cfg.ring_depth; ++r) {
     RingEntry& R = c->ring[r];
-    void* qs[] = {R.obs, R.actions, R.logprobs, R.values, R.rewards, R.logits, R.dones, R.firststeps, R.env_ids};
-    for (void* p : qs) if (p) hipFree(p);
-    for (int s = 0; s < c->S; ++s) hipEventDestroy(R.ready[s]);
-    hipEventDestroy(R.consumed);
+    for (int s = 0; s < c->S; ++s) if (R.ready[s]) hipEventDestroy(R.ready[s]);
+    if (R.consumed) hipEventDestroy(R.consumed);
   }
   for (int s = 0; s < c->S; ++s) {
     nature_ws_free(c->slots[s].ws);
@@ -254,7 +289,7 @@ extern "C" int cbm_ctx_destroy(cbm_ctx* c) {
   if (c->bwd_ev) hipEventDestroy(c->bwd_ev);
   cbm_comm_destroy_all(c);
   if (c->comm_prof_created) for (int i = 0; i < 4 * CBM_COMM_PROF_MAX; ++i) hipEventDestroy(c->comm_prof_ev[i]);
-  if (c->comm_scratch) hipFree(c->comm_scratch);
+  for (int w = 0; w < CBM_WINDOWS; ++w) if (c->win[w]) hipFree(c->win[w]);   // the ring, the actor parameter versions, gradient / statistics / scratch
   if (c->cstream) hipStreamDestroy(c->cstream);
   if (c->iostream) hipStreamDestroy(c->iostream);
   hipStreamDestroy(c->lstream);
@@ -737,6 +772,12 @@ extern "C" int cbm_learner_finish(cbm_ctx* c, float* stats_out) {
     CBM_HIP(hipStreamSynchronize(c->lstream));
     if (cbm_comm_check_native(c)) return -1;
     for (int r = 0; r < c->stat_rows; ++r) for (int q = 0; q < w; ++q) stats_out[r * w + q] = h[(size_t)r * 8 + q] * inv;
+  }
+  else if (c->comms[CBM_COMM_LEARNERS].native) {
+    // a timed-out flag wait (a dead peer) leaves an unreduced gradient behind: with the native backend the update's outcome is checked before
+    // version v is announced, statistics or not (RCCL reports its failures through its own calls)
+    CBM_HIP(hipStreamSynchronize(c->lstream));
+    if (cbm_comm_check_native(c)) return -1;
   }
   cbm_publish(c, c->updates_done, v);
   return 0;

@@ -4,6 +4,7 @@
 #include <mutex>
 #include <condition_variable>
 #include <atomic>
+#include <vector>
 
 #define MAX_SLOTS 16
 #define MAX_RING 4
@@ -12,6 +13,7 @@
 #define CBM_COMM_PROF_MAX 1024
 
 #define CBM_NATIVE_BUFS 4          // grads | loss statistics | f64 scratch | signal block  (cbm_comm_native_export order)
+#define CBM_WINDOWS 2              // export windows of a context: 0 = ring fields + versioned actor parameters, 1 = gradient + statistics + f64 scratch
 struct CbmComm {
   void* comm = nullptr;   // ncclComm_t
   int nranks = 0, rank = -1;
@@ -20,7 +22,7 @@ struct CbmComm {
   // process (HIP IPC, or the plain pointer when the peer context lives in this process); one kernel per collective, flags in the signal blocks
   bool native = false;
   void* nat_peer[CBM_NATIVE_BUFS][CBM_NATIVE_MAX_RANKS] = {};
-  bool nat_mapped[CBM_NATIVE_BUFS][CBM_NATIVE_MAX_RANKS] = {};   // opened with hipIpcOpenMemHandle (closed on destroy)
+  void* nat_win[2][CBM_NATIVE_MAX_RANKS] = {};   // mappings this communicator holds of rank r's communication window / signal block (cbm_ipc_map; null: own or same process)
   uint32_t nat_seq = 0;          // collective sequence number: the flag value of the next call
   void* nat_sig_local = nullptr; // this rank's signal block (owned)
   int* nat_err = nullptr;        // page-locked host word: a flag wait timed out (a peer died) — checked when the host next synchronises
@@ -90,6 +92,14 @@ struct cbm_ctx {
   int comm_prof_n = 0;
   hipEvent_t comm_prof_ev[4 * CBM_COMM_PROF_MAX];
   std::atomic<bool> aborted{false};   // cbm_ctx_abort: every blocking wait returns an error from now on
+  // ---- export windows: everything another process may map lives in ONE allocation per purpose, so a peer holds one mapping per context pair
+  // and addresses fields by offset (window 0: ring fields + actor parameter versions; window 1: flat gradient | loss statistics | f64 scratch,
+  // fine-grained when a native communicator is to span devices)
+  uint8_t* win[CBM_WINDOWS] = {nullptr, nullptr};
+  size_t win_bytes[CBM_WINDOWS] = {0, 0};
+  bool win_fine[CBM_WINDOWS] = {false, false};
+  std::mutex maps_mu;
+  std::vector<void*> maps;   // peer windows this context opened with cbm_ipc_open_window (closed by cbm_ipc_close_all / destroy)
 };
 // publish: store the sequence number (release), then wake the sleepers
 static inline void cbm_publish(cbm_ctx* c, std::atomic<int>& var, int value) {
@@ -111,4 +121,5 @@ int cbm_learner_allreduce_grads_impl(cbm_ctx* c, float* grad_div);
 int cbm_learner_allreduce_stats_impl(cbm_ctx* c);
 int cbm_comm_destroy_all(cbm_ctx* c);
 int cbm_comm_check_native(cbm_ctx* c);   // -1 (with the error set) when a native collective's flag wait timed out
+int cbm_ipc_close_all_impl(cbm_ctx* c);  // unmaps every peer window and native-communicator mapping the context holds (idempotent)
 

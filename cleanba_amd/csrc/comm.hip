@@ -16,6 +16,8 @@
 #include <string.h>
 #include <string>
 #include <unistd.h>
+#include <time.h>
+#include <vector>
 
 // ------------------------------------------------------------------------------------------ RCCL binding
 namespace {
@@ -89,6 +91,7 @@ __global__ void comm_scale_f64_kernel(double* x, int n, double f) {
 #define NAT_THREADS 512
 #define NAT_SMALL_MAX 4096
 #define NAT_SIG_WORDS (2 * NAT_BLOCKS * CBM_NATIVE_MAX_RANKS)
+#define NAT_SIG_ALLOC ((size_t)4 << 20)   // bytes allocated for the signal block (NAT_SIG_WORDS * 4 used)
 struct NatArgs {
   void* data[CBM_NATIVE_MAX_RANKS];
   uint32_t* sig[CBM_NATIVE_MAX_RANKS];
@@ -96,29 +99,135 @@ struct NatArgs {
   int64_t off, n;                     // element range of this collective inside the registered buffer
   uint32_t seq;
   int* err;                           // page-locked host word: 1 / 2 = the start / end wait timed out
+  int* err_dev;                       // the same word in device memory (what the kernels poll: sticky, so later collectives return at once)
   unsigned long long timeout_ticks;   // wall_clock64() ticks (100 MHz)
 };
-struct NatBlob {   // what a rank publishes (CBM_NATIVE_BLOB_BYTES): IPC handles for other processes, plain pointers for contexts of the same process
-  uint8_t ipc[CBM_NATIVE_BUFS][CBM_IPC_HANDLE_BYTES];
-  uint64_t ptr[CBM_NATIVE_BUFS];
+// What an exporter publishes about one of its windows (CBM_IPC_WINDOW_BYTES): the HIP IPC handle plus everything an error message on the
+// importing side should be able to say about the buffer it could not map.
+struct WinBlob {
+  uint8_t handle[CBM_IPC_HANDLE_BYTES];
+  uint64_t bytes, owner_ptr, nonce;   // nonce: per-process random word (pid alone does not identify a process across pid namespaces)
   uint32_t pid, device;
+  int32_t window, tag;                // tag: free-form label chosen by the exporting host (its rank)
+  uint32_t fine;
+  uint8_t pad_[CBM_IPC_WINDOW_BYTES - CBM_IPC_HANDLE_BYTES - 3 * 8 - 5 * 4];
+};
+static_assert(sizeof(WinBlob) == CBM_IPC_WINDOW_BYTES, "window blob size");
+struct NatBlob {   // what a rank publishes (CBM_NATIVE_BLOB_BYTES): its communication window, its signal block, and where the three buffers sit in the window
+  WinBlob win, sig;
+  uint64_t off[3];   // gradient | loss statistics | f64 scratch
 };
 static_assert(sizeof(NatBlob) <= CBM_NATIVE_BLOB_BYTES, "blob size");
 
-static __device__ __forceinline__ void nat_signal_and_wait(const NatArgs& a, int phase) {
+// ---- one mapping per (process, exported allocation): opening the same window twice returns the same base (reference-counted), a failed
+// hipIpcOpenMemHandle is retried a few times (the runtime hands the buffer over through a socket served by a thread of the exporting process)
+// and every failed attempt is reported on stderr with both sides' identities.
+namespace {
+struct IpcMapping { void* base; int refs; std::string handle; };
+std::mutex g_ipc_mu;
+std::vector<IpcMapping> g_ipc_maps;
+uint64_t process_nonce() {
+  static const uint64_t n = [] {
+    uint64_t v = 0;
+    FILE* f = fopen("/dev/urandom", "rb");
+    if (f) { if (fread(&v, 1, sizeof(v), f) != sizeof(v)) v = 0; fclose(f); }
+    return v ? v : ((uint64_t)getpid() << 32) ^ (uint64_t)(uintptr_t)&g_ipc_mu ^ (uint64_t)time(nullptr);
+  }();
+  return n;
+}
+bool same_process(const WinBlob& b) { return b.pid == (uint32_t)getpid() && b.nonce == process_nonce(); }
+}  // namespace
+
+static int fill_win_blob(cbm_ctx* c, void* base, size_t bytes, int window, int tag, bool fine, WinBlob* b) {
+  memset(b, 0, sizeof(*b));
+  hipIpcMemHandle_t h;
+  const hipError_t e = hipIpcGetMemHandle(&h, base);
+  if (e != hipSuccess) {
+    cbm_set_error("hipIpcGetMemHandle(window %d: %p, %zu bytes, GPU %d, pid %d) failed: %s (needs HSA_ENABLE_IPC_MODE_LEGACY=0)", window, base, bytes,
+                  c->cfg.device, (int)getpid(), hipGetErrorString(e));
+    return -1;
+  }
+  static_assert(sizeof(hipIpcMemHandle_t) == CBM_IPC_HANDLE_BYTES, "hipIpcMemHandle_t size");
+  memcpy(b->handle, &h, sizeof(h));
+  b->bytes = bytes; b->owner_ptr = (uint64_t)(uintptr_t)base; b->nonce = process_nonce();
+  b->pid = (uint32_t)getpid(); b->device = (uint32_t)c->cfg.device; b->window = window; b->tag = tag; b->fine = fine ? 1 : 0;
+  return 0;
+}
+// maps b (or returns the owner's own pointer when the exporter lives in this process); *mapped = true when cbm_ipc_unmap must be called for it
+static int cbm_ipc_map(cbm_ctx* c, const WinBlob& b, const char* what, void** base, bool* mapped) {
+  *mapped = false;
+  if (same_process(b)) {   // a context of this process: no IPC needed (nor possible)
+    if (b.device != (uint32_t)c->cfg.device) {
+      const hipError_t e = hipDeviceEnablePeerAccess((int)b.device, 0);
+      if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { cbm_set_error("hipDeviceEnablePeerAccess(GPU %d -> GPU %u) failed: %s", c->cfg.device, b.device, hipGetErrorString(e)); return -1; }
+      (void)hipGetLastError();
+    }
+    *base = (void*)(uintptr_t)b.owner_ptr;
+    return 0;
+  }
+  std::lock_guard<std::mutex> lk(g_ipc_mu);
+  const std::string key((const char*)b.handle, CBM_IPC_HANDLE_BYTES);
+  for (IpcMapping& m : g_ipc_maps)
+    if (m.handle == key) { m.refs += 1; *base = m.base; *mapped = true; return 0; }
+  hipIpcMemHandle_t h;
+  memcpy(&h, b.handle, sizeof(h));
+  const int attempts = 4;
+  hipError_t e = hipSuccess;
+  for (int a = 0; a < attempts; ++a) {
+    void* p = nullptr;
+    e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+    if (e == hipSuccess) {
+      if (a) fprintf(stderr, "cleanba_mi: hipIpcOpenMemHandle of %s succeeded on attempt %d\n", what, a + 1);
+      g_ipc_maps.push_back({p, 1, key});
+      *base = p; *mapped = true;
+      return 0;
+    }
+    (void)hipGetLastError();
+    fprintf(stderr, "cleanba_mi: hipIpcOpenMemHandle attempt %d/%d failed: %s — %s: window %d of exporter tag %d (pid %u, GPU %u, owner address 0x%llx, %llu bytes%s) "
+                    "into pid %d on GPU %d\n", a + 1, attempts, hipGetErrorString(e), what, b.window, b.tag, b.pid, b.device,
+            (unsigned long long)b.owner_ptr, (unsigned long long)b.bytes, b.fine ? ", fine-grained" : "", (int)getpid(), c->cfg.device);
+    usleep(20000u << (2 * a));   // 20, 80, 320 ms
+  }
+  cbm_set_error("hipIpcOpenMemHandle failed %d times: %s — %s: window %d of exporter tag %d (pid %u, GPU %u, owner address 0x%llx, %llu bytes) cannot be mapped into "
+                "pid %d on GPU %d (needs HSA_ENABLE_IPC_MODE_LEGACY=0 in BOTH processes, a live exporter, and a peer path between the two GPUs)",
+                attempts, hipGetErrorString(e), what, b.window, b.tag, b.pid, b.device, (unsigned long long)b.owner_ptr, (unsigned long long)b.bytes,
+                (int)getpid(), c->cfg.device);
+  return -1;
+}
+static void cbm_ipc_unmap(void* base) {
+  std::lock_guard<std::mutex> lk(g_ipc_mu);
+  for (size_t i = 0; i < g_ipc_maps.size(); ++i) {
+    if (g_ipc_maps[i].base != base) continue;
+    if (--g_ipc_maps[i].refs == 0) {
+      const hipError_t e = hipIpcCloseMemHandle(base);
+      if (e != hipSuccess) { (void)hipGetLastError(); fprintf(stderr, "cleanba_mi: hipIpcCloseMemHandle(%p) in pid %d failed: %s\n", base, (int)getpid(), hipGetErrorString(e)); }
+      g_ipc_maps.erase(g_ipc_maps.begin() + i);
+    }
+    return;
+  }
+}
+
+// returns false (block-uniform) when this or an earlier collective's wait timed out: the caller skips its data phase — a dead peer costs ONE
+// timeout, not one per remaining collective, and nothing is reduced from / written to buffers whose owners never arrived
+static __device__ __forceinline__ bool nat_signal_and_wait(const NatArgs& a, int phase) {
   __syncthreads();
   const int t = threadIdx.x;
   if (t < a.nranks) {
     const size_t row = ((size_t)phase * NAT_BLOCKS + blockIdx.x) * CBM_NATIVE_MAX_RANKS;
-    __hip_atomic_store(a.sig[t] + row + a.rank, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    uint32_t* mine = a.sig[a.rank] + row + t;
-    const unsigned long long t0 = wall_clock64();
-    while ((int32_t)(__hip_atomic_load(mine, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - a.seq) < 0) {
-      __builtin_amdgcn_s_sleep(16);
-      if (wall_clock64() - t0 > a.timeout_ticks) { *(volatile int*)a.err = 1 + phase; break; }
+    __hip_atomic_store(a.sig[t] + row + a.rank, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);   // (always: live peers must not wait for us)
+    if (*(volatile int*)a.err_dev == 0) {
+      uint32_t* mine = a.sig[a.rank] + row + t;
+      const unsigned long long t0 = wall_clock64();
+      while ((int32_t)(__hip_atomic_load(mine, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - a.seq) < 0) {
+        __builtin_amdgcn_s_sleep(16);
+        if (wall_clock64() - t0 > a.timeout_ticks) { *(volatile int*)a.err_dev = 1 + phase; *(volatile int*)a.err = 1 + phase; break; }
+        if (*(volatile int*)a.err_dev != 0) break;   // another block of this rank has given up already
+      }
     }
   }
+  __threadfence();
   __syncthreads();
+  return *(volatile int*)a.err_dev == 0;
 }
 
 // NR > 0: the rank count is a compile-time constant — the NR peer loads of an element are all requested before the first add (one fabric round trip
@@ -126,7 +235,7 @@ static __device__ __forceinline__ void nat_signal_and_wait(const NatArgs& a, int
 template <int NR>
 __global__ __launch_bounds__(NAT_THREADS) void nat_allreduce_f32_kernel(const NatArgs a) {
   __threadfence_system();
-  nat_signal_and_wait(a, 0);
+  if (!nat_signal_and_wait(a, 0)) return;
   __threadfence_system();               // acquire for every thread: no load below may be served by anything fetched before the peers signalled
   const int N = NR > 0 ? NR : a.nranks;
   const int64_t chunk = (((a.n + N - 1) / N) + 3) & ~(int64_t)3;
@@ -168,7 +277,7 @@ __global__ __launch_bounds__(NAT_THREADS) void nat_allreduce_f32_kernel(const Na
 template <class Tv, int OP>   // OP: 0 sum, 1 max, 2 min; one block, n <= NAT_SMALL_MAX
 __global__ __launch_bounds__(1024) void nat_allreduce_small_kernel(const NatArgs a) {
   __threadfence_system();
-  nat_signal_and_wait(a, 0);
+  if (!nat_signal_and_wait(a, 0)) return;
   __threadfence_system();
   Tv keep[NAT_SMALL_MAX / 1024];
 #pragma unroll
@@ -185,7 +294,7 @@ __global__ __launch_bounds__(1024) void nat_allreduce_small_kernel(const NatArgs
     keep[j] = sum;
   }
   __threadfence_system();
-  nat_signal_and_wait(a, 1);            // every rank has read every input: the in-place results may go out
+  if (!nat_signal_and_wait(a, 1)) return;   // every rank has read every input: the in-place results may go out
 #pragma unroll
   for (int j = 0; j < NAT_SMALL_MAX / 1024; ++j) {
     const int64_t i = threadIdx.x + 1024 * j;
@@ -212,7 +321,7 @@ static NatArgs nat_args(CbmComm& k, int b, int64_t off, int64_t n) {
   NatArgs a;
   memset(&a, 0, sizeof(a));
   for (int r = 0; r < k.nranks; ++r) { a.data[r] = k.nat_peer[b][r]; a.sig[r] = (uint32_t*)k.nat_peer[3][r]; }
-  a.nranks = k.nranks; a.rank = k.rank; a.off = off; a.n = n; a.seq = ++k.nat_seq; a.err = k.nat_err; a.timeout_ticks = nat_timeout_ticks();
+  a.nranks = k.nranks; a.rank = k.rank; a.off = off; a.n = n; a.seq = ++k.nat_seq; a.err = k.nat_err; a.err_dev = (int*)k.nat_sig_local + NAT_SIG_WORDS + 64; a.timeout_ticks = nat_timeout_ticks();
   return a;
 }
 static int nat_allreduce_f32(cbm_ctx* c, CbmComm& k, float* buf, int64_t n, hipStream_t st) {
@@ -307,10 +416,10 @@ extern "C" int cbm_comm_native_export(cbm_ctx* c, int32_t which, uint8_t blob[CB
   CbmComm& k = c->comms[which];
   if (!k.nat_sig_local) {
     // the signal block: uncached device memory when the runtime offers it (flags are polled by other GPUs), plain device memory otherwise
-    // (the flag accesses are system-scope atomics either way)
+    // (the flag accesses are system-scope atomics either way); 4 MB, so that it is an allocation of its own and not a fragment of a shared block
     void* p = nullptr;
-    if (hipExtMallocWithFlags(&p, NAT_SIG_WORDS * 4, hipDeviceMallocUncached) != hipSuccess) { (void)hipGetLastError(); CBM_HIP(hipMalloc(&p, NAT_SIG_WORDS * 4)); }
-    CBM_HIP(hipMemset(p, 0, NAT_SIG_WORDS * 4));
+    if (hipExtMallocWithFlags(&p, NAT_SIG_ALLOC, hipDeviceMallocUncached) != hipSuccess) { (void)hipGetLastError(); CBM_HIP(hipMalloc(&p, NAT_SIG_ALLOC)); }
+    CBM_HIP(hipMemset(p, 0, NAT_SIG_ALLOC));
     CBM_HIP(hipDeviceSynchronize());
     k.nat_sig_local = p;
     CBM_HIP(hipHostMalloc((void**)&k.nat_err, 64, hipHostMallocDefault));
@@ -318,18 +427,19 @@ extern "C" int cbm_comm_native_export(cbm_ctx* c, int32_t which, uint8_t blob[CB
   }
   NatBlob b;
   memset(&b, 0, sizeof(b));
-  void* const bufs[CBM_NATIVE_BUFS] = {c->grads, c->stats_dev, c->comm_scratch, k.nat_sig_local};
-  for (int i = 0; i < CBM_NATIVE_BUFS; ++i) {
-    hipIpcMemHandle_t h;
-    CBM_HIP(hipIpcGetMemHandle(&h, bufs[i]));
-    memcpy(b.ipc[i], &h, sizeof(h));
-    b.ptr[i] = (uint64_t)(uintptr_t)bufs[i];
-  }
-  b.pid = (uint32_t)getpid();
-  b.device = (uint32_t)c->cfg.device;
+  if (fill_win_blob(c, c->win[1], c->win_bytes[1], 1, -1, c->win_fine[1], &b.win)) return -1;
+  if (fill_win_blob(c, k.nat_sig_local, NAT_SIG_ALLOC, 2, -1, false, &b.sig)) return -1;
+  b.off[0] = (uint64_t)((uint8_t*)c->grads - c->win[1]); b.off[1] = (uint64_t)((uint8_t*)c->stats_dev - c->win[1]);
+  b.off[2] = (uint64_t)((uint8_t*)c->comm_scratch - c->win[1]);
   memset(blob, 0, CBM_NATIVE_BLOB_BYTES);
   memcpy(blob, &b, sizeof(b));
   return 0;
+}
+
+static void nat_unmap(CbmComm& k) {
+  for (int w = 0; w < 2; ++w)
+    for (int r = 0; r < CBM_NATIVE_MAX_RANKS; ++r)
+      if (k.nat_win[w][r]) { cbm_ipc_unmap(k.nat_win[w][r]); k.nat_win[w][r] = nullptr; }
 }
 
 extern "C" int cbm_comm_native_init(cbm_ctx* c, int32_t which, int32_t nranks, int32_t rank, const uint8_t* blobs) {
@@ -340,23 +450,37 @@ extern "C" int cbm_comm_native_init(cbm_ctx* c, int32_t which, int32_t nranks, i
   if (!k.nat_sig_local) { cbm_set_error("cbm_comm_native_export must be called on this context first"); return -1; }
   CBM_HIP(hipSetDevice(c->cfg.device));
   void* const own[CBM_NATIVE_BUFS] = {c->grads, c->stats_dev, c->comm_scratch, k.nat_sig_local};
+  bool spans_devices = false;
   for (int r = 0; r < nranks; ++r) {
     NatBlob b;
     memcpy(&b, blobs + (size_t)r * CBM_NATIVE_BLOB_BYTES, sizeof(b));
-    for (int i = 0; i < CBM_NATIVE_BUFS; ++i) {
-      if (r == rank) { k.nat_peer[i][r] = own[i]; continue; }
-      if (b.pid == (uint32_t)getpid()) { k.nat_peer[i][r] = (void*)(uintptr_t)b.ptr[i]; continue; }   // a context of this process: no IPC needed (nor possible)
-      hipIpcMemHandle_t h;
-      memcpy(&h, b.ipc[i], sizeof(h));
-      void* p = nullptr;
-      const hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
-      if (e != hipSuccess) {
-        cbm_set_error("native communicator: hipIpcOpenMemHandle of rank %d's buffer %d (GPU %u) failed on GPU %d: %s (needs HSA_ENABLE_IPC_MODE_LEGACY=0 in "
-                      "every process and a peer path between the GPUs)", r, i, b.device, c->cfg.device, hipGetErrorString(e));
+    if (b.win.device != (uint32_t)c->cfg.device) spans_devices = true;
+    if (r == rank) { for (int i = 0; i < CBM_NATIVE_BUFS; ++i) k.nat_peer[i][r] = own[i]; continue; }
+    b.win.tag = b.sig.tag = r;
+    char what[96];
+    void* base[2] = {nullptr, nullptr};
+    bool mapped[2] = {false, false};
+    snprintf(what, sizeof(what), "native communicator %d, rank %d maps rank %d's communication window", which, rank, r);
+    if (cbm_ipc_map(c, b.win, what, &base[0], &mapped[0])) { nat_unmap(k); return -1; }
+    if (mapped[0]) k.nat_win[0][r] = base[0];
+    snprintf(what, sizeof(what), "native communicator %d, rank %d maps rank %d's signal block", which, rank, r);
+    if (cbm_ipc_map(c, b.sig, what, &base[1], &mapped[1])) { nat_unmap(k); return -1; }
+    if (mapped[1]) k.nat_win[1][r] = base[1];
+    for (int i = 0; i < 3; ++i) k.nat_peer[i][r] = (uint8_t*)base[0] + b.off[i];
+    k.nat_peer[3][r] = base[1];
+  }
+  if (spans_devices) {
+    // the all-reduce kernels read and write PEER memory while they run: coarse-grained memory is coherent across devices only at kernel
+    // boundaries, so every rank's communication window must be fine-grained (CBM_COMM=native allocates it so; CBM_NATIVE_FINEGRAINED=1 forces it)
+    for (int r = 0; r < nranks; ++r) {
+      NatBlob b;
+      memcpy(&b, blobs + (size_t)r * CBM_NATIVE_BLOB_BYTES, sizeof(b));
+      if (!b.win.fine) {
+        nat_unmap(k);
+        cbm_set_error("native communicator across devices: rank %d's gradient window (GPU %u) is coarse-grained — create every context with CBM_COMM=native "
+                      "(or CBM_NATIVE_FINEGRAINED=1) in the environment so that it is allocated fine-grained", r, b.win.device);
         return -1;
       }
-      k.nat_peer[i][r] = p;
-      k.nat_mapped[i][r] = true;
     }
   }
   k.native = true;
@@ -380,15 +504,35 @@ int cbm_comm_destroy_all(cbm_ctx* c) {
   for (int i = 0; i < CBM_COMM_SLOTS; ++i) {
     CbmComm& k = c->comms[i];
     if (k.comm) { g_rccl.CommDestroy((ncclComm_t)k.comm); k.comm = nullptr; }
-    for (int b = 0; b < CBM_NATIVE_BUFS; ++b)
-      for (int r = 0; r < CBM_NATIVE_MAX_RANKS; ++r)
-        if (k.nat_mapped[b][r]) { (void)hipIpcCloseMemHandle(k.nat_peer[b][r]); k.nat_mapped[b][r] = false; }
+    nat_unmap(k);
     if (k.nat_sig_local) { (void)hipFree(k.nat_sig_local); k.nat_sig_local = nullptr; }
     if (k.nat_err) { (void)hipHostFree(k.nat_err); k.nat_err = nullptr; }
     k.native = false;
     k.nranks = 0;
   }
   return 0;
+}
+
+// Unmaps every peer buffer this context holds (windows opened with cbm_ipc_open_window, the native communicators' peer windows and signal
+// blocks); the native communicators are unusable afterwards.  Teardown order of a multi-process host: every process calls this, THEN a host
+// barrier, THEN cbm_ctx_destroy — so that no owner frees a buffer a peer still has mapped.
+int cbm_ipc_close_all_impl(cbm_ctx* c) {
+  for (int i = 0; i < CBM_COMM_SLOTS; ++i) {
+    CbmComm& k = c->comms[i];
+    if (!k.native) continue;
+    nat_unmap(k);
+    k.native = false;
+    k.nranks = 0;
+  }
+  std::vector<void*> maps;
+  { std::lock_guard<std::mutex> lk(c->maps_mu); maps.swap(c->maps); }
+  for (void* p : maps) cbm_ipc_unmap(p);
+  return 0;
+}
+extern "C" int cbm_ipc_close_all(cbm_ctx* c) {
+  CBM_HIP(hipSetDevice(c->cfg.device));
+  CBM_HIP(hipDeviceSynchronize());   // nothing of this context may still be writing through a mapping
+  return cbm_ipc_close_all_impl(c);
 }
 
 // all-reduce of a few host doubles (barriers, max-over-ranks timing): staged through the context's scratch on the communication stream
@@ -502,46 +646,55 @@ extern "C" int cbm_comm_profile_read(cbm_ctx* c, double* tail_ms, double* expose
 }
 
 // ------------------------------------------------------------------------------------------ peer writes (split topologies)
-extern "C" int cbm_ipc_export(cbm_ctx* c, const char* name, int32_t ring_index, uint8_t handle[CBM_IPC_HANDLE_BYTES]) {
-  static_assert(sizeof(hipIpcMemHandle_t) == CBM_IPC_HANDLE_BYTES, "hipIpcMemHandle_t size");
+extern "C" int cbm_ipc_export_window(cbm_ctx* c, int32_t window, int32_t tag, uint8_t blob[CBM_IPC_WINDOW_BYTES]) {
+  if (window < 0 || window >= CBM_WINDOWS) { cbm_set_error("window %d outside [0,%d)", window, CBM_WINDOWS); return -1; }
   CBM_HIP(hipSetDevice(c->cfg.device));
+  WinBlob b;
+  if (fill_win_blob(c, c->win[window], c->win_bytes[window], window, tag, c->win_fine[window], &b)) return -1;
+  memcpy(blob, &b, sizeof(b));
+  return 0;
+}
+// where a named buffer (any cbm_buffer name that lives in an export window) sits: *window, *offset, *nbytes
+extern "C" int cbm_ipc_window_offset(cbm_ctx* c, const char* name, int32_t ring_index, int32_t* window, int64_t* offset, int64_t* nbytes) {
   void* p = nullptr;
   int64_t n = 0;
   if (cbm_buffer(c, name, ring_index, &p, &n)) return -1;
   if (!p) { cbm_set_error("buffer '%s' is not allocated in this context", name); return -1; }
-  hipIpcMemHandle_t h;
-  CBM_HIP(hipIpcGetMemHandle(&h, p));
-  memcpy(handle, &h, sizeof(h));
-  return 0;
-}
-extern "C" int cbm_ipc_open(cbm_ctx* c, const uint8_t handle[CBM_IPC_HANDLE_BYTES], void** dev_ptr) {
-  CBM_HIP(hipSetDevice(c->cfg.device));
-  hipIpcMemHandle_t h;
-  memcpy(&h, handle, sizeof(h));
-  const hipError_t e = hipIpcOpenMemHandle(dev_ptr, h, hipIpcMemLazyEnablePeerAccess);
-  if (e != hipSuccess) {
-    cbm_set_error("hipIpcOpenMemHandle failed on GPU %d: %s — the peer's buffer cannot be mapped here (needs HSA_ENABLE_IPC_MODE_LEGACY=0 in BOTH "
-                  "processes and peer access between the two GPUs)", c->cfg.device, hipGetErrorString(e));
-    return -1;
+  for (int w = 0; w < CBM_WINDOWS; ++w) {
+    const int64_t d = (uint8_t*)p - c->win[w];
+    if (d >= 0 && (size_t)(d + n) <= c->win_bytes[w]) { if (window) *window = w; if (offset) *offset = d; if (nbytes) *nbytes = n; return 0; }
   }
-  // The mapping exists.  Diagnostic only (never validated on a multi-GPU node, and ROCm may report an imported pointer's device
-  // either way): when the runtime says this GPU has no peer path to the owner, say which two devices — once, on stderr — and keep the mapping;
-  // if the path really is missing, the first copy through it fails with the runtime's own error and this hint is already in the log.
-  hipPointerAttribute_t at;
-  if (hipPointerGetAttributes(&at, *dev_ptr) == hipSuccess && at.device != c->cfg.device) {
+  cbm_set_error("buffer '%s' is not in an export window (ring fields, actor_params_v*, grads, stats are)", name);
+  return -1;
+}
+extern "C" int cbm_ipc_open_window(cbm_ctx* c, const uint8_t blob[CBM_IPC_WINDOW_BYTES], const char* what, void** base) {
+  CBM_HIP(hipSetDevice(c->cfg.device));
+  WinBlob b;
+  memcpy(&b, blob, sizeof(b));
+  bool mapped = false;
+  if (cbm_ipc_map(c, b, what && *what ? what : "cbm_ipc_open_window", base, &mapped)) return -1;
+  if (mapped) { std::lock_guard<std::mutex> lk(c->maps_mu); c->maps.push_back(*base); }
+  // Diagnostic only: when the runtime says this GPU has no peer path to the owner, say which two devices — once, on stderr — and keep the
+  // mapping; if the path really is missing, the first copy through it fails with the runtime's own error and this hint is already in the log.
+  if (b.device != (uint32_t)c->cfg.device) {
     int can = 1;
     static std::atomic<bool> warned{false};
-    if (hipDeviceCanAccessPeer(&can, c->cfg.device, at.device) == hipSuccess && !can && !warned.exchange(true))
-      fprintf(stderr, "cleanba_mi: hipDeviceCanAccessPeer(GPU %d -> GPU %d) = 0: the split topology writes shards / parameters peer to peer and needs an "
-                      "xGMI or PCIe P2P path between every actor GPU and every learner GPU of a group\n", c->cfg.device, at.device);
-  } else {
+    if (hipDeviceCanAccessPeer(&can, c->cfg.device, (int)b.device) == hipSuccess && !can && !warned.exchange(true))
+      fprintf(stderr, "cleanba_mi: hipDeviceCanAccessPeer(GPU %d -> GPU %u) = 0: the split topology writes shards / parameters peer to peer and needs an "
+                      "xGMI or PCIe P2P path between every actor GPU and every learner GPU of a group\n", c->cfg.device, b.device);
     (void)hipGetLastError();
   }
   return 0;
 }
-extern "C" int cbm_ipc_close(cbm_ctx* c, void* dev_ptr) {
+extern "C" int cbm_ipc_close_window(cbm_ctx* c, void* base) {
   CBM_HIP(hipSetDevice(c->cfg.device));
-  CBM_HIP(hipIpcCloseMemHandle(dev_ptr));
+  bool mine = false;
+  {
+    std::lock_guard<std::mutex> lk(c->maps_mu);
+    for (size_t i = 0; i < c->maps.size(); ++i)
+      if (c->maps[i] == base) { c->maps.erase(c->maps.begin() + i); mine = true; break; }
+  }
+  if (mine) cbm_ipc_unmap(base);   // (a window of a context of this process was never mapped: nothing to do)
   return 0;
 }
 

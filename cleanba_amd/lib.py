@@ -54,13 +54,14 @@ SYMBOLS = [
     "cbm_params_publish_external", "cbm_actor_stream", "cbm_actor_ring_index", "cbm_actor_step_async", "cbm_gae_async", "cbm_mb_advnorm",
     "cbm_synth_env_step_host_ids", "cbm_synth_env_step_host_to", "cbm_synth_env_render_host", "cbm_learner_grad_tail_offset", "cbm_vtrace", "cbm_comm_init_loopback",
     "cbm_comm_load", "cbm_comm_unique_id", "cbm_comm_init", "cbm_comm_size", "cbm_comm_allreduce_f64", "cbm_comm_barrier",
-    "cbm_learner_allreduce_grads", "cbm_comm_profile", "cbm_comm_profile_read", "cbm_ipc_export", "cbm_ipc_open", "cbm_ipc_close",
+    "cbm_learner_allreduce_grads", "cbm_comm_profile", "cbm_comm_profile_read", "cbm_ipc_export_window", "cbm_ipc_window_offset", "cbm_ipc_open_window",
+    "cbm_ipc_close_window", "cbm_ipc_close_all",
     "cbm_host_register", "cbm_host_unregister", "cbm_actor_ship_shard", "cbm_io_sync", "cbm_params_push", "cbm_params_mark_published", "cbm_ctx_abort", "cbm_profile_read_all", "cbm_profile_kernel_name",
     "cbm_comm_native_export", "cbm_comm_native_init", "cbm_comm_backend",
 ]
 
 COMM_LEARNERS, COMM_WORLD = 0, 1
-COMM_ID_BYTES, IPC_HANDLE_BYTES = 128, 64
+COMM_ID_BYTES, IPC_HANDLE_BYTES, IPC_WINDOW_BYTES = 128, 64, 128
 NATIVE_BLOB_BYTES, NATIVE_MAX_RANKS = 320, 16
 RING_FIELDS = ("obs", "actions", "logprobs", "values", "rewards", "dones", "firststeps", "logits")
 
@@ -393,19 +394,32 @@ class Context:
         return a.value, b.value, n.value
 
     # ---- peer writes (split topologies)
-    def ipc_export(self, name, ring=0):
-        h = (C.c_uint8 * IPC_HANDLE_BYTES)()
-        _chk(self.lib.cbm_ipc_export(self.h, name.encode(), int(ring), h))
-        return bytes(h)
+    def ipc_export_window(self, window, tag=-1):
+        """The blob of export window `window` (0: ring fields + actor parameter versions, 1: gradient / statistics / scratch); `tag` is quoted by
+        the importing side's error messages (the exporting rank)."""
+        b = (C.c_uint8 * IPC_WINDOW_BYTES)()
+        _chk(self.lib.cbm_ipc_export_window(self.h, int(window), int(tag), b))
+        return bytes(b)
 
-    def ipc_open(self, handle):
+    def ipc_window_offset(self, name, ring=0):
+        w, off, n = C.c_int32(), C.c_int64(), C.c_int64()
+        _chk(self.lib.cbm_ipc_window_offset(self.h, name.encode(), int(ring), C.byref(w), C.byref(off), C.byref(n)))
+        return w.value, off.value, n.value
+
+    def ipc_open_window(self, blob, what=""):
         p = C.c_void_p()
-        buf = (C.c_uint8 * IPC_HANDLE_BYTES).from_buffer_copy(bytes(handle))
-        _chk(self.lib.cbm_ipc_open(self.h, buf, C.byref(p)))
+        buf = (C.c_uint8 * IPC_WINDOW_BYTES).from_buffer_copy(bytes(blob))
+        _chk(self.lib.cbm_ipc_open_window(self.h, buf, what.encode(), C.byref(p)))
         return p.value
 
-    def ipc_close(self, ptr):
-        _chk(self.lib.cbm_ipc_close(self.h, C.c_void_p(ptr)))
+    def ipc_close_window(self, base):
+        _chk(self.lib.cbm_ipc_close_window(self.h, C.c_void_p(base)))
+
+    def unmap_peers(self):
+        """cbm_ipc_close_all: every peer window this context mapped and the native communicators' peer mappings.  Multi-process teardown =
+        unmap_peers() on every process, a host barrier, close()."""
+        if self.h:
+            _chk(self.lib.cbm_ipc_close_all(self.h))
 
     def actor_ship_shard(self, slot, ring, li, n_learners, peer_ring, dst_cols, dst_col0):
         _chk(self.lib.cbm_actor_ship_shard(self.h, int(slot), int(ring), int(li), int(n_learners), C.byref(peer_ring), int(dst_cols), int(dst_col0)))

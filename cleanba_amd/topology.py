@@ -73,6 +73,7 @@ class Rendezvous:
     vanished server ends the wait instead of hanging it."""
 
     _base = {}   # (addr, port, world, rank) -> TCPStore: one connection (and, on rank 0, one server) per process, whatever the number of runs
+    _runs = {}   # (store key, prefix) -> how many Rendezvous objects of this process used that prefix so far
 
     def __init__(self, world, rank, addr, port, timeout_s=1800.0, prefix=None):
         from torch.distributed import TCPStore
@@ -84,7 +85,12 @@ class Rendezvous:
         k = (addr, int(port), world, rank)
         if k not in Rendezvous._base:
             Rendezvous._base[k] = TCPStore(addr, int(port), world, rank == 0, timeout=datetime.timedelta(seconds=timeout_s), wait_for_workers=False)
-        self.store = PrefixStore(prefix or os.environ.get("CBM_RDV_PREFIX", "cbm"), Rendezvous._base[k])
+        # a second run of the same process under the same prefix must not inherit the first one's keys (a sticky 'abort', barrier counters that
+        # already stand at `world`): the n-th use of a prefix gets "<prefix>#n" — every rank builds its Rendezvous objects in the same order
+        prefix = prefix or os.environ.get("CBM_RDV_PREFIX", "cbm")
+        n = Rendezvous._runs.get((k, prefix), 0)
+        Rendezvous._runs[(k, prefix)] = n + 1
+        self.store = PrefixStore(prefix if n == 0 else f"{prefix}#{n}", Rendezvous._base[k])
 
     def put(self, key, value=b"1"):
         self.store.set(key, value)
@@ -192,7 +198,8 @@ class ActorShipper:
         self.stop = threading.Event()   # set by a failing sibling (a rollout thread that died will never commit): _run must not wait for it forever
         g = layout.group
         # map every learner's ring (ppo:358-363's device_put_sharded targets)
-        self.peer = [engine.open_peer_ring(pickle.loads(rdv.get(f"g{g}/ring/{li}"))) for li in range(layout.nl)]
+        self.peer = [engine.open_peer_ring(pickle.loads(rdv.get(f"g{g}/ring/{li}")), f"actor rank {rdv.rank} (group {g}, actor {layout.actor_index}) maps the ring of learner {li} (rank {layout.learner_ranks[li]})")
+                     for li in range(layout.nl)]
 
     def on_commit(self, slot, update, ring_index):
         """Called by the thread's rollout loop right after cbm_actor_commit (the commit event orders the copies after the rollout)."""
@@ -235,7 +242,7 @@ class ParamReceiver:
         self.engine, self.lay, self.rdv, self.n = engine, layout, rdv, num_updates
         self.thread = threading.Thread(target=self._run, daemon=True)
         self.error = None
-        rdv.put(f"g{layout.group}/aparams/{layout.actor_index}", pickle.dumps(engine.export_actor_params()))
+        rdv.put(f"g{layout.group}/aparams/{layout.actor_index}", pickle.dumps(engine.export_actor_params(tag=rdv.rank)))
 
     def _run(self):
         try:
@@ -258,7 +265,7 @@ class LearnerReceiver:
         self.fields = PPO_FIELDS if algo == "ppo" else IMPALA_FIELDS
         self.thread = threading.Thread(target=self._run, daemon=True)
         self.error = None
-        rdv.put(f"g{layout.group}/ring/{layout.learner_index}", pickle.dumps(engine.export_ring(self.fields)))
+        rdv.put(f"g{layout.group}/ring/{layout.learner_index}", pickle.dumps(engine.export_ring(self.fields, tag=rdv.rank)))
 
     def _run(self):
         try:
@@ -282,7 +289,8 @@ class ParamSender:
     def __init__(self, engine, layout, rdv):
         self.engine, self.lay, self.rdv = engine, layout, rdv
         g = layout.group
-        self.peers = [engine.open_peer_params(pickle.loads(rdv.get(f"g{g}/aparams/{ai}"))) for ai in range(layout.na)]
+        self.peers = [engine.open_peer_params(pickle.loads(rdv.get(f"g{g}/aparams/{ai}")), f"learner rank {rdv.rank} (group {g}, learner 0) maps the parameter buffers of actor {ai} (rank {layout.actor_ranks[ai]})")
+                      for ai in range(layout.na)]
 
     def __call__(self, version):
         for ai, peer in enumerate(self.peers):

@@ -463,6 +463,7 @@ def _train_single(args, algo, engine, rdv, writer, key, learner_key, world_size,
         th.join()
     result = {"updates": learner_policy_version, "global_step": learner_policy_version * args.local_batch_size * world_size,
               "elapsed_s": elapsed, "stats": last_stats, "params": engine.get_params(), "run_name": run_name}
+    _unmap_then_close(engine, rdv)   # (unmap -> barrier -> free: the native all-reduce's peers still map this rank's gradient window)
     if args.save_model and rank == 0:
         from .checkpoint import save_cleanrl_model
         path = f"runs/{run_name}/{args.exp_name}.cleanrl_model"
@@ -530,9 +531,9 @@ def _train_split(args, algo, engine, lay, rdv, writer, key, rank, run_name, on_u
         engine.sync()
         result = {"updates": args.num_updates, "elapsed_s": elapsed, "stats": None, "params": engine.get_actor_params(),
                   "run_name": run_name, "role": "actor" if lay.na == 1 else f"actor{lay.actor_index}"}
-        rdv.barrier("done")   # keep this actor's buffers mapped until every peer has stopped writing into them
+        rdv.barrier("done")       # keep this actor's buffers mapped until every peer has stopped writing into them
+        _unmap_then_close(engine, rdv)
         writer.close()
-        engine.close()
         return result
     ingest = topology.LearnerReceiver(engine, lay, rdv, args, algo, args.num_updates)   # publishes this learner's ring handles
     send_params = topology.ParamSender(engine, lay, rdv) if lay.learner_index == 0 else None
@@ -568,9 +569,19 @@ def _train_split(args, algo, engine, lay, rdv, writer, key, rank, run_name, on_u
     result = {"updates": args.num_updates, "elapsed_s": time.time() - start, "stats": stats, "params": engine.get_params(), "run_name": run_name,
               "role": f"learner{lay.learner_index}"}
     rdv.barrier("done")
+    _unmap_then_close(engine, rdv)
     writer.close()
-    engine.close()
     return result
+
+
+def _unmap_then_close(engine, rdv, tag="unmapped"):
+    """Teardown order of a run that shares device buffers between processes: every process unmaps what it mapped of its peers, a barrier, and
+    only then does an owner free (engine.close) — no owner frees a window a peer still maps."""
+    if hasattr(engine, "unmap_peers"):
+        engine.unmap_peers()
+    if rdv is not None:
+        rdv.barrier(tag)
+    engine.close()
 
 
 class HipEngine(L.Context):
@@ -590,25 +601,29 @@ class HipEngine(L.Context):
     def comm_init(self, uid, nranks, rank, which=L.COMM_LEARNERS):
         super().comm_init(which, uid, nranks, rank)
 
-    # ---- split topologies: IPC handles of the ring fields / the versioned actor parameter buffers, and their mappings
-    def export_ring(self, fields):
-        return {"cols": self.cfg.local_num_envs * self.cfg.num_actor_slots,
-                "entries": [{f: self.ipc_export(f, r) for f in fields} for r in range(self.cfg.ring_depth)]}
+    # ---- split topologies: the context's export window 0 (ring fields + versioned actor parameter buffers) and the peers' mappings of it:
+    # ONE HIP IPC mapping per peer context, fields addressed by offset (include/cleanba_mi.h, "EXPORT WINDOWS")
+    def export_ring(self, fields, tag=-1):
+        return {"cols": self.cfg.local_num_envs * self.cfg.num_actor_slots, "window": self.ipc_export_window(0, tag), "tag": tag, "pid": os.getpid(),
+                "entries": [{f: self.ipc_window_offset(f, r)[1] for f in fields} for r in range(self.cfg.ring_depth)]}
 
-    def open_peer_ring(self, desc):
+    def open_peer_ring(self, desc, what=""):
+        base = self.ipc_open_window(desc["window"], what or f"ring of exporter tag {desc.get('tag')} (pid {desc.get('pid')})")
         out = []
         for entry in desc["entries"]:
             pr = L.PeerRing()
-            for f, h in entry.items():
-                setattr(pr, f, self.ipc_open(h))
+            for f, off in entry.items():
+                setattr(pr, f, base + off)
             out.append(pr)
         return out
 
-    def export_actor_params(self):
-        return [self.ipc_export(f"actor_params_v{i}") for i in range(3)]
+    def export_actor_params(self, tag=-1):
+        return {"window": self.ipc_export_window(0, tag), "tag": tag, "pid": os.getpid(),
+                "offsets": [self.ipc_window_offset(f"actor_params_v{i}")[1] for i in range(3)]}
 
-    def open_peer_params(self, handles):
-        return [self.ipc_open(h) for h in handles]
+    def open_peer_params(self, desc, what=""):
+        base = self.ipc_open_window(desc["window"], what or f"actor parameter buffers of exporter tag {desc.get('tag')} (pid {desc.get('pid')})")
+        return [base + off for off in desc["offsets"]]
 
     def get_actor_params(self):
         return self.read("actor_params_latest", np.float32)

@@ -189,12 +189,23 @@ int cbm_comm_profile_read(cbm_ctx* ctx, double* tail_ms, double* exposed_ms, int
  * straight into the actor's version buffers (HIP IPC mappings, strided copies on a side stream).  Replaces jax.device_put_sharded
  * (ppo:358-363) and jax.device_put(params, actor device) (ppo:721-725) between processes. */
 #define CBM_IPC_HANDLE_BYTES 64
-typedef struct {   /* device pointers of ONE ring entry of the destination context (mapped with cbm_ipc_open, or cbm_buffer of a local ctx); NULL = skip */
+#define CBM_IPC_WINDOW_BYTES 128
+typedef struct {   /* device pointers of ONE ring entry of the destination context (mapped window base + cbm_ipc_window_offset, or cbm_buffer of a local ctx); NULL = skip */
   void *obs, *actions, *logprobs, *values, *rewards, *dones, *firststeps, *logits;
 } cbm_peer_ring;
-int cbm_ipc_export(cbm_ctx* ctx, const char* name, int32_t ring_index, uint8_t handle[CBM_IPC_HANDLE_BYTES]);   /* any cbm_buffer name */
-int cbm_ipc_open(cbm_ctx* ctx, const uint8_t handle[CBM_IPC_HANDLE_BYTES], void** dev_ptr);
-int cbm_ipc_close(cbm_ctx* ctx, void* dev_ptr);
+/* EXPORT WINDOWS.  Everything another process may map lives in one device allocation per context and purpose — window 0: every ring entry's
+ * fields and the three versioned actor parameter buffers; window 1: the flat gradient, the loss statistics and the f64 scratch (what the native
+ * all-reduce works on; fine-grained memory when CBM_COMM=native is to span devices) — so a peer maps ONE HIP IPC handle per context pair and
+ * addresses fields by offset.  The owner publishes the window's blob (handle + size + its pid / GPU / `tag`, an integer of the host's choosing —
+ * its rank — that error messages quote) and the offsets of the fields; a peer opens the blob once (opening the same window again in the same
+ * process returns the same mapping, reference-counted; a failed hipIpcOpenMemHandle is retried and every failure names both sides on stderr).
+ * TEARDOWN ORDER of a multi-process host: cbm_ipc_close_all on every process -> a host barrier -> cbm_ctx_destroy; an owner must not free a
+ * window while a peer still maps it. */
+int cbm_ipc_export_window(cbm_ctx* ctx, int32_t window, int32_t tag, uint8_t blob[CBM_IPC_WINDOW_BYTES]);
+int cbm_ipc_window_offset(cbm_ctx* ctx, const char* name /* a cbm_buffer name */, int32_t ring_index, int32_t* window, int64_t* offset, int64_t* nbytes);
+int cbm_ipc_open_window(cbm_ctx* ctx, const uint8_t blob[CBM_IPC_WINDOW_BYTES], const char* what /* for error messages, may be NULL */, void** base);
+int cbm_ipc_close_window(cbm_ctx* ctx, void* base);
+int cbm_ipc_close_all(cbm_ctx* ctx);   /* every window this context opened + the native communicators' peer mappings (those communicators end here) */
 /* Enqueues, on the io stream and after the commit of `slot`'s rollout in ring entry `ring_index`, the copy of learner `li`'s column shard
  * (columns [slot*E + li*E/L, +E/L) of every [T+1][B] field) into columns [dst_col0, +E/L) of `dst`, whose rows have dst_cols columns. */
 int cbm_actor_ship_shard(cbm_ctx* ctx, int32_t slot, int32_t ring_index, int32_t li, int32_t n_learners, const cbm_peer_ring* dst,

@@ -245,10 +245,10 @@ class OracleEngine:
     def actor_ring_index(self, s):
         return self.slot[s]["ring"]
 
-    def export_ring(self, fields):
+    def export_ring(self, fields, tag=-1):
         return {"cols": self.B, "entries": [{f: self.ring_handles[r][f] for f in fields} for r in range(self.depth)]}
 
-    def open_peer_ring(self, desc):
+    def open_peer_ring(self, desc, what=""):
         return [{f: self.shm.open(h) for f, h in entry.items()} for entry in desc["entries"]]
 
     def actor_ship_shard(self, slot, ring, li, n_learners, peer_ring, dst_cols, dst_col0):
@@ -262,10 +262,10 @@ class OracleEngine:
     def io_sync(self):
         pass
 
-    def export_actor_params(self):
+    def export_actor_params(self, tag=-1):
         return list(self.apv_handles)
 
-    def open_peer_params(self, handles):
+    def open_peer_params(self, handles, what=""):
         return [self.shm.open(h) for h in handles]
 
     def params_push(self, peer_versions):
