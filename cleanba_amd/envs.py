@@ -44,6 +44,7 @@ class SyntheticAtariEnv:
         self._st = None
         self._obs = None
         self._pending = None
+        self._ring = None
         self._env_id = np.arange(self.num_envs, dtype=np.int32)
 
     def _info(self, reward, terminated, elapsed):
@@ -54,10 +55,22 @@ class SyntheticAtariEnv:
         self._st, self._obs = L.synth_env_reset_host(self.seed, self.num_envs, atari57_mix=is_atari57_mix(self.env_id))
         return self._obs.copy()
 
+    OBS_RING = 4   # observation buffers handed out round robin
+
     def step(self, actions):
-        self._obs, r, d, term, el = L.synth_env_step_host_to(self.seed, self._st, self._obs, actions, self.spec.config.max_episode_steps)
-        self._obs.flags.writeable = False    # a fresh array per step like envpool's; the env reads it once more (next step's older planes)
-        return self._obs, r, d.astype(bool), self._info(r, term, el)
+        # Like envpool's state-buffer queue, the observations of a step land in one of a few PRE-ALLOCATED buffers (a different array object
+        # and address than the previous step's; its content stays valid for OBS_RING - 1 further steps): no 3.4 MB allocation — mmap, page faults,
+        # munmap — on the step's critical path, which two actor threads of one process would serialise on the kernel's address-space lock.
+        if self._ring is None:
+            self._ring = [np.empty_like(self._obs) for _ in range(self.OBS_RING)]
+            self._ring_i = 0
+        out = self._ring[self._ring_i]
+        self._ring_i = (self._ring_i + 1) % self.OBS_RING
+        out.flags.writeable = True
+        _, r, d, term, el = L.synth_env_step_host_to(self.seed, self._st, self._obs, actions, self.spec.config.max_episode_steps, out=out)
+        out.flags.writeable = False          # the env reads it once more (next step's older planes)
+        self._obs = out
+        return out, r, d.astype(bool), self._info(r, term, el)
 
     # async API (impala:308,352,365).  batch_size == num_envs: every recv() returns all envs sorted by env_id (what cleanba_impala.py
     # relies on).  batch_size < num_envs (legacy --async-batch-size, naturecnn:119-133): recv() returns the batch_size envs whose step

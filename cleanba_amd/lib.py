@@ -503,11 +503,11 @@ def synth_env_render_host(state, layered):
     return plane
 
 
-def synth_env_step_host_to(seed, st, obs_prev, actions, max_episode_steps=27000):
-    """Out-of-place step: returns (obs_next, reward, done, terminated, elapsed) with obs_next a fresh array (envpool's recv() contract)."""
+def synth_env_step_host_to(seed, st, obs_prev, actions, max_episode_steps=27000, out=None):
+    """Out-of-place step: returns (obs_next, reward, done, terminated, elapsed) with obs_next a fresh array (envpool's recv() contract) or `out`."""
     n = obs_prev.shape[0]
     actions = np.ascontiguousarray(actions, np.int32)
-    obs_next = np.empty_like(obs_prev)
+    obs_next = np.empty_like(obs_prev) if out is None else out
     reward = np.zeros(n, np.float32)
     done = np.zeros(n, np.uint8)
     term = np.zeros(n, np.uint8)

@@ -192,21 +192,31 @@ def _rollout(key, args, algo, engine, writer, slot, world_size, process_index, s
     rollout_queue_put_time = deque(maxlen=10)
     actions = np.empty(E, np.int32)
     first_rollout = True
-    # an env that hands back the SAME observation buffer every step (a pool that steps in place) gets that buffer page-locked once, so the per-step
-    # 3.39 MB upload is a plain DMA instead of a pageable copy (cbm_host_register); fresh arrays per step (envpool's contract, the synthetic twin)
-    # never repeat an address twice in a row and are left alone
-    pinned, last_ptr = {}, [0]
+    arange_E, ident_ids = np.arange(E), [None, False]
+    # An env that hands its observations back in RECURRING buffers — the same one every step (a pool that steps in place) or a few in rotation
+    # (a state-buffer queue) — gets each such buffer page-locked the second time its address shows up, so the per-step 3.39 MB upload is a plain
+    # DMA the host does not wait for instead of a staged pageable copy (cbm_host_register).  Arrays that never come back are left alone; at most
+    # MAX_PINNED distinct buffers are registered.
+    MAX_PINNED = 8
+    pinned, seen = {}, {}
     register = getattr(engine, "host_register", None)
 
     def maybe_pin(obs):
         ptr = obs.ctypes.data
-        if register is not None and ptr == last_ptr[0] and ptr not in pinned and obs.flags.c_contiguous:
+        if register is None or ptr in pinned:
+            return
+        n = seen.get(ptr, 0) + 1
+        if n >= 2 and len(pinned) < MAX_PINNED and obs.flags.c_contiguous:
             try:
                 register(obs)
                 pinned[ptr] = obs          # keeps the array alive while it is registered
             except RuntimeError:
                 pinned[ptr] = None         # not registrable (e.g. a read-only mapping): do not retry every step
-        last_ptr[0] = ptr
+            seen.pop(ptr, None)
+            return
+        if len(seen) > 64:                 # fresh arrays every step: forget the oldest addresses
+            seen.pop(next(iter(seen)))
+        seen[ptr] = n
 
     if not device_env:
         if algo == "ppo":
@@ -259,15 +269,27 @@ def _rollout(key, args, algo, engine, writer, slot, world_size, process_index, s
                     envs.send(actions, info["env_id"])
                     env_send_time += time.time() - t1
                     t1 = time.time()
+                # episode bookkeeping of ppo:326-339 (same values; written with in-place numpy calls and, when the pool returns every env in id order
+                # — `env_id` is arange, checked once per array object —, without the gather / scatter through env_id)
                 env_id = info["env_id"]
+                if env_id is not ident_ids[0]:
+                    ident_ids[0], ident_ids[1] = env_id, bool(env_id.shape[0] == E and np.array_equal(env_id, arange_E))
                 truncated = info["elapsed_step"] >= envs.spec.config.max_episode_steps  # ppo:328
                 ended = (info["terminated"] + truncated) > 0
-                episode_returns[env_id] += info["reward"]
-                returned_episode_returns[env_id] = np.where(ended, episode_returns[env_id], returned_episode_returns[env_id])
-                episode_returns[env_id] *= (1 - info["terminated"]) * (1 - truncated)
-                episode_lengths[env_id] += 1
-                returned_episode_lengths[env_id] = np.where(ended, episode_lengths[env_id], returned_episode_lengths[env_id])
-                episode_lengths[env_id] *= (1 - info["terminated"]) * (1 - truncated)
+                if ident_ids[1]:
+                    episode_returns += info["reward"]
+                    np.copyto(returned_episode_returns, episode_returns, where=ended)
+                    episode_returns[ended] = 0.0
+                    episode_lengths += 1
+                    np.copyto(returned_episode_lengths, episode_lengths, where=ended)
+                    episode_lengths[ended] = 0.0
+                else:
+                    episode_returns[env_id] += info["reward"]
+                    returned_episode_returns[env_id] = np.where(ended, episode_returns[env_id], returned_episode_returns[env_id])
+                    episode_returns[env_id] *= (1 - info["terminated"]) * (1 - truncated)
+                    episode_lengths[env_id] += 1
+                    returned_episode_lengths[env_id] = np.where(ended, episode_lengths[env_id], returned_episode_lengths[env_id])
+                    episode_lengths[env_id] *= (1 - info["terminated"]) * (1 - truncated)
                 storage_time += time.time() - t1
         rollout_time.append(time.time() - rollout_time_start)
         first_rollout = False

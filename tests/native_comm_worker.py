@@ -54,5 +54,7 @@ if os.environ.get("CBM_NATIVE_BENCH"):      # tools/native_allreduce_bench.py: r
     res["bytes"] = np.int64(ctx.P * 4)
 rdv.barrier("done")                      # nobody unmaps while a peer may still be inside a collective
 np.savez(out, **res)
+ctx.unmap_peers()                        # teardown order: unmap -> barrier -> free (include/cleanba_mi.h, EXPORT WINDOWS)
+rdv.barrier("unmapped")
 ctx.close()
 print("rank", rank, "ok", flush=True)

@@ -321,8 +321,9 @@ def test_bench_workload_constants():
 
 
 def test_trainer_page_locks_an_observation_buffer_the_env_reuses(monkeypatch, tmp_path):
-    """An env that hands back the SAME observation array every step (a pool that steps in place) gets it page-locked once (cbm_host_register through
-    engine.host_register); the synthetic twin, which returns a fresh array per step like envpool, never triggers it."""
+    """An env that hands its observations back in RECURRING buffers gets each of them page-locked once (cbm_host_register through
+    engine.host_register): the synthetic twin rotates through SyntheticAtariEnv.OBS_RING pre-allocated buffers (a state-buffer queue), a pool that
+    steps in place has one; an env that returns a never-seen array every step triggers nothing."""
     sys.path.insert(0, HERE)
     from oracle_engine import OracleEngine
     from cleanba_amd import trainer
@@ -358,8 +359,29 @@ def test_trainer_page_locks_an_observation_buffer_the_env_reuses(monkeypatch, tm
     os.chdir(str(tmp_path))
     argv = ["--local-num-envs", "4", "--num-actor-threads", "1", "--num-steps", "4", "--env-backend", "host", "--network", "nature",
             "--total-timesteps", "32", "--log-frequency", "1000", "--update-epochs", "1", "--num-minibatches", "2"]
+    from cleanba_amd.envs import SyntheticAtariEnv
     trainer.train(parse_args(argv, "ppo"), "ppo", engine_factory=Eng)
-    assert calls == []                                  # fresh arrays per step: nothing to pin
+    assert 2 <= len(calls) == len(set(calls)) <= SyntheticAtariEnv.OBS_RING   # the twin's rotating buffers, each registered once (the second time it comes round)
+    del calls[:]
     monkeypatch.setattr(trainer, "make_env", reusing)
     trainer.train(parse_args(argv, "ppo"), "ppo", engine_factory=Eng)
     assert len(calls) == 1                              # the reused buffer, once
+
+    def fresh(env_id, seed, n, **kw):
+        thunk = real(env_id, seed, n, **kw)
+
+        def make():
+            e = thunk()
+            step0, keep = e.step, []
+
+            def step(a):
+                o, r, d, i = step0(a)
+                keep.append(o.copy())                   # a new array (and address: the old ones stay alive) every step
+                return keep[-1], r, d, i
+            e.step = step
+            return e
+        return make
+    del calls[:]
+    monkeypatch.setattr(trainer, "make_env", fresh)
+    trainer.train(parse_args(argv, "ppo"), "ppo", engine_factory=Eng)
+    assert calls == []
