@@ -372,13 +372,17 @@ def test_trainer_page_locks_an_observation_buffer_the_env_reuses(monkeypatch, tm
 
         def make():
             e = thunk()
-            step0, keep = e.step, []
+            step0, reset0, keep = e.step, e.reset, []
 
             def step(a):
                 o, r, d, i = step0(a)
                 keep.append(o.copy())                   # a new array (and address: the old ones stay alive) every step
                 return keep[-1], r, d, i
-            e.step = step
+
+            def reset():
+                keep.append(reset0())
+                return keep[-1]
+            e.step, e.reset = step, reset
             return e
         return make
     del calls[:]
