@@ -260,6 +260,13 @@ def run_dp(a, world, rank, local_rank):
                                  "exposed_us_avg": round(exposed_ms / max(n, 1) * 1e3, 1),
                                  "note": "tail (dense + heads) runs on the communication stream under the conv backward; exposed = end of the "
                                          "backward pass -> optimizer may start on the learner stream (head all-reduce + whatever of the tail was not hidden)"}
+    if comm and world > 1 and not a.no_allreduce_ab:
+        try:
+            ab = allreduce_ab(ctx, rdv, world, rank)
+        except BaseException as e:  # noqa: BLE001
+            ab = {"error": f"{type(e).__name__}: {e}"}
+        if line is not None:
+            line["allreduce_ab"] = ab
     # teardown of a run whose ranks map each other's buffers (native all-reduce): unmap -> barrier -> free.  An owner that frees a window a peer
     # still maps leaves the exporting process's IPC state broken for its NEXT export (tools/ipc_stress.py racy: hipIpcGetMemHandle "invalid
     # argument" / the peers' hipIpcOpenMemHandle "invalid device pointer" one cycle later) — the round-4 failure of the topology phase below.
@@ -431,22 +438,68 @@ def _resnet_exec_mflop():
 RESNET_EXEC_MFLOP_PER_ENV_STEP = _resnet_exec_mflop()
 
 
-def baseline_topology_on_one_gpu(a):
-    """BASELINE configs[3] (`a0-l1,2,3`: one actor + three learner role processes, README.md:62) with every role on THIS GPU: what a one-GPU box can
-    run of it — real shards by IPC peer copies, a real reduction of three different gradients per minibatch through the library's native
-    all-reduce (RCCL refuses two ranks per device).  A functional measurement: four processes share one GPU."""
-    env = dict(os.environ, CBM_FORCE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
-        env.pop(k, None)
-    try:
-        p = subprocess.run([sys.executable, os.path.abspath(__file__), "--topology", "a0-l1,2,3", "--steps", "4", "--warmup", "2"], env=env,
-                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240)
-        d = json.loads(p.stdout.decode().strip().splitlines()[-1])
-        return {"config": "BASELINE configs[3] PPO a0-l1,2,3-d1, all four role processes on one GPU (CBM_FORCE_DEVICE=0)", "value": d.get("value"),
-                "unit": "env-steps/s", "ms_per_step": d.get("ms_per_step"), "steps": d.get("steps"), "allreduce": d.get("allreduce"),
-                "note": "functional: the roles time-share one MI355X; the multi-GPU number comes from `bench.py --gpus 4` (key baseline_config)"}
-    except BaseException as e:  # noqa: BLE001
-        return {"config": "BASELINE configs[3] on one GPU", "value": None, "error": f"{type(e).__name__}: {e}"}
+def allreduce_ab(ctx, rdv, world, rank, iters=20):
+    """A/B of the two gradient all-reduce backends on IDENTICAL data inside the same N rank processes: the backend the run
+    used stays in communicator slot 0, the other one is brought up in the spare slot; each all-reduces an integer-valued pattern (every order of
+    summation gives the same fp32 result, so 'exact' means: every element of every rank arrived exactly once — what a stale cache line or a missed
+    flag would break) and is then timed over `iters` blocking all-reduces of the 6.78 MB flat gradient.  `equal` = the two results agree bit for
+    bit.  RCCL needs one device per rank; the native backend across devices needs fine-grained gradient windows (CBM_NATIVE_FINEGRAINED=1 or
+    CBM_COMM=native when the contexts are created) — an unavailable backend is reported as such, never guessed at."""
+    from cleanba_amd import topology
+    P = ctx.P
+    idx = np.arange(P, dtype=np.int64)
+
+    def pattern(r):
+        return (((idx * 2654435761 + r * 40503) >> 7) % 1024 - 512).astype(np.float32)
+
+    want = np.zeros(P, np.float64)
+    for r in range(world):
+        want += pattern(r)
+    want = want.astype(np.float32)
+    primary = ctx.comm_backend()
+    one_device = os.environ.get("CBM_FORCE_DEVICE") is not None
+    out, results = {"bytes": int(P * 4), "ranks": world, "iters": iters, "primary": primary}, {}
+    for be in ("rccl", "native"):
+        which = L.COMM_LEARNERS if be == primary else L.COMM_WORLD
+        if be != primary:
+            if be == "rccl" and one_device:
+                out[be] = {"available": False, "why": "RCCL takes one rank per device; the ranks of this run share GPU %s (CBM_FORCE_DEVICE)" % os.environ["CBM_FORCE_DEVICE"]}
+                continue
+            if be == "native" and not one_device and os.environ.get("CBM_NATIVE_FINEGRAINED") != "1" and os.environ.get("CBM_COMM") != "native":
+                out[be] = {"available": False, "why": "across devices the native kernels need fine-grained gradient windows: run with CBM_NATIVE_FINEGRAINED=1"}
+                continue
+            if primary == "loopback":
+                out[be] = {"available": False, "why": "CBM_COMM_LOOPBACK run"}
+                continue
+            ranks = list(range(world))
+            if be == "native":
+                blob = ctx.comm_native_export(which)
+                rdv.put(f"ab/native/{rank}", blob)
+                ctx.comm_native_init([blob if i == rank else bytes(rdv.get(f"ab/native/{i}")) for i in ranks], rank, which)
+            else:
+                uid = rdv.share("ab/uid", ctx.comm_unique_id, 0)
+                L.Context.comm_init(ctx, which, uid, world, rank)
+        ctx.write("grads", pattern(rank))
+        ctx.sync()
+        ctx.comm_allreduce_grads(which)
+        got = ctx.read("grads", np.float32)
+        results[be] = got
+        ctx.comm_barrier(which)
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            ctx.comm_allreduce_grads(which)
+        dt = time.perf_counter() - t0
+        us = float(ctx.comm_allreduce_f64([dt / iters * 1e6], "max", which)[0])
+        exact = bool(np.array_equal(got, want))
+        exact_all = bool(ctx.comm_allreduce_f64([1.0 if exact else 0.0], "min", which)[0] == 1.0)
+        out[be] = {"available": True, "us_per_allreduce": round(us, 1), "busbw_gbps": round(2.0 * (world - 1) / world * P * 4 / (us * 1e-6) / 1e9, 1),
+                   "exact_on_every_rank": exact_all}
+    if "rccl" in results and "native" in results:
+        eq = bool(np.array_equal(results["rccl"], results["native"]))
+        out["equal"] = bool(ctx.comm_allreduce_f64([1.0 if eq else 0.0], "min")[0] == 1.0)
+    out["note"] = ("blocking all-reduce of the whole flat gradient, host-timed (max over ranks), nothing else on the GPU; integer-valued test pattern: 'exact' = equals "
+                   "the analytic sum on every rank, 'equal' = the two backends agree bit for bit")
+    return out
 
 
 def baseline_config_phase(a, world, rank):
@@ -586,7 +639,8 @@ def main():
     ap.add_argument("--prof-kernel", type=int, default=-2, help="-2: HIP events around every GEMM launch (ids 0-11, default); k: only kernel k; -1: off")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-env", action="store_true", help="skip the secondary envpool-API measurement")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary workloads (IMPALA configs[2], IMPALA fp32, PPO-ResNet) and the configs[3]-on-one-GPU row")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary workloads (IMPALA configs[2], IMPALA fp32, PPO-ResNet)")
+    ap.add_argument("--no-allreduce-ab", action="store_true", help="with N > 1 ranks: skip the RCCL / native all-reduce A/B after the timed steps")
     ap.add_argument("--no-baseline-config", action="store_true", help="with 4 / 8 ranks: skip the BASELINE configs[3] / configs[4] topology line after the dp line")
     ap.add_argument("--bwd-split", type=int, default=0, choices=[0, 2, 3],
                     help="build-only extension (NOT the headline): backward GEMMs on split-bf16 MFMA, see cbm_config.backward_split")
@@ -601,6 +655,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and os.environ.get("CBM_FORCE_DEVICE") is None:
+        # one rank per GPU: the gradient windows are allocated fine-grained so that the native all-reduce can run ACROSS devices in the A/B after the
+        # timed steps (allreduce_ab); measured cost on one GPU: none (33.56 vs 33.56 ms pipelined, profiles/r05_finegrained_window.txt)
+        os.environ.setdefault("CBM_NATIVE_FINEGRAINED", "1")
     if a.topology == "dp" and world != a.gpus and rank == 0:
         print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: running the {world} ranks that were launched", file=sys.stderr)
     try:
@@ -622,9 +680,12 @@ def main():
     if rank == 0:
         if world == 1 and not a.no_host_env:
             line["host_env"] = host_env_value(a, params)
+            # the envpool-step-API figure (the path north_star calls the drop-in) as a named second figure beside the headline
+            line["config"]["envpool_api_env_steps_per_s"] = line["host_env"].get("actor_threads_1")
+            line["envpool_api_env_steps_per_s"] = {"actor_threads_1": line["host_env"].get("actor_threads_1"),
+                                                   "actor_threads_2": line["host_env"].get("actor_threads_2"), "unit": "env-steps/s"}
         if world == 1 and not a.no_secondary:
             line["secondary"] = secondary_values()
-            line["secondary"]["configs3_on_one_gpu"] = baseline_topology_on_one_gpu(a)
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         _emit(json.dumps(line))

@@ -558,6 +558,16 @@ extern "C" int cbm_comm_allreduce_f64(cbm_ctx* c, int32_t which, double* host_in
   return cbm_comm_check_native(c);
 }
 
+// all-reduce(SUM) of the WHOLE flat gradient through communicator `which`, blocking — the A/B of the two backends on identical data
+// (bench.py --gpus N: `allreduce_ab`); the learner's own path is cbm_learner_allreduce_grads
+extern "C" int cbm_comm_allreduce_grads(cbm_ctx* c, int32_t which) {
+  if (comm_check(c, which)) return -1;
+  CBM_HIP(hipSetDevice(c->cfg.device));
+  if (comm_allreduce_f32(c, c->comms[which], c->grads, c->P, c->cstream)) return -1;
+  CBM_HIP(hipStreamSynchronize(c->cstream));
+  return cbm_comm_check_native(c);
+}
+
 extern "C" int cbm_comm_barrier(cbm_ctx* c, int32_t which) {
   double one = 1.0;
   return cbm_comm_allreduce_f64(c, which, &one, 1, 0);

@@ -730,19 +730,27 @@ __global__ __launch_bounds__(256, P::Tile::MINW) void igemm_dma_kernel(const P p
   constexpr int ASZ = BR * BX, BSZ = BR * BY, PB = BY;
   constexpr int NIA = (BR / 4) * (BX / 64), NIB = BR * BY / 4 / 64;     // wave-instructions per tile
   static_assert(NIA % 4 == 0 && NIB % 4 == 0, "every wave issues the same number of DMA instructions");
-  __shared__ __attribute__((aligned(16))) float smem[2 * ASZ + 2 * BSZ];
+  constexpr int NST = 3;                                                   // LDS stages: two chunks of copies in flight under the one being multiplied
+  __shared__ __attribute__((aligned(16))) float smem[NST * (ASZ + BSZ)];
   float* As = smem;
-  float* Bs = smem + 2 * ASZ;
+  float* Bs = smem + NST * ASZ;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, h = lane >> 5;
   const int wx = wave / WY, wy = wave % WY;
-  int bx = blockIdx.x;
+  // XCD-aware tile order.  Workgroups go to the eight XCDs round robin by LINEAR id, and each XCD has its own L2: the linear id (1-D grid over all
+  // x and y tiles) is turned into "XCD j owns tiles [start_j, start_j + n_j) of the x-major list (g = x_tile * NY + y_tile)", so the NY column tiles of
+  // an A row panel run on ONE XCD at the same time (the panel is fetched into one L2 once) and an XCD touches 1/8 of A.  (The round-4 form
+  // remapped blockIdx.x alone: with 60 x-tiles, odd blockIdx.y rows land four XCDs further and every panel was fetched by two XCDs — 2.8x the
+  // operand bytes in the PMC traffic.)
+  const int NY = (p.Y() + BY - 1) / BY;
+  int g = blockIdx.x;
   {
-    const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = bx & 7, k = bx >> 3;
-    bx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = g & 7, k = g >> 3;
+    g = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
   }
-  const int x0 = bx * BX, y0 = (int)blockIdx.y * BY, z = blockIdx.z;
+  const int bx = g / NY, by = g - bx * NY;
+  const int x0 = bx * BX, y0 = by * BY, z = blockIdx.z;
   int rlo, rhi;
   p.r_range(z, rlo, rhi);
 
@@ -771,12 +779,19 @@ __global__ __launch_bounds__(256, P::Tile::MINW) void igemm_dma_kernel(const P p
     }
   };
 
+  // Three-stage ring: chunk i is multiplied while the copies of chunks i+1 and i+2 are in flight (a chunk's 16 MFMAs per wave are ~0.45 us, an L2 /
+  // fabric round trip under load is longer).  Each wave issues NIA/4 + NIB/4 copy instructions per chunk, in order, so "chunk i has landed" is
+  // vmcnt(<= one chunk's instructions) while chunk i+1 is still outstanding; ONE barrier per chunk — it also says that every wave has left chunk
+  // i-1, whose stage the copies of chunk i+2 overwrite.
+  constexpr int NIW = NIA / 4 + NIB / 4;
   dma(rlo, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+  if (rlo + BR < rhi) dma(rlo + BR, 1);
   int buf = 0;
   for (int r0 = rlo; r0 < rhi; r0 += BR) {
-    if (r0 + BR < rhi) dma(r0 + BR, buf ^ 1);
+    if (r0 + BR < rhi) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NIW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");                    // (not __syncthreads(): its fence would wait for every copy in flight)
+    if (r0 + 2 * BR < rhi) dma(r0 + 2 * BR, buf >= 1 ? buf - 1 : NST - 1);      // stage (i + 2) % 3 = (buf + 2) % 3
     const float* A_ = As + buf * ASZ;
     const float* B_ = Bs + buf * BSZ;
     {
@@ -810,9 +825,7 @@ __global__ __launch_bounds__(256, P::Tile::MINW) void igemm_dma_kernel(const P p
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    buf ^= 1;
+    buf = buf + 1 == NST ? 0 : buf + 1;
   }
 
 #pragma unroll
@@ -831,7 +844,7 @@ __global__ __launch_bounds__(256, P::Tile::MINW) void igemm_dma_kernel(const P p
 template <class P>
 static inline void igemm_dma_launch(const P& p, int nsplit, hipStream_t stream) {
   using T = typename P::Tile;
-  dim3 grid((p.X() + T::BX - 1) / T::BX, (p.Y() + T::BY - 1) / T::BY, nsplit);
+  dim3 grid(((p.X() + T::BX - 1) / T::BX) * ((p.Y() + T::BY - 1) / T::BY), 1, nsplit);   // 1-D over the tiles: the kernel orders them per XCD
   hipLaunchKernelGGL(igemm_dma_kernel<P>, grid, dim3(256), 0, stream, p);
 }
 

@@ -57,7 +57,7 @@ SYMBOLS = [
     "cbm_learner_allreduce_grads", "cbm_comm_profile", "cbm_comm_profile_read", "cbm_ipc_export_window", "cbm_ipc_window_offset", "cbm_ipc_open_window",
     "cbm_ipc_close_window", "cbm_ipc_close_all",
     "cbm_host_register", "cbm_host_unregister", "cbm_actor_ship_shard", "cbm_io_sync", "cbm_params_push", "cbm_params_mark_published", "cbm_ctx_abort", "cbm_profile_read_all", "cbm_profile_kernel_name",
-    "cbm_comm_native_export", "cbm_comm_native_init", "cbm_comm_backend",
+    "cbm_comm_native_export", "cbm_comm_native_init", "cbm_comm_backend", "cbm_comm_allreduce_grads",
 ]
 
 COMM_LEARNERS, COMM_WORLD = 0, 1
@@ -379,6 +379,10 @@ class Context:
 
     def comm_barrier(self, which=COMM_LEARNERS):
         _chk(self.lib.cbm_comm_barrier(self.h, int(which)))
+
+    def comm_allreduce_grads(self, which=COMM_LEARNERS):
+        """all-reduce(SUM) of the whole flat gradient through communicator `which`, blocking (cbm_comm_allreduce_grads)."""
+        _chk(self.lib.cbm_comm_allreduce_grads(self.h, int(which)))
 
     def learner_allreduce_grads(self):
         d = C.c_float()
