@@ -200,7 +200,7 @@ static int ctx_create_impl(const cbm_config* cfg, cbm_ctx** out, cbm_ctx** parti
     for (int s = 0; s < c->S; ++s) CBM_HIP(hipEventCreateWithFlags(&R.ready[s], hipEventDisableTiming));
     CBM_HIP(hipEventCreateWithFlags(&R.consumed, hipEventDisableTiming));
   }
-  // stream priorities (experiment knob, DESIGN.md section 4.1: nothing measurable either way): CBM_STREAM_PRIO=learner|actor|actor_hi|learner_lo
+  // stream priorities (experiment knob, profiles/NOTES_r03_r04.md, round 4: nothing measurable either way): CBM_STREAM_PRIO=learner|actor|actor_hi|learner_lo
   int prio_lo = 0, prio_hi = 0;
   hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
   const char* pe = getenv("CBM_STREAM_PRIO");

@@ -8,7 +8,7 @@
 
 // A uniform loop bound (number of actions, rollout length) copied into a VGPR the compiler cannot see through: comparisons against it become
 // per-lane selects.  Against the SGPR itself an `if (j < A)` inside an unrolled loop is a scalar branch per iteration — in the small latency-bound
-// kernels (loss heads, heads' input gradient) those branches, each with its own wait in front, were most of the run time.
+// kernels (loss heads, heads' input gradient) those branches, each with its own wait in front, were most of the run time (profiles/NOTES_r03_r04.md, round 4).
 static __device__ __forceinline__ int cbm_opaque_vgpr(int x) { asm volatile("" : "+v"(x)); return x; }
 
 #define CBM_FRAME 28224  // 4*84*84 uint8

@@ -134,7 +134,7 @@ static void host_step_one(uint32_t seed, int e, int32_t action, int32_t max_epis
 }
 // envpool steps its envs on a C++ thread pool; the twin does the same so that host-env runs are not bound by one core: the k envs of a call
 // are cut into contiguous chunks, one std::thread each (an env's trajectory depends only on its own id, seed and actions — any
-// partition gives the same bytes).  CBM_ENV_THREADS overrides the thread count (default min(16, cores), at least 4 envs per thread — round 4's 8 per thread stepped 60 envs on 7 threads in 72 us against 120 on 15 in 47, so two actor threads of 60 envs paid more per step than one of 120; 32 threads measured WORSE, 101-186 us: every worker is woken every step).  A worker spins for ~0.5 ms before it sleeps on the futex when the host has cores to spare (>= 64): a 120-env step comes round every ~0.33 ms, and a futex wake-up per worker per step was most of the env's step time.
+// partition gives the same bytes).  CBM_ENV_THREADS overrides the thread count (default min(16, cores), at least 8 envs per thread: 120 envs step on 15 threads in 47 us, on 8 in 72).  Measured in round 5 and NOT taken (tools/host_loop_probe.py, profiles/r05_host_loop_probe.txt): 4 envs per thread / up to 32 threads — env step 101-186 us instead of 48-86 (every worker is woken every step); workers that spin ~0.5 ms before sleeping — two actor threads' pools then starve each other and the Python threads (env step 237-298 us).
 // The workers are a persistent pool per calling thread (envpool keeps its worker threads too; spawning eight std::threads per step cost
 // ~0.4 ms of a 120-env step): the caller publishes a generation number, every worker runs its chunk and counts down, the caller runs
 // chunk 0 itself and waits for the count.  thread_local, so two actor threads stepping their own envs never share a pool.
@@ -145,13 +145,12 @@ struct HostPool {
   std::atomic<bool> stop{false};
   std::function<void(int)> job;   // job(t) runs chunk t
   const pid_t owner = getpid();   // a fork()ed child inherits the object but not the threads: it steps serially
-  const int spin_limit = std::thread::hardware_concurrency() >= 64 ? 20000 : 2000;   // pauses before a worker sleeps (~0.5 ms / ~50 us)
   explicit HostPool(int workers) {
     for (int t = 1; t <= workers; ++t)
       th.emplace_back([this, t] {
         uint32_t seen = 0;
         for (;;) {
-          for (int spin = 0; spin < spin_limit && gen.load(std::memory_order_acquire) == seen; ++spin) __builtin_ia32_pause();
+          for (int spin = 0; spin < 2000 && gen.load(std::memory_order_acquire) == seen; ++spin) __builtin_ia32_pause();
           gen.wait(seen, std::memory_order_acquire);
           seen = gen.load(std::memory_order_acquire);
           if (stop.load(std::memory_order_acquire)) return;
@@ -186,7 +185,7 @@ static void host_parallel_for(int k, F body) {
     int n = e ? atoi(e) : (int)std::thread::hardware_concurrency();
     return n < 1 ? 1 : (n > 16 && !e ? 16 : n);
   }();
-  const int nt = k / 4 < max_threads ? k / 4 : max_threads;   // at least 4 envs per thread (an env's step is ~6-8 us, a hand-off ~5)
+  const int nt = k / 8 < max_threads ? k / 8 : max_threads;
   if (nt <= 1) { for (int j = 0; j < k; ++j) body(j); return; }
   thread_local HostPool pool(max_threads - 1);
   if (pool.owner != getpid()) { for (int j = 0; j < k; ++j) body(j); return; }

@@ -558,7 +558,7 @@ __global__ __launch_bounds__(256) void ppo_heads_fused_kernel(const float* hid, 
   // (A) hid rows and both weight matrices -> LDS by the load unit (global_load_lds: 1 KB per wave instruction, no staging registers, no ds_write):
   // a hid row is two such copies behind its padded row base, the actor matrix HD / 256 * A of them as it lies in memory, the critic column HD / 64
   // 256-byte ones.  (Through registers this phase and the chain below were 31 us for a block that owns a CU alone — the same pattern the actor tail
-  // had: DESIGN 4.1.)
+  // had: profiles/NOTES_r03_r04.md round 4.)
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   // the samples' scalars are a gather through idx — two dependent round trips: the index is requested first, the scalars once the staging copies are
   // on their way (vmcnt retires in order: waiting for the index does not wait for the copies behind it)
@@ -1218,12 +1218,12 @@ int nature_forward(const NatureLayout& L, const float* P, const uint8_t* obs, co
     Conv1Fwd<T64x64k16> p1{obs, idx, P + L.w[0], P + L.b[0], ws.act1, B * 400, nullptr};
     // conv1 on 64-row tiles (750 blocks instead of 1500): no faster alone (rollout 6.52 -> 6.53 ms), but beside the learner's CU-filling kernels half as
     // many blocks wait for a slot — pipelined step 33.87 -> 33.64 ms over six A/B pairs, IMPALA and the host-stepped path unchanged; the same 64 rows
-    // for conv2 / conv3 / dense cost the rollout alone 0.1-0.4 ms and IMPALA 2-4 %
+    // for conv2 / conv3 / dense cost the rollout alone 0.1-0.4 ms and IMPALA 2-4 % (profiles/NOTES_r03_r04.md, round 4)
     igemm_s16_launch<64, 32, 32>(p1, 1, st);
     ConvFwd<T64x64k16, 4, 4, 2, 32, 64, 20, 20, 9, 9> p2{ws.act1, P + L.w[1], P + L.b[1], ws.act2, B * 81, nullptr};
     igemm_s16_launch<32, 32, 32>(p2, 1, st);   // (K chunks of 32 like conv1 / dense: 21.5 KB of LDS and 65 VGPRs per block instead of 42 KB / 129 —
     ConvFwd<T64x64k16, 3, 3, 1, 64, 64, 9, 9, 7, 7> p3{ws.act2, P + L.w[2], P + L.b[2], ws.act3, B * 49, nullptr};
-    igemm_s16_launch<32, 32, 32>(p3, 1, st);   //  no slower alone, and more of these blocks find room beside the learner's: DESIGN.md section 4.1)
+    igemm_s16_launch<32, 32, 32>(p3, 1, st);   //  no slower alone, and more of these blocks find room beside the learner's: profiles/NOTES_r03_r04.md, round 4)
     if (dense_ksplit > 1) {
       DenseFwd<T64x64k16, true> pd{ws.act3, P + L.w[3], P + L.b[3], ws.dense_part, B, 3136, 512, 3136 / dense_ksplit};
       igemm_s16_launch<32, 32, 32>(pd, dense_ksplit, st);

@@ -9,6 +9,8 @@ and envpool installed, the real ALE env is returned instead (not available in th
 """
 from types import SimpleNamespace
 
+import ctypes as C
+
 import numpy as np
 
 from . import lib as L
@@ -53,24 +55,35 @@ class SyntheticAtariEnv:
 
     def reset(self):
         self._st, self._obs = L.synth_env_reset_host(self.seed, self.num_envs, atari57_mix=is_atari57_mix(self.env_id))
+        self._ring = None   # (step() caches the addresses of the state block and of the current observations: both are new now)
         return self._obs.copy()
 
     OBS_RING = 4   # observation buffers handed out round robin
 
     def step(self, actions):
-        # Like envpool's state-buffer queue, the observations of a step land in one of a few PRE-ALLOCATED buffers (a different array object
-        # and address than the previous step's; its content stays valid for OBS_RING - 1 further steps): no 3.4 MB allocation — mmap, page faults,
-        # munmap — on the step's critical path, which two actor threads of one process would serialise on the kernel's address-space lock.
+        # Like envpool's state-buffer queue, the results of a step land in one of a few PRE-ALLOCATED slots (a different array object and address
+        # than the previous step's; a slot's content stays valid for OBS_RING - 1 further steps): no 3.4 MB allocation — mmap, page faults,
+        # munmap — on the step's critical path, which two actor threads of one process would serialise on the kernel's address-space lock, and the
+        # slots' addresses are taken once (a numpy -> pointer conversion is 1-3 us of GIL time, a step passes ten).
         if self._ring is None:
-            self._ring = [np.empty_like(self._obs) for _ in range(self.OBS_RING)]
+            n = self.num_envs
+            self._ring = []
+            for _ in range(self.OBS_RING):
+                arrs = (np.empty_like(self._obs), np.zeros(n, np.float32), np.zeros(n, np.uint8), np.zeros(n, np.uint8), np.zeros(n, np.int32))
+                self._ring.append((arrs, tuple(a.ctypes.data for a in arrs)))
             self._ring_i = 0
-        out = self._ring[self._ring_i]
+            self._fn = L.load().cbm_synth_env_step_host_to
+            self._st_p = C.addressof(self._st)
+            self._seed32 = int(self.seed) & 0xFFFFFFFF
+            self._obs_p = self._obs.ctypes.data
+        (out, r, d, term, el), (out_p, r_p, d_p, term_p, el_p) = self._ring[self._ring_i]
         self._ring_i = (self._ring_i + 1) % self.OBS_RING
-        out.flags.writeable = True
-        _, r, d, term, el = L.synth_env_step_host_to(self.seed, self._st, self._obs, actions, self.spec.config.max_episode_steps, out=out)
-        out.flags.writeable = False          # the env reads it once more (next step's older planes)
-        self._obs = out
-        return out, r, d.astype(bool), self._info(r, term, el)
+        a = actions if actions.dtype == np.int32 and actions.flags.c_contiguous else np.ascontiguousarray(actions, np.int32)
+        if self._fn(self._seed32, self.num_envs, int(self.spec.config.max_episode_steps), a.ctypes.data, self._st_p, self._obs_p, out_p, r_p, d_p,
+                    term_p, el_p) != 0:
+            raise L.CbmError(L.load().cbm_last_error().decode())
+        self._obs, self._obs_p = out, out_p   # the env reads it once more (next step's older planes)
+        return out, r, d.view(np.bool_), self._info(r, term, el)
 
     # async API (impala:308,352,365).  batch_size == num_envs: every recv() returns all envs sorted by env_id (what cleanba_impala.py
     # relies on).  batch_size < num_envs (legacy --async-batch-size, naturecnn:119-133): recv() returns the batch_size envs whose step

@@ -122,6 +122,10 @@ def load():
     lib.cbm_learner_stream.argtypes = [C.c_void_p]
     lib.cbm_actor_stream.restype = C.c_void_p
     lib.cbm_actor_stream.argtypes = [C.c_void_p, C.c_int32]
+    vp = C.c_void_p
+    lib.cbm_actor_step_host.argtypes = [vp, C.c_int32, vp, vp, vp, vp, vp]
+    lib.cbm_actor_record_host.argtypes = [vp, C.c_int32, vp]
+    lib.cbm_synth_env_step_host_to.argtypes = [C.c_uint32, C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.cbm_comm_load.argtypes = [C.c_char_p]
     lib.cbm_comm_backend.restype = C.c_char_p
     _lib = lib
@@ -137,7 +141,7 @@ def _p(a):
     if a is None:
         return None
     if isinstance(a, np.ndarray):
-        return a.ctypes.data_as(C.c_void_p)
+        return C.c_void_p(a.ctypes.data)   # (data_as() costs 2.7 us a call, this 1.3: a 120-env host step makes a dozen of them under the GIL)
     return C.c_void_p(a)
 
 
@@ -194,6 +198,7 @@ class Context:
         _chk(self.lib.cbm_ctx_create(C.byref(cfg), C.byref(h)))
         self.h = h
         self.A = cfg.num_actions
+        self._ao = (None, 0)   # (the caller's action array of the last host step, its address)
         self.P = param_count(cfg.network, cfg.num_actions, cfg.hiddens[0] if cfg.network == NET_IMPALA_RESNET else 0)
 
     def close(self):
@@ -256,11 +261,18 @@ class Context:
         E = self.cfg.local_num_envs
         if actions_out is None:
             actions_out = np.empty(E, np.int32)
-        obs = np.ascontiguousarray(obs, np.uint8)
-        done = np.ascontiguousarray(done, np.uint8)
+        # per-step call of the envpool-API loop: everything here runs under the GIL, so addresses of arrays that come back every step (the
+        # caller's action buffer) are cached and the rest is taken with one attribute read each
+        if actions_out is not self._ao[0]:
+            assert actions_out.dtype == np.int32 and actions_out.flags.c_contiguous and actions_out.size >= E
+            self._ao = (actions_out, actions_out.ctypes.data)
+        if obs.dtype != np.uint8 or not obs.flags.c_contiguous:
+            obs = np.ascontiguousarray(obs, np.uint8)
+        done = done.view(np.uint8) if done.dtype == np.bool_ and done.flags.c_contiguous else np.ascontiguousarray(done, np.uint8)
         fs = None if firststep is None else np.ascontiguousarray(firststep, np.uint8)
         rw = None if reward_with_obs is None else np.ascontiguousarray(reward_with_obs, np.float32)
-        _chk(self.lib.cbm_actor_step_host(self.h, int(slot), _p(obs), _p(done), _p(fs), _p(rw), _p(actions_out)))
+        _chk(self.lib.cbm_actor_step_host(self.h, int(slot), obs.ctypes.data, done.ctypes.data, None if fs is None else fs.ctypes.data,
+                                          None if rw is None else rw.ctypes.data, self._ao[1]))
         return actions_out
 
     def actor_step_async(self, slot, obs, reward, done, env_id, actions_out=None):
@@ -278,8 +290,8 @@ class Context:
         return actions_out
 
     def actor_record_host(self, slot, reward):
-        r = np.ascontiguousarray(reward, np.float32)
-        _chk(self.lib.cbm_actor_record_host(self.h, int(slot), _p(r)))
+        r = reward if reward.dtype == np.float32 and reward.flags.c_contiguous else np.ascontiguousarray(reward, np.float32)
+        _chk(self.lib.cbm_actor_record_host(self.h, int(slot), r.ctypes.data))
 
     def host_register(self, arr):
         """Page-locks a numpy array the env reuses for its observations (cbm_host_register)."""

@@ -1,7 +1,7 @@
 #!/bin/bash
 # No kernel of the library may ask for the dispatch packet pointer: the compiler does when it has moved a private array to LDS
 # (amdgpu-promote-alloca needs the block shape), and reading that packet at kernel entry is a host-memory round trip — 9-16 us per launch
-# measured on the actor tail.  Compiles every translation unit to ISA and lists offenders; exit 1 if any.
+# measured on the actor tail (profiles/NOTES_r03_r04.md round 4).  Compiles every translation unit to ISA and lists offenders; exit 1 if any.
 cd "$(dirname "$0")/../cleanba_amd/csrc"
 F="-O3 -std=c++20 --offload-arch=gfx950 -ffp-contract=off -fno-math-errno -S --cuda-device-only"
 bad=0
