@@ -39,10 +39,14 @@ void cbm_launch_fail(const char* fmt, ...) {
   va_end(ap);
   g_launch_failed.store(true, std::memory_order_release);
 }
+// reports a recorded launch failure ONCE — to the entry point that drove the failing pass — and clears it: one context's geometry failure must
+// not make every later call of every other context in the process (an eval context, the next test) return -1 with a stale message
 int cbm_launch_check(void) {
   if (!g_launch_failed.load(std::memory_order_acquire)) return 0;
   std::lock_guard<std::mutex> lk(g_launch_mu);
+  if (!g_launch_failed.load(std::memory_order_acquire)) return 0;
   cbm_set_error("%s", g_launch_err);
+  g_launch_failed.store(false, std::memory_order_release);
   return -1;
 }
 extern "C" const char* cbm_build_info(void) { return "cleanba-mi gfx950 f32-mfma abi=2 built " __DATE__ " " __TIME__; }
@@ -234,8 +238,17 @@ static int ctx_create_impl(const cbm_config* cfg, cbm_ctx** out, cbm_ctx** parti
   if (c->asyncB && dalloc(&c->advn, T1 * B)) return -1;
   if (dalloc(&c->adv, T1 * B) || dalloc(&c->target, T1 * B) || dalloc(&c->next_value, B) ||
       dalloc(&c->loss_partials, (size_t)4 * (lmax / 8 + 2) + 3 * B) || dalloc(&c->norm_partials, CBM_NORM_PARTS) ||
-      dalloc(&c->perm, (size_t)c->epochs * T1 * B) || dalloc(&c->perm_tmp, (size_t)c->epochs * T1 * B) ||
-      dalloc(&c->ckeys, std::max(permutation_scratch_u64((int)(T1 * B)), permutation_batch_scratch_u64((int)(T1 * B), c->epochs)))) return -1;
+      false) return -1;
+  {
+    // permutation buffers: [epochs][n] rows and the batched scratch (~512 B per sample and (epoch, round) job) only where the batched path can run
+    // — a PPO context with >= 2 epochs whose jobs fit CBM_PERM_BATCH_MAX; IMPALA never permutes, one epoch / too many jobs permute epoch by epoch
+    const int n_perm = (int)(c->T * c->Bdev);
+    c->perm_batched = is_ppo(c) && permutation_batch_ok(n_perm, c->epochs);
+    const size_t rows = c->perm_batched ? (size_t)c->epochs : 1;
+    const size_t scratch = c->perm_batched ? std::max(permutation_scratch_u64((int)(T1 * B)), permutation_batch_scratch_u64(n_perm, c->epochs))
+                                           : permutation_scratch_u64((int)(T1 * B));
+    if (dalloc(&c->perm, rows * T1 * B) || dalloc(&c->perm_tmp, rows * T1 * B) || dalloc(&c->ckeys, scratch)) return -1;
+  }
   c->perm_cur = c->perm;
   if (!is_ppo(c)) {  // static minibatch index table: contiguous env-column chunks, all T+1 rows (impala:623-634)
     const int Bm = c->Bdev / c->nmicro;
@@ -679,7 +692,7 @@ static int learner_epoch_perm(cbm_ctx* c, uint32_t key[2]) {
 // The whole-update call knows every epoch's subkey before its first minibatch: all permutations in four launches (pointwise.hip) instead of six
 // per epoch on the learner stream; epoch e then reads rows [e][...] of c->perm.  The key advances exactly as epoch-by-epoch calls advance it.
 static bool learner_all_epoch_perms(cbm_ctx* c, uint32_t key[2]) {
-  if (c->epochs < 2 || c->epochs > CBM_PERM_BATCH_MAX) return false;
+  if (!c->perm_batched || c->epochs > CBM_PERM_BATCH_MAX) return false;
   uint32_t subs[CBM_PERM_BATCH_MAX][2];
   uint32_t k0 = key[0], k1 = key[1];
   for (int e = 0; e < c->epochs; ++e) {

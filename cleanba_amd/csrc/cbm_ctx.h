@@ -70,6 +70,7 @@ struct cbm_ctx {
   float *adv = nullptr, *target = nullptr, *next_value = nullptr, *stats_dev = nullptr, *loss_partials = nullptr, *norm_partials = nullptr;
   int32_t *perm = nullptr, *perm_tmp = nullptr, *impala_idx = nullptr;   // perm: [epochs][T * Bdev] (row 0 alone when the epochs are permuted one by one)
   const int32_t* perm_cur = nullptr;   // the current epoch's row of perm
+  bool perm_batched = false;           // perm / perm_tmp / ckeys are sized for every epoch's permutation at once (launch_permutations_batch)
   float* gacc = nullptr;   // MultiSteps running mean (grad_accum_steps > 1)
   int accum = 1, nmicro = 0;
   uint64_t* ckeys = nullptr;

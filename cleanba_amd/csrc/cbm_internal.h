@@ -141,6 +141,7 @@ void launch_permutation(const uint32_t key[2], int n, int32_t* perm, int32_t* tm
 // taken (one epoch, or more than CBM_PERM_BATCH_MAX epoch x round jobs): the caller permutes epoch by epoch
 #define CBM_PERM_BATCH_MAX 16
 size_t permutation_batch_scratch_u64(int n, int ne);
+bool permutation_batch_ok(int n, int ne);   // whether launch_permutations_batch takes this (n, ne)
 bool launch_permutations_batch(const uint32_t (*epoch_keys)[2], int ne, int n, int32_t* perms, int32_t* tmps, uint64_t* scratch, hipStream_t st);
 void launch_ppo_loss(const float* logits, const float* value, int N, int A, const int32_t* idx, const int32_t* actions,
                      const float* old_logprob, const float* adv, const float* target, float clip_coef, float ent_coef,
@@ -188,7 +189,7 @@ void launch_env_stats(const cbm_env_state* st_dev, int E, float* out2, hipStream
 // error plumbing
 void cbm_set_error(const char* fmt, ...);
 // A launch helper found an internal invariant violated (a ring / partial-region geometry that does not cover the batch it was handed): the
-// launch is skipped, the message is kept process-wide, and the C-ABI entry point that drove the pass returns -1 with it (cbm_launch_check) —
+// launch is skipped, the message is kept until the C-ABI entry point that drove the pass returns -1 with it (cbm_launch_check, which then clears it) —
 // the host gets a cbm error instead of an abort().
 void cbm_launch_fail(const char* fmt, ...);
 int cbm_launch_check(void);   // 0 = no launch helper has failed; -1 = one has, cbm_last_error() carries its message

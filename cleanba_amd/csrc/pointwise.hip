@@ -320,13 +320,18 @@ __global__ __launch_bounds__(256) void perm_place_batch_kernel(const uint64_t* l
   const int e = blockIdx.z, job = e * rounds + r;
   perm_place_body(lists + (size_t)job * PERM_G * n, counts + job * PERM_G, n, in_base ? in_base + (size_t)e * n : nullptr, out_base + (size_t)e * n);
 }
+// does launch_permutations_batch take (n, ne)?  (the contexts that do size their buffers for it, the others keep the one-epoch sizes)
+bool permutation_batch_ok(int n, int ne) {
+  const int rounds = perm_rounds(n);
+  return ne >= 2 && rounds >= 1 && ne * rounds <= CBM_PERM_BATCH_MAX;
+}
 size_t permutation_batch_scratch_u64(int n, int ne) {
   const size_t jobs = (size_t)ne * perm_rounds(n);
   return jobs * PERM_G * (size_t)n + jobs * PERM_G / 2 + 64;
 }
 bool launch_permutations_batch(const uint32_t (*epoch_keys)[2], int ne, int n, int32_t* perms, int32_t* tmps, uint64_t* scratch, hipStream_t st) {
   const int rounds = perm_rounds(n), jobs = ne * rounds;
-  if (ne < 2 || rounds < 1 || jobs > CBM_PERM_BATCH_MAX) return false;
+  if (!permutation_batch_ok(n, ne)) return false;
   PermKeys keys;
   for (int e = 0; e < ne; ++e) {
     uint32_t k0 = epoch_keys[e][0], k1 = epoch_keys[e][1];

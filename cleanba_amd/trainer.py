@@ -225,105 +225,117 @@ def _rollout(key, args, algo, engine, writer, slot, world_size, process_index, s
         else:
             envs.async_reset()
 
-    for update in range(1, args.num_updates + 2):
-        if stop_event.is_set():
-            return
-        update_time_start = time.time()
-        env_recv_time = inference_time = storage_time = d2h_time = env_send_time = 0.0
-        t0 = time.time()
-        actor_policy_version = engine.actor_begin_rollout(slot, args.concurrency)  # params_queue.get() + ring slot
-        params_queue_get_time.append(time.time() - t0)
-        rollout_time_start = time.time()
-        if algo == "ppo":
-            nsteps = args.num_steps
-        else:
-            nsteps = args.num_steps + 1 if first_rollout else args.num_steps  # impala:327-329
-        step_inc = E * args.num_actor_threads * len_actor_device_ids * world_size
-        if device_env:
-            t1 = time.time()
-            engine.actor_rollout_device(slot, nsteps)
-            inference_time += time.time() - t1
-            global_step += nsteps * step_inc
-        else:
-            for _ in range(nsteps):
-                global_step += step_inc
-                if algo == "ppo":
-                    t1 = time.time()
-                    maybe_pin(next_obs)
-                    engine.actor_step_host(slot, next_obs, next_done, None, None, actions)
-                    inference_time += time.time() - t1
-                    t1 = time.time()
-                    next_obs, next_reward, next_done, info = envs.step(actions)
-                    env_send_time += time.time() - t1
-                    t1 = time.time()
-                    engine.actor_record_host(slot, next_reward)
-                else:
-                    t1 = time.time()
-                    next_obs, next_reward, next_done, info = envs.recv()
-                    env_recv_time += time.time() - t1
-                    t1 = time.time()
-                    maybe_pin(next_obs)
-                    engine.actor_step_host(slot, next_obs, next_done, info["elapsed_step"] == 0, next_reward, actions)
-                    inference_time += time.time() - t1
-                    t1 = time.time()
-                    envs.send(actions, info["env_id"])
-                    env_send_time += time.time() - t1
-                    t1 = time.time()
-                # episode bookkeeping of ppo:326-339 (same values; written with in-place numpy calls and, when the pool returns every env in id order
-                # — `env_id` is arange, checked once per array object —, without the gather / scatter through env_id)
-                env_id = info["env_id"]
-                if env_id is not ident_ids[0]:
-                    ident_ids[0], ident_ids[1] = env_id, bool(env_id.shape[0] == E and np.array_equal(env_id, arange_E))
-                truncated = info["elapsed_step"] >= envs.spec.config.max_episode_steps  # ppo:328
-                ended = (info["terminated"] + truncated) > 0
-                if ident_ids[1]:
-                    episode_returns += info["reward"]
-                    np.copyto(returned_episode_returns, episode_returns, where=ended)
-                    episode_returns[ended] = 0.0
-                    episode_lengths += 1
-                    np.copyto(returned_episode_lengths, episode_lengths, where=ended)
-                    episode_lengths[ended] = 0.0
-                else:
-                    episode_returns[env_id] += info["reward"]
-                    returned_episode_returns[env_id] = np.where(ended, episode_returns[env_id], returned_episode_returns[env_id])
-                    episode_returns[env_id] *= (1 - info["terminated"]) * (1 - truncated)
-                    episode_lengths[env_id] += 1
-                    returned_episode_lengths[env_id] = np.where(ended, episode_lengths[env_id], returned_episode_lengths[env_id])
-                    episode_lengths[env_id] *= (1 - info["terminated"]) * (1 - truncated)
-                storage_time += time.time() - t1
-        rollout_time.append(time.time() - rollout_time_start)
-        first_rollout = False
-
-        t0 = time.time()
-        if device_env or algo != "ppo":
-            engine.actor_commit(slot, None, None)
-        else:
-            engine.actor_commit(slot, next_obs, next_done)  # next_obs / next_done are still on the host (ppo:361-363)
-        rollout_queue_put_time.append(time.time() - t0)
-        if on_commit is not None:  # split topology: ship this slot's shards to the learner processes
-            on_commit(slot, update, engine.actor_ring_index(slot))
-
-        if update % args.log_frequency == 0:
-            if device_env:
-                avg_episodic_return, avg_len = engine.actor_episode_stats(slot)
+    try:
+        for update in range(1, args.num_updates + 2):
+            if stop_event.is_set():
+                return
+            update_time_start = time.time()
+            env_recv_time = inference_time = storage_time = d2h_time = env_send_time = 0.0
+            t0 = time.time()
+            actor_policy_version = engine.actor_begin_rollout(slot, args.concurrency)  # params_queue.get() + ring slot
+            params_queue_get_time.append(time.time() - t0)
+            rollout_time_start = time.time()
+            if algo == "ppo":
+                nsteps = args.num_steps
             else:
-                avg_episodic_return, avg_len = float(np.mean(returned_episode_returns)), float(np.mean(returned_episode_lengths))
-            if slot == 0:
-                print(f"global_step={global_step}, avg_episodic_return={avg_episodic_return}, rollout_time={np.mean(rollout_time)}")
-                print("SPS:", int(global_step / (time.time() - start_time)))
-            writer.add_scalar("stats/rollout_time", np.mean(rollout_time), global_step)
-            writer.add_scalar("charts/avg_episodic_return", avg_episodic_return, global_step)
-            writer.add_scalar("charts/avg_episodic_length", avg_len, global_step)
-            writer.add_scalar("stats/params_queue_get_time", np.mean(params_queue_get_time), global_step)
-            writer.add_scalar("stats/env_recv_time", env_recv_time, global_step)
-            writer.add_scalar("stats/inference_time", inference_time, global_step)
-            writer.add_scalar("stats/storage_time", storage_time, global_step)
-            writer.add_scalar("stats/d2h_time", d2h_time, global_step)
-            writer.add_scalar("stats/env_send_time", env_send_time, global_step)
-            writer.add_scalar("stats/rollout_queue_put_time", np.mean(rollout_queue_put_time), global_step)
-            writer.add_scalar("charts/SPS", int(global_step / (time.time() - start_time)), global_step)
-            writer.add_scalar("charts/SPS_update", int(E * args.num_steps * len_actor_device_ids * args.num_actor_threads * world_size /
-                                                       (time.time() - update_time_start)), global_step)
+                nsteps = args.num_steps + 1 if first_rollout else args.num_steps  # impala:327-329
+            step_inc = E * args.num_actor_threads * len_actor_device_ids * world_size
+            if device_env:
+                t1 = time.time()
+                engine.actor_rollout_device(slot, nsteps)
+                inference_time += time.time() - t1
+                global_step += nsteps * step_inc
+            else:
+                for _ in range(nsteps):
+                    global_step += step_inc
+                    if algo == "ppo":
+                        t1 = time.time()
+                        maybe_pin(next_obs)
+                        engine.actor_step_host(slot, next_obs, next_done, None, None, actions)
+                        inference_time += time.time() - t1
+                        t1 = time.time()
+                        next_obs, next_reward, next_done, info = envs.step(actions)
+                        env_send_time += time.time() - t1
+                        t1 = time.time()
+                        engine.actor_record_host(slot, next_reward)
+                    else:
+                        t1 = time.time()
+                        next_obs, next_reward, next_done, info = envs.recv()
+                        env_recv_time += time.time() - t1
+                        t1 = time.time()
+                        maybe_pin(next_obs)
+                        engine.actor_step_host(slot, next_obs, next_done, info["elapsed_step"] == 0, next_reward, actions)
+                        inference_time += time.time() - t1
+                        t1 = time.time()
+                        envs.send(actions, info["env_id"])
+                        env_send_time += time.time() - t1
+                        t1 = time.time()
+                    # episode bookkeeping of ppo:326-339 (same values; written with in-place numpy calls and, when the pool returns every env in id order
+                    # — `env_id` is arange, checked once per array object —, without the gather / scatter through env_id)
+                    env_id = info["env_id"]
+                    if env_id is not ident_ids[0]:
+                        ident_ids[0], ident_ids[1] = env_id, bool(env_id.shape[0] == E and np.array_equal(env_id, arange_E))
+                    truncated = info["elapsed_step"] >= envs.spec.config.max_episode_steps  # ppo:328
+                    ended = (info["terminated"] + truncated) > 0
+                    if ident_ids[1]:
+                        episode_returns += info["reward"]
+                        np.copyto(returned_episode_returns, episode_returns, where=ended)
+                        episode_returns[ended] = 0.0
+                        episode_lengths += 1
+                        np.copyto(returned_episode_lengths, episode_lengths, where=ended)
+                        episode_lengths[ended] = 0.0
+                    else:
+                        episode_returns[env_id] += info["reward"]
+                        returned_episode_returns[env_id] = np.where(ended, episode_returns[env_id], returned_episode_returns[env_id])
+                        episode_returns[env_id] *= (1 - info["terminated"]) * (1 - truncated)
+                        episode_lengths[env_id] += 1
+                        returned_episode_lengths[env_id] = np.where(ended, episode_lengths[env_id], returned_episode_lengths[env_id])
+                        episode_lengths[env_id] *= (1 - info["terminated"]) * (1 - truncated)
+                    storage_time += time.time() - t1
+            rollout_time.append(time.time() - rollout_time_start)
+            first_rollout = False
+
+            t0 = time.time()
+            if device_env or algo != "ppo":
+                engine.actor_commit(slot, None, None)
+            else:
+                engine.actor_commit(slot, next_obs, next_done)  # next_obs / next_done are still on the host (ppo:361-363)
+            rollout_queue_put_time.append(time.time() - t0)
+            if on_commit is not None:  # split topology: ship this slot's shards to the learner processes
+                on_commit(slot, update, engine.actor_ring_index(slot))
+
+            if update % args.log_frequency == 0:
+                if device_env:
+                    avg_episodic_return, avg_len = engine.actor_episode_stats(slot)
+                else:
+                    avg_episodic_return, avg_len = float(np.mean(returned_episode_returns)), float(np.mean(returned_episode_lengths))
+                if slot == 0:
+                    print(f"global_step={global_step}, avg_episodic_return={avg_episodic_return}, rollout_time={np.mean(rollout_time)}")
+                    print("SPS:", int(global_step / (time.time() - start_time)))
+                writer.add_scalar("stats/rollout_time", np.mean(rollout_time), global_step)
+                writer.add_scalar("charts/avg_episodic_return", avg_episodic_return, global_step)
+                writer.add_scalar("charts/avg_episodic_length", avg_len, global_step)
+                writer.add_scalar("stats/params_queue_get_time", np.mean(params_queue_get_time), global_step)
+                writer.add_scalar("stats/env_recv_time", env_recv_time, global_step)
+                writer.add_scalar("stats/inference_time", inference_time, global_step)
+                writer.add_scalar("stats/storage_time", storage_time, global_step)
+                writer.add_scalar("stats/d2h_time", d2h_time, global_step)
+                writer.add_scalar("stats/env_send_time", env_send_time, global_step)
+                writer.add_scalar("stats/rollout_queue_put_time", np.mean(rollout_queue_put_time), global_step)
+                writer.add_scalar("charts/SPS", int(global_step / (time.time() - start_time)), global_step)
+                writer.add_scalar("charts/SPS_update", int(E * args.num_steps * len_actor_device_ids * args.num_actor_threads * world_size /
+                                                           (time.time() - update_time_start)), global_step)
+    finally:
+        # page-locked observation buffers are un-registered before their arrays can be freed: a stale registration over recycled addresses makes a
+        # later upload from there fail with "invalid argument"
+        unregister = getattr(engine, "host_unregister", None)
+        for arr in pinned.values():
+            if arr is not None and unregister is not None:
+                try:
+                    unregister(arr)
+                except Exception:  # noqa: BLE001  (the context may already be gone on an error path)
+                    pass
+        pinned.clear()
 
 
 def schedules(args, algo, opt_count, n_steps):
