@@ -383,6 +383,9 @@ def secondary_values():
              "BASELINE configs[2]: IMPALA a0-l0-d1, V-trace, Nature-CNN bf16-MFMA forward / fp32 returns, 120 envs x 128 steps"),
             ("impala_fp32_t128", "impala", ["--network", "nature"], T, 5, 20, "IMPALA a0-l0-d1 fp32, 120 envs x 128 steps"),
             ("impala_fp32_t20", "impala", ["--network", "nature"], 20, 40, 40, "IMPALA a0-l0-d1 fp32 at the script's default num_steps = 20 (40 warm + 40 timed updates of ~2.7 ms)"),
+            ("ppo_nature_backward_split3", "ppo", ["--network", "nature", "--backward-split", "3"], T, 2, 8,
+             "EXTENSION, not the headline: configs[1] with the input-gradient GEMMs as three-term split-bf16 products on bf16 MFMA, fp32 accumulate "
+             "(cbm_config.backward_split = 3; gradients within 1e-7 of the fp32-MFMA path, tests/test_gpu_parity.py); forward and weight gradients stay fp32 MFMA"),
             ("ppo_resnet", "ppo", ["--network", "impala_resnet"], T, 2, 5, "PPO a0-l0-d1 with the IMPALA-ResNet torso (the CLI's default network, ppo:149-189), 120 envs x 128 steps")]
     out = {}
     for name, algo, extra, t, warm, n_up, what in rows:
@@ -413,7 +416,7 @@ def secondary_values():
         # executed flops per env-step of the ResNet PPO step (rollout forward + 4 epochs x (forward + input gradients except conv0's + weight gradients))
         r["executed_mflop_per_env_step"] = RESNET_EXEC_MFLOP_PER_ENV_STEP
         r["executed_frac_of_fp32_mfma_peak"] = round(r["value"] * RESNET_EXEC_MFLOP_PER_ENV_STEP * 1e6 / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)
-        r["per_kernel"] = "profiles/r04_resnet_roofline.md (tools/resnet_roofline.py over the rocprofv3 --kernel-trace of tools/rn_microbench.py: executed flops per launch from each kernel's geometry)"
+        r["per_kernel"] = "profiles/r05_resnet_roofline.md (tools/resnet_roofline.py over the rocprofv3 --kernel-trace of tools/rn_microbench.py: executed flops per launch from each kernel's geometry)"
     return out
 
 
@@ -459,6 +462,7 @@ def allreduce_ab(ctx, rdv, world, rank, iters=20):
     primary = ctx.comm_backend()
     one_device = os.environ.get("CBM_FORCE_DEVICE") is not None
     out, results = {"bytes": int(P * 4), "ranks": world, "iters": iters, "primary": primary}, {}
+    os.environ["CBM_NATIVE_TIMEOUT_S"] = os.environ.get("CBM_AB_TIMEOUT_S", "20")   # (read at every native launch: a stuck A/B costs seconds, not the default 120)
     for be in ("rccl", "native"):
         which = L.COMM_LEARNERS if be == primary else L.COMM_WORLD
         if be != primary:
@@ -472,13 +476,25 @@ def allreduce_ab(ctx, rdv, world, rank, iters=20):
                 out[be] = {"available": False, "why": "CBM_COMM_LOOPBACK run"}
                 continue
             ranks = list(range(world))
-            if be == "native":
-                blob = ctx.comm_native_export(which)
-                rdv.put(f"ab/native/{rank}", blob)
-                ctx.comm_native_init([blob if i == rank else bytes(rdv.get(f"ab/native/{i}")) for i in ranks], rank, which)
-            else:
-                uid = rdv.share("ab/uid", ctx.comm_unique_id, 0)
-                L.Context.comm_init(ctx, which, uid, world, rank)
+            err = ""
+            try:
+                if be == "native":
+                    blob = ctx.comm_native_export(which)
+                    rdv.put(f"ab/native/{rank}", blob)
+                    ctx.comm_native_init([blob if i == rank else bytes(rdv.get(f"ab/native/{i}")) for i in ranks], rank, which)
+                else:
+                    uid = rdv.share("ab/uid", ctx.comm_unique_id, 0)
+                    L.Context.comm_init(ctx, which, uid, world, rank)
+            except Exception as e:  # noqa: BLE001
+                err = f"rank {rank}: {type(e).__name__}: {e}"
+            # every rank learns whether EVERY rank brought the second backend up before anybody enters a collective on it (a rank that could not map
+            # a peer must not leave the others waiting inside a kernel)
+            rdv.put(f"ab/{be}/up/{rank}", err.encode() or b"ok")
+            ups = [bytes(rdv.get(f"ab/{be}/up/{i}")).decode() for i in ranks]
+            bad = [u for u in ups if u != "ok"]
+            if bad:
+                out[be] = {"available": False, "why": "could not be brought up on every rank: " + bad[0][:400]}
+                continue
         ctx.write("grads", pattern(rank))
         ctx.sync()
         ctx.comm_allreduce_grads(which)
