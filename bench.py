@@ -64,6 +64,30 @@ def _free_port():
 
 
 # --------------------------------------------------------------------------------------------- CPU baseline (same harness)
+def _cpu_budget():
+    """CPUs this process may actually use: os.cpu_count() capped by the cgroup's CPU quota (the GPU boxes of this pool show 256 cores and
+    a cpu.max of 16 CPUs: 64 OpenMP threads there are 64 threads time-sliced onto 16)."""
+    n = os.cpu_count() or 1
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except Exception:  # noqa: BLE001
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except Exception:  # noqa: BLE001
+            pass
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:  # noqa: BLE001
+        pass
+    return n, quota
+
+
 def cpu_baseline(n_envs=16, n_steps=32, updates=3, full_updates=3):
     """The CPU restatement (oracle/, kind "port") driven by the SAME host program as the GPU run — cleanba_amd.trainer.train with the
     oracle-backed engine (tests/oracle_engine.py) in place of the HIP library: same actor thread, same ring hand-off, same counters — on a
@@ -97,7 +121,8 @@ def cpu_baseline(n_envs=16, n_steps=32, updates=3, full_updates=3):
         dts = np.diff(np.array(stamps))          # the first update's completion is the start mark (warm-up: page-in, thread start)
         return float(n_envs * n_steps / np.median(dts)), [round(float(x), 3) for x in dts]
 
-    ncpu = os.cpu_count() or 1
+    ncpu_seen, quota = _cpu_budget()
+    ncpu = max(1, min(ncpu_seen, int(quota + 0.5))) if quota else ncpu_seen   # threads beyond the quota only time-slice
     # value: the benchmark's OWN configuration (E = 120 envs x T = 128 steps, 3840-frame minibatches) on all the cores the oracle's OpenMP-over-frames
     # can use, `full_updates` timed update interval(s) after one warm-up update (~10-20 s each)
     cores_full = max(1, min(ncpu, 64))
@@ -129,7 +154,8 @@ def cpu_baseline(n_envs=16, n_steps=32, updates=3, full_updates=3):
             "sample": f"the benchmark's configuration itself: same harness as the GPU run (cleanba_amd.trainer.train, actor thread + learner thread, "
                       f"--concurrency) on the oracle engine, PPO Nature-CNN fp32, {E} envs x {T} steps per rollout, 4 epochs x 4 minibatches of {MB} frames, "
                       f"host synthetic env; {full_updates} timed update interval(s) {dts_full} s after one warm-up update, {cores_full} OpenMP threads in the "
-                      f"learner (+1 actor thread) on {ncpu} host cores.  A timing of the C restatement, not of JAX.",
+                      f"learner (+1 actor thread); the host shows {ncpu_seen} cores" + (f" under a cgroup quota of {quota:g} CPUs" if quota else "") +
+                      ".  A timing of the C restatement, not of JAX.", "host_cpus_visible": ncpu_seen, "host_cpu_quota": quota,
             "reduced_sample": {"value": round(sps, 2), "cores": cores + 1, "estimate": True,
                                "note": f"{n_envs} envs x {n_steps} steps per rollout (128-frame minibatches cap OpenMP at {cores} threads): median of {updates} "
                                        f"update intervals {dts} s — small batches depress CPU efficiency; NOT the benchmark's configuration"},

@@ -26,6 +26,18 @@ extern "C" int cbm_debug_conv1_trace(unsigned long long* out) { return hipMemcpy
 #define C1T(k) do { } while (0)
 #endif
 
+// timing build only (-DCBM_BLOCK_TRACE): start / end wall-clock stamps (100 MHz, one clock for the whole chip) of EVERY block of the last launch of
+// the two conv1 kernels (tools/block_trace.py: how unevenly do a persistent kernel's blocks finish beside the rollout?)
+#ifdef CBM_BLOCK_TRACE
+__device__ unsigned long long cbm_block_trace_c1[2][512][2];
+extern "C" int cbm_debug_block_trace_conv1(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(cbm_block_trace_c1), sizeof(cbm_block_trace_c1)) == hipSuccess ? 0 : -1; }
+#define BT_START(k) do { if (threadIdx.x == 0 && blockIdx.x < 512) cbm_block_trace_c1[k][blockIdx.x][0] = wall_clock64(); } while (0)
+#define BT_END(k) do { if (threadIdx.x == 0 && blockIdx.x < 512) cbm_block_trace_c1[k][blockIdx.x][1] = wall_clock64(); } while (0)
+#else
+#define BT_START(k) do { } while (0)
+#define BT_END(k) do { } while (0)
+#endif
+
 static __device__ __forceinline__ float relu_(float v) { return v > 0.0f ? v : 0.0f; }
 
 // async global -> LDS copy of one 16-byte piece per lane (global_load_lds_dwordx4): the LDS destination is the
@@ -55,6 +67,7 @@ static __device__ __forceinline__ void frame_to_lds(const uint8_t* frame, unsign
 __global__ __launch_bounds__(256, 2) void conv1_fwd_planes_kernel(const uint8_t* obs, const int32_t* idx, const float* W, const float* bias,
                                                                   float* out, uint32_t* mask, int S, int frames_per_block) {
   __shared__ __attribute__((aligned(16))) float smem_f[256 * 32 + 2 * 84 * 42];
+  BT_START(0);
   float* Wl = smem_f;                 // [256][32]
   float* Pf = smem_f + 256 * 32;      // [2][84][42]
   const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, h = lane >> 5;
@@ -200,6 +213,7 @@ __global__ __launch_bounds__(256, 2) void conv1_fwd_planes_kernel(const uint8_t*
     }
     C1T(21);
   }
+  BT_END(0);
 }
 
 void launch_conv1_fwd_frames(const uint8_t* obs, const int32_t* idx, const float* W, const float* bias, float* out, uint32_t* mask, int S,
@@ -220,6 +234,7 @@ void launch_conv1_fwd_frames(const uint8_t* obs, const int32_t* idx, const float
 __global__ __launch_bounds__(256, 2) void conv1_wgrad_frames_kernel(const uint8_t* obs, const int32_t* idx, const float* dy, float* part,
                                                                     float* bpart, int S, int frames_per_block) {
   __shared__ __attribute__((aligned(16))) unsigned char F[FR];
+  BT_START(1);
   const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int s_lo = blockIdx.x * frames_per_block, s_hi = min(S, s_lo + frames_per_block);
@@ -280,6 +295,7 @@ __global__ __launch_bounds__(256, 2) void conv1_wgrad_frames_kernel(const uint8_
     bs += __shfl_xor(bs, 32, 64);
     if (h == 0) bpart[blockIdx.x * 32 + li] = bs;
   }
+  BT_END(1);
 }
 
 // Split-bf16 flavour (cbm_config.backward_split): pixels are integers 0..255, exact in bf16, so only dY needs splitting (two terms):

@@ -12,6 +12,12 @@
 #include "cbm_internal.h"
 // (Tile order: igemm.h ORDER 2 — the four parity classes of a conv2 dgrad pixel tile back to back on one XCD — is what the merged position-major
 // conv2 dgrad does by construction; ORDER 1 for the weight-gradient tap tiles measured slower and is gone with the im2col wgrads.)
+#ifdef CBM_BLOCK_TRACE   // timing build: wall-clock stamps of every block of the last igemm_dma_kernel launch (the dense forward), tools/block_trace.py
+__device__ unsigned long long cbm_block_trace_dma[512][2];
+extern "C" int cbm_debug_block_trace_dma(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(cbm_block_trace_dma), sizeof(cbm_block_trace_dma)) == hipSuccess ? 0 : -1; }
+#define IG_BT_START() do { if (threadIdx.x == 0 && blockIdx.x < 512) cbm_block_trace_dma[blockIdx.x][0] = wall_clock64(); } while (0)
+#define IG_BT_END() do { if (threadIdx.x == 0 && blockIdx.x < 512) cbm_block_trace_dma[blockIdx.x][1] = wall_clock64(); } while (0)
+#endif
 #include "igemm.h"
 #include "env_model.h"
 #include "ppo_loss.h"

@@ -22,6 +22,10 @@
 #include <stdint.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+#ifndef IG_BT_START   // timing builds (-DCBM_BLOCK_TRACE, gemm_layers.hip) stamp every block's start / end in igemm_dma_kernel
+#define IG_BT_START() do { } while (0)
+#define IG_BT_END() do { } while (0)
+#endif
 // Functors with KSKIP = true give every x-tile its own compressed reduction range: block_ctx(x0, cls) packs what the block needs,
 // block_k(ctx) is the length of its range, r_map(ctx, r) turns a chunk-aligned compressed r into the real one (the chunk never
 // straddles a 64-wide tap).  Used by the position-major dgrads, whose border tiles multiply only the taps that can be non-zero.
@@ -734,6 +738,7 @@ __global__ __launch_bounds__(256, P::Tile::MINW) void igemm_dma_kernel(const P p
   __shared__ __attribute__((aligned(16))) float smem[NST * (ASZ + BSZ)];
   float* As = smem;
   float* Bs = smem + NST * ASZ;
+  IG_BT_START();
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, h = lane >> 5;
@@ -839,6 +844,7 @@ __global__ __launch_bounds__(256, P::Tile::MINW) void igemm_dma_kernel(const P p
         p.store(x0 + wx * (BX / WX) + i * 32 + row, y, acc[i][j][e], z, 0);
       }
     }
+  IG_BT_END();
 }
 
 template <class P>
