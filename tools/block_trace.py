@@ -66,11 +66,16 @@ rollout(); ctx.sync()
 rollout()
 update(); ctx.sync()
 report("alone", read())
-# beside the rollout: bench.py's order (rollout u+1 enqueued before update u), several steps, the stamps of the LAST launches
+# beside the rollout: a rollout is enqueued (640 launches, ~6.5 ms alone), then the first minibatches of an update through the split API; the stamps
+# read back are those of minibatch 2, launched ~4 ms into the rollout
 for rep in range(3):
-    for _ in range(3):
-        rollout(); update()
+    rollout()                      # (rollout u+1: its parameters exist, its ring entry is free)
+    ctx.learner_wait()
+    k = ctx.learner_prepare(lkey)
+    k = ctx.learner_epoch_begin(k)
+    for mb in range(3):
+        ctx.learner_minibatch_grad(0, mb)
     ctx.sync()
-    report("pipelined", read())
-    update(); ctx.sync()   # drain the extra committed rollout so that the next round starts in the same state
-    rollout()
+    report("beside", read())
+    ctx.learner_finish(n_opt, want_stats=False)     # (no optimizer steps were taken: the stamps are all this loop is for) version + ring entry advance
+    ctx.sync()
