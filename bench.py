@@ -409,6 +409,9 @@ def secondary_values():
              "BASELINE configs[2]: IMPALA a0-l0-d1, V-trace, Nature-CNN bf16-MFMA forward / fp32 returns, 120 envs x 128 steps"),
             ("impala_fp32_t128", "impala", ["--network", "nature"], T, 5, 20, "IMPALA a0-l0-d1 fp32, 120 envs x 128 steps"),
             ("impala_fp32_t20", "impala", ["--network", "nature"], 20, 40, 40, "IMPALA a0-l0-d1 fp32 at the script's default num_steps = 20 (40 warm + 40 timed updates of ~2.7 ms)"),
+            ("ppo_nature_backward_split2", "ppo", ["--network", "nature", "--backward-split", "2"], T, 2, 8,
+             "EXTENSION, not the headline: configs[1] with the backward GEMMs as two-term split-bf16 products on bf16 MFMA, fp32 accumulate "
+             "(cbm_config.backward_split = 2; gradients within 1.2e-6 of the fp32-MFMA path); the forward stays fp32 MFMA, bit-exact"),
             ("ppo_nature_backward_split3", "ppo", ["--network", "nature", "--backward-split", "3"], T, 2, 8,
              "EXTENSION, not the headline: configs[1] with the input-gradient GEMMs as three-term split-bf16 products on bf16 MFMA, fp32 accumulate "
              "(cbm_config.backward_split = 3; gradients within 1e-7 of the fp32-MFMA path, tests/test_gpu_parity.py); forward and weight gradients stay fp32 MFMA"),
