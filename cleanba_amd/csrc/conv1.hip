@@ -372,7 +372,14 @@ __global__ __launch_bounds__(256, 2) void conv1_wgrad_frames_split_kernel(const 
   }
 }
 
-static const int C1W_BLOCKS = 768;   // 3840-frame minibatch: 5 frames per block; 225 vs 233 us for 1024 blocks (and 25 MB of partials instead of 31)
+// 3840-frame minibatch: 1280 blocks of 3 frames.  Alone 768 blocks of 5 frames were the fastest (225 us against 233 for 1024, and 25 MB of partials
+// instead of 42), but beside the rollout the blocks of a grid that is resident all at once end 180-267 us after the first start (the CUs that also host
+// actor blocks run theirs slower; tools/block_trace.py) and the kernel waits for the slowest: with a second, dynamically dispatched wave of shorter
+// blocks the step is 0.3 ms shorter (pipelined 33.55 -> 33.23 ms, threaded 33.11 -> 32.82, three A/B rounds; 960 / 1024 / 1920 blocks: no gain).
+#ifndef CBM_C1W_BLOCKS
+#define CBM_C1W_BLOCKS 1280
+#endif
+static const int C1W_BLOCKS = CBM_C1W_BLOCKS;
 int conv1_wgrad_frames_splits(int S) {
   int blocks = C1W_BLOCKS;
   if (S < blocks) blocks = S;
