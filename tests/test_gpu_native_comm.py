@@ -171,3 +171,19 @@ def test_configs3_a0_l123_full_size_on_one_gpu(tmp_path):
     assert np.abs(o0["params"] - o0["p0"]).max() > 1e-4
     np.testing.assert_allclose(l0["stats"], o0["stats"], rtol=1e-5, atol=1e-7)
     assert np.median(d) <= 1e-7 and np.quantile(d, 0.9999) <= 5e-6 and d.max() <= 1e-5, (np.median(d), np.quantile(d, 0.9999), d.max())
+
+
+def test_export_windows_survive_repeated_create_map_free_cycles_in_the_same_processes():
+    """Round 4's red driver run: `bench.py --gpus 8` freed the gradient buffers of its data-parallel phase while peers still mapped them, and the SAME
+    processes' next exports (the topology phase) could not be mapped ("hipIpcOpenMemHandle: invalid device pointer").  tools/ipc_stress.py cycles
+    four processes six times through create -> export windows -> map every peer -> native all-reduce -> unmap -> barrier -> free (the order the product
+    keeps now); with the round-4 order ('racy') the second cycle fails on this stack."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "ipc_stress.py"), "4", "6", "safe"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       timeout=300)
+    out = p.stdout.decode()
+    assert p.returncode == 0 and "FAIL" not in out, out[-3000:]
+    assert out.count("6 cycles ok, 0 failure(s)") == 4, out[-3000:]

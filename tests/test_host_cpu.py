@@ -389,3 +389,19 @@ def test_trainer_page_locks_an_observation_buffer_the_env_reuses(monkeypatch, tm
     monkeypatch.setattr(trainer, "make_env", fresh)
     trainer.train(parse_args(argv, "ppo"), "ppo", engine_factory=Eng)
     assert calls == []
+
+
+def test_rendezvous_gives_a_reused_prefix_fresh_keys():
+    """a second run of the same process under the same prefix must not inherit the first run's keys (a sticky 'abort', barrier counters
+    already at `world`)."""
+    from cleanba_amd import topology
+    port = _free_port()
+    a = topology.Rendezvous(1, 0, "127.0.0.1", port, timeout_s=20.0, prefix="same")
+    a.put("k", b"1")
+    a.abort("first run failed")
+    a.barrier("b")
+    b = topology.Rendezvous(1, 0, "127.0.0.1", port, timeout_s=20.0, prefix="same")
+    assert not b.store.check(["k"]) and not b.store.check(["abort"])
+    b.barrier("b")                      # would hang on the stale counter under a shared prefix
+    b.put("k", b"2")
+    assert bytes(a.get("k")) == b"1" and bytes(b.get("k")) == b"2"
