@@ -382,7 +382,9 @@ __global__ __launch_bounds__(256, 2) void conv1_wgrad_frames_split_kernel(const 
 static const int C1W_BLOCKS = CBM_C1W_BLOCKS;
 int conv1_wgrad_frames_splits(int S) {
   int blocks = C1W_BLOCKS;
-  if (S < blocks) blocks = S;
+  if ((S + 2) / 3 < blocks) blocks = (S + 2) / 3;   // at least three frames per block: a partial per frame (1280-frame minibatches of a three-learner
+                                                    // split) only lengthens the fp32 chain of the partial reduction
+  if (blocks < 1) blocks = 1;
   const int fpb = (S + blocks - 1) / blocks;
   return (S + fpb - 1) / fpb;
 }
