@@ -381,10 +381,10 @@ __global__ __launch_bounds__(256, 2) void conv1_wgrad_frames_split_kernel(const 
 #endif
 static const int C1W_BLOCKS = CBM_C1W_BLOCKS;
 int conv1_wgrad_frames_splits(int S) {
-  int blocks = C1W_BLOCKS;
-  if ((S + 2) / 3 < blocks) blocks = (S + 2) / 3;   // at least three frames per block: a partial per frame (1280-frame minibatches of a three-learner
-                                                    // split) only lengthens the fp32 chain of the partial reduction
-  if (blocks < 1) blocks = 1;
+  // below 2048 frames (IMPALA's 21 x 30, the 1280-frame minibatches of a three-learner split) the round-4 rule stays: at most 768 blocks — those
+  // launches fit one wave either way, and more partials only lengthen the fp32 chain of the partial reduction
+  int blocks = S >= 2048 ? C1W_BLOCKS : (C1W_BLOCKS < 768 ? C1W_BLOCKS : 768);
+  if (S < blocks) blocks = S;
   const int fpb = (S + blocks - 1) / blocks;
   return (S + fpb - 1) / fpb;
 }
