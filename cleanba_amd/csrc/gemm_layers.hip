@@ -1310,6 +1310,12 @@ static void conv3_order_build(NatureWs& ws, int S, int BX, hipStream_t st) {
   ws.c3_order_S = S;
 }
 
+// dense input gradient on 128x64 tiles (1470 blocks, three dispatch waves) instead of 128x128 (750 blocks, one and a half): 7 us slower alone (125 vs
+// 118), 13 us faster beside the rollout (156 -> 143), step -0.03 ... -0.19 ms in five A/B pairs — shorter blocks in more waves suffer less from the CUs the
+// rollout slows down (tools/block_trace.py)
+#ifndef CBM_DD_TILE
+#define CBM_DD_TILE T128x64
+#endif
 void nature_backward(const NatureLayout& L, const float* P, const uint8_t* obs, const int32_t* idx, int B, NatureWs& ws, float* grads,
                      hipStream_t st) {
   if (L.kind == CBM_NET_IMPALA_RESNET) { resnet_backward(L, P, obs, idx, B, ws, grads, st); return; }
@@ -1335,7 +1341,7 @@ void nature_backward(const NatureLayout& L, const float* P, const uint8_t* obs, 
   }
   // dense: dgrad -> dact3pad, wgrad
   {
-    DenseDgrad<T128x128k16> pd{ws.dhid, P + L.w[3], ws.act3, ws.dact3pad, B, ws.mask3};
+    DenseDgrad<CBM_DD_TILE> pd{ws.dhid, P + L.w[3], ws.act3, ws.dact3pad, B, ws.mask3};
     plaunch_bwd(ws, K_DENSE_DGRAD, pd, 1, st);
     // split-bf16 mode: the staging of a tile is the bottleneck, so it wants the bigger 128x64 tile (and more splits to fill the chip)
     const int nz = ws.bwd_split == 2 ? (B >= 2048 ? 4 : 1) : (dense_wgrad_dma_slices(B) ? dense_wgrad_dma_slices(B) : dense_wgrad_splits(B));
