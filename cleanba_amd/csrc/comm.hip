@@ -166,7 +166,8 @@ static int cbm_ipc_map(cbm_ctx* c, const WinBlob& b, const char* what, void** ba
     return 0;
   }
   std::lock_guard<std::mutex> lk(g_ipc_mu);
-  const std::string key((const char*)b.handle, CBM_IPC_HANDLE_BYTES);
+  std::string key((const char*)b.handle, CBM_IPC_HANDLE_BYTES);
+  key.push_back((char)c->cfg.device);   // a mapping is made for the importing context's GPU: contexts of one process on different GPUs each make their own
   for (IpcMapping& m : g_ipc_maps)
     if (m.handle == key) { m.refs += 1; *base = m.base; *mapped = true; return 0; }
   hipIpcMemHandle_t h;
