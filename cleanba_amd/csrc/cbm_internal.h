@@ -13,6 +13,30 @@ static __device__ __forceinline__ int cbm_opaque_vgpr(int x) { asm volatile("" :
 
 #define CBM_FRAME 28224  // 4*84*84 uint8
 
+// global -> LDS copy by the load unit (global_load_lds_dwordx4: 16 bytes per lane to wave-uniform LDS byte address + lane * 16), issued from inline
+// asm so that hipcc does NOT know it writes LDS.  Through __builtin_amdgcn_global_load_lds the compiler tracks the copy as a pending LDS store and puts
+// `s_waitcnt vmcnt(0)` in front of the next ds_read it cannot tell apart from it — whether it can depends on memory-operand bookkeeping that changes
+// with unrelated edits (a second __shared__ object, two reads merged into a ds_read2st64): in round 5's frame-resident weight gradients that wait sat
+// between "issue the copy of frame s+1" and "multiply frame s", i.e. the double buffer never overlapped anything (tools/isa_audit.py lists such
+// waits).  Hidden, the copy is ordered ONLY by the kernel's own `s_waitcnt vmcnt(N)` + barrier; the "memory" clobber keeps the compiler's LDS
+// accesses on their side of the statement, and a copy the compiler does not count only makes its own vmcnt waits for ordinary loads more
+// conservative (the counter retires in order).  M0 is saved and restored inside the statement (cdna_hip_programming.md section 5.7).
+static __device__ __forceinline__ uint32_t cbm_lds_addr(const void* lds_ptr) {
+  return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)lds_ptr;
+}
+static __device__ __forceinline__ void cbm_glds16_hidden(const void* g_lane, uint32_t lds_byte_addr_wave) {
+  uint32_t keep;
+  const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_byte_addr_wave);
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(g_lane), "s"(dst) : "memory");
+}
+static __device__ __forceinline__ void cbm_glds4_hidden(const void* g_lane, uint32_t lds_byte_addr_wave) {   // 4 bytes per lane (256-byte copies)
+  uint32_t keep;
+  const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_byte_addr_wave);
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(g_lane), "s"(dst) : "memory");
+}
+
 // ---- parameter layout (flax shapes): Nature-CNN ------------------------------
 struct NatureLayout {
   int A;

@@ -25,8 +25,10 @@ template <int N> static __device__ __forceinline__ void dw_wait_vm() { asm volat
 __global__ __launch_bounds__(256, 2) void dense_wgrad_dma_kernel(const float* __restrict__ A, const float* __restrict__ G, float* __restrict__ part,
                                                                  float* __restrict__ bpart, int F, int X, int Y, int fslice) {
   constexpr int ASZ = DW_BM * DW_BK, BSZ = DW_BN * DW_BK, DA = ASZ / 256 / 4, DB = BSZ / 256 / 4, DPW = DA + DB;   // 1 KiB copies per wave and chunk
+  // ONE LDS object: with a second one (round 5 had `__shared__ float bred[256]` for the bias sums) hipcc cannot tell the fragment reads from the copies
+  // in flight and puts `s_waitcnt vmcnt(0)` in front of the first ds_read of every chunk — the three-stage ring then waits for the copy it has just
+  // issued (tools/isa_audit.py; cdna_hip_programming.md section 5, ".s-level traps" (a)): 130 us instead of the 111 the same loop ran in tools/ubench/gemm2.hip
   __shared__ __attribute__((aligned(16))) float smem[DW_ST * (ASZ + BSZ)];
-  __shared__ float bred[256];
   const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wx = wave >> 1, wy = wave & 1;
@@ -104,6 +106,7 @@ __global__ __launch_bounds__(256, 2) void dense_wgrad_dma_kernel(const float* __
       }
     }
   if (do_bias) {
+    float* bred = smem;      // the ring is free: every chunk has been multiplied
     __syncthreads();
     bred[tid] = bsum;
     __syncthreads();

@@ -875,6 +875,26 @@ struct Conv2DgradMergedPos {
     const int kh = (cls >> 1) + 2 * (1 - jh), kw = (cls & 1) + 2 * (1 - jw);
     return *reinterpret_cast<const float4*>(W + ((size_t)(kh * 4 + kw) * 32 + ci) * 64 + co);
   }
+  // row / chunk split of the same addresses (igemm.h ROWPTR; a 16-wide chunk never leaves one 64-wide tap): the generic load_a above decodes
+  // (frame, ihh, iwh) with two integer divisions for every 16-byte load of every chunk — 4.46 VALU instructions per MFMA in round 5's counters
+  static constexpr bool ROWPTR = 64 % TileT::BR == 0;
+  __device__ const float* a_origin() const { return dypad; }
+  __device__ const float* b_origin() const { return W; }
+  __device__ uint32_t a_off(int x, int rl, int) const {
+    int s, ihh, iwh;
+    decode(x, s, ihh, iwh);
+    s = min(s, S - 1);
+    return (uint32_t)(((s * 11 + ihh) * 11 + iwh) * 64 + rl);
+  }
+  __device__ uint32_t a_chunk(int r0) const { return (uint32_t)((r0 >> 7) * (11 * 64) + (r0 & 127)); }
+  __device__ uint32_t b_off(int rl, int y, int) const {        // B[r .. r+3][y] = W[kh][kw][ci][co .. co+3]: the class part of (kh, kw) and ci belong to the row
+    const int cls = y >> 5, ci = y & 31;
+    return (uint32_t)((((cls >> 1) * 4 + (cls & 1)) * 32 + ci) * 64 + rl);
+  }
+  __device__ uint32_t b_chunk(int r0) const {                  // the tap part of (kh, kw) = (2 (1 - jh), 2 (1 - jw)) and the chunk's first co
+    const int jh = r0 >> 7, jw = (r0 >> 6) & 1;
+    return (uint32_t)(((2 * (1 - jh)) * 4 + 2 * (1 - jw)) * 32 * 64 + (r0 & 63));
+  }
   __device__ size_t pixel(int x, int cls, bool& ok) const {
     int s, ihh, iwh;
     decode(x, s, ihh, iwh);

@@ -454,6 +454,10 @@ __global__ __launch_bounds__(256, P::Tile::MINW) void igemm_pf2_kernel(const P p
     }
   };
 
+  // (Round 6 measured the prefetches made unconditional — with `if (c + 2 < nchunk)` hipcc's wait in front of the staging store is the conservative
+  // merge of two paths, `vmcnt(1)` / `vmcnt(0)` where `vmcnt(NV..)` would do (tools/isa_audit.py) — and it changed nothing: the loads of chunk c+2
+  // are a whole chunk of MFMAs old by then.  dense / conv3 / conv2 input gradients 125.0 / 144.7 / 224.3 -> 126.8 / 145.4 / 223.5 us, the actor's
+  // small-batch kernels slower (rollout alone 6.52 -> 6.7-6.8 ms: two more chunk loads per block).  Not kept: profiles/r06_isa_fixes_ab.txt.)
   float4 a0[NVA], b0[NVB], a1[NVA], b1[NVB];
   gload(0, a0, b0);
   sstore(0, a0, b0);

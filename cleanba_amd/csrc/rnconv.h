@@ -761,9 +761,8 @@ struct RnW2Geom {
   static int strips(int B) { return NF == 1 ? B * STRIPS : (B + NF - 1) / NF; }
 };
 
-static __device__ __forceinline__ void rn_glds16(const void* g_lane, void* lds_wave_base) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g_lane, (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
+// (hidden from the compiler, cbm_internal.h: through the builtin hipcc waited for the copy of strip s+1 in front of the sweep of strip s)
+static __device__ __forceinline__ void rn_glds16(const void* g_lane, void* lds_wave_base) { cbm_glds16_hidden(g_lane, cbm_lds_addr(lds_wave_base)); }
 
 template <class WG, bool RELU_PASS>
 __global__ __launch_bounds__(WG::NW * 64, 1) void rn_wgrad2_kernel(const float* in, const float* dy, float* part, float* bpart, int B, int nstrips) {

@@ -17,10 +17,9 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-static __device__ __forceinline__ void glds16(const void* g_lane, void* lds_wave_base) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g_lane, (__attribute__((address_space(3))) void*)lds_wave_base,
-                                   16, 0, 0);
-}
+// (hidden from the compiler: with the builtin, hipcc waited vmcnt(0) for the copy of frame s+1 in front of the first fragment read of frame s —
+// cbm_internal.h cbm_glds16_hidden, tools/isa_audit.py)
+static __device__ __forceinline__ void glds16(const void* g_lane, void* lds_wave_base) { cbm_glds16_hidden(g_lane, cbm_lds_addr(lds_wave_base)); }
 // linear copy of `pieces` 16-byte pieces global -> LDS with all 4 waves (wave-uniform LDS base + lane * 16)
 template <int PIECES>
 static __device__ __forceinline__ void slab_to_lds(const float* src, float* dst, int wave, int lane) {

@@ -34,8 +34,13 @@ def is_atari57_mix(env_id):
 
 
 class SyntheticAtariEnv:
-    def __init__(self, env_id="Breakout-v5", num_envs=8, seed=1, max_episode_steps=ATARI_MAX_FRAMES, num_actions=18, batch_size=None, **_):
+    def __init__(self, env_id="Breakout-v5", num_envs=8, seed=1, max_episode_steps=ATARI_MAX_FRAMES, num_actions=18, batch_size=None,
+                 reuse_buffers=False, **_):
         self.env_id, self.num_envs, self.seed = env_id, int(num_envs), int(seed)
+        # reuse_buffers=False (default, the envpool contract): every step() returns arrays nobody else writes again — a reference-style rollout keeps
+        # 128 steps of them (ppo:329-342).  True (what the trainer's own loop asks for: it copies a step's results into the ring at once): results
+        # live in OBS_RING rotating slots and are overwritten OBS_RING - 1 steps later.
+        self.reuse_buffers = bool(reuse_buffers)
         self.batch_size = int(batch_size or num_envs)   # envpool async mode: recv() hands back this many envs (naturecnn:119-125)
         assert 0 < self.batch_size <= self.num_envs
         self.action_space = _Space(n=num_actions)
@@ -65,19 +70,26 @@ class SyntheticAtariEnv:
         # than the previous step's; a slot's content stays valid for OBS_RING - 1 further steps): no 3.4 MB allocation — mmap, page faults,
         # munmap — on the step's critical path, which two actor threads of one process would serialise on the kernel's address-space lock, and the
         # slots' addresses are taken once (a numpy -> pointer conversion is 1-3 us of GIL time, a step passes ten).
+        n = self.num_envs
+
+        def slot():
+            arrs = (np.empty_like(self._obs), np.zeros(n, np.float32), np.zeros(n, np.uint8), np.zeros(n, np.uint8), np.zeros(n, np.int32))
+            ptrs = tuple(a.ctypes.data for a in arrs)
+            arrs[0].flags.writeable = False   # handed out read-only (the env itself writes through the address): it is next step's older planes
+            return arrs, ptrs
         if self._ring is None:
-            n = self.num_envs
-            self._ring = []
-            for _ in range(self.OBS_RING):
-                arrs = (np.empty_like(self._obs), np.zeros(n, np.float32), np.zeros(n, np.uint8), np.zeros(n, np.uint8), np.zeros(n, np.int32))
-                self._ring.append((arrs, tuple(a.ctypes.data for a in arrs)))
+            self._ring = [slot() for _ in range(self.OBS_RING)] if self.reuse_buffers else []
             self._ring_i = 0
             self._fn = L.load().cbm_synth_env_step_host_to
             self._st_p = C.addressof(self._st)
             self._seed32 = int(self.seed) & 0xFFFFFFFF
             self._obs_p = self._obs.ctypes.data
-        (out, r, d, term, el), (out_p, r_p, d_p, term_p, el_p) = self._ring[self._ring_i]
-        self._ring_i = (self._ring_i + 1) % self.OBS_RING
+        if self.reuse_buffers:
+            (out, r, d, term, el), (out_p, r_p, d_p, term_p, el_p) = self._ring[self._ring_i]
+            self._ring_i = (self._ring_i + 1) % self.OBS_RING
+        else:
+            (out, r, d, term, el), (out_p, r_p, d_p, term_p, el_p) = slot()
+        actions = np.asarray(actions)   # (lists and foreign array types, as envpool takes them)
         a = actions if actions.dtype == np.int32 and actions.flags.c_contiguous else np.ascontiguousarray(actions, np.int32)
         if self._fn(self._seed32, self.num_envs, int(self.spec.config.max_episode_steps), a.ctypes.data, self._st_p, self._obs_p, out_p, r_p, d_p,
                     term_p, el_p) != 0:
@@ -160,7 +172,7 @@ class SyntheticAtariEnv:
         self._st = None
 
 
-def make_env(env_id, seed, num_envs, backend="host", num_actions=18, async_batch_size=None):
+def make_env(env_id, seed, num_envs, backend="host", num_actions=18, async_batch_size=None, reuse_buffers=False):
     """Same thunk contract as the reference's make_env (ppo:126-146); async_batch_size = envpool's batch_size (naturecnn:119-125)."""
     def thunk():
         if backend == "envpool":
@@ -173,5 +185,5 @@ def make_env(env_id, seed, num_envs, backend="host", num_actions=18, async_batch
             envs.single_observation_space = envs.observation_space
             envs.is_vector_env = True
             return envs
-        return SyntheticAtariEnv(env_id, num_envs, seed, num_actions=num_actions, batch_size=async_batch_size)
+        return SyntheticAtariEnv(env_id, num_envs, seed, num_actions=num_actions, batch_size=async_batch_size, reuse_buffers=reuse_buffers)
     return thunk

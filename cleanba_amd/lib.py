@@ -198,7 +198,7 @@ class Context:
         _chk(self.lib.cbm_ctx_create(C.byref(cfg), C.byref(h)))
         self.h = h
         self.A = cfg.num_actions
-        self._ao = (None, 0)   # (the caller's action array of the last host step, its address)
+        self._ao = {}          # slot -> (that actor thread's action array of its last host step, its address)
         self.P = param_count(cfg.network, cfg.num_actions, cfg.hiddens[0] if cfg.network == NET_IMPALA_RESNET else 0)
 
     def close(self):
@@ -263,16 +263,20 @@ class Context:
             actions_out = np.empty(E, np.int32)
         # per-step call of the envpool-API loop: everything here runs under the GIL, so addresses of arrays that come back every step (the
         # caller's action buffer) are cached and the rest is taken with one attribute read each
-        if actions_out is not self._ao[0]:
+        # (per SLOT, and read into a local: several actor threads step the same context, each with its own buffer — one shared field let a thread
+        # switch between the check and the call hand thread A's call thread B's buffer)
+        ao = self._ao.get(slot)
+        if ao is None or actions_out is not ao[0]:
             assert actions_out.dtype == np.int32 and actions_out.flags.c_contiguous and actions_out.size >= E
-            self._ao = (actions_out, actions_out.ctypes.data)
+            ao = (actions_out, actions_out.ctypes.data)
+            self._ao[slot] = ao
         if obs.dtype != np.uint8 or not obs.flags.c_contiguous:
             obs = np.ascontiguousarray(obs, np.uint8)
         done = done.view(np.uint8) if done.dtype == np.bool_ and done.flags.c_contiguous else np.ascontiguousarray(done, np.uint8)
         fs = None if firststep is None else np.ascontiguousarray(firststep, np.uint8)
         rw = None if reward_with_obs is None else np.ascontiguousarray(reward_with_obs, np.float32)
         _chk(self.lib.cbm_actor_step_host(self.h, int(slot), obs.ctypes.data, done.ctypes.data, None if fs is None else fs.ctypes.data,
-                                          None if rw is None else rw.ctypes.data, self._ao[1]))
+                                          None if rw is None else rw.ctypes.data, ao[1]))
         return actions_out
 
     def actor_step_async(self, slot, obs, reward, done, env_id, actions_out=None):

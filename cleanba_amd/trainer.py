@@ -180,7 +180,8 @@ def _rollout(key, args, algo, engine, writer, slot, world_size, process_index, s
         from .envs import is_atari57_mix
         engine.actor_env_reset_device(slot, env_seed, is_atari57_mix(args.env_id))
     else:
-        envs = make_env(args.env_id, env_seed, E, backend=args.env_backend, num_actions=args.num_actions)()
+        # (reuse_buffers: this loop hands every step's results to the engine before the next step — the twin may rotate its result buffers)
+        envs = make_env(args.env_id, env_seed, E, backend=args.env_backend, num_actions=args.num_actions, reuse_buffers=True)()
     global_step = 0
     start_time = time.time()
     episode_returns = np.zeros((E,), dtype=np.float32)
