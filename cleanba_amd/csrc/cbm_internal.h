@@ -30,6 +30,14 @@ static __device__ __forceinline__ void cbm_glds16_hidden(const void* g_lane, uin
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(g_lane), "s"(dst) : "memory");
 }
+// write-through (sc1) 4-byte store: the value leaves this XCD's L2 at once — what a workgroup of the same launch on another XCD can read with an sc1 load
+#ifndef AF_ABL   // timing builds only (tools/variants.sh): 1 = plain stores, 2 = plain loads, 4 = no waiting — wrong results, informative times
+#define AF_ABL 0
+#endif
+static __device__ __forceinline__ void cbm_store_wt(float* p, float v) {
+  if (AF_ABL & 1) { *p = v; return; }
+  __hip_atomic_store(reinterpret_cast<uint32_t*>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 static __device__ __forceinline__ void cbm_glds4_hidden(const void* g_lane, uint32_t lds_byte_addr_wave) {   // 4 bytes per lane (256-byte copies)
   uint32_t keep;
   const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_byte_addr_wave);
@@ -99,6 +107,12 @@ struct NatureWs {
   void* rn_m[3][5] = {};   // relu bit masks (value > 0, C bits per position) of rn_t[s][1..4], written by the forward at learner sizes (learner workspaces only)
   float* rn_g[2] = {};
   float* rn_wT = nullptr;  // flipped/transposed conv weights for the dgrad convs (rebuilt per backward)
+  // dataflow actor step (gemm_layers.hip actor_fused_kernel): per-frame arrival counters of act1 / act2 / act3 (3 x maxB words, monotonic: never reset),
+  // the number of fused launches so far, and a page-locked word a block sets when it gives up waiting for its producers
+  uint32_t* af_cnt = nullptr;
+  uint32_t af_epoch = 0;
+  uint32_t* af_err_host = nullptr;   // host address of the mapped word
+  uint32_t* af_err_dev = nullptr;    // its device address
 };
 int nature_ws_alloc(NatureWs& ws, int maxB, bool with_grad, int dense_ksplit_small, int kind = 0);
 void nature_ws_free(NatureWs& ws);

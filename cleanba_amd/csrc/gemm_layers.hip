@@ -112,6 +112,9 @@ struct Conv1Fwd {
     return o > 0.0f;
   }
   __device__ void put_mask(int m, int, uint32_t word) const { if (mask && m < M) mask[m] = word; }
+  // write-through (sc1) form of store_pre for the dataflow actor step: the consumer is another workgroup of the SAME launch (actor_fused_kernel)
+  __device__ void store_wt(int m, int n, float v, float b, int) const { if (m < M) cbm_store_wt(out + (size_t)m * 32 + n, relu(v + b)); }
+  __device__ const void* a_origin_wt() const { return obs; }   // (frames come from the previous launch: plain loads)
 };
 
 // generic VALID NHWC conv forward, k = (kh, kw, ci)
@@ -164,6 +167,8 @@ struct ConvFwd {
     return o > 0.0f;
   }
   __device__ void put_mask(int m, int n32, uint32_t word) const { if (mask && m < M) mask[(size_t)m * (CO / 32) + (n32 >> 5)] = word; }
+  __device__ void store_wt(int m, int n, float v, float b, int) const { if (m < M) cbm_store_wt(out + (size_t)m * CO + n, relu(v + b)); }   // (see Conv1Fwd)
+  __device__ const void* a_origin_wt() const { return in; }
 };
 
 // dense forward C[m][n] = sum_k A[m][k] W[k][n]; SPLIT: partials [z][M][N], else relu(+bias)
@@ -206,6 +211,10 @@ struct DenseFwd {
   static constexpr bool BIAS_PRE = !SPLIT;
   __device__ float bias_pre(int n) const { return bias[min(n, N - 1)]; }
   __device__ void store_pre(int m, int n, float v, float b) const { if (m < M && n < N) out[(size_t)m * N + n] = relu(v + b); }
+  __device__ void store_wt(int m, int n, float v, float, int z) const {   // split-K partial, write-through (the next LAUNCH reads it: plain stores would do; kept uniform)
+    if (m < M && n < N) out[((size_t)z * M + m) * N + n] = v;
+  }
+  __device__ const void* a_origin_wt() const { return A; }
 };
 
 __global__ void dense_reduce_kernel(const float* part, const float* bias, float* out, int M, int N, int S) {
@@ -502,6 +511,214 @@ __global__ __launch_bounds__(256) void actor_tail_rows_kernel(const float* part,
   }
   TT(10);
 }
+// ================================================================================================ dataflow actor step (round 6)
+// An actor step was five dependent launches of ~10 us for 2.2 GFLOP (conv1, conv2, conv3, split-K dense, per-frame tail): every boundary drains the chip,
+// costs 1.5-1.9 us of its own and makes the next layer's blocks start cold.  Here conv1, conv2, conv3 and the dense layer are ONE launch: the grid is the
+// concatenation of the four layers' block lists in layer order, every block runs igemm_s16_kernel's body (same tiles, same k-ascending 16x16x4 MFMA chain ->
+// the same bits), and instead of a kernel boundary a consumer block waits for the FRAMES its rows read: per layer and frame a monotonic arrival counter
+// counts the (row, column-block) pieces stored so far; launch number `epoch` is complete for a frame at epoch * pieces-per-frame (never reset, wrap-safe
+// compare).  Rules on gfx950 (DESIGN 8, MI355X_MICROARCH "inter-workgroup visibility"): producer data leaves through write-through (sc1) stores, every
+// storing wave drains vmcnt, one barrier, then ONE lane bumps the counters with relaxed agent-scope atomics; consumers poll relaxed (one lane per watched
+// frame, s_sleep between polls) and read the activations with sc1 loads — no agent-scope fence anywhere (a release fence writes back the XCD's whole L2,
+// i.e. the learner's working set).  Progress does not depend on placement or timing: a block only waits for blocks with LOWER ids, and the dispatcher hands out
+// workgroups in id order, so the unfinished block with the lowest id is always running or next in line.  Should that order ever not hold, a bounded spin turns
+// the deadlock into an error word the host checks (af_err).  The per-frame tail (split-K reduce + heads + sampling + env step) stays its own launch: its
+// 57 KB of LDS would cap every stage of a common kernel at two blocks per CU.
+// RESULT (round 6, one MI355X, nothing else on the GPU): bit-identical actions / log-probs / values (the parity and end-to-end suites run it), and
+// 106-110 us per 120-env step against 51 for the five launches.  Timing builds (-DAF_ABL, results wrong on purpose): plain stores only 110, plain loads only
+// 104, no waiting 91, all three 39 (= 29 for the four layers with nothing between them + the tail).  These small-batch blocks are LATENCY-bound — a chunk is 256
+// cycles of MFMA per wave behind a two-chunk register prefetch — and what a kernel boundary gives them for free is exactly what coherent dataflow takes
+// away: the im2col re-reads of a tile hit the CU's L1 (an sc1 load never does), and a write-through store drops its line from the XCD's L2, so every first
+// touch of an activation is a fabric round trip, eight times over (the consumers of a frame sit on all eight XCDs).  The legal variant that keeps L1 / L2
+// (plain stores + an agent-scope release per producer block) writes back the XCD's whole L2 per block — the learner's working set, round 5's finding.  Even
+// the unreachable 39 us would be 24 % of the rollout.  Kept behind CBM_ACTOR_FUSED=1 as the measured experiment; the product runs the five launches.
+static __device__ __forceinline__ float4 af_ld16_wt(__amdgpu_buffer_rsrc_t r, uint32_t float_off) {
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(float_off * 4u), 0, (AF_ABL & 2) ? 0 : 16 /* sc1: served by L2, never by this CU's L1 */);
+  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+// wave 0: lane l < n watches counter cnt[first + l]; returns (block-wide) once every watched counter has reached `target`
+static __device__ __forceinline__ void af_wait(const uint32_t* cnt, int first, int n, uint32_t target, uint32_t* err) {
+  if (AF_ABL & 4) return;
+  if (threadIdx.x < 64) {
+    const int l = threadIdx.x;
+    const uint32_t* p = cnt + first + (l < n ? l : 0);
+    for (unsigned spins = 0;; ++spins) {
+      const uint32_t v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (__all((int)(v - target) >= 0)) break;
+      if (spins > (1u << 22)) { if (l == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }   // (~1 s: a producer that never ran)
+      __builtin_amdgcn_s_sleep(4);
+    }
+  }
+  __syncthreads();
+}
+// after the epilogue's write-through stores: rows [x0, x0 + BX) of a layer with RPF rows per frame touch at most two frames (BX <= RPF)
+static __device__ __forceinline__ void af_signal(uint32_t* cnt, int x0, int BX, int M, int RPF) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave: its stores have left
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    const int hi = min(x0 + BX, M), f = x0 / RPF + (int)threadIdx.x;
+    const int lo_f = max(x0, f * RPF), hi_f = min(hi, (f + 1) * RPF);
+    if (hi_f > lo_f) __hip_atomic_fetch_add(cnt + f, (uint32_t)(hi_f - lo_f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+// igemm_s16_kernel's body (ROWPTR_S16 path) for block (bxi, byi, z) of problem p; A_WT: the A operand was produced by this launch -> sc1 loads
+template <class P, int BX, int BY, int BR, bool A_WT>
+static __device__ __forceinline__ void af_stage(const P& p, float* smem, int bxi, int byi, int z, size_t a_bytes) {
+  static_assert(BX % 16 == 0 && BY == 32 && BR % 32 == 0 && igemm_rowptr_s16<P>::value, "small-batch tile");
+  constexpr int NT16 = (BX / 16) * (BY / 16) / 4;
+  constexpr int PA = BR + 4, PB = BY, ASZ = BX * PA, BSZ = BR * PB;
+  constexpr int NVA = (BX * BR / 4 + 255) / 256, NVB = (BR * BY / 4 + 255) / 256;
+  float* As = smem;
+  float* Bs = smem + 2 * ASZ;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r16 = lane & 15, g4 = lane >> 4;
+  const int x0 = bxi * BX, y0 = byi * BY;
+  int rlo, rhi;
+  p.r_range(z, rlo, rhi);
+  const int nchunk = (rhi - rlo + BR - 1) / BR;
+  f32x4_mfma acc[NT16];
+#pragma unroll
+  for (int i = 0; i < NT16; ++i) acc[i] = f32x4_mfma{0.0f, 0.0f, 0.0f, 0.0f};
+  __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.a_origin_wt(), 0, (int)a_bytes, 0x00020000);
+  uint32_t arow[NVA], brow[NVB];
+#pragma unroll
+  for (int j = 0; j < NVA; ++j) { const int v = tid + 256 * j, rq = v % (BR / 4), xl = v / (BR / 4); arow[j] = p.a_off(x0 + xl, 4 * rq, 0); }
+#pragma unroll
+  for (int j = 0; j < NVB; ++j) { const int v = tid + 256 * j, yq = v % (BY / 4), rl = v / (BY / 4); brow[j] = p.b_off(rl, y0 + 4 * yq, 0); }
+  auto gload = [&](int c, float4 (&ra)[NVA], float4 (&rb)[NVB]) {
+    const int r0 = rlo + c * BR;
+    const uint32_t ao = p.a_chunk(r0), bo = p.b_chunk(r0);
+#pragma unroll
+    for (int j = 0; j < NVA; ++j)
+      if (BX * BR / 4 % 256 == 0 || tid + 256 * j < BX * BR / 4) { if constexpr (A_WT) ra[j] = af_ld16_wt(arsrc, arow[j] + ao); else ra[j] = p.rp_a(arow[j] + ao); }
+#pragma unroll
+    for (int j = 0; j < NVB; ++j)
+      if (BR * BY / 4 % 256 == 0 || tid + 256 * j < BR * BY / 4) rb[j] = p.rp_b(brow[j] + bo);
+  };
+  auto sstore = [&](int buf, const float4 (&ra)[NVA], const float4 (&rb)[NVB]) {
+    float* A_ = As + buf * ASZ;
+    float* B_ = Bs + buf * BSZ;
+#pragma unroll
+    for (int j = 0; j < NVA; ++j) {
+      const int v = tid + 256 * j;
+      if (BX * BR / 4 % 256 == 0 || v < BX * BR / 4) { const int rq = v % (BR / 4), xl = v / (BR / 4); *reinterpret_cast<float4*>(A_ + xl * PA + 4 * rq) = ra[j]; }
+    }
+#pragma unroll
+    for (int j = 0; j < NVB; ++j) {
+      const int v = tid + 256 * j;
+      if (BR * BY / 4 % 256 == 0 || v < BR * BY / 4) { const int yq = v % (BY / 4), rl = v / (BY / 4); *reinterpret_cast<float4*>(B_ + rl * PB + ((4 * yq) ^ (((rl ^ (rl >> 1)) & 1) << 4))) = rb[j]; }
+    }
+  };
+  auto compute = [&](int buf) {
+    const float* A_ = As + buf * ASZ;
+    const float* B_ = Bs + buf * BSZ;
+#pragma unroll
+    for (int st = 0; st < BR / 4; ++st) {
+#pragma unroll
+      for (int i = 0; i < NT16; ++i) {
+        const int q = wave * NT16 + i, tx = q / (BY / 16), ty = q % (BY / 16);
+        const float a = A_[(tx * 16 + r16) * PA + 4 * st + g4];
+        const float b = B_[(4 * st + g4) * PB + ((ty * 16 + r16) ^ (((g4 ^ (g4 >> 1)) & 1) << 4))];
+        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
+      }
+    }
+  };
+  float4 a0[NVA], b0[NVB], a1[NVA], b1[NVB];
+  float bpre[NT16];
+#pragma unroll
+  for (int i = 0; i < NT16; ++i) { const int q = wave * NT16 + i, ty = q % (BY / 16); bpre[i] = igemm_bias_pre<P>::value ? p.bias_pre(y0 + ty * 16 + r16) : 0.0f; }
+  gload(0, a0, b0);
+  sstore(0, a0, b0);
+  if (nchunk > 1) gload(1, a0, b0);
+  __syncthreads();
+  int buf = 0, c = 0;
+  while (true) {
+    if (c + 2 < nchunk) gload(c + 2, a1, b1);
+    compute(buf);
+    if (c + 1 < nchunk) sstore(buf ^ 1, a0, b0);
+    __syncthreads();
+    buf ^= 1;
+    if (++c >= nchunk) break;
+    if (c + 2 < nchunk) gload(c + 2, a0, b0);
+    compute(buf);
+    if (c + 1 < nchunk) sstore(buf ^ 1, a1, b1);
+    __syncthreads();
+    buf ^= 1;
+    if (++c >= nchunk) break;
+  }
+#pragma unroll
+  for (int i = 0; i < NT16; ++i) {
+    const int q = wave * NT16 + i, tx = q / (BY / 16), ty = q % (BY / 16);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) p.store_wt(x0 + tx * 16 + 4 * g4 + e, y0 + ty * 16 + r16, acc[i][e], bpre[i], z);
+  }
+}
+struct ActorFusedArgs {
+  const uint8_t* obs; const float* P; int64_t w[4], b[4];
+  float* act1; float* act2; float* act3; float* dense_part;
+  int E, ksplit; uint32_t* cnt; uint32_t epoch; uint32_t* err; int n1, n2, n3, nd, maxB;
+};
+using AfC1 = Conv1Fwd<IgemmTile<64, 64, 16, 2, 2>>;
+using AfC2 = ConvFwd<IgemmTile<64, 64, 16, 2, 2>, 4, 4, 2, 32, 64, 20, 20, 9, 9>;
+using AfC3 = ConvFwd<IgemmTile<64, 64, 16, 2, 2>, 3, 3, 1, 64, 64, 9, 9, 7, 7>;
+using AfD = DenseFwd<IgemmTile<64, 64, 16, 2, 2>, true>;
+__global__ __launch_bounds__(256, 2) void actor_fused_kernel(const ActorFusedArgs a) {
+  __shared__ __attribute__((aligned(16))) float smem[2 * 64 * 36 + 2 * 32 * 32];     // the largest stage (conv1: 64-row tiles); ONE LDS object
+  __builtin_amdgcn_s_setprio(3);   // (see igemm_s16_kernel)
+  int b = blockIdx.x;
+  const int E = a.E;
+  uint32_t* c1 = a.cnt; uint32_t* c2 = a.cnt + a.maxB; uint32_t* c3 = a.cnt + 2 * a.maxB;
+  if (b < a.n1) {                                   // conv1: uint8 frames -> act1 [E*400][32]
+    const AfC1 p{a.obs, nullptr, a.P + a.w[0], a.P + a.b[0], a.act1, E * 400, nullptr};
+    af_stage<AfC1, 64, 32, 32, false>(p, smem, b, 0, 0, 0);
+    af_signal(c1, b * 64, 64, E * 400, 400);
+    return;
+  }
+  b -= a.n1;
+  if (b < a.n2) {                                   // conv2: act1 -> act2 [E*81][64], two column blocks per row tile
+    const int bx = b >> 1, by = b & 1, x0 = bx * 32, M = E * 81;
+    const int f0 = x0 / 81, f1 = (min(x0 + 32, M) - 1) / 81;
+    af_wait(c1, f0, f1 - f0 + 1, a.epoch * 400u, a.err);
+    const AfC2 p{a.act1, a.P + a.w[1], a.P + a.b[1], a.act2, M, nullptr};
+    af_stage<AfC2, 32, 32, 32, true>(p, smem, bx, by, 0, (size_t)E * 12800 * 4);
+    af_signal(c2, x0, 32, M, 81);
+    return;
+  }
+  b -= a.n2;
+  if (b < a.n3) {                                   // conv3: act2 -> act3 [E*49][64]
+    const int bx = b >> 1, by = b & 1, x0 = bx * 32, M = E * 49;
+    const int f0 = x0 / 49, f1 = (min(x0 + 32, M) - 1) / 49;
+    af_wait(c2, f0, f1 - f0 + 1, a.epoch * 162u, a.err);
+    const AfC3 p{a.act2, a.P + a.w[2], a.P + a.b[2], a.act3, M, nullptr};
+    af_stage<AfC3, 32, 32, 32, true>(p, smem, bx, by, 0, (size_t)E * 5184 * 4);
+    af_signal(c3, x0, 32, M, 49);
+    return;
+  }
+  b -= a.n3;
+  {                                                 // dense, split-K partials [ksplit][E][512]: x tile (32 frames) major, then K slice, then column block
+    const int per_x = a.ksplit * 16, bx = b / per_x, r = b - bx * per_x, z = r >> 4, by = r & 15, x0 = bx * 32;
+    af_wait(c3, x0, min(32, E - x0), a.epoch * 98u, a.err);
+    const AfD p{a.act3, a.P + a.w[3], a.P + a.b[3], a.dense_part, E, 3136, 512, 3136 / a.ksplit};
+    af_stage<AfD, 32, 32, 32, true>(p, smem, bx, by, z, (size_t)E * 3136 * 4);
+  }
+}
+static bool actor_fused_ok(const NatureLayout& L, int B, int dense_ksplit, const NatureWs& ws) {
+  // OFF by default: measured 2.1x SLOWER than the five launches (106-110 vs 51 us per 120-env step, profiles/r06_actor_dataflow.txt) — see the note below
+  static const bool on = [] { const char* e = getenv("CBM_ACTOR_FUSED"); return e && e[0] == '1'; }();
+  return on && ws.af_cnt && B <= ws.maxB && dense_ksplit > 1 && dense_ksplit <= 16 && 3136 % (dense_ksplit * 32) == 0 && L.A + 1 <= 32;
+}
+static void launch_actor_fused(const NatureLayout& L, const float* P, const uint8_t* obs, int B, int dense_ksplit, NatureWs& ws, hipStream_t st) {
+  if (ws.af_err_host && *ws.af_err_host) { cbm_launch_fail("dataflow actor step: a block gave up waiting for its producers (workgroups not dispatched in id order?)"); return; }
+  ActorFusedArgs a;
+  a.obs = obs; a.P = P;
+  for (int i = 0; i < 4; ++i) { a.w[i] = L.w[i]; a.b[i] = L.b[i]; }
+  a.act1 = ws.act1; a.act2 = ws.act2; a.act3 = ws.act3; a.dense_part = ws.dense_part;
+  a.E = B; a.ksplit = dense_ksplit; a.cnt = ws.af_cnt; a.epoch = ++ws.af_epoch; a.err = ws.af_err_dev; a.maxB = ws.maxB;
+  a.n1 = (B * 400 + 63) / 64; a.n2 = 2 * ((B * 81 + 31) / 32); a.n3 = 2 * ((B * 49 + 31) / 32); a.nd = ((B + 31) / 32) * dense_ksplit * 16;
+  hipLaunchKernelGGL(actor_fused_kernel, dim3(a.n1 + a.n2 + a.n3 + a.nd), dim3(256), 0, st, a);
+}
+
 static void launch_heads_fwd(const float* hid, const float* Wa, const float* ba, const float* Wc, const float* bc, int B, int A, int HD,
                              float* logits, float* value, hipStream_t st) {
   if (HD % 64 == 0 && A + 1 <= 32) {
@@ -1130,6 +1347,14 @@ int nature_ws_alloc(NatureWs& ws, int maxB, bool with_grad, int dense_ksplit_sma
   if (dmalloc(&ws.act1, B * 12800) || dmalloc(&ws.act2, B * 5184) || dmalloc(&ws.act3, B * 3136) || dmalloc(&ws.hid, B * 512) ||
       dmalloc(&ws.logits, B * 32) || dmalloc(&ws.value, B)) return -1;
   ws.dense_part_ksplit = dense_ksplit_small;
+  if (!with_grad) {   // actor-side workspaces: the dataflow step's arrival counters (zero = no launch yet) and its give-up word in mapped host memory
+    if (hipMalloc((void**)&ws.af_cnt, 3 * B * sizeof(uint32_t)) != hipSuccess) { cbm_set_error("hipMalloc failed"); return -1; }
+    hipMemset(ws.af_cnt, 0, 3 * B * sizeof(uint32_t));
+    ws.af_epoch = 0;
+    if (hipHostMalloc((void**)&ws.af_err_host, sizeof(uint32_t), hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer((void**)&ws.af_err_dev, ws.af_err_host, 0) != hipSuccess) { cbm_set_error("hipHostMalloc failed"); return -1; }
+    *ws.af_err_host = 0;
+  }
   // split-K partials are only used for small batches (M <= 1024 frames: actor steps, bootstrap value)
   if (dense_ksplit_small > 1) { if (dmalloc(&ws.dense_part, (size_t)dense_ksplit_small * (B < 1024 ? B : 1024) * 512)) return -1; }
   if (with_grad) {
@@ -1163,6 +1388,8 @@ void nature_ws_free(NatureWs& ws) {
   for (int j = 0; j < 2; ++j) { if (ws.rn_g[j]) hipFree(ws.rn_g[j]); ws.rn_g[j] = nullptr; }
   if (ws.rn_wT) { hipFree(ws.rn_wT); ws.rn_wT = nullptr; }
   if (ws.c3_order) { hipFree(ws.c3_order); ws.c3_order = nullptr; }
+  if (ws.af_cnt) { hipFree(ws.af_cnt); ws.af_cnt = nullptr; }
+  if (ws.af_err_host) { hipHostFree(ws.af_err_host); ws.af_err_host = nullptr; ws.af_err_dev = nullptr; }
   for (uint32_t** m : {&ws.mask1, &ws.mask2, &ws.mask3}) { if (*m) hipFree(*m); *m = nullptr; }
   ws.c3_order_S = -1;
 }
@@ -1240,6 +1467,13 @@ int nature_forward(const NatureLayout& L, const float* P, const uint8_t* obs, co
   const bool small = B <= 512;
   // actor-size forward passes (no ReLU masks wanted) run on the 16x16x4 small-batch kernel (igemm.h igemm_s16_kernel), same bits
   // (forward_bf16 too: at <= 512 frames the bf16 MFMA buys nothing over these latency-bound launches, so the actor's behaviour logits stay fp32)
+  if (small && !ws.mask1 && !ws.prof && !idx && sample && actor_fused_ok(L, B, dense_ksplit, ws)) {
+    // actor step: conv1 .. dense as ONE dataflow launch (actor_fused_kernel), then the per-frame tail — two launches instead of five, same bits
+    launch_actor_fused(L, P, obs, B, dense_ksplit, ws, st);
+    hipLaunchKernelGGL(actor_tail_rows_kernel<512>, dim3(B), dim3(256), 0, st, ws.dense_part, P + L.b[3], dense_ksplit, P + L.w[4], P + L.b[4],
+                       P + L.w[5], P + L.b[5], B, L.A, *sample);
+    return sample->env_obs_next ? 2 : 1;
+  }
   if (small && !ws.mask1 && !ws.prof) {
     Conv1Fwd<T64x64k16> p1{obs, idx, P + L.w[0], P + L.b[0], ws.act1, B * 400, nullptr};
     // conv1 on 64-row tiles (750 blocks instead of 1500): no faster alone (rollout 6.52 -> 6.53 ms), but beside the learner's CU-filling kernels half as

@@ -1,6 +1,8 @@
 """End-to-end GPU parity: a whole device-env rollout and a whole learner update through the C ABI,
 replayed step by step with the host env twin + the CPU oracle.  Frames, actions, rewards, dones are
 compared bit-for-bit; losses and post-update parameters within 1e-5."""
+import os
+import sys
 import numpy as np
 import pytest
 
@@ -480,3 +482,16 @@ def test_backward_split_training_run_matches_the_oracle_engine(tmp_path, split):
     d = np.abs(gpu["params"] - cpu["params"]).max()
     assert d <= (2e-5 if split == 3 else 1e-4) * max(1.0, np.abs(cpu["params"]).max()), d
     np.testing.assert_allclose(gpu["stats"], cpu["stats"], rtol=5e-4, atol=5e-5)
+
+
+@pytest.mark.gpu
+def test_dataflow_actor_step_experiment_is_bit_exact():
+    """CBM_ACTOR_FUSED=1 (gemm_layers.hip actor_fused_kernel: conv1 .. dense of an actor step as ONE launch, blocks waiting on per-frame arrival
+    counters instead of kernel boundaries) is a measured experiment that does not ship (profiles/r06_actor_dataflow.txt: 2.1x slower) — but while it is
+    in the tree it has to produce the oracle's rollouts: the switch is read once per process, so the rollout parity tests run again in a child."""
+    import subprocess
+    env = dict(os.environ, CBM_ACTOR_FUSED="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.abspath(__file__), "-k",
+                        "test_ppo_rollout_and_update_match_oracle or test_impala_rollouts_and_update_match_oracle or host_env_loop_equals_device_env_loop"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
