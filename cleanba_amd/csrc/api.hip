@@ -27,26 +27,24 @@ void cbm_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* cbm_last_error(void) { return g_err; }
-static std::mutex g_launch_mu;
-static char g_launch_err[512] = "";
-static std::atomic<bool> g_launch_failed{false};
+// A launch helper's failure is recorded PER THREAD: the helpers run inside the C-ABI call that drives the pass, on the caller's thread, and that call ends
+// in cbm_launch_check() on the same thread.  (A process-wide flag — rounds 4-5 — let thread B's entry point consume and report a launch that thread
+// A's pass had skipped, while A's own call returned 0 although its kernel never ran)  Reported once, then cleared: one context's geometry
+// failure does not make later calls on that thread fail with a stale message.
+static thread_local char g_launch_err[512] = "";
+static thread_local bool g_launch_failed = false;
 void cbm_launch_fail(const char* fmt, ...) {
-  std::lock_guard<std::mutex> lk(g_launch_mu);
-  if (g_launch_failed.load()) return;   // keep the first one
+  if (g_launch_failed) return;   // keep the first one
   va_list ap;
   va_start(ap, fmt);
   vsnprintf(g_launch_err, sizeof(g_launch_err), fmt, ap);
   va_end(ap);
-  g_launch_failed.store(true, std::memory_order_release);
+  g_launch_failed = true;
 }
-// reports a recorded launch failure ONCE — to the entry point that drove the failing pass — and clears it: one context's geometry failure must
-// not make every later call of every other context in the process (an eval context, the next test) return -1 with a stale message
 int cbm_launch_check(void) {
-  if (!g_launch_failed.load(std::memory_order_acquire)) return 0;
-  std::lock_guard<std::mutex> lk(g_launch_mu);
-  if (!g_launch_failed.load(std::memory_order_acquire)) return 0;
+  if (!g_launch_failed) return 0;
   cbm_set_error("%s", g_launch_err);
-  g_launch_failed.store(false, std::memory_order_release);
+  g_launch_failed = false;
   return -1;
 }
 extern "C" const char* cbm_build_info(void) { return "cleanba-mi gfx950 f32-mfma abi=2 built " __DATE__ " " __TIME__; }
@@ -175,7 +173,7 @@ static int ctx_create_impl(const cbm_config* cfg, cbm_ctx** out, cbm_ctx** parti
     // host asked for the native backend (CBM_COMM=native) without pinning every rank to one device (CBM_FORCE_DEVICE).
     const char* fg = getenv("CBM_NATIVE_FINEGRAINED");
     const char* be = getenv("CBM_COMM");
-    c->win_fine[1] = fg ? atoi(fg) != 0 : (be && !strcmp(be, "native") && !getenv("CBM_FORCE_DEVICE") && ndev > 1);
+    c->win_fine[1] = fg ? atoi(fg) != 0 : (be && !strcasecmp(be, "native") && !getenv("CBM_FORCE_DEVICE") && ndev > 1);
     for (int w = 0; w < CBM_WINDOWS; ++w) {
       void* p = nullptr;
       const hipError_t e = c->win_fine[w] ? hipExtMallocWithFlags(&p, c->win_bytes[w], hipDeviceMallocFinegrained) : hipMalloc(&p, c->win_bytes[w]);

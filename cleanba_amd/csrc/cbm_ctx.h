@@ -24,6 +24,8 @@ struct CbmComm {
   void* nat_peer[CBM_NATIVE_BUFS][CBM_NATIVE_MAX_RANKS] = {};
   void* nat_win[2][CBM_NATIVE_MAX_RANKS] = {};   // mappings this communicator holds of rank r's communication window / signal block (cbm_ipc_map; null: own or same process)
   uint32_t nat_seq = 0;          // collective sequence number: the flag value of the next call
+  bool nat_closed = false;       // cbm_ipc_close_all unmapped this communicator: the slot cannot be initialised again (its signal block still holds the old
+                                 // sequence numbers and sticky error words; a fresh context is the way to a fresh communicator)
   void* nat_sig_local = nullptr; // this rank's signal block (owned)
   int* nat_err = nullptr;        // page-locked host word: a flag wait timed out (a peer died) — checked when the host next synchronises
 };

@@ -208,36 +208,72 @@ static void cbm_ipc_unmap(void* base) {
   }
 }
 
+// Cross-rank visibility WITHOUT fences (round 6).  Round 4's kernels bracketed the data phase with __threadfence_system() and signalled with release /
+// acquire atomics; on gfx950 every one of those is `buffer_wbl2 sc0 sc1` and / or `buffer_inv sc0 sc1` — a write-back / invalidate of the XCD's whole L2,
+// six per collective and rank, issued on the communication stream UNDER the conv backward pass whose working set lives in that L2
+// (profiles/r05_interference_experiments.txt (3)).  Now every access to memory another rank reads or writes is itself a system-scope (sc0 sc1) access:
+// peer data by buffer_load / buffer_store ... sc0 sc1 (served by / written through to memory, never a cache of this GPU), flags by relaxed system-scope
+// atomics; ordering = every wave drains its stores (s_waitcnt vmcnt(0)), one block barrier, then the flag stores.  What a rank reads of ITS OWN buffer was
+// written by earlier kernels of this process (the kernel boundary released it); what the peers wrote into it is read by later kernels (whose start
+// acquires).  FENCES = true (CBM_NATIVE_FENCES=1) is the round-4 protocol, kept as the fallback should the first multi-GPU run disagree.
+typedef unsigned int nat_u32x4 __attribute__((ext_vector_type(4)));
+static __device__ __forceinline__ __amdgpu_buffer_rsrc_t nat_rsrc(const void* base) { return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7ffffff0, 0x00020000); }
+template <bool FENCES> static __device__ __forceinline__ float4 nat_ld4(const void* base, int64_t e) {
+  if constexpr (FENCES) return *reinterpret_cast<const float4*>((const float*)base + e);
+  const nat_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(nat_rsrc(base), (int)(e * 4), 0, 17 /* sc0 sc1 */);
+  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+template <bool FENCES> static __device__ __forceinline__ void nat_st4(void* base, int64_t e, float4 s) {
+  if constexpr (FENCES) { *reinterpret_cast<float4*>((float*)base + e) = s; return; }
+  const nat_u32x4 v = {__float_as_uint(s.x), __float_as_uint(s.y), __float_as_uint(s.z), __float_as_uint(s.w)};
+  __builtin_amdgcn_raw_buffer_store_b128(v, nat_rsrc(base), (int)(e * 4), 0, 17);
+}
+template <bool FENCES, class Tv> static __device__ __forceinline__ Tv nat_ld1(const void* base, int64_t e) {
+  if constexpr (FENCES) return ((const Tv*)base)[e];
+  if constexpr (sizeof(Tv) == 4) { const uint32_t u = __hip_atomic_load((const uint32_t*)base + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); return __builtin_bit_cast(Tv, u); }
+  else { const uint64_t u = __hip_atomic_load((const uint64_t*)base + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); return __builtin_bit_cast(Tv, u); }
+}
+template <bool FENCES, class Tv> static __device__ __forceinline__ void nat_st1(void* base, int64_t e, Tv v) {
+  if constexpr (FENCES) { ((Tv*)base)[e] = v; return; }
+  if constexpr (sizeof(Tv) == 4) __hip_atomic_store((uint32_t*)base + e, __builtin_bit_cast(uint32_t, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  else __hip_atomic_store((uint64_t*)base + e, __builtin_bit_cast(uint64_t, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 // returns false (block-uniform) when this or an earlier collective's wait timed out: the caller skips its data phase — a dead peer costs ONE
 // timeout, not one per remaining collective, and nothing is reduced from / written to buffers whose owners never arrived
+template <bool FENCES>
 static __device__ __forceinline__ bool nat_signal_and_wait(const NatArgs& a, int phase) {
+  if constexpr (!FENCES) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every wave: its write-through stores of the data phase have left
   __syncthreads();
   const int t = threadIdx.x;
   if (t < a.nranks) {
     const size_t row = ((size_t)phase * NAT_BLOCKS + blockIdx.x) * CBM_NATIVE_MAX_RANKS;
-    __hip_atomic_store(a.sig[t] + row + a.rank, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);   // (always: live peers must not wait for us)
+    // (always: live peers must not wait for us)
+    if constexpr (FENCES) __hip_atomic_store(a.sig[t] + row + a.rank, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    else __hip_atomic_store(a.sig[t] + row + a.rank, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (*(volatile int*)a.err_dev == 0) {
       uint32_t* mine = a.sig[a.rank] + row + t;
       const unsigned long long t0 = wall_clock64();
-      while ((int32_t)(__hip_atomic_load(mine, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - a.seq) < 0) {
+      while (true) {
+        const uint32_t v = FENCES ? __hip_atomic_load(mine, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) : __hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if ((int32_t)(v - a.seq) >= 0) break;
         __builtin_amdgcn_s_sleep(16);
         if (wall_clock64() - t0 > a.timeout_ticks) { *(volatile int*)a.err_dev = 1 + phase; *(volatile int*)a.err = 1 + phase; break; }
         if (*(volatile int*)a.err_dev != 0) break;   // another block of this rank has given up already
       }
     }
   }
-  __threadfence();
+  if constexpr (FENCES) __threadfence();
   __syncthreads();
   return *(volatile int*)a.err_dev == 0;
 }
 
 // NR > 0: the rank count is a compile-time constant — the NR peer loads of an element are all requested before the first add (one fabric round trip
 // per element instead of NR); NR = 0: any count up to CBM_NATIVE_MAX_RANKS, one load after the other
-template <int NR>
+template <int NR, bool FENCES>
 __global__ __launch_bounds__(NAT_THREADS) void nat_allreduce_f32_kernel(const NatArgs a) {
-  __threadfence_system();
-  if (!nat_signal_and_wait(a, 0)) return;
-  __threadfence_system();               // acquire for every thread: no load below may be served by anything fetched before the peers signalled
+  if constexpr (FENCES) __threadfence_system();
+  if (!nat_signal_and_wait<FENCES>(a, 0)) return;
+  if constexpr (FENCES) __threadfence_system();   // acquire for every thread: no load below may be served by anything fetched before the peers signalled
   const int N = NR > 0 ? NR : a.nranks;
   const int64_t chunk = (((a.n + N - 1) / N) + 3) & ~(int64_t)3;
   const int64_t lo = chunk * a.rank < a.n ? chunk * a.rank : a.n;
@@ -250,58 +286,59 @@ __global__ __launch_bounds__(NAT_THREADS) void nat_allreduce_f32_kernel(const Na
     if constexpr (NR > 0) {
       float4 v[NR];
 #pragma unroll
-      for (int r = 0; r < NR; ++r) v[r] = *reinterpret_cast<const float4*>((const float*)a.data[r] + e);
+      for (int r = 0; r < NR; ++r) v[r] = nat_ld4<FENCES>(a.data[r], e);
       sum = v[0];
 #pragma unroll
       for (int r = 1; r < NR; ++r) { sum.x = sum.x + v[r].x; sum.y = sum.y + v[r].y; sum.z = sum.z + v[r].z; sum.w = sum.w + v[r].w; }   // rank order
 #pragma unroll
-      for (int r = 0; r < NR; ++r) *reinterpret_cast<float4*>((float*)a.data[r] + e) = sum;
+      for (int r = 0; r < NR; ++r) nat_st4<FENCES>(a.data[r], e, sum);
     } else {
-      sum = *reinterpret_cast<const float4*>((const float*)a.data[0] + e);
+      sum = nat_ld4<FENCES>(a.data[0], e);
       for (int r = 1; r < N; ++r) {
-        const float4 v = *reinterpret_cast<const float4*>((const float*)a.data[r] + e);
+        const float4 v = nat_ld4<FENCES>(a.data[r], e);
         sum.x = sum.x + v.x; sum.y = sum.y + v.y; sum.z = sum.z + v.z; sum.w = sum.w + v.w;
       }
-      for (int r = 0; r < N; ++r) *reinterpret_cast<float4*>((float*)a.data[r] + e) = sum;
+      for (int r = 0; r < N; ++r) nat_st4<FENCES>(a.data[r], e, sum);
     }
   }
   for (int64_t i = lo + 4 * nvec + tid; i < hi; i += nth) {
     const int64_t e = a.off + i;
-    float sum = ((const float*)a.data[0])[e];
-    for (int r = 1; r < N; ++r) sum = sum + ((const float*)a.data[r])[e];
-    for (int r = 0; r < N; ++r) ((float*)a.data[r])[e] = sum;
+    float sum = nat_ld1<FENCES, float>(a.data[0], e);
+    for (int r = 1; r < N; ++r) sum = sum + nat_ld1<FENCES, float>(a.data[r], e);
+    for (int r = 0; r < N; ++r) nat_st1<FENCES, float>(a.data[r], e, sum);
   }
-  __threadfence_system();               // release: the peer writes above are out before the flag is
-  nat_signal_and_wait(a, 1);
+  if constexpr (FENCES) __threadfence_system();   // release: the peer writes above are out before the flag is
+  nat_signal_and_wait<FENCES>(a, 1);
 }
 
-template <class Tv, int OP>   // OP: 0 sum, 1 max, 2 min; one block, n <= NAT_SMALL_MAX
+template <class Tv, int OP, bool FENCES>   // OP: 0 sum, 1 max, 2 min; one block, n <= NAT_SMALL_MAX
 __global__ __launch_bounds__(1024) void nat_allreduce_small_kernel(const NatArgs a) {
-  __threadfence_system();
-  if (!nat_signal_and_wait(a, 0)) return;
-  __threadfence_system();
+  if constexpr (FENCES) __threadfence_system();
+  if (!nat_signal_and_wait<FENCES>(a, 0)) return;
+  if constexpr (FENCES) __threadfence_system();
   Tv keep[NAT_SMALL_MAX / 1024];
 #pragma unroll
   for (int j = 0; j < NAT_SMALL_MAX / 1024; ++j) {
     const int64_t i = threadIdx.x + 1024 * j;
     Tv sum = 0;
     if (i < a.n) {
-      sum = ((const Tv*)a.data[0])[a.off + i];
+      sum = nat_ld1<FENCES, Tv>(a.data[0], a.off + i);
       for (int r = 1; r < a.nranks; ++r) {
-        const Tv v = ((const Tv*)a.data[r])[a.off + i];
+        const Tv v = nat_ld1<FENCES, Tv>(a.data[r], a.off + i);
         sum = OP == 0 ? sum + v : (OP == 1 ? (v > sum ? v : sum) : (v < sum ? v : sum));
       }
     }
     keep[j] = sum;
   }
-  __threadfence_system();
-  if (!nat_signal_and_wait(a, 1)) return;   // every rank has read every input: the in-place results may go out
+  if constexpr (FENCES) __threadfence_system();
+  if (!nat_signal_and_wait<FENCES>(a, 1)) return;   // every rank has read every input: the in-place results may go out
 #pragma unroll
   for (int j = 0; j < NAT_SMALL_MAX / 1024; ++j) {
     const int64_t i = threadIdx.x + 1024 * j;
-    if (i < a.n) ((Tv*)a.data[a.rank])[a.off + i] = keep[j];
+    if (i < a.n) nat_st1<FENCES, Tv>(a.data[a.rank], a.off + i, keep[j]);
   }
 }
+static bool nat_fences() { static const bool f = [] { const char* e = getenv("CBM_NATIVE_FENCES"); return e && e[0] == '1'; }(); return f; }
 
 static unsigned long long nat_timeout_ticks() {
   const char* e = getenv("CBM_NATIVE_TIMEOUT_S");
@@ -330,18 +367,23 @@ static int nat_allreduce_f32(cbm_ctx* c, CbmComm& k, float* buf, int64_t n, hipS
   int b = 0; int64_t offb = 0;
   if (nat_locate(c, buf, n * 4, &b, &offb)) return -1;
   const NatArgs a = nat_args(k, b, offb / 4, n);
-  if (n <= NAT_SMALL_MAX) hipLaunchKernelGGL((nat_allreduce_small_kernel<float, 0>), dim3(1), dim3(1024), 0, st, a);
-  else {
+  const bool fn = nat_fences();
+#define NAT_LAUNCH_F32(NR) do { if (fn) hipLaunchKernelGGL((nat_allreduce_f32_kernel<NR, true>), g, t, 0, st, a); else hipLaunchKernelGGL((nat_allreduce_f32_kernel<NR, false>), g, t, 0, st, a); } while (0)
+  if (n <= NAT_SMALL_MAX) {
+    if (fn) hipLaunchKernelGGL((nat_allreduce_small_kernel<float, 0, true>), dim3(1), dim3(1024), 0, st, a);
+    else hipLaunchKernelGGL((nat_allreduce_small_kernel<float, 0, false>), dim3(1), dim3(1024), 0, st, a);
+  } else {
     const dim3 g(NAT_BLOCKS), t(NAT_THREADS);
     switch (k.nranks) {
-      case 2: hipLaunchKernelGGL(nat_allreduce_f32_kernel<2>, g, t, 0, st, a); break;
-      case 3: hipLaunchKernelGGL(nat_allreduce_f32_kernel<3>, g, t, 0, st, a); break;
-      case 4: hipLaunchKernelGGL(nat_allreduce_f32_kernel<4>, g, t, 0, st, a); break;
-      case 6: hipLaunchKernelGGL(nat_allreduce_f32_kernel<6>, g, t, 0, st, a); break;
-      case 8: hipLaunchKernelGGL(nat_allreduce_f32_kernel<8>, g, t, 0, st, a); break;
-      default: hipLaunchKernelGGL(nat_allreduce_f32_kernel<0>, g, t, 0, st, a);
+      case 2: NAT_LAUNCH_F32(2); break;
+      case 3: NAT_LAUNCH_F32(3); break;
+      case 4: NAT_LAUNCH_F32(4); break;
+      case 6: NAT_LAUNCH_F32(6); break;
+      case 8: NAT_LAUNCH_F32(8); break;
+      default: NAT_LAUNCH_F32(0);
     }
   }
+#undef NAT_LAUNCH_F32
   CBM_HIP(hipGetLastError());
   return 0;
 }
@@ -449,6 +491,10 @@ extern "C" int cbm_comm_native_init(cbm_ctx* c, int32_t which, int32_t nranks, i
   CbmComm& k = c->comms[which];
   if (k.nranks) { cbm_set_error("communicator %d already initialised", which); return -1; }
   if (!k.nat_sig_local) { cbm_set_error("cbm_comm_native_export must be called on this context first"); return -1; }
+  if (k.nat_closed) {   // (a re-init restarted the sequence at 0 under flags that only grow — the first collectives would pass their waits unsynchronised)
+    cbm_set_error("native communicator %d was closed by cbm_ipc_close_all and cannot be initialised again on this context: create a new context", which);
+    return -1;
+  }
   CBM_HIP(hipSetDevice(c->cfg.device));
   void* const own[CBM_NATIVE_BUFS] = {c->grads, c->stats_dev, c->comm_scratch, k.nat_sig_local};
   bool spans_devices = false;
@@ -524,6 +570,7 @@ int cbm_ipc_close_all_impl(cbm_ctx* c) {
     nat_unmap(k);
     k.native = false;
     k.nranks = 0;
+    k.nat_closed = true;
   }
   std::vector<void*> maps;
   { std::lock_guard<std::mutex> lk(c->maps_mu); maps.swap(c->maps); }
@@ -547,9 +594,12 @@ extern "C" int cbm_comm_allreduce_f64(cbm_ctx* c, int32_t which, double* host_in
     if (op == 0) comm_scale_f64_kernel<<<dim3(1), dim3(64), 0, c->cstream>>>(c->comm_scratch, n, (double)c->comms[which].nranks);
   } else if (c->comms[which].native) {
     const NatArgs a = nat_args(c->comms[which], 2, 0, n);
-    if (op == 1) hipLaunchKernelGGL((nat_allreduce_small_kernel<double, 1>), dim3(1), dim3(1024), 0, c->cstream, a);
-    else if (op == 2) hipLaunchKernelGGL((nat_allreduce_small_kernel<double, 2>), dim3(1), dim3(1024), 0, c->cstream, a);
-    else hipLaunchKernelGGL((nat_allreduce_small_kernel<double, 0>), dim3(1), dim3(1024), 0, c->cstream, a);
+    const bool fn = nat_fences();
+#define NAT_LAUNCH_F64(OP) do { if (fn) hipLaunchKernelGGL((nat_allreduce_small_kernel<double, OP, true>), dim3(1), dim3(1024), 0, c->cstream, a); else hipLaunchKernelGGL((nat_allreduce_small_kernel<double, OP, false>), dim3(1), dim3(1024), 0, c->cstream, a); } while (0)
+    if (op == 1) NAT_LAUNCH_F64(1);
+    else if (op == 2) NAT_LAUNCH_F64(2);
+    else NAT_LAUNCH_F64(0);
+#undef NAT_LAUNCH_F64
   } else {
     CBM_NCCL(g_rccl.AllReduce(c->comm_scratch, c->comm_scratch, (size_t)n, ncclFloat64, op == 1 ? ncclMax : (op == 2 ? ncclMin : ncclSum),
                               (ncclComm_t)c->comms[which].comm, c->cstream));
@@ -567,6 +617,56 @@ extern "C" int cbm_comm_allreduce_grads(cbm_ctx* c, int32_t which) {
   if (comm_allreduce_f32(c, c->comms[which], c->grads, c->P, c->cstream)) return -1;
   CBM_HIP(hipStreamSynchronize(c->cstream));
   return cbm_comm_check_native(c);
+}
+
+// What does an all-reduce on the communication stream cost the backward pass it is hidden under?  (bench.py allreduce_ab, VERDICT r5 "next" 3a: a
+// backend is judged by the learner-stream time it adds, not only by its own duration.)  `iters` backward passes of one learner minibatch on the learner
+// stream (whatever the last forward pass left in the workspace: only the time matters), first alone, then each with ONE all-reduce of the whole flat
+// gradient through communicator `which` started on the communication stream at the top of the pass.  out = {ms per backward alone, ms per backward beside
+// the all-reduce, us per all-reduce beside the backward}.  Every rank of the communicator must call it with the same `iters`.  The gradient buffer is
+// written by both sides while this runs: call it when its contents no longer matter.
+extern "C" int cbm_comm_overlap_probe(cbm_ctx* c, int32_t which, int32_t iters, double out[3]) {
+  if (comm_check(c, which)) return -1;
+  if (iters < 1 || !out) { cbm_set_error("cbm_comm_overlap_probe: iters >= 1 and an output array"); return -1; }
+  CBM_HIP(hipSetDevice(c->cfg.device));
+  const bool ppo = c->cfg.algo == CBM_ALGO_PPO;
+  const int B = ppo ? c->MB : c->MB - c->Bdev / c->nmicro;
+  RingEntry& R = c->ring[0];
+  hipEvent_t e0, e1, es, ec0, ec1, ecd;
+  for (hipEvent_t* e : {&e0, &e1, &es, &ec0, &ec1, &ecd}) CBM_HIP(hipEventCreate(e));
+  hipEvent_t const saved_tail = c->lws.tail_ev;
+  c->lws.tail_ev = nullptr;
+  auto backward = [&] { nature_backward(c->L, c->params, R.obs, nullptr, B, c->lws, c->grads, c->lstream); };
+  backward();                                                     // warm
+  CBM_HIP(hipEventRecord(e0, c->lstream));
+  for (int i = 0; i < iters; ++i) backward();
+  CBM_HIP(hipEventRecord(e1, c->lstream));
+  CBM_HIP(hipStreamSynchronize(c->lstream));
+  float ms_alone = 0.0f, ms_with = 0.0f, ms_ar = 0.0f;
+  CBM_HIP(hipEventElapsedTime(&ms_alone, e0, e1));
+  double ar_total = 0.0;
+  CBM_HIP(hipEventRecord(e0, c->lstream));
+  int rc = 0;
+  for (int i = 0; i < iters && !rc; ++i) {
+    CBM_HIP(hipEventRecord(es, c->lstream));
+    CBM_HIP(hipStreamWaitEvent(c->cstream, es, 0));
+    CBM_HIP(hipEventRecord(ec0, c->cstream));
+    rc = comm_allreduce_f32(c, c->comms[which], c->grads, c->P, c->cstream);
+    CBM_HIP(hipEventRecord(ec1, c->cstream));
+    backward();
+    CBM_HIP(hipStreamSynchronize(c->cstream));                    // (one collective in flight at a time: every rank enters the next one together)
+    CBM_HIP(hipEventElapsedTime(&ms_ar, ec0, ec1));
+    ar_total += ms_ar;
+  }
+  CBM_HIP(hipEventRecord(e1, c->lstream));
+  CBM_HIP(hipStreamSynchronize(c->lstream));
+  CBM_HIP(hipEventElapsedTime(&ms_with, e0, e1));
+  c->lws.tail_ev = saved_tail;
+  for (hipEvent_t e : {e0, e1, es, ec0, ec1, ecd}) (void)hipEventDestroy(e);
+  if (rc) return -1;
+  out[0] = ms_alone / iters; out[1] = ms_with / iters; out[2] = ar_total / iters * 1e3;
+  if (cbm_comm_check_native(c)) return -1;
+  return cbm_launch_check();
 }
 
 extern "C" int cbm_comm_barrier(cbm_ctx* c, int32_t which) {

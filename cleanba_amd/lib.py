@@ -57,7 +57,7 @@ SYMBOLS = [
     "cbm_learner_allreduce_grads", "cbm_comm_profile", "cbm_comm_profile_read", "cbm_ipc_export_window", "cbm_ipc_window_offset", "cbm_ipc_open_window",
     "cbm_ipc_close_window", "cbm_ipc_close_all",
     "cbm_host_register", "cbm_host_unregister", "cbm_actor_ship_shard", "cbm_io_sync", "cbm_params_push", "cbm_params_mark_published", "cbm_ctx_abort", "cbm_profile_read_all", "cbm_profile_kernel_name",
-    "cbm_comm_native_export", "cbm_comm_native_init", "cbm_comm_backend", "cbm_comm_allreduce_grads",
+    "cbm_comm_native_export", "cbm_comm_native_init", "cbm_comm_backend", "cbm_comm_allreduce_grads", "cbm_comm_overlap_probe",
 ]
 
 COMM_LEARNERS, COMM_WORLD = 0, 1
@@ -399,6 +399,12 @@ class Context:
     def comm_allreduce_grads(self, which=COMM_LEARNERS):
         """all-reduce(SUM) of the whole flat gradient through communicator `which`, blocking (cbm_comm_allreduce_grads)."""
         _chk(self.lib.cbm_comm_allreduce_grads(self.h, int(which)))
+
+    def comm_overlap_probe(self, which=COMM_LEARNERS, iters=8):
+        """(ms per backward pass alone, ms beside one whole-gradient all-reduce through `which`, us per all-reduce beside it): cbm_comm_overlap_probe."""
+        o = (C.c_double * 3)()
+        _chk(self.lib.cbm_comm_overlap_probe(self.h, int(which), int(iters), o))
+        return o[0], o[1], o[2]
 
     def learner_allreduce_grads(self):
         d = C.c_float()

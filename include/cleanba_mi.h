@@ -177,6 +177,10 @@ int cbm_comm_size(cbm_ctx* ctx, int32_t which);              /* ranks of an init
 int cbm_comm_allreduce_f64(cbm_ctx* ctx, int32_t which, double* host_inout, int32_t n, int32_t op);   /* op: 0 sum, 1 max, 2 min; blocking */
 int cbm_comm_barrier(cbm_ctx* ctx, int32_t which);
 int cbm_comm_allreduce_grads(cbm_ctx* ctx, int32_t which);   /* all-reduce(SUM) of the whole flat gradient through communicator `which`, blocking (backend A/B on identical data) */
+/* the learner-stream cost of a concurrent all-reduce (pmean under value_and_grad's backward, ppo:619-628): `iters` backward passes of one learner
+ * minibatch alone, then each beside ONE whole-gradient all-reduce through `which` on the communication stream.
+ * out = {ms per backward alone, ms per backward beside the all-reduce, us per all-reduce beside the backward}; overwrites the gradient buffer */
+int cbm_comm_overlap_probe(cbm_ctx* ctx, int32_t which, int32_t iters, double out[3]);
 /* pmean of the flat gradient after cbm_learner_minibatch_grad (ppo:628): all-reduce(SUM) over CBM_COMM_LEARNERS on the library's
  * communication stream — the dense + heads tail under the conv backward, the head after it — and the learner stream joins.
  * *grad_div = rank count, to be passed to cbm_learner_optimizer_step / cbm_learner_accumulate.  Without a communicator: no work,

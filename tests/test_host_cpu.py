@@ -405,3 +405,28 @@ def test_rendezvous_gives_a_reused_prefix_fresh_keys():
     b.barrier("b")                      # would hang on the stale counter under a shared prefix
     b.put("k", b"2")
     assert bytes(a.get("k")) == b"1" and bytes(b.get("k")) == b"2"
+
+
+@pytest.mark.parametrize("n", [2, 4] + ([8] if os.environ.get("CBM_TEST_DRY8") == "1" else []))
+def test_bench_dry_run_runs_the_multi_rank_code_on_cpu(n, tmp_path):
+    """`bench.py --gpus N --dry-run` (VERDICT r5 "next" 3c): the launcher (self_launch), the TCP rendezvous, the communicator bring-up, the barrier +
+    max-over-ranks timing protocol, the N = 4 / 8 topology phase with its watchdog and the JSON merge — the code of the driver's N > 1 lines — on the
+    CPU oracle engine over gloo at tiny sizes.  Exactly one JSON line, tagged as a dry run, one device ordinal per rank."""
+    import json
+    import subprocess
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, TMPDIR=str(tmp_path))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "CBM_FORCE_DEVICE", "CBM_COMM"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--dry-run", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["dry_run"] is True and d["n_gpus"] == n and d["value"] > 0 and d["distinct_devices"] == n and d["allreduce"]["ranks"] == n
+    assert "DRY RUN" in d["data"] and d["roofline"] is None
+    if n in (4, 8):
+        bc = d["baseline_config"]
+        assert bc.get("error") is None and bc["value"] > 0 and bc["n_gpus"] == n, bc
+        assert bc["allreduce"]["ranks"] == (3 if n == 4 else 6)
