@@ -424,27 +424,31 @@ def host_env_value(a, params):
 
 
 def secondary_values():
-    """Secondary workloads under the same clock: a few warm-up + 5 (PPO-ResNet) / 20 (IMPALA T = 128) / 40 (T = 20) timed updates each through the product trainer
+    """Secondary workloads under the same clock: a few warm-up + 6 (PPO-ResNet) / 21 (IMPALA T = 128) / 42 (T = 20) timed updates each, in three blocks through the product trainer
     (cleanba_amd.trainer.train, device env, --concurrency), two device syncs per run.  Not the headline."""
     from cleanba_amd.args import parse_args
     from cleanba_amd.trainer import train
-    rows = [("impala_bf16_configs2", "impala", ["--network", "nature", "--bf16-forward"], T, 5, 20,
+    # every row: `warm` warm-up updates, then THREE timed blocks of n_up / 3 updates each (a device sync at every block edge); value = the MEDIAN block,
+    # the fastest / slowest block ride along — a 5 % move between two driver runs can then be read against the spread inside one (VERDICT r5 "next" 6)
+    rows = [("impala_bf16_configs2", "impala", ["--network", "nature", "--bf16-forward"], T, 5, 21,
              "BASELINE configs[2]: IMPALA a0-l0-d1, V-trace, Nature-CNN bf16-MFMA forward / fp32 returns, 120 envs x 128 steps"),
-            ("impala_fp32_t128", "impala", ["--network", "nature"], T, 5, 20, "IMPALA a0-l0-d1 fp32, 120 envs x 128 steps"),
-            ("impala_fp32_t20", "impala", ["--network", "nature"], 20, 40, 40, "IMPALA a0-l0-d1 fp32 at the script's default num_steps = 20 (40 warm + 40 timed updates of ~2.7 ms)"),
-            ("ppo_nature_backward_split2", "ppo", ["--network", "nature", "--backward-split", "2"], T, 2, 8,
+            ("impala_fp32_t128", "impala", ["--network", "nature"], T, 5, 21, "IMPALA a0-l0-d1 fp32, 120 envs x 128 steps"),
+            ("impala_fp32_t20", "impala", ["--network", "nature"], 20, 40, 42, "IMPALA a0-l0-d1 fp32 at the script's default num_steps = 20 (40 warm + 42 timed updates of ~2.7 ms)"),
+            ("ppo_nature_backward_split2", "ppo", ["--network", "nature", "--backward-split", "2"], T, 2, 9,
              "EXTENSION, not the headline: configs[1] with the backward GEMMs as two-term split-bf16 products on bf16 MFMA, fp32 accumulate "
              "(cbm_config.backward_split = 2; gradients within 1.2e-6 of the fp32-MFMA path); the forward stays fp32 MFMA, bit-exact"),
-            ("ppo_nature_backward_split3", "ppo", ["--network", "nature", "--backward-split", "3"], T, 2, 8,
+            ("ppo_nature_backward_split3", "ppo", ["--network", "nature", "--backward-split", "3"], T, 2, 9,
              "EXTENSION, not the headline: configs[1] with the input-gradient GEMMs as three-term split-bf16 products on bf16 MFMA, fp32 accumulate "
              "(cbm_config.backward_split = 3; gradients within 1e-7 of the fp32-MFMA path, tests/test_gpu_parity.py); forward and weight gradients stay fp32 MFMA"),
-            ("ppo_resnet", "ppo", ["--network", "impala_resnet"], T, 2, 5, "PPO a0-l0-d1 with the IMPALA-ResNet torso (the CLI's default network, ppo:149-189), 120 envs x 128 steps")]
+            ("ppo_resnet", "ppo", ["--network", "impala_resnet"], T, 2, 6, "PPO a0-l0-d1 with the IMPALA-ResNet torso (the CLI's default network, ppo:149-189), 120 envs x 128 steps")]
     out = {}
     for name, algo, extra, t, warm, n_up, what in rows:
         marks = {}
 
-        def on_update(v, st, e, marks=marks, warm=warm, last=warm + n_up):
-            if v == warm or v == last:
+        edges = [warm + k * (n_up // 3) for k in range(4)]
+
+        def on_update(v, st, e, marks=marks, edges=edges):
+            if v in edges:
                 e.sync()
                 marks[v] = time.perf_counter()
 
@@ -456,8 +460,11 @@ def secondary_values():
         sys.stdout = open(os.devnull, "w")
         try:
             train(parse_args(argv, algo), algo, on_update=on_update)
-            dt = (marks[warm + n_up] - marks[warm]) / n_up
-            out[name] = {"value": round(E * t / dt, 1), "unit": "env-steps/s", "ms_per_update": round(dt * 1e3, 3), "updates_timed": n_up, "workload": what}
+            blk = sorted((marks[edges[k + 1]] - marks[edges[k]]) / (n_up // 3) for k in range(3))   # seconds per update, fastest block first
+            dt = blk[1]
+            out[name] = {"value": round(E * t / dt, 1), "unit": "env-steps/s", "ms_per_update": round(dt * 1e3, 3), "updates_timed": n_up,
+                         "value_is": "median of three timed blocks of %d updates" % (n_up // 3),
+                         "block_values_min_max": [round(E * t / blk[2], 1), round(E * t / blk[0], 1)], "workload": what}
         except BaseException as e:  # noqa: BLE001
             out[name] = {"value": None, "error": f"{type(e).__name__}: {e}", "workload": what}
         finally:
@@ -468,7 +475,7 @@ def secondary_values():
         # executed flops per env-step of the ResNet PPO step (rollout forward + 4 epochs x (forward + input gradients except conv0's + weight gradients))
         r["executed_mflop_per_env_step"] = RESNET_EXEC_MFLOP_PER_ENV_STEP
         r["executed_frac_of_fp32_mfma_peak"] = round(r["value"] * RESNET_EXEC_MFLOP_PER_ENV_STEP * 1e6 / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)
-        r["per_kernel"] = "profiles/r05_resnet_roofline.md (tools/resnet_roofline.py over the rocprofv3 --kernel-trace of tools/rn_microbench.py: executed flops per launch from each kernel's geometry)"
+        r["per_kernel"] = "profiles/r06_resnet_roofline.md (tools/resnet_roofline.py over the rocprofv3 --kernel-trace of tools/rn_microbench.py: executed flops per launch from each kernel's geometry)"
     return out
 
 

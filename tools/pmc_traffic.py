@@ -30,11 +30,16 @@ def avg(path, counter):
 def git_rev():
     import os
     import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     try:
-        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
         return subprocess.check_output(["git", "-C", root, "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
-    except Exception:  # noqa: BLE001  (the GPU box's snapshot has no .git: pmc_collect.sh passes GIT_REV)
-        return os.environ.get("GIT_REV", "unknown")
+    except Exception:  # noqa: BLE001  (the GPU box's snapshot has no .git: GIT_REV, or the .build_rev file tools/r06_artifacts.sh's caller writes before gpurun)
+        if os.environ.get("GIT_REV"):
+            return os.environ["GIT_REV"]
+        try:
+            return open(os.path.join(root, ".build_rev")).read().strip() or "unknown"
+        except OSError:
+            return "unknown"
 
 
 def same_kernel(launched, full):
