@@ -32,7 +32,18 @@ __global__ __launch_bounds__(256, 2) void dense_wgrad_dma_kernel(const float* __
   const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wx = wave >> 1, wy = wave & 1;
-  const int m0 = blockIdx.x * DW_BM, n0 = blockIdx.y * DW_BN, z = blockIdx.z;
+  // XCD-aware tile order (1-D grid).  Workgroups go to the eight XCDs round robin by linear id and each XCD has its own L2: the id is turned into "XCD j
+  // owns the contiguous run [start_j, start_j + n_j) of the list ordered (slice, row tile, column tile)", so the NY column tiles that multiply the same
+  // 128-row panel of `act` run back to back on ONE XCD and the panel is fetched into one L2 once.  (As a 3-D grid the four column tiles of a panel sat 25 ids
+  // apart — four different XCDs: 246 MB of fabric traffic per launch for 62.5 MB of operands in round 5's counters.)
+  const int NX = (X + DW_BM - 1) / DW_BM, NY = (Y + DW_BN - 1) / DW_BN;
+  int g = blockIdx.x;
+  {
+    const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = g & 7, k = g >> 3;
+    g = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+  }
+  const int by = g % NY, bx = (g / NY) % NX, z = g / (NY * NX);
+  const int m0 = bx * DW_BM, n0 = by * DW_BN;
   const int f_lo = z * fslice, f_hi = min(F, f_lo + fslice), nc = (f_hi - f_lo + DW_BK - 1) / DW_BK;
   // element offsets of this wave's copies inside a chunk: copy j moves 256 consecutive floats of the [16][128] tile = 2 k-rows of 128
   uint32_t aoff[DA], boff[DB];
@@ -59,7 +70,7 @@ __global__ __launch_bounds__(256, 2) void dense_wgrad_dma_kernel(const float* __
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
   float bsum = 0.0f;
-  const bool do_bias = blockIdx.x == 0;            // the column sums of dhid (bias gradient) come from the B tiles of the first row of blocks
+  const bool do_bias = bx == 0;            // the column sums of dhid (bias gradient) come from the B tiles of the first row of blocks
   // skip > 0 only for a ragged last chunk: its first `skip` k rows were already multiplied by the chunk before
   auto compute = [&](int c, int skip) __attribute__((always_inline)) {
     const float* As = smem + (c % DW_ST) * (ASZ + BSZ);
@@ -117,6 +128,6 @@ __global__ __launch_bounds__(256, 2) void dense_wgrad_dma_kernel(const float* __
 int dense_wgrad_dma_slices(int F) { return F >= 2048 ? 5 : 0; }   // 0: batch not handled here (small batches stay on igemm_kernel)
 void launch_dense_wgrad_dma(const float* act, const float* dhid, float* part, float* bpart, int F, int X, int Y, int nz, hipStream_t st) {
   const int fslice = ((F + nz - 1) / nz + DW_BK - 1) / DW_BK * DW_BK;
-  dim3 grid((X + DW_BM - 1) / DW_BM, (Y + DW_BN - 1) / DW_BN, nz);
+  dim3 grid(((X + DW_BM - 1) / DW_BM) * ((Y + DW_BN - 1) / DW_BN) * nz);   // 1-D: the kernel orders the tiles per XCD
   hipLaunchKernelGGL(dense_wgrad_dma_kernel, grid, dim3(256), 0, st, act, dhid, part, bpart, F, X, Y, fslice);
 }
