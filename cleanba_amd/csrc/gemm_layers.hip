@@ -1567,8 +1567,21 @@ static void conv3_order_build(NatureWs& ws, int S, int BX, hipStream_t st) {
 // dense input gradient on 128x64 tiles (1470 blocks, three dispatch waves) instead of 128x128 (750 blocks, one and a half): 7 us slower alone (125 vs
 // 118), 13 us faster beside the rollout (156 -> 143), step -0.03 ... -0.19 ms in five A/B pairs — shorter blocks in more waves suffer less from the CUs the
 // rollout slows down (tools/block_trace.py)
+// Round 6, K chunks of 32 for the dense and conv3 input gradients: timing builds of igemm_pf2_kernel (-DPF2_ABL, profiles/r06_pf2_ablation.txt) put 14-17 % of
+// these kernels into their global loads — not the latency (a true two-chunk prefetch changed nothing) but the request count: with 16-wide chunks a row
+// contributes 64 bytes per chunk, half a cache line, twice.  dense dgrad 125 -> 116 us (128x64x32, four waves per SIMD), conv3 dgrad 143.6 -> 141.2
+// (two per SIMD); the merged conv2 dgrad is SLOWER on 32-wide chunks (222 -> 228: 66 KB of LDS per block) and keeps 16.
+using T128x64k32 = IgemmTile<128, 64, 32, 2, 2, 2>;
+using T128x128k32 = IgemmTile<128, 128, 32, 2, 2, 2>;
+using T128x64k32w4 = IgemmTile<128, 64, 32, 2, 2, 4>;
 #ifndef CBM_DD_TILE
-#define CBM_DD_TILE T128x64
+#define CBM_DD_TILE T128x64k32w4
+#endif
+#ifndef CBM_C3D_TILE
+#define CBM_C3D_TILE T128x64k32
+#endif
+#ifndef CBM_C2D_TILE
+#define CBM_C2D_TILE T128x128k16
 #endif
 void nature_backward(const NatureLayout& L, const float* P, const uint8_t* obs, const int32_t* idx, int B, NatureWs& ws, float* grads,
                      hipStream_t st) {
@@ -1617,8 +1630,8 @@ void nature_backward(const NatureLayout& L, const float* P, const uint8_t* obs, 
   if (ws.tail_ev) hipEventRecord(ws.tail_ev, st);   // 95 % of the flat gradient is final here: its all-reduce can overlap the conv backward
   // conv3: dgrad -> dact2pad (position-major with tap skipping), wgrad
   {
-    conv3_order_build(ws, B, T128x64::BX, st);
-    Conv3DgradPos<T128x64> pd{ws.dact3pad, P + L.w[2], ws.act2, ws.dact2pad, B, ws.c3_order, ws.mask2};
+    conv3_order_build(ws, B, CBM_C3D_TILE::BX, st);
+    Conv3DgradPos<CBM_C3D_TILE> pd{ws.dact3pad, P + L.w[2], ws.act2, ws.dact2pad, B, ws.c3_order, ws.mask2};
     plaunch_bwd(ws, K_CONV3_DGRAD, pd, 1, st);
     // frame-resident kernel (wgrad_frames.hip): the whole 576x64 gradient in the block's accumulators, act2 / dY frames copied once into LDS
     // (fp32 MFMA also in split mode: the split weight-gradient kernel measured slower than the im2col fp32 one already)
@@ -1630,7 +1643,7 @@ void nature_backward(const NatureLayout& L, const float* P, const uint8_t* obs, 
   }
   // conv2: dgrad -> dact1 (merged position-major form, N = 128, one dY tile for the four classes: 268 -> 246 us), wgrad
   {
-    Conv2DgradMergedPos<T128x128k16> pd{ws.dact2pad, P + L.w[1], ws.dact1, B, ws.mask1};
+    Conv2DgradMergedPos<CBM_C2D_TILE> pd{ws.dact2pad, P + L.w[1], ws.dact1, B, ws.mask1};
     plaunch_bwd(ws, K_CONV2_DGRAD, pd, 1, st);
     if (ws.bwd_split != 2) {   // frame-resident kernel
       const int nz = conv2_wgrad_frames_splits(B);

@@ -458,25 +458,40 @@ __global__ __launch_bounds__(256, P::Tile::MINW) void igemm_pf2_kernel(const P p
   // merge of two paths, `vmcnt(1)` / `vmcnt(0)` where `vmcnt(NV..)` would do (tools/isa_audit.py) — and it changed nothing: the loads of chunk c+2
   // are a whole chunk of MFMAs old by then.  dense / conv3 / conv2 input gradients 125.0 / 144.7 / 224.3 -> 126.8 / 145.4 / 223.5 us, the actor's
   // small-batch kernels slower (rollout alone 6.52 -> 6.7-6.8 ms: two more chunk loads per block).  Not kept: profiles/r06_isa_fixes_ab.txt.)
+#ifndef PF2_ABL   // timing builds only (tools/variants.sh): 1 no epilogue stores, 2 no staging stores, 4 no global loads in the loop, 8 no MFMAs, 16 no barrier
+#define PF2_ABL 0
+#endif
   float4 a0[NVA], b0[NVB], a1[NVA], b1[NVB];
   gload(0, a0, b0);
   sstore(0, a0, b0);
   if (nchunk > 1) gload(1, a0, b0);
+  if (PF2_ABL & 4) gload(0, a1, b1);
   __syncthreads();
   int buf = 0, c = 0;
   while (true) {
-    if (c + 2 < nchunk) gload(c + 2, a1, b1);        // set 0 holds chunk c+1
-    compute(buf);
-    if (c + 1 < nchunk) sstore(buf ^ 1, a0, b0);
-    __syncthreads();
+    if (!(PF2_ABL & 4) && c + 2 < nchunk) gload(c + 2, a1, b1);        // set 0 holds chunk c+1
+    if (!(PF2_ABL & 8)) compute(buf);
+    if (!(PF2_ABL & 2) && c + 1 < nchunk) sstore(buf ^ 1, a0, b0);
+    if (!(PF2_ABL & 16)) __syncthreads();
     buf ^= 1;
     if (++c >= nchunk) break;
-    if (c + 2 < nchunk) gload(c + 2, a0, b0);        // set 1 holds chunk c+1
-    compute(buf);
-    if (c + 1 < nchunk) sstore(buf ^ 1, a1, b1);
-    __syncthreads();
+    if (!(PF2_ABL & 4) && c + 2 < nchunk) gload(c + 2, a0, b0);        // set 1 holds chunk c+1
+    if (!(PF2_ABL & 8)) compute(buf);
+    if (!(PF2_ABL & 2) && c + 1 < nchunk) sstore(buf ^ 1, a1, b1);
+    if (!(PF2_ABL & 16)) __syncthreads();
     buf ^= 1;
     if (++c >= nchunk) break;
+  }
+  if (PF2_ABL & 1) {   // (the accumulators stay live through a sum that is stored on a condition no run meets)
+    float sabl = 0.0f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sabl += acc[i][j][e];
+    if (sabl == 1.2345e-33f) p.store(x0, y0, sabl, z, cls);
+    return;
   }
 
 #pragma unroll
