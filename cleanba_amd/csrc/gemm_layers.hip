@@ -1574,6 +1574,12 @@ static void conv3_order_build(NatureWs& ws, int S, int BX, hipStream_t st) {
 using T128x64k32 = IgemmTile<128, 64, 32, 2, 2, 2>;
 using T128x128k32 = IgemmTile<128, 128, 32, 2, 2, 2>;
 using T128x64k32w4 = IgemmTile<128, 64, 32, 2, 2, 4>;
+using T64x128k16w4 = IgemmTile<64, 128, 16, 2, 2, 4>;
+using T128x64k16w41 = IgemmTile<128, 64, 16, 4, 1, 4>;
+using T128x64k16w3 = IgemmTile<128, 64, 16, 2, 2, 3>;
+using T64x64k32w4 = IgemmTile<64, 64, 32, 2, 2, 4>;
+using T64x64k16w4 = IgemmTile<64, 64, 16, 2, 2, 4>;
+using T128x64k32w3 = IgemmTile<128, 64, 32, 2, 2, 3>;
 #ifndef CBM_DD_TILE
 #define CBM_DD_TILE T128x64k32w4
 #endif
@@ -1581,7 +1587,7 @@ using T128x64k32w4 = IgemmTile<128, 64, 32, 2, 2, 4>;
 #define CBM_C3D_TILE T128x64k32
 #endif
 #ifndef CBM_C2D_TILE
-#define CBM_C2D_TILE T128x128k16
+#define CBM_C2D_TILE T128x64     // (round 6: two column tiles of 64 per pixel tile, four waves per SIMD: 224 -> 214 us against the 128x128 tile; 128x64x32 218-231, 64x128 228)
 #endif
 void nature_backward(const NatureLayout& L, const float* P, const uint8_t* obs, const int32_t* idx, int B, NatureWs& ws, float* grads,
                      hipStream_t st) {
