@@ -815,7 +815,10 @@ __global__ __launch_bounds__(256, P::Tile::MINW) void igemm_dma_kernel(const P p
     if (r0 + BR < rhi) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NIW) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_barrier" ::: "memory");                    // (not __syncthreads(): its fence would wait for every copy in flight)
-    if (r0 + 2 * BR < rhi) dma(r0 + 2 * BR, buf >= 1 ? buf - 1 : NST - 1);      // stage (i + 2) % 3 = (buf + 2) % 3
+#ifndef DMA_ABL   // timing builds only: 1 no epilogue stores, 2 no copies inside the K loop, 8 no MFMAs
+#define DMA_ABL 0
+#endif
+    if (!(DMA_ABL & 2) && r0 + 2 * BR < rhi) dma(r0 + 2 * BR, buf >= 1 ? buf - 1 : NST - 1);      // stage (i + 2) % 3 = (buf + 2) % 3
     const float* A_ = As + buf * ASZ;
     const float* B_ = Bs + buf * BSZ;
     {
@@ -844,12 +847,25 @@ __global__ __launch_bounds__(256, P::Tile::MINW) void igemm_dma_kernel(const P p
 #pragma unroll
           for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g & 1][q][i], fb[g & 1][q][j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < TN; ++j) {
+              if (DMA_ABL & 8) acc[i][j][0] += fa[g & 1][q][i] * fb[g & 1][q][j];
+              else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g & 1][q][i], fb[g & 1][q][j], acc[i][j], 0, 0, 0);
+            }
         __builtin_amdgcn_sched_barrier(0);
       }
     }
     buf = buf + 1 == NST ? 0 : buf + 1;
+  }
+  if (DMA_ABL & 1) {
+    float sabl = 0.0f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sabl += acc[i][j][e];
+    if (sabl == 1.2345e-33f) p.store(x0, y0, sabl, z, 0);
+    return;
   }
 
 #pragma unroll
