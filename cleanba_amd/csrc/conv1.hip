@@ -88,7 +88,9 @@ __global__ __launch_bounds__(256, 2) void conv1_fwd_planes_kernel(const uint8_t*
     const int c = k >> 6, kh = (k >> 3) & 7, kw = k & 7;
     *reinterpret_cast<float4*>(Wl + k * 32 + n4) = *reinterpret_cast<const float4*>(W + ((kh * 8 + kw) * 4 + c) * 32 + n4);
   }
-  const float bn = bias[li];
+  float bch[16];                                            // bias of this lane's 16 channels: c(e) = (e & 3) + 8 (e >> 2) + 4 h
+#pragma unroll
+  for (int e = 0; e < 16; ++e) bch[e] = bias[(e & 3) + 8 * (e >> 2) + 4 * h];
   constexpr int MAXT = 3;
   typedef float f32x4_t __attribute__((ext_vector_type(4)));
   typedef float f32x2_t __attribute__((ext_vector_type(2)));
@@ -118,9 +120,13 @@ __global__ __launch_bounds__(256, 2) void conv1_fwd_planes_kernel(const uint8_t*
       C1T(5 * c);
       __syncthreads();                       // every wave is done with the previous plane (and, for c == 0, with the weights' staging loads)
       C1T(5 * c + 1);
+#ifndef C1F_ABL   // timing builds only: 1 no epilogue stores, 2 planes converted / stored to LDS only for the block's first plane, 4 no plane loads after the first, 16 one barrier per plane
+#define C1F_ABL 0
+#endif
 #pragma unroll
       for (int j = 0; j < 7; ++j) {
         const int v = tid + 256 * j;
+        if ((C1F_ABL & 2) && !(s == s_lo && c == 0)) break;
         if (v < 1764) {
           const int y = v / 21, xw = v - y * 21;
           const uint32_t w = pw[j];
@@ -129,10 +135,12 @@ __global__ __launch_bounds__(256, 2) void conv1_fwd_planes_kernel(const uint8_t*
           *reinterpret_cast<f32x2_t*>(Pf + 3528 + y * 42 + 2 * xw) = od;
         }
       }
+      if (!(C1F_ABL & 4)) {
       if (c < 3) load_plane(frame + (c + 1) * 7056);                                           // lands while this plane is multiplied
       else if (s + 1 < s_hi) load_plane(obs + (size_t)(idx ? idx[s + 1] : s + 1) * FR);
+      }
       C1T(5 * c + 2);
-      __syncthreads();
+      if (!(C1F_ABL & 16)) __syncthreads();
       C1T(5 * c + 3);
       f32x2_t aa[2][MAXT][2];
       float ta[2][2], wv[2][6];
@@ -159,10 +167,10 @@ __global__ __launch_bounds__(256, 2) void conv1_fwd_planes_kernel(const uint8_t*
         for (int j = 0; j < 4; ++j)
 #pragma unroll
           for (int t = 0; t < MAXT; ++t)
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aa[set][t][j >> 1][j & 1], wv[set][j], acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[set][j], aa[set][t][j >> 1][j & 1], acc[t], 0, 0, 0);   // D[channel][position]: see the epilogue
         if (four) {
 #pragma unroll
-          for (int st = 0; st < 2; ++st) tacc = __builtin_amdgcn_mfma_f32_16x16x4f32(ta[set][st], wv[set][4 + st], tacc, 0, 0, 0);
+          for (int st = 0; st < 2; ++st) tacc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[set][4 + st], ta[set][st], tacc, 0, 0, 0);
         }
       };
       fetch(0, 0);
@@ -180,36 +188,47 @@ __global__ __launch_bounds__(256, 2) void conv1_fwd_planes_kernel(const uint8_t*
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     C1T(22);
 #endif
-    float* o = out + (size_t)s * 400 * 32 + li;
+    if (C1F_ABL & 1) {
+      float sabl = tacc[0];
+#pragma unroll
+      for (int t = 0; t < MAXT; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sabl += acc[t][e];
+      if (sabl == 1.2345e-33f) out[0] = sabl;
+      continue;
+    }
+    // The products are formed TRANSPOSED — the weights are the MFMA's A operand, the pixels its B operand (the same two registers, swapped: same products,
+    // same k order, same bits) — so that a lane ends up with 16 CHANNELS of ONE position, in four runs of four: four 16-byte stores per tile instead of
+    // sixteen 4-byte ones, and the position's ReLU word is this lane's own bits | its partner half's (one cross-half exchange) instead of sixteen
+    // ballots handed round with two v_writelane each.  (Round 6: with NO epilogue the kernel is 18 us shorter, 254 -> 236, profiles/r06_pf2_ablation.txt — and
+    // this four-times-leaner one measures the SAME 251-256 us as the old: what the epilogue costs is its 197 MB of writes, not its instructions.  Kept: less code.)
 #pragma unroll
     for (int t = 0; t < MAXT; ++t) {
       C1T(23 + t);
-      const int m0 = (first + 4 * t) * 32 + 4 * h;
-      uint32_t word = 0;
+      const int m = (first + 4 * t) * 32 + li;                   // position (tiles 0..11: always < 384)
+      float* o = out + ((size_t)s * 400 + m) * 32 + 4 * h;
+      uint32_t bits = 0;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int r0 = (e & 3) + 8 * (e >> 2);
-        const float v = relu_(acc[t][e] + bn);
-        o[(m0 + r0) * 32] = v;
-        const unsigned long long bal = __ballot(v > 0.0f);
-        asm volatile("s_nop 4\n\tv_writelane_b32 %0, %1, %2" : "+v"(word) : "s"((uint32_t)bal), "n"(r0));
-        asm volatile("s_nop 4\n\tv_writelane_b32 %0, %1, %2" : "+v"(word) : "s"((uint32_t)(bal >> 32)), "n"(r0 + 4));
+      for (int g = 0; g < 4; ++g) {
+        float4 v;
+        v.x = relu_(acc[t][4 * g] + bch[4 * g]); v.y = relu_(acc[t][4 * g + 1] + bch[4 * g + 1]);
+        v.z = relu_(acc[t][4 * g + 2] + bch[4 * g + 2]); v.w = relu_(acc[t][4 * g + 3] + bch[4 * g + 3]);
+        *reinterpret_cast<float4*>(o + 8 * g) = v;               // channels 8g + 4h .. + 3
+        bits |= ((v.x > 0.0f ? 1u : 0u) | (v.y > 0.0f ? 2u : 0u) | (v.z > 0.0f ? 4u : 0u) | (v.w > 0.0f ? 8u : 0u)) << (8 * g + 4 * h);
       }
-      if (mask && lane < 32) mask[(size_t)s * 400 + (first + 4 * t) * 32 + lane] = word;
+      bits |= (uint32_t)__shfl_xor((int)bits, 32, 64);
+      if (mask && lane < 32) mask[(size_t)s * 400 + m] = bits;
     }
     C1T(26);
-    if (four) {
-      const float bt = bias[16 * tj + r16];
-      uint32_t word = 0;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float v = relu_(tacc[i] + bt);
-        out[((size_t)s * 400 + 384 + 4 * g4 + i) * 32 + 16 * tj + r16] = v;
-        const unsigned long long bal = __ballot(v > 0.0f);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) asm volatile("s_nop 4\n\tv_writelane_b32 %0, %1, %2" : "+v"(word) : "s"((uint32_t)((bal >> (16 * g)) & 0xFFFFull)), "n"(4 * g + i));
-      }
-      if (mask && lane < 16) reinterpret_cast<uint16_t*>(mask + (size_t)s * 400 + 384 + lane)[tj] = (uint16_t)word;
+    if (four) {   // tail tile, also transposed: lane (g4, r16) holds channels 16 tj + 4 g4 .. + 3 of position 384 + r16
+      const float4 bt = *reinterpret_cast<const float4*>(bias + 16 * tj + 4 * g4);
+      float4 v;
+      v.x = relu_(tacc[0] + bt.x); v.y = relu_(tacc[1] + bt.y); v.z = relu_(tacc[2] + bt.z); v.w = relu_(tacc[3] + bt.w);
+      *reinterpret_cast<float4*>(out + ((size_t)s * 400 + 384 + r16) * 32 + 16 * tj + 4 * g4) = v;
+      uint32_t bits = ((v.x > 0.0f ? 1u : 0u) | (v.y > 0.0f ? 2u : 0u) | (v.z > 0.0f ? 4u : 0u) | (v.w > 0.0f ? 8u : 0u)) << (4 * g4);
+      bits |= (uint32_t)__shfl_xor((int)bits, 16, 64);
+      bits |= (uint32_t)__shfl_xor((int)bits, 32, 64);
+      if (mask && lane < 16) reinterpret_cast<uint16_t*>(mask + (size_t)s * 400 + 384 + lane)[tj] = (uint16_t)bits;
     }
     C1T(21);
   }
