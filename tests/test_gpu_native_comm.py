@@ -187,3 +187,21 @@ def test_export_windows_survive_repeated_create_map_free_cycles_in_the_same_proc
     out = p.stdout.decode()
     assert p.returncode == 0 and "FAIL" not in out, out[-3000:]
     assert out.count("6 cycles ok, 0 failure(s)") == 4, out[-3000:]
+
+
+def test_native_communicator_cannot_be_initialised_again_after_close():
+    """cbm_ipc_close_all leaves the slot's signal block (old sequence numbers, sticky error words) in place, and a re-init restarted the
+    sequence at 0 under flags that only grow — now the slot refuses; a one-rank communicator is enough to show it."""
+    cfg = L.default_config(L.ALGO_PPO)
+    cfg.local_num_envs, cfg.num_actor_slots, cfg.num_steps = 8, 1, 8
+    ctx = L.Context(cfg)
+    try:
+        blob = ctx.comm_native_export()
+        ctx.comm_native_init([blob], 0)
+        assert ctx.comm_backend() == "native"
+        ctx.comm_barrier()
+        ctx.unmap_peers()
+        with pytest.raises(L.CbmError, match="closed"):
+            ctx.comm_native_init([blob], 0)
+    finally:
+        ctx.close()
