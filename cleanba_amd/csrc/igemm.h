@@ -335,12 +335,23 @@ __global__ __launch_bounds__(256, P::Tile::MINW) void igemm_pf2_kernel(const P p
   const int li = lane & 31, h = lane >> 5;
   const int wx = wave / WY, wy = wave % WY;
   const int cls = P::NCLS > 1 ? (int)(blockIdx.y % P::NCLS) : 0;
-  int bx = blockIdx.x;
-  {
+  int bx = blockIdx.x, by = P::NCLS > 1 ? (int)(blockIdx.y / P::NCLS) : (int)blockIdx.y;
+  if (P::NCLS == 1 && gridDim.y > 1 && (gridDim.x & 7) != 0) {
+    // Many column tiles on a row count that is not a multiple of 8 (the dense input gradient: 30 x 49): workgroups go to the XCDs round robin by
+    // LINEAR id x + NX * y, so "XCD = blockIdx.x % 8" (the remap below) only holds in the first row of the grid, and every XCD ended up fetching every
+    // operand panel (206 MB of L2 misses for 14 MB of operands in round 6's counters).  Here the linear id is mapped onto the list ordered
+    // (super-row of ceil(NX / 8) row tiles, column tile, row tile) and XCD j owns a contiguous run of it: its few A panels stay in its L2 for all columns.
+    const int NX = gridDim.x, NY = gridDim.y, nb = NX * NY, L = (int)blockIdx.x + NX * (int)blockIdx.y;
+    const int q = nb >> 3, r = nb & 7, xcd = L & 7, k = L >> 3;
+    const int o = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    const int chunk = (NX + 7) >> 3, per = chunk * NY, sr = o / per, rem = o - sr * per, w = min(chunk, NX - sr * chunk);
+    by = rem / w;
+    bx = sr * chunk + (rem - by * w);
+  } else {
     const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = bx & 7, k = bx >> 3;
     bx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
   }
-  const int x0 = bx * BX, y0 = (P::NCLS > 1 ? (int)(blockIdx.y / P::NCLS) : (int)blockIdx.y) * BY, z = blockIdx.z;
+  const int x0 = bx * BX, y0 = by * BY, z = blockIdx.z;
   int rlo, rhi;
   p.r_range(z, rlo, rhi);
   constexpr bool KSKIP = igemm_kskip<P>::value;
