@@ -452,8 +452,10 @@ def secondary_values():
                 e.sync()
                 marks[v] = time.perf_counter()
 
+        # (three more updates than are timed: the run's last updates have no rollout beside them — the actor is done — and would make the third block
+        # 5-8 % faster than the other two; rounds 3-5 timed them, which is part of why r05's ppo_resnet read 64.0 k where the median block reads 62 k)
         argv = ["--local-num-envs", str(E), "--num-actor-threads", "1", "--num-steps", str(t), "--env-backend", "device", "--total-timesteps",
-                str((warm + n_up) * E * t), "--log-frequency", "100000", "--concurrency"] + extra
+                str((warm + n_up + 3) * E * t), "--log-frequency", "100000", "--concurrency"] + extra
         cwd = os.getcwd()
         os.chdir(os.environ.get("TMPDIR", "/tmp"))
         so = sys.stdout
