@@ -38,12 +38,6 @@ static __device__ __forceinline__ void cbm_store_wt(float* p, float v) {
   if (AF_ABL & 1) { *p = v; return; }
   __hip_atomic_store(reinterpret_cast<uint32_t*>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-static __device__ __forceinline__ void cbm_glds4_hidden(const void* g_lane, uint32_t lds_byte_addr_wave) {   // 4 bytes per lane (256-byte copies)
-  uint32_t keep;
-  const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_byte_addr_wave);
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(g_lane), "s"(dst) : "memory");
-}
 
 // ---- parameter layout (flax shapes): Nature-CNN ------------------------------
 struct NatureLayout {

@@ -1572,14 +1572,9 @@ static void conv3_order_build(NatureWs& ws, int S, int BX, hipStream_t st) {
 // contributes 64 bytes per chunk, half a cache line, twice.  dense dgrad 125 -> 116 us (128x64x32, four waves per SIMD), conv3 dgrad 143.6 -> 141.2
 // (two per SIMD); the merged conv2 dgrad is SLOWER on 32-wide chunks (222 -> 228: 66 KB of LDS per block) and keeps 16.
 using T128x64k32 = IgemmTile<128, 64, 32, 2, 2, 2>;
-using T128x128k32 = IgemmTile<128, 128, 32, 2, 2, 2>;
 using T128x64k32w4 = IgemmTile<128, 64, 32, 2, 2, 4>;
-using T64x128k16w4 = IgemmTile<64, 128, 16, 2, 2, 4>;
-using T128x64k16w41 = IgemmTile<128, 64, 16, 4, 1, 4>;
-using T128x64k16w3 = IgemmTile<128, 64, 16, 2, 2, 3>;
-using T64x64k32w4 = IgemmTile<64, 64, 32, 2, 2, 4>;
-using T64x64k16w4 = IgemmTile<64, 64, 16, 2, 2, 4>;
-using T128x64k32w3 = IgemmTile<128, 64, 32, 2, 2, 3>;
+// (other shapes tried through -DCBM_DD_TILE / -DCBM_C3D_TILE / -DCBM_C2D_TILE and not kept: 128x128x32, 64x128x16, 64x64x16 and x32, 128x64x16 at three and four
+// waves per SIMD, a 4x1 wave grid — results in profiles/r06_isa_fixes_ab.txt)
 #ifndef CBM_DD_TILE
 #define CBM_DD_TILE T128x64k32w4
 #endif

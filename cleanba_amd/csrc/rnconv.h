@@ -405,6 +405,179 @@ static void rn_conv0_pool_launch(const uint8_t* obs, const int32_t* idx, const f
   hipLaunchKernelGGL((rn_conv0_pool_kernel<PR>), dim3(nb), dim3(256), lds, st, obs, idx, W, bias, pooled, pidx, B, nstrips, mask);
 }
 
+// ---- round 6: the same layer with the max_pool done ON THE ACCUMULATORS (learner batches).  rn_conv0_pool_kernel above writes every conv value to LDS
+// (four 4-way-conflicting ds_write_b32 per tile), re-reads each one 2.25 times as float4 in a separate pooling pass behind a block barrier, and computes
+// one conv row in seven twice: 585 us per 3840-frame minibatch for 198 us of MFMA time (0.34).  Here ONE WAVE owns ONE FRAME and nothing is shared:
+//   * a tile is 4 rows x 4 columns of conv outputs (A operand: lane -> position (li >> 2, li & 3)), so an accumulator lane holds four consecutive
+//     COLUMNS of one row for its channel: the horizontal 3-max of both pooled columns of the tile (columns 4ct..4ct+2 and 4ct+2..4ct+4) is in-lane
+//     arithmetic — the one value from the next column tile is the same lane's accumulator of that tile, computed one tile ahead;
+//   * the vertical 3-max goes through 1 KB of wave-private LDS (one ds_write_b128, three ds_read_b64 per tile).  Rows 4g, 4g+1, 4g+2 give pooled row
+//     2g (lanes 0-31); rows 4g+2, 4g+3 give the first two thirds of pooled row 2g+1, which stay in REGISTERS (lanes 32-63, one pair per column tile:
+//     the 21-tile sweep is unrolled) until the next row group supplies row 4g+4 — 84 = 21 x 4 rows and columns: no conv value is computed twice, no
+//     tile slot is empty;
+//   * the scan order of the reference's max_pool (first maximum in (kh, kw) order wins, ppo:158-166 / rn_pool_fwd_kernel) is kept by merging in that
+//     order with strict compares: same values, same arg-max bytes, same mask bits as the kernel above;
+//   * the input rows of a group (4 new + 2 old, 6 x 84 x 4 bytes) are requested before the previous group's sweep and converted after it; 16 waves
+//     per CU (9.8 KB of LDS each), no block barrier anywhere.
+#ifndef RN_P0_ABL   // timing builds only (tools/variants.sh): 1 no global stores, 2 no LDS exchange, 4 no MFMAs, 8 no staging
+#define RN_P0_ABL 0
+#endif
+#ifndef RN_P0_DEPTH
+#define RN_P0_DEPTH 2
+#endif
+struct RnPool0Reg {
+  static constexpr int H = 84, HP = 42, CO = 16, NCT = 21, NG = 21, NW = 3;
+  static constexpr int RP = 88;                 // slab row pitch: 4 zero cells, then the 84 columns (the right pad is the next row's first cell)
+  static constexpr int PL = 548;                // plane pitch >= 6 * 88 + 4, = 4 mod 32: the 4 planes x 4 rows x 4 columns of a fragment read sit on 32 banks per half wave
+  static constexpr int SLAB = 4 * PL, HB = 64 * 4, WAVE_FLOATS = SLAB + HB;
+  static_assert(PL % 32 == 4 && PL >= 6 * RP + 4 && PL % 4 == 0, "plane pitch");
+};
+__global__ __launch_bounds__(64 * RnPool0Reg::NW, 4) void rn_conv0_pool_reg_kernel(const uint8_t* __restrict__ obs, const int32_t* __restrict__ idx,
+                                                                                  const float* __restrict__ W, const float* __restrict__ bias,
+                                                                                  float* __restrict__ pooled, uint8_t* __restrict__ pidx, int B,
+                                                                                  uint16_t* __restrict__ mask) {
+  using G = RnPool0Reg;
+  constexpr int H = G::H, HP = G::HP, RP = G::RP, PL = G::PL;
+  extern __shared__ __attribute__((aligned(16))) float rn_smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, kq = lane >> 4;
+  const int b = blockIdx.x * G::NW + wave;
+  if (b >= B) return;                                             // (no block barrier below)
+  float* slab = rn_smem + wave * G::WAVE_FLOATS;
+  float4* hb4 = reinterpret_cast<float4*>(slab + G::SLAB);        // [row kq][channel li] -> (max j=0, kw j=0, max j=1, kw j=1)
+  const float2* hb2 = reinterpret_cast<const float2*>(slab + G::SLAB);
+  for (int v = lane; v < G::SLAB / 4; v += 64) reinterpret_cast<float4*>(slab)[v] = make_float4(0.f, 0.f, 0.f, 0.f);   // pad cells stay zero
+  const uint8_t* fr = obs + (size_t)(idx ? idx[b] : b) * CBM_FRAME;
+  float bv[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) bv[t] = W[(t * 4 + kq) * 16 + li];
+  const float bz = bias[li];
+  // slab rows 0..5 of group g = input rows 4g-1 .. 4g+4; uint32 v = (plane p, slab row r, 4 columns cq)
+  constexpr int NV = 4 * 6 * 21, NI = (NV + 63) / 64;
+  uint32_t ru[NI];
+  auto fetch = [&](int g) __attribute__((always_inline)) {
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {
+      const int v = min(lane + 64 * it, NV - 1);
+      const int cq = v % 21, t = v / 21, r = t % 6, p = t / 6;
+      const int y = min(max(4 * g - 1 + r, 0), H - 1);
+      ru[it] = *reinterpret_cast<const uint32_t*>(fr + p * (H * H) + y * H + 4 * cq);
+    }
+  };
+  auto commit = [&](int g) __attribute__((always_inline)) {
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {
+      const int v = lane + 64 * it;
+      if (NV % 64 != 0 && v >= NV) break;
+      const int cq = v % 21, t = v / 21, r = t % 6, p = t / 6;
+      const int y = 4 * g - 1 + r;
+      const bool ok = y >= 0 && y < H;
+      float4 o;
+      o.x = ok ? cbm_u8_unit(ru[it] & 0xffu) : 0.0f;
+      o.y = ok ? cbm_u8_unit((ru[it] >> 8) & 0xffu) : 0.0f;
+      o.z = ok ? cbm_u8_unit((ru[it] >> 16) & 0xffu) : 0.0f;
+      o.w = ok ? cbm_u8_unit(ru[it] >> 24) : 0.0f;
+      *reinterpret_cast<float4*>(slab + p * PL + r * RP + 4 + 4 * cq) = o;
+    }
+  };
+  // A fragment of tap (kh, kw) of column tile ct: plane kq, slab row (li >> 2) + kh, column 4 ct + (li & 3) + kw - 1 -> one base + immediates
+  const float* abase = slab + kq * PL + (li >> 2) * RP + 3 + (li & 3);
+  const bool hi = kq >= 2;                                        // lanes 32-63 finish pooled row 2g-1, lanes 0-31 produce pooled row 2g
+  const int j = kq & 1;                                           // pooled column 2 ct + j
+  const int ra = hi ? 2 : 0, rc = hi ? 0 : 2;                     // (rb = ra + 1)
+  const float2* hA = hb2 + ((ra * 16 + li) * 2 + j);
+  const float2* hC = hb2 + ((rc * 16 + li) * 2 + j);
+  float cv_[G::NCT];                                              // rows 4g+2, 4g+3 of pooled row 2g+1: running maximum and its arg (lanes 32-63)
+  uint32_t ck_[(G::NCT + 7) / 8] = {0u, 0u, 0u};                 // (4 bits per column tile)
+#pragma unroll
+  for (int ct = 0; ct < G::NCT; ++ct) cv_[ct] = 0.0f;
+  const size_t fb = (size_t)b * (HP * HP * 16);
+  const int lc = (j - (hi ? HP : 0)) * 16 + li;                   // element offset of this lane's output relative to (row 2g, column 2ct)
+  auto tile_mfma = [&](int ct, rn_f32x4& acc) __attribute__((always_inline)) {
+    acc = rn_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int kh = t / 3, kw = t - 3 * kh;
+      if (RN_P0_ABL & 4) acc[t & 3] = __uint_as_float(__float_as_uint(acc[t & 3]) ^ __float_as_uint(abase[kh * RP + kw + 4 * ct]));
+      else acc = __builtin_amdgcn_mfma_f32_16x16x4f32(abase[kh * RP + kw + 4 * ct], bv[t], acc, 0, 0, 0);
+    }
+  };
+  fetch(0);
+#pragma unroll 1
+  for (int g = 0; g < G::NG; ++g) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (!(RN_P0_ABL & 8) || g == 0) commit(g);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (g + 1 < G::NG && !(RN_P0_ABL & 8)) fetch(g + 1);
+    const long ob = (long)fb + g * (2 * HP * 16) + lc;            // + ct * 32
+    float* po = pooled + ob;
+    uint8_t* pi = pidx + ob;
+    uint16_t* pm = mask + (ob >> 4);                              // (li == 0 lanes only)
+    const bool live = !(hi && g == 0);                            // there is no pooled row -1
+    // RN_P0_DEPTH tiles are multiplied ahead of the one being pooled: their 9-step chains are independent of each other
+    rn_f32x4 acc[RN_P0_DEPTH + 1];
+#pragma unroll
+    for (int d = 0; d < RN_P0_DEPTH; ++d) tile_mfma(d, acc[d]);
+    float a0 = acc[0][0] + bz;
+#pragma unroll
+    for (int ct = 0; ct < G::NCT; ++ct) {
+      if (ct + RN_P0_DEPTH < G::NCT) tile_mfma(ct + RN_P0_DEPTH, acc[RN_P0_DEPTH]);
+      const float a1 = acc[0][1] + bz, a2 = acc[0][2] + bz, a3 = acc[0][3] + bz;
+      const float x4 = ct + 1 < G::NCT ? acc[1][0] + bz : -INFINITY;
+      float m0 = a0, m1 = a2;
+      uint32_t k0 = 0u, k1 = 0u;
+      if (a1 > m0) { m0 = a1; k0 = 1u; }
+      if (a2 > m0) { m0 = a2; k0 = 2u; }
+      if (a3 > m1) { m1 = a3; k1 = 1u; }
+      if (x4 > m1) { m1 = x4; k1 = 2u; }
+      if (!(RN_P0_ABL & 2)) hb4[lane] = make_float4(m0, __uint_as_float(k0), m1, __uint_as_float(k1));
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      float2 qa, qb, qc;                                          // rows ra, ra + 1 (16 channels x 2 pairs further), rc
+      if (RN_P0_ABL & 2) { qa = make_float2(m0, __uint_as_float(k0)); qb = make_float2(m1, __uint_as_float(k1)); qc = make_float2(a3, __uint_as_float(k0 ^ k1)); }
+      else { qa = hA[0]; qb = hA[32]; qc = hC[0]; }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      float mv = qa.x;
+      uint32_t mk = __float_as_uint(qa.y);
+      if (qb.x > mv) { mv = qb.x; mk = __float_as_uint(qb.y) + 3u; }
+      float fv = hi ? cv_[ct] : mv;
+      uint32_t fk = hi ? (ck_[ct >> 3] >> (4 * (ct & 7))) & 15u : mk;
+      cv_[ct] = mv;
+      ck_[ct >> 3] = (ck_[ct >> 3] & ~(15u << (4 * (ct & 7)))) | (mk << (4 * (ct & 7)));
+      if (qc.x > fv) { fv = qc.x; fk = __float_as_uint(qc.y) + 6u; }
+      const unsigned long long bal = __ballot(fv > 0.0f);
+      if ((RN_P0_ABL & 1) ? (live && fv == 123.456f && fk == 77u) : live) {
+        po[ct * 32] = fv;
+        pi[ct * 32] = (uint8_t)fk;
+        if (mask && li == 0) pm[ct * 2] = (uint16_t)(bal >> (16 * kq));
+      }
+      a0 = x4;
+#pragma unroll
+      for (int d = 0; d < RN_P0_DEPTH; ++d) acc[d] = acc[d + 1];
+    }
+  }
+  // pooled row 41: rows 82 and 83 only (row 84 is padding)
+  if (hi) {
+    const long ob = (long)fb + G::NG * (2 * HP * 16) + lc;
+#pragma unroll
+    for (int ct = 0; ct < G::NCT; ++ct) {
+      const unsigned long long bal = __ballot(cv_[ct] > 0.0f);
+      pooled[ob + ct * 32] = cv_[ct];
+      pidx[ob + ct * 32] = (uint8_t)((ck_[ct >> 3] >> (4 * (ct & 7))) & 15u);
+      if (mask && li == 0) mask[(ob + ct * 32) >> 4] = (uint16_t)(bal >> (16 * kq));
+    }
+  }
+}
+static void rn_conv0_pool_reg_launch(const uint8_t* obs, const int32_t* idx, const float* W, const float* bias, float* pooled, uint8_t* pidx, int B,
+                                     hipStream_t st, uint16_t* mask) {
+  using G = RnPool0Reg;
+  constexpr size_t lds = (size_t)G::NW * G::WAVE_FLOATS * sizeof(float);
+  hipLaunchKernelGGL(rn_conv0_pool_reg_kernel, dim3((B + G::NW - 1) / G::NW), dim3(64 * G::NW), lds, st, obs, idx, W, bias, pooled, pidx, B, mask);
+}
+
 // dgrad as a forward conv: Wt[(jh,jw)][co][ci] = W[(2-jh,2-jw)][ci][co]   (all 14 convs that need a dgrad, one launch)
 struct RnFlipJob { int src, dst, ci, co; };
 struct RnFlipJobs { RnFlipJob j[14]; int n; };

@@ -129,3 +129,14 @@ def test_resnet_device_rollout_replayed_by_the_oracle(oracle):
         assert (o == obs[T]).all() and (ctx.actor_get_key(0) == k).all()
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("which", ["reg", "lds"])
+def test_resnet_first_conv_pool_kernels_agree_with_the_oracle(rctx, oracle, which, monkeypatch):
+    """The first conv + max_pool has two kernels: strips with the conv rows in LDS (small batches) and one wave per frame pooling on the accumulators
+    (learner batches, B >= 1024).  CBM_RN_POOL0 forces either at any batch: logits / values bit for bit, gradients (through the arg-max bytes and the
+    relu mask bits the kernel writes) within the usual bar — at 12 / 5 / 16 frames, with and without a gather index."""
+    monkeypatch.setenv("CBM_RN_POOL0", which)
+    test_resnet_forward_bit_exact(rctx, oracle)
+    for N in (16, 5):
+        test_resnet_ppo_loss_and_grads(rctx, oracle, N)
