@@ -451,32 +451,32 @@ __global__ __launch_bounds__(64 * RnPool0Reg::NW, 4) void rn_conv0_pool_reg_kern
 #pragma unroll
   for (int t = 0; t < 9; ++t) bv[t] = W[(t * 4 + kq) * 16 + li];
   const float bz = bias[li];
-  // slab rows 0..5 of group g = input rows 4g-1 .. 4g+4; uint32 v = (plane p, slab row r, 4 columns cq)
-  constexpr int NV = 4 * 6 * 21, NI = (NV + 63) / 64;
+  // slab rows 0..5 of group g = input rows 4g-1 .. 4g+4.  Copy it (0..7) moves rows 3 (it & 1) .. + 2 of plane it >> 1: lane -> (row lane / 21, four columns
+  // lane % 21), decoded once; lane 63 idles.  Rows outside the frame are zero BYTES (0 / 255 = 0.0f exactly)
+  constexpr int NI = 8;
   uint32_t ru[NI];
+  const int sr = min(lane / 21, 2), scq = lane - 21 * (lane / 21);
+  const uint8_t* fsrc = fr + sr * H + 4 * scq;
+  float* sdst = slab + sr * RP + 4 + 4 * scq;
   auto fetch = [&](int g) __attribute__((always_inline)) {
 #pragma unroll
     for (int it = 0; it < NI; ++it) {
-      const int v = min(lane + 64 * it, NV - 1);
-      const int cq = v % 21, t = v / 21, r = t % 6, p = t / 6;
-      const int y = min(max(4 * g - 1 + r, 0), H - 1);
-      ru[it] = *reinterpret_cast<const uint32_t*>(fr + p * (H * H) + y * H + 4 * cq);
+      const int y = 4 * g - 1 + 3 * (it & 1) + sr;
+      const uint32_t w = *reinterpret_cast<const uint32_t*>(fsrc + (it >> 1) * (H * H) + (min(max(y, 0), H - 1) - sr) * H);
+      ru[it] = (y >= 0 && y < H) ? w : 0u;
     }
   };
   auto commit = [&](int g) __attribute__((always_inline)) {
+    if (lane < 63) {
 #pragma unroll
-    for (int it = 0; it < NI; ++it) {
-      const int v = lane + 64 * it;
-      if (NV % 64 != 0 && v >= NV) break;
-      const int cq = v % 21, t = v / 21, r = t % 6, p = t / 6;
-      const int y = 4 * g - 1 + r;
-      const bool ok = y >= 0 && y < H;
-      float4 o;
-      o.x = ok ? cbm_u8_unit(ru[it] & 0xffu) : 0.0f;
-      o.y = ok ? cbm_u8_unit((ru[it] >> 8) & 0xffu) : 0.0f;
-      o.z = ok ? cbm_u8_unit((ru[it] >> 16) & 0xffu) : 0.0f;
-      o.w = ok ? cbm_u8_unit(ru[it] >> 24) : 0.0f;
-      *reinterpret_cast<float4*>(slab + p * PL + r * RP + 4 + 4 * cq) = o;
+      for (int it = 0; it < NI; ++it) {
+        float4 o;
+        o.x = cbm_u8_unit(ru[it] & 0xffu);
+        o.y = cbm_u8_unit((ru[it] >> 8) & 0xffu);
+        o.z = cbm_u8_unit((ru[it] >> 16) & 0xffu);
+        o.w = cbm_u8_unit(ru[it] >> 24);
+        *reinterpret_cast<float4*>(sdst + (it >> 1) * PL + 3 * (it & 1) * RP) = o;
+      }
     }
   };
   // A fragment of tap (kh, kw) of column tile ct: plane kq, slab row (li >> 2) + kh, column 4 ct + (li & 3) + kw - 1 -> one base + immediates
