@@ -19,7 +19,7 @@ for ln in open(sys.argv[1]):
         ci, co, h = (int(x) for x in g.groups())
         flops = 2.0 * MB * h * h * 9 * ci * co
         kind = "wgrad" if "wgrad" in name else ("dgrad" if re.search(r", (2|3|4), (true|false)$", targs) else "fwd")
-    elif name == "rn_conv0_pool_kernel":
+    elif name in ("rn_conv0_pool_kernel", "rn_conv0_pool_reg_kernel"):   # strips (small batches) / one wave per frame, pooled on the accumulators
         ci, co, h, kind = 4, 16, 84, "fwd+pool"
         flops = 2.0 * MB * 84 * 84 * 9 * 4 * 16
     elif name == "rn_wgrad0_sparse_kernel":
