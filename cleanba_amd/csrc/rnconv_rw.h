@@ -23,6 +23,9 @@
 // 32->32 @ 21) = the MFMA + address arithmetic + barrier skeleton.
 #pragma once
 #include <type_traits>
+#ifndef RW_ABL   // timing builds only (tools/variants.sh): 1 no per-step address decode, 2 no relu on the fragments
+#define RW_ABL 0
+#endif
 
 __device__ float rn_rw_zero_row[42 * 32];
 
@@ -131,11 +134,15 @@ __global__ __launch_bounds__(512) void rn_rw_kernel(const float* __restrict__ in
     for (int j = 0; j < NTL; ++j) {
       uint32_t q = (uint32_t)(qspan + NT * r16 + j);
       if (!FULL) q = min(q, (uint32_t)(P - 1));
+#if RW_ABL & 1   // timing build: no address decode (wrong results)
+      for (int kw = 0; kw < 3; ++kw) base[j][kw] = (int)((q & 1023u) + kw * 16 + g4);
+#else
       const uint32_t Gr = q / H, x = q - Gr * H, f = Gr / H, y = Gr - f * H;   // (unsigned: the divisions by constants are a multiply and a shift)
       const uint32_t s = (f * (H + 1) + y) % NR;                        // slot of the window's first row (virtual row vc - 1)
       const uint32_t p0 = G::GP + s * G::RPX + x - 1;
 #pragma unroll
       for (int kw = 0; kw < 3; ++kw) { const uint32_t p = p0 + kw; base[j][kw] = (int)((p / G::GP) * GF + (p % G::GP) * CI + g4); }
+#endif
     }
     // element e of tile j sits at 32-bit element offset ob[j] + e * CO + 16 jc: one VGPR per tile, the rest immediates (at most 216 M elements per tensor)
     uint32_t ob[NTL];
@@ -193,7 +200,7 @@ __global__ __launch_bounds__(512) void rn_rw_kernel(const float* __restrict__ in
 #pragma unroll
         for (int j = 0; j < NTL; ++j) {
           float av = a[u & 1][j][c];
-          if (PRE_RELU) av = fmaxf(av, 0.0f);
+          if (PRE_RELU && !(RW_ABL & 2)) av = fmaxf(av, 0.0f);
 #pragma unroll
           for (int jc = 0; jc < NCO; ++jc) acc[j][jc] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, w[jc][u * QC + c], acc[j][jc], 0, 0, 0);
         }
