@@ -23,6 +23,9 @@
 // 32->32 @ 21) = the MFMA + address arithmetic + barrier skeleton.
 #pragma once
 #include <type_traits>
+#ifndef RW_LDS_RELU   // 1: relu of a PRE_RELU kernel's input applied once per landed row in LDS (relu_rows below) instead of on every fragment.  Measured,
+#define RW_LDS_RELU 0 // same bits: 16 -> 16 @ 42x42 397 -> 388 us, 32 -> 32 @ 21x21 311 -> 314: the pass sits in front of the step's barrier and costs most of
+#endif                // the 61 / 25 us the 144 v_max per step cost (profiles/r06_resnet_sinks.txt); off
 #ifndef RW_ABL   // timing builds only (tools/variants.sh): 1 no per-step address decode, 2 no relu on the fragments
 #define RW_ABL 0
 #endif
@@ -101,7 +104,28 @@ __global__ __launch_bounds__(512) void rn_rw_kernel(const float* __restrict__ in
     for (int v = issued + wave; v < lim; v += G::NW) issue_row(v);
     issued = max(issued, lim);
   };
+  // RW_LDS_RELU (PRE_RELU kernels): the relu in front of the conv is applied ONCE per landed row, in LDS, by the wave that requested the row — between
+  // its own vmcnt(0) and the step's barrier, a whole step before the row's first reader — instead of on every fragment (each LDS element is read by
+  // nine taps: 144 v_max per 144 MFMAs per wave and step, none of them hidden behind an fp32 MFMA)
+  int relu_lo = 0, relu_hi = 0;                                          // rows [relu_lo, relu_hi) were requested by the last issue_upto
+  auto relu_rows = [&]() __attribute__((always_inline)) {
+    for (int v = relu_lo + wave; v < relu_hi; v += G::NW) {
+      const int fz = v / (H + 1), yy = v - fz * (H + 1);
+      if (yy == 0) continue;                                             // a zero row
+      const int pr = v % NR;
+      float* dst = rw_smem + (1 + pr * NG) * GF + lane;
+#pragma unroll
+      for (int g = 0; g < NGD; ++g)
+        if (g < NGD - 1 || LASTN == 64 || lane < LASTN) {
+          const float x = fmaxf(dst[g * GF], 0.0f);
+          dst[g * GF] = x;
+          if (pr < 2) dst[NR * NG * GF + g * GF] = x;                    // its mirror copy
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  };
   issue_upto(G::need_hi(nsteps > 1 ? 1 : 0, P) + 1);
+  relu_hi = issued;
 
   float w[NCO][G::NSTEP];
 #pragma unroll
@@ -115,8 +139,11 @@ __global__ __launch_bounds__(512) void rn_rw_kernel(const float* __restrict__ in
 
   auto sync_and_issue = [&](int t) __attribute__((always_inline)) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // everything requested one step ago has landed (for this wave)
+    if constexpr (PRE_RELU && RW_LDS_RELU) relu_rows();
     asm volatile("s_barrier" ::: "memory");                     // ... for every wave; and every wave has left step t-1: rows below need_lo(t) are free
+    relu_lo = issued;
     issue_upto(G::need_lo(t, P) + NR);
+    relu_hi = issued;
   };
 
   // FULL: every position of the step exists (all steps but the last): no clamps, no store predicates, element offsets are immediates
@@ -200,7 +227,7 @@ __global__ __launch_bounds__(512) void rn_rw_kernel(const float* __restrict__ in
 #pragma unroll
         for (int j = 0; j < NTL; ++j) {
           float av = a[u & 1][j][c];
-          if (PRE_RELU && !(RW_ABL & 2)) av = fmaxf(av, 0.0f);
+          if (PRE_RELU && !RW_LDS_RELU && !(RW_ABL & 2)) av = fmaxf(av, 0.0f);
 #pragma unroll
           for (int jc = 0; jc < NCO; ++jc) acc[j][jc] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, w[jc][u * QC + c], acc[j][jc], 0, 0, 0);
         }
@@ -241,6 +268,7 @@ __global__ __launch_bounds__(512) void rn_rw_kernel(const float* __restrict__ in
   };
 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if constexpr (PRE_RELU && RW_LDS_RELU) relu_rows();
   asm volatile("s_barrier" ::: "memory");                       // the rows of the first step and a half are in LDS
   for (int t = 0; t < nsteps; ++t) {
     if (G::TSP * (t + 1) <= P) { step(std::integral_constant<int, NT>{}, std::true_type{}, t); continue; }
