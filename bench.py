@@ -424,23 +424,25 @@ def host_env_value(a, params):
 
 
 def secondary_values():
-    """Secondary workloads under the same clock: a few warm-up + 6 (PPO-ResNet) / 21 (IMPALA T = 128) / 42 (T = 20) timed updates each, in three blocks through the product trainer
+    """Secondary workloads under the same clock: a few warm-up + 12 (PPO-ResNet) / 18 (backward-split) / 63 (IMPALA T = 128) / 300 (T = 20) timed updates each, in three blocks through the product trainer
     (cleanba_amd.trainer.train, device env, --concurrency), two device syncs per run.  Not the headline."""
     from cleanba_amd.args import parse_args
     from cleanba_amd.trainer import train
     # every row: `warm` warm-up updates, then THREE timed blocks of n_up / 3 updates each (a device sync at every block edge); value = the MEDIAN block,
-    # the fastest / slowest block ride along — a 5 % move between two driver runs can then be read against the spread inside one (VERDICT r5 "next" 6)
-    rows = [("impala_bf16_configs2", "impala", ["--network", "nature", "--bf16-forward"], T, 5, 21,
+    # the fastest / slowest block ride along — a 5 % move between two driver runs can then be read against the spread inside one (VERDICT r5 "next" 6).
+    # A block edge drains the actor / learner pipeline: blocks are a quarter of a second or longer (PPO-ResNet timed in blocks of two updates read 63.4 k where
+    # twelve updates between two syncs read 65.7 k, IMPALA T = 128 in blocks of seven 1.162 M against 1.217 M: tools/readme_table.py)
+    rows = [("impala_bf16_configs2", "impala", ["--network", "nature", "--bf16-forward"], T, 5, 63,
              "BASELINE configs[2]: IMPALA a0-l0-d1, V-trace, Nature-CNN bf16-MFMA forward / fp32 returns, 120 envs x 128 steps"),
-            ("impala_fp32_t128", "impala", ["--network", "nature"], T, 5, 21, "IMPALA a0-l0-d1 fp32, 120 envs x 128 steps"),
-            ("impala_fp32_t20", "impala", ["--network", "nature"], 20, 40, 42, "IMPALA a0-l0-d1 fp32 at the script's default num_steps = 20 (40 warm + 42 timed updates of ~2.7 ms)"),
-            ("ppo_nature_backward_split2", "ppo", ["--network", "nature", "--backward-split", "2"], T, 2, 9,
+            ("impala_fp32_t128", "impala", ["--network", "nature"], T, 5, 63, "IMPALA a0-l0-d1 fp32, 120 envs x 128 steps"),
+            ("impala_fp32_t20", "impala", ["--network", "nature"], 20, 40, 300, "IMPALA a0-l0-d1 fp32 at the script's default num_steps = 20 (40 warm + 300 timed updates of ~2.5 ms)"),
+            ("ppo_nature_backward_split2", "ppo", ["--network", "nature", "--backward-split", "2"], T, 2, 18,
              "EXTENSION, not the headline: configs[1] with the backward GEMMs as two-term split-bf16 products on bf16 MFMA, fp32 accumulate "
              "(cbm_config.backward_split = 2; gradients within 1.2e-6 of the fp32-MFMA path); the forward stays fp32 MFMA, bit-exact"),
-            ("ppo_nature_backward_split3", "ppo", ["--network", "nature", "--backward-split", "3"], T, 2, 9,
+            ("ppo_nature_backward_split3", "ppo", ["--network", "nature", "--backward-split", "3"], T, 2, 18,
              "EXTENSION, not the headline: configs[1] with the input-gradient GEMMs as three-term split-bf16 products on bf16 MFMA, fp32 accumulate "
              "(cbm_config.backward_split = 3; gradients within 1e-7 of the fp32-MFMA path, tests/test_gpu_parity.py); forward and weight gradients stay fp32 MFMA"),
-            ("ppo_resnet", "ppo", ["--network", "impala_resnet"], T, 2, 6, "PPO a0-l0-d1 with the IMPALA-ResNet torso (the CLI's default network, ppo:149-189), 120 envs x 128 steps")]
+            ("ppo_resnet", "ppo", ["--network", "impala_resnet"], T, 2, 12, "PPO a0-l0-d1 with the IMPALA-ResNet torso (the CLI's default network, ppo:149-189), 120 envs x 128 steps")]
     out = {}
     for name, algo, extra, t, warm, n_up, what in rows:
         marks = {}

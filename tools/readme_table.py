@@ -1,5 +1,7 @@
 """Re-measures README.md's table of secondary workloads on the GPU box through the product trainer (cleanba_amd.trainer.train): device time
-between the completion of update 3 and of update 15 (two syncs per run).  usage: python tools/readme_table.py [substring filter]"""
+between the completion of update 3 and of update 15 (two syncs per run); the run goes on for three more updates, because its LAST updates have no
+rollout beside them (the actor is done) and are 5-15 % faster than a steady-state one — round 6 found the table 3-4 % above bench.py's secondary
+rows for that reason.  usage: python tools/readme_table.py [substring filter]"""
 import os
 import sys
 import time
@@ -44,7 +46,7 @@ for name, algo, extra, threads, t, *rest in ROWS:
             marks[v] = time.perf_counter()
 
     argv = ["--local-num-envs", str(E), "--num-actor-threads", str(threads), "--num-steps", str(t), "--total-timesteps",
-            str(total * E * threads * t), "--log-frequency", "100000", "--concurrency"] + extra
+            str((total + 3) * E * threads * t), "--log-frequency", "100000", "--concurrency"] + extra
     so = sys.stdout
     sys.stdout = open(os.devnull, "w")
     try:
