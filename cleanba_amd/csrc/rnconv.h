@@ -417,8 +417,11 @@ static void rn_conv0_pool_launch(const uint8_t* obs, const int32_t* idx, const f
 //     tile slot is empty;
 //   * the scan order of the reference's max_pool (first maximum in (kh, kw) order wins, ppo:158-166 / rn_pool_fwd_kernel) is kept by merging in that
 //     order with strict compares: same values, same arg-max bytes, same mask bits as the kernel above;
-//   * the input rows of a group (4 new + 2 old, 6 x 84 x 4 bytes) are requested before the previous group's sweep and converted after it; 16 waves
-//     per CU (9.8 KB of LDS each), no block barrier anywhere.
+//   * the input rows of a group (4 new + 2 old, 6 x 84 x 4 bytes) are requested before the previous group's sweep and converted after it; blocks of
+//     three waves (9.8 KB of LDS per wave), five per CU: the 3840 frames of a learner minibatch are 15 waves on each of the 256 CUs, all resident at once;
+//     no block barrier anywhere.
+// What bounds it now (timing builds, profiles/r06_resnet_sinks.txt): the 441 x 9 MFMAs of a frame alone are 227 us per minibatch, everything else alone
+// 231 us, together 378 — an fp32 MFMA does not overlap VALU work on this chip, and a tile carries ~33 VALU instructions.
 #ifndef RN_P0_ABL   // timing builds only (tools/variants.sh): 1 no global stores, 2 no LDS exchange, 4 no MFMAs, 8 no staging
 #define RN_P0_ABL 0
 #endif
