@@ -99,6 +99,7 @@ struct NatureWs {
   float* rn_t[3][6] = {};
   uint8_t* rn_pidx[3] = {};
   void* rn_m[3][5] = {};   // relu bit masks (value > 0, C bits per position) of rn_t[s][1..4], written by the forward at learner sizes (learner workspaces only)
+  float* rn_tr[3][2] = {};   // relu'd copies of rn_t[s][1] / rn_t[s][3] (the inputs of the residual blocks' first convs), learner workspaces: see rn_seq_forward
   float* rn_g[2] = {};
   float* rn_wT = nullptr;  // flipped/transposed conv weights for the dgrad convs (rebuilt per backward)
   // dataflow actor step (gemm_layers.hip actor_fused_kernel): per-frame arrival counters of act1 / act2 / act3 (3 x maxB words, monotonic: never reset),

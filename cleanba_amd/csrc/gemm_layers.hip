@@ -1384,6 +1384,7 @@ void nature_ws_free(NatureWs& ws) {
     if (ws.rn_pidx[s]) hipFree(ws.rn_pidx[s]);
     ws.rn_pidx[s] = nullptr;
     for (int j = 0; j < 5; ++j) { if (ws.rn_m[s][j]) hipFree(ws.rn_m[s][j]); ws.rn_m[s][j] = nullptr; }
+    for (int j = 0; j < 2; ++j) { if (ws.rn_tr[s][j]) hipFree(ws.rn_tr[s][j]); ws.rn_tr[s][j] = nullptr; }
   }
   for (int j = 0; j < 2; ++j) { if (ws.rn_g[j]) hipFree(ws.rn_g[j]); ws.rn_g[j] = nullptr; }
   if (ws.rn_wT) { hipFree(ws.rn_wT); ws.rn_wT = nullptr; }

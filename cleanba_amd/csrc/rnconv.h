@@ -438,7 +438,7 @@ struct RnPool0Reg {
 __global__ __launch_bounds__(64 * RnPool0Reg::NW, 4) void rn_conv0_pool_reg_kernel(const uint8_t* __restrict__ obs, const int32_t* __restrict__ idx,
                                                                                   const float* __restrict__ W, const float* __restrict__ bias,
                                                                                   float* __restrict__ pooled, uint8_t* __restrict__ pidx, int B,
-                                                                                  uint16_t* __restrict__ mask) {
+                                                                                  uint16_t* __restrict__ mask, float* __restrict__ pooled_relu) {
   using G = RnPool0Reg;
   constexpr int H = G::H, HP = G::HP, RP = G::RP, PL = G::PL;
   extern __shared__ __attribute__((aligned(16))) float rn_smem[];
@@ -515,6 +515,7 @@ __global__ __launch_bounds__(64 * RnPool0Reg::NW, 4) void rn_conv0_pool_reg_kern
     if (g + 1 < G::NG && !(RN_P0_ABL & 8)) fetch(g + 1);
     const long ob = (long)fb + g * (2 * HP * 16) + lc;            // + ct * 32
     float* po = pooled + ob;
+    float* pr = pooled_relu + ob;                                 // (may be null: relu(pooled), what the first residual block's first conv reads)
     uint8_t* pi = pidx + ob;
     uint16_t* pm = mask + (ob >> 4);                              // (li == 0 lanes only)
     const bool live = !(hi && g == 0);                            // there is no pooled row -1
@@ -554,6 +555,7 @@ __global__ __launch_bounds__(64 * RnPool0Reg::NW, 4) void rn_conv0_pool_reg_kern
       const unsigned long long bal = __ballot(fv > 0.0f);
       if ((RN_P0_ABL & 1) ? (live && fv == 123.456f && fk == 77u) : live) {
         po[ct * 32] = fv;
+        if (pooled_relu) pr[ct * 32] = fmaxf(fv, 0.0f);
         pi[ct * 32] = (uint8_t)fk;
         if (mask && li == 0) pm[ct * 2] = (uint16_t)(bal >> (16 * kq));
       }
@@ -569,16 +571,17 @@ __global__ __launch_bounds__(64 * RnPool0Reg::NW, 4) void rn_conv0_pool_reg_kern
     for (int ct = 0; ct < G::NCT; ++ct) {
       const unsigned long long bal = __ballot(cv_[ct] > 0.0f);
       pooled[ob + ct * 32] = cv_[ct];
+      if (pooled_relu) pooled_relu[ob + ct * 32] = fmaxf(cv_[ct], 0.0f);
       pidx[ob + ct * 32] = (uint8_t)((ck_[ct >> 3] >> (4 * (ct & 7))) & 15u);
       if (mask && li == 0) mask[(ob + ct * 32) >> 4] = (uint16_t)(bal >> (16 * kq));
     }
   }
 }
 static void rn_conv0_pool_reg_launch(const uint8_t* obs, const int32_t* idx, const float* W, const float* bias, float* pooled, uint8_t* pidx, int B,
-                                     hipStream_t st, uint16_t* mask) {
+                                     hipStream_t st, uint16_t* mask, float* pooled_relu = nullptr) {
   using G = RnPool0Reg;
   constexpr size_t lds = (size_t)G::NW * G::WAVE_FLOATS * sizeof(float);
-  hipLaunchKernelGGL(rn_conv0_pool_reg_kernel, dim3((B + G::NW - 1) / G::NW), dim3(64 * G::NW), lds, st, obs, idx, W, bias, pooled, pidx, B, mask);
+  hipLaunchKernelGGL(rn_conv0_pool_reg_kernel, dim3((B + G::NW - 1) / G::NW), dim3(64 * G::NW), lds, st, obs, idx, W, bias, pooled, pidx, B, mask, pooled_relu);
 }
 
 // dgrad as a forward conv: Wt[(jh,jw)][co][ci] = W[(2-jh,2-jw)][ci][co]   (all 14 convs that need a dgrad, one launch)

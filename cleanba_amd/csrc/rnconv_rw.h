@@ -65,7 +65,8 @@ static __device__ __forceinline__ void rn_rw_glds4(const float* g_lane, float* l
 // 3.6-4.0 TB/s; a third / a quarter of that was the mask source.  mask_out (EPI 1 / 5 / 6, may be null): emit that mask for this kernel's output.
 template <class G, bool PRE_RELU, int EPI, bool MASKIN>
 __global__ __launch_bounds__(512) void rn_rw_kernel(const float* __restrict__ in, const float* __restrict__ W, const float* __restrict__ bias,
-                                                    const float* aux, float* out, int B, int fpb, const void* __restrict__ mask_in, void* __restrict__ mask_out) {
+                                                    const float* aux, float* out, int B, int fpb, const void* __restrict__ mask_in, void* __restrict__ mask_out,
+                                                    float* __restrict__ out_relu) {   // out_relu (EPI 1, may be null): a second copy of the output, through a relu
   constexpr int H = G::H, CI = G::CI, CO = G::CO, NT = G::NT, NCO = G::NCO, QPT = G::QPT, NG = G::NG, GF = G::GF, NR = G::NR;
   constexpr bool AUX = EPI == 1 || EPI == 3 || EPI == 4 || EPI == 6, BIAS = EPI == 0 || EPI == 1 || EPI == 5 || EPI == 6;
   constexpr bool MIN = MASKIN && (EPI == 3 || EPI == 4), MOUT = EPI == 1 || EPI == 5 || EPI == 6;
@@ -254,6 +255,7 @@ __global__ __launch_bounds__(512) void rn_rw_kernel(const float* __restrict__ in
           else if (EPI == 3) v = on ? v : 0.0f;
           else if (EPI == 4) v = ao[j][jc][e] + (on ? v : 0.0f);
           if (valid) out[ob[j] + e * NT * CO + 16 * jc] = v;
+          if constexpr (EPI == 1) { if (out_relu && valid) out_relu[ob[j] + e * NT * CO + 16 * jc] = fmaxf(v, 0.0f); }
           if constexpr (MOUT) pos[e] = __ballot(valid && v > 0.0f);
         }
         if constexpr (MOUT) {
@@ -279,7 +281,7 @@ __global__ __launch_bounds__(512) void rn_rw_kernel(const float* __restrict__ in
 
 template <class G, bool PRE_RELU, int EPI, bool MASKIN = false>
 static void rn_rw_launch(const float* in, const float* W, const float* bias, const float* aux, float* out, int B, hipStream_t st,
-                         const void* mask_in = nullptr, void* mask_out = nullptr) {
+                         const void* mask_in = nullptr, void* mask_out = nullptr, float* out_relu = nullptr) {
   constexpr int lds = G::LDS_FLOATS * 4;
   static bool attr = false;
   if (!attr) { hipFuncSetAttribute((const void*)rn_rw_kernel<G, PRE_RELU, EPI, MASKIN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
@@ -289,7 +291,7 @@ static void rn_rw_launch(const float* in, const float* W, const float* bias, con
     if (!G::ring_ok(fpb)) { cbm_launch_fail("rn_rw_kernel: row ring of %d slots too small for H=%d TSP=%d at %d frames per block", G::NR, G::H, G::TSP, fpb); return; }
     checked_fpb = fpb;
   }
-  hipLaunchKernelGGL((rn_rw_kernel<G, PRE_RELU, EPI, MASKIN>), dim3(blocks), dim3(512), lds, st, in, W, bias, aux, out, B, fpb, mask_in, mask_out);
+  hipLaunchKernelGGL((rn_rw_kernel<G, PRE_RELU, EPI, MASKIN>), dim3(blocks), dim3(512), lds, st, in, W, bias, aux, out, B, fpb, mask_in, mask_out, out_relu);
 }
 
 // geometry per layer shape: tiles per wave and step, ring slots (checked by ring_ok at launch)
