@@ -104,6 +104,7 @@ static int ctx_create_impl(const cbm_config* cfg, cbm_ctx** out, cbm_ctx** parti
   if (cfg->num_actions < 2 || cfg->num_actions > 28) { cbm_set_error("num_actions must be in [2,28]"); return -1; }
   if (cfg->algo == CBM_ALGO_IMPALA && cfg->num_steps + 1 > 2000) { cbm_set_error("IMPALA num_steps must be <= 1999 (the V-trace kernel keeps 8 floats per step in LDS)"); return -1; }
   if (cfg->backward_split != 0 && cfg->backward_split != 2 && cfg->backward_split != 3) { cbm_set_error("backward_split must be 0, 2 or 3"); return -1; }
+  if (cfg->conv1_fp32_chain < 0 || cfg->conv1_fp32_chain > 3) { cbm_set_error("conv1_fp32_chain must be 0..3 (bit 0: forward, bit 1: weight gradient on the fp32 chain)"); return -1; }
   if (cfg->backward_split && cfg->network != CBM_NET_NATURE) { cbm_set_error("backward_split is built for the Nature-CNN torso only"); return -1; }
   if (cfg->network == CBM_NET_IMPALA_RESNET) {
     // the slab-convolution geometries are compiled for the reference's channel widths (ppo:92-93); the hidden layer (ppo:94) may be any multiple of
@@ -225,6 +226,13 @@ static int ctx_create_impl(const cbm_config* cfg, cbm_ctx** out, cbm_ctx** parti
   if (nature_ws_alloc(c->lws, lmax, true, cfg->actor_dense_ksplit, cfg->network)) return -1;
   c->lws.bf16_fwd = cfg->forward_bf16 != 0 && cfg->network == CBM_NET_NATURE;
   c->lws.bwd_split = cfg->backward_split;
+  {   // conv1 at learner sizes: exact uint8 x split-bf16 products unless the fp32 chain is asked for (bit 0: forward, bit 1: weight gradient).
+      // CBM_CONV1_EXACT=0|1 overrides the config for A/B runs (0 = both on the chain, 1 = both exact)
+    const char* e = getenv("CBM_CONV1_EXACT");
+    const int chain = e ? (e[0] == '0' ? 3 : 0) : cfg->conv1_fp32_chain;
+    c->lws.conv1_exact_fwd = cfg->network == CBM_NET_NATURE && !(chain & 1);
+    c->lws.conv1_exact_wgrad = cfg->network == CBM_NET_NATURE && !(chain & 2);
+  }
   CBM_HIP(hipEventCreateWithFlags(&c->tail_ev, hipEventDisableTiming));
   CBM_HIP(hipEventCreateWithFlags(&c->ext_ev, hipEventDisableTiming));
   CBM_HIP(hipEventCreateWithFlags(&c->bwd_ev, hipEventDisableTiming));

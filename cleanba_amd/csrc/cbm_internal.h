@@ -79,6 +79,7 @@ struct NatureWs {
   bool with_grad = false;
   hipEvent_t tail_ev = nullptr;   // when set: recorded by the backward pass once the gradients of dense + heads (the flat tail [w[3], total)) are final
   int bwd_split = 0;       // cbm_config.backward_split: 0 fp32 MFMA, 2 / 3 split-bf16 backward GEMMs (igemm_split_kernel)
+  bool conv1_exact_fwd = false, conv1_exact_wgrad = false;   // learner-size conv1 forward / weight gradient as exact uint8 x 3-term-bf16 products on the bf16 matrix cores (conv1.hip); false = fp32 MFMA chains
   bool bf16_fwd = false;   // cbm_config.forward_bf16: conv2/conv3/dense forward on bf16 MFMA (Nature-CNN)
   bool skip_heads = false; // set around a forward / backward pair whose heads forward, PPO loss and heads dgrad run as launch_ppo_heads_fused
   float *act1 = nullptr, *act2 = nullptr, *act3 = nullptr, *hid = nullptr;
@@ -134,11 +135,11 @@ void nature_backward(const NatureLayout& L, const float* P, const uint8_t* obs, 
 
 // frame-resident conv1 kernels (conv1.hip)
 void launch_conv1_fwd_frames(const uint8_t* obs, const int32_t* idx, const float* W, const float* bias, float* out, uint32_t* mask, int S,
-                             hipStream_t st);
+                             hipStream_t st, bool exact = false);
 int conv1_wgrad_frames_splits(int S);
 int conv1_wgrad_frames_splits_bound(int maxS);   // >= conv1_wgrad_frames_splits(S) for every S <= maxS (the split count is not monotone in S)
 void launch_conv1_wgrad_frames(const uint8_t* obs, const int32_t* idx, const float* dy, float* part, float* bpart, int S, hipStream_t st,
-                               bool split = false);
+                               bool split = false, bool exact = false);
 
 // frame-resident conv2 / conv3 weight gradients (wgrad_frames.hip): partials part[z][(kh,kw,ci)][co], bpart[z][co]
 int conv2_wgrad_frames_splits(int S);

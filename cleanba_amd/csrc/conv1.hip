@@ -235,16 +235,167 @@ __global__ __launch_bounds__(256, 2) void conv1_fwd_planes_kernel(const uint8_t*
   BT_END(0);
 }
 
+// ------------------------------------------------------------------------------------------ forward, exact products on the bf16 matrix cores
+// conv1's A operand is special: a pixel is an integer 0..255, which a bf16 (8 significant bits) holds EXACTLY.  So only the weight needs splitting:
+// w/255 (fp32) = w1 + w2 + w3 with each term the next 8 significant bits (truncation, so every remainder is exact and the third term holds what is
+// left: 24 = 8 + 8 + 8), and px * w/255 = px*w1 + px*w2 + px*w3 where every product is EXACT (8 x 8 bits) and the sums are fp32 — no bit of either
+// operand is dropped; what differs from the fp32 fmaf chain is the order of the roundings only (measured against the oracle's chain:
+// tests/test_gpu_conv1_exact.py).  v_mfma_f32_32x32x16_bf16 retires sixteen k per 8 passes where v_mfma_f32_32x32x2_f32 retires two per 16: three
+// products cost 3/16 of the fp32 kernel's matrix time, and the kernel becomes what the layer's bytes say it should be — HBM-bound (108 MB of frames
+// in, 197 MB of activations + 6 MB of ReLU words out).
+//   LDS: the three weight terms as MFMA A fragments  Wl[term][q][h][channel][8 kw]  (48 KB, 16 bytes per lane: conflict-free ds_read_b128)
+//        + ONE frame as bytes (28,224 B); two blocks per CU cover each other's frame turn-over, the next frame's bytes wait in registers.
+//   K step q = (c, kh pair): lane (position, h) needs the 8 bytes of patch row kh = 2 (q & 3) + h — contiguous in the frame — converted with
+//        v_cvt_f32_ubyte + v_perm (12 VALU per fragment, used by three MFMAs); k order inside an instruction is (kh parity, kw).
+//   13 tiles of 32 positions per frame (the last one half empty: the matrix time is not what bounds this kernel), tiles {first, first+4, first+8[, 12]}
+//        per wave with `first` rotating from frame to frame; products formed transposed (weights = the MFMA's A operand) so that the epilogue is the fp32
+//        kernel's: a lane holds 16 channels of one position -> four 16-byte stores and the position's ReLU word.
+typedef uint32_t c1_u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 c1_bf16x8 __attribute__((ext_vector_type(8)));
+static __device__ __forceinline__ uint32_t c1_pack_hi16(float lo, float hi) {   // the two upper halves (bf16 by truncation; exact for integers < 256)
+  return __builtin_amdgcn_perm(__float_as_uint(hi), __float_as_uint(lo), 0x07060302u);
+}
+static __device__ __forceinline__ c1_bf16x8 c1_px8_bf16(uint32_t w0, uint32_t w1) {
+  c1_u32x4 r;
+  r[0] = c1_pack_hi16((float)(w0 & 255u), (float)((w0 >> 8) & 255u));
+  r[1] = c1_pack_hi16((float)((w0 >> 16) & 255u), (float)(w0 >> 24));
+  r[2] = c1_pack_hi16((float)(w1 & 255u), (float)((w1 >> 8) & 255u));
+  r[3] = c1_pack_hi16((float)((w1 >> 16) & 255u), (float)(w1 >> 24));
+  return __builtin_bit_cast(c1_bf16x8, r);
+}
+// three bf16 terms of an fp32 value by truncation: t1 + t2 + t3 == v exactly
+static __device__ __forceinline__ void c1_split3(float v, uint32_t& t1, uint32_t& t2, uint32_t& t3) {
+  t1 = __float_as_uint(v) & 0xffff0000u;
+  const float r1 = v - __uint_as_float(t1);
+  t2 = __float_as_uint(r1) & 0xffff0000u;
+  const float r2 = r1 - __uint_as_float(t2);
+  t3 = __float_as_uint(r2);            // at most 8 significant bits left: its lower half is zero
+}
+#define C1X_WBYTES (3 * 16 * 2 * 32 * 16)
+__global__ __launch_bounds__(256, 2) void conv1_fwd_exact_kernel(const uint8_t* obs, const int32_t* idx, const float* W, const float* bias,
+                                                                 float* out, uint32_t* mask, int S, int frames_per_block) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem_x[C1X_WBYTES + FR + 16];
+  c1_u32x4* Wl = reinterpret_cast<c1_u32x4*>(smem_x);   // [term][q][h][channel] x 8 bf16
+  unsigned char* F = smem_x + C1X_WBYTES;
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int s_lo = blockIdx.x * frames_per_block, s_hi = min(S, s_lo + frames_per_block);
+  if (s_lo >= s_hi) return;
+  c1_u32x4 pw[7];
+  auto load_frame = [&](const uint8_t* frame) __attribute__((always_inline)) {
+    const c1_u32x4* g = reinterpret_cast<const c1_u32x4*>(frame);
+#pragma unroll
+    for (int j = 0; j < 7; ++j) pw[j] = g[min(tid + 256 * j, FR / 16 - 1)];
+  };
+  auto put_frame = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      const int v = tid + 256 * j;
+      if (v < FR / 16) *reinterpret_cast<c1_u32x4*>(F + 16 * v) = pw[j];
+    }
+  };
+  load_frame(obs + (size_t)(idx ? idx[s_lo] : s_lo) * FR);
+  // weight terms: item = (q, h, channel) -> the 8 kw of patch row (c = q >> 2, kh = 2 (q & 3) + h)
+#pragma unroll 1
+  for (int it = 0; it < 4; ++it) {
+    const int item = tid + 256 * it, n = item & 31, hh = (item >> 5) & 1, q = item >> 6;
+    const int c = q >> 2, kh = 2 * (q & 3) + hh;
+    uint32_t t1[8], t2[8], t3[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) c1_split3(W[((kh * 8 + j) * 4 + c) * 32 + n] / 255.0f, t1[j], t2[j], t3[j]);
+    c1_u32x4 v1, v2, v3;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      v1[j] = (t1[2 * j] >> 16) | t1[2 * j + 1];
+      v2[j] = (t2[2 * j] >> 16) | t2[2 * j + 1];
+      v3[j] = (t3[2 * j] >> 16) | (t3[2 * j + 1] & 0xffff0000u);
+    }
+    Wl[((0 * 16 + q) * 2 + hh) * 32 + n] = v1;
+    Wl[((1 * 16 + q) * 2 + hh) * 32 + n] = v2;
+    Wl[((2 * 16 + q) * 2 + hh) * 32 + n] = v3;
+  }
+  float bch[16];                                            // bias of this lane's 16 channels: c(e) = (e & 3) + 8 (e >> 2) + 4 h
+#pragma unroll
+  for (int e = 0; e < 16; ++e) bch[e] = bias[(e & 3) + 8 * (e >> 2) + 4 * h];
+  put_frame();
+  __syncthreads();
+  for (int s = s_lo; s < s_hi; ++s) {
+    if (s + 1 < s_hi) load_frame(obs + (size_t)(idx ? idx[s + 1] : s + 1) * FR);   // lands while this frame is multiplied
+    const int first = (wave + (s - s_lo)) & 3;
+    const bool four = first == 0;
+    int base[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int p = min((first + 4 * t) * 32 + li, 399);
+      const int oh = p / 20, ow = p - oh * 20;
+      base[t] = (oh * 4 + h) * 84 + ow * 4;
+    }
+    auto frame_tiles = [&](auto nt_) __attribute__((always_inline)) {
+      constexpr int NT = decltype(nt_)::value;
+      f32x16 acc[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.0f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int foff = (q >> 2) * 7056 + (q & 3) * 168;
+        c1_bf16x8 wf[3], xb[NT];
+#pragma unroll
+        for (int tm = 0; tm < 3; ++tm) wf[tm] = __builtin_bit_cast(c1_bf16x8, Wl[((tm * 16 + q) * 2 + h) * 32 + li]);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const uint32_t* px = reinterpret_cast<const uint32_t*>(F + base[t] + foff);
+          xb[t] = c1_px8_bf16(px[0], px[1]);
+        }
+#pragma unroll
+        for (int tm = 2; tm >= 0; --tm)          // small terms first; consecutive MFMAs go to different accumulators
+#pragma unroll
+          for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[tm], xb[t], acc[t], 0, 0, 0);
+      }
+      // epilogue: the fp32 kernel's (D[channel][position]: a lane holds 16 channels of one position)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int m = (first + 4 * t) * 32 + li;
+        if (m < 400) {
+          float* o = out + ((size_t)s * 400 + m) * 32 + 4 * h;
+          uint32_t bits = 0;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            float4 v;
+            v.x = relu_(acc[t][4 * g] + bch[4 * g]); v.y = relu_(acc[t][4 * g + 1] + bch[4 * g + 1]);
+            v.z = relu_(acc[t][4 * g + 2] + bch[4 * g + 2]); v.w = relu_(acc[t][4 * g + 3] + bch[4 * g + 3]);
+            *reinterpret_cast<float4*>(o + 8 * g) = v;               // channels 8g + 4h .. + 3
+            bits |= ((v.x > 0.0f ? 1u : 0u) | (v.y > 0.0f ? 2u : 0u) | (v.z > 0.0f ? 4u : 0u) | (v.w > 0.0f ? 8u : 0u)) << (8 * g + 4 * h);
+          }
+          bits |= (uint32_t)__shfl_xor((int)bits, 32, 64);
+          if (mask && lane < 32) mask[(size_t)s * 400 + m] = bits;
+        }
+      }
+    };
+    if (four) frame_tiles(std::integral_constant<int, 4>{});
+    else frame_tiles(std::integral_constant<int, 3>{});
+    __syncthreads();                 // every wave is done with this frame's bytes
+    if (s + 1 < s_hi) put_frame();
+    __syncthreads();
+  }
+}
+
+#ifndef CBM_C1X_BLOCKS
+#define CBM_C1X_BLOCKS 1024
+#endif
+static const int C1X_BLOCKS = [] { const char* e = getenv("CBM_C1X_BLOCKS"); return e && atoi(e) > 0 ? atoi(e) : CBM_C1X_BLOCKS; }();
 void launch_conv1_fwd_frames(const uint8_t* obs, const int32_t* idx, const float* W, const float* bias, float* out, uint32_t* mask, int S,
-                             hipStream_t st) {
+                             hipStream_t st, bool exact) {
   // two frames per block at 3840 frames.  512 persistent blocks (exactly two per CU) were fragile under the concurrent rollout: a CU that could
   // not take its second block (LDS held by actor blocks) left a straggler — 375 us under load against 286 isolated; with many short blocks the
   // dispatcher balances.  Under load / isolated: 4096 blocks 279 / 260 us, 2048 275 / 253, 1280 283 / 276, 768 292 / 245
-  int blocks = 2048;
+  int blocks = exact ? C1X_BLOCKS : 2048;
   if (S < blocks) blocks = S;
   const int fpb = (S + blocks - 1) / blocks;
   blocks = (S + fpb - 1) / fpb;
-  hipLaunchKernelGGL(conv1_fwd_planes_kernel, dim3(blocks), dim3(256), 0, st, obs, idx, W, bias, out, mask, S, fpb);
+  if (exact) hipLaunchKernelGGL(conv1_fwd_exact_kernel, dim3(blocks), dim3(256), 0, st, obs, idx, W, bias, out, mask, S, fpb);
+  else hipLaunchKernelGGL(conv1_fwd_planes_kernel, dim3(blocks), dim3(256), 0, st, obs, idx, W, bias, out, mask, S, fpb);
 }
 
 // ------------------------------------------------------------------------------------------ wgrad
@@ -321,7 +472,6 @@ __global__ __launch_bounds__(256, 2) void conv1_wgrad_frames_kernel(const uint8_
 // dW += px * dy1 + px * dy2 on v_mfma_f32_32x32x16_bf16, sixteen output positions per instruction instead of two.  Same frame-resident
 // structure, same partial layout (the reduce applies 1/255).  A frame's 400 positions are 25 groups of 16 consecutive positions; lane
 // (li, h) supplies positions 8h..8h+7 of the group for k-row li (A) / channel li (B).
-typedef __bf16 c1_bf16x8 __attribute__((ext_vector_type(8)));
 __global__ __launch_bounds__(256, 2) void conv1_wgrad_frames_split_kernel(const uint8_t* obs, const int32_t* idx, const float* dy, float* part,
                                                                           float* bpart, int S, int frames_per_block) {
   __shared__ __attribute__((aligned(16))) unsigned char F[FR];
@@ -391,6 +541,131 @@ __global__ __launch_bounds__(256, 2) void conv1_wgrad_frames_split_kernel(const 
   }
 }
 
+// Exact-product flavour (the default at learner sizes, cbm_config.conv1_fp32_chain = 0): like the forward above, the pixel operand is exact in bf16,
+// so dW = sum_pos px * dY needs only dY split — into THREE terms that sum to it exactly (c1_split3) — and every product px * dy_i is exact; the sums are
+// fp32.  v_mfma_f32_32x32x16_bf16 takes sixteen positions per instruction.  The frame is converted ONCE per block and frame into bf16 (LDS), so an A
+// fragment is eight 16-bit LDS reads and four packs, no per-use conversion.  Work split: a frame's 400 positions are 25 groups of 16; a wave takes every
+// fourth group and ALL eight k-tiles of dW[256][32] for it (128 accumulator registers), so the split of dY (5.5 VALU instructions per element) and
+// the row-wrap address arithmetic are paid once per 24 MFMAs; the four waves' sums are added through LDS when the block ends (two rounds).
+// Partials part[z][k][n] in pixel units, as the fp32 kernel writes them (the reduce applies 1/255).
+#define C1WX_LDS 65536
+__global__ __launch_bounds__(256, 2) void conv1_wgrad_exact_kernel(const uint8_t* obs, const int32_t* idx, const float* dy, float* part,
+                                                                   float* bpart, int S, int frames_per_block) {
+  __shared__ __attribute__((aligned(16))) unsigned short FB[C1WX_LDS / 2];   // one frame as bf16 (56,448 B); 64 KB for the closing reduction
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int s_lo = blockIdx.x * frames_per_block, s_hi = min(S, s_lo + frames_per_block);
+  if (s_lo >= s_hi) return;
+  const int kb = (li >> 3) * 84 + (li & 7);          // tap (kh' = li >> 3, kw = li & 7) of k-tile tt = (c = tt >> 1, kh = 4 (tt & 1) + kh'): + c * 7056 + (tt & 1) * 336
+  f32x16 acc[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[t][e] = 0.0f;
+  float bs = 0.0f;
+  c1_u32x4 pw[7];
+  auto load_frame = [&](const uint8_t* frame) __attribute__((always_inline)) {
+    const c1_u32x4* g = reinterpret_cast<const c1_u32x4*>(frame);
+#pragma unroll
+    for (int j = 0; j < 7; ++j) pw[j] = g[min(tid + 256 * j, FR / 16 - 1)];
+  };
+  load_frame(obs + (size_t)(idx ? idx[s_lo] : s_lo) * FR);
+  for (int s = s_lo; s < s_hi; ++s) {
+    __syncthreads();  // previous frame fully consumed
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      const int v = tid + 256 * j;
+      if (v < FR / 16) {
+        *reinterpret_cast<c1_u32x4*>(FB + 16 * v) = __builtin_bit_cast(c1_u32x4, c1_px8_bf16(pw[j][0], pw[j][1]));
+        *reinterpret_cast<c1_u32x4*>(FB + 16 * v + 8) = __builtin_bit_cast(c1_u32x4, c1_px8_bf16(pw[j][2], pw[j][3]));
+      }
+    }
+    if (s + 1 < s_hi) load_frame(obs + (size_t)(idx ? idx[s + 1] : s + 1) * FR);   // lands while this frame is multiplied
+    const int g0 = (wave + 4 - ((s - s_lo) & 3)) & 3;          // this wave's groups: g0, g0 + 4, ... (the wave with seven of them rotates)
+    const float* g = dy + ((size_t)s * 400 + 8 * h) * 32 + li;  // position 8h of group 0, channel li
+    float bc[8], bn[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bc[j] = g[(g0 * 16 + j) * 32];
+    __syncthreads();
+#pragma unroll 1
+    for (int grp = g0; grp < 25; grp += 4) {
+      if (grp + 4 < 25) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bn[j] = g[((grp + 4) * 16 + j) * 32];
+      }
+      const int p0 = grp * 16 + 8 * h, oh0 = p0 / 20, ow0 = p0 - oh0 * 20;
+      const unsigned short* fl = FB + kb + oh0 * 336 + ow0 * 4;
+      const int wrap = 20 - ow0;                      // positions j >= wrap sit in the next output row
+      c1_u32x4 b1, b2, b3, a[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        uint32_t x1, x2, x3, y1, y2, y3;
+        bs += bc[2 * j] + bc[2 * j + 1];
+        c1_split3(bc[2 * j], x1, x2, x3);
+        c1_split3(bc[2 * j + 1], y1, y2, y3);
+        b1[j] = __builtin_amdgcn_perm(y1, x1, 0x07060302u);
+        b2[j] = __builtin_amdgcn_perm(y2, x2, 0x07060302u);
+        b3[j] = __builtin_amdgcn_perm(y3, x3, 0x07060302u);
+        const int off0 = 8 * j + (2 * j >= wrap ? 336 - 80 : 0), off1 = 8 * j + 4 + (2 * j + 1 >= wrap ? 336 - 80 : 0);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          const int ko = (t >> 1) * 7056 + (t & 1) * 336;
+          a[t][j] = (uint32_t)fl[ko + off0] | ((uint32_t)fl[ko + off1] << 16);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 8; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(c1_bf16x8, a[t]), __builtin_bit_cast(c1_bf16x8, b3), acc[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < 8; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(c1_bf16x8, a[t]), __builtin_bit_cast(c1_bf16x8, b2), acc[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < 8; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(c1_bf16x8, a[t]), __builtin_bit_cast(c1_bf16x8, b1), acc[t], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) bc[j] = bn[j];
+    }
+  }
+  // the four waves' sums: (1 -> 0, 3 -> 2), then 2 -> 0; a wave's 8 x 16 values per lane go through LDS as 32 pieces of 16 bytes, lane-contiguous
+  float* R = reinterpret_cast<float*>(FB);
+#pragma unroll 1
+  for (int round = 0; round < 2; ++round) {
+    __syncthreads();
+    const bool writer = round == 0 ? (wave & 1) : wave == 2;
+    const bool reader = round == 0 ? !(wave & 1) : wave == 0;
+    float* slot = R + (round == 0 ? (wave >> 1) : 0) * 8192 + lane * 4;
+    if (writer) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *reinterpret_cast<float4*>(slot + (t * 4 + q) * 256) = make_float4(acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]);
+    }
+    __syncthreads();
+    if (reader) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 v = *reinterpret_cast<const float4*>(slot + (t * 4 + q) * 256);
+          acc[t][4 * q] += v.x; acc[t][4 * q + 1] += v.y; acc[t][4 * q + 2] += v.z; acc[t][4 * q + 3] += v.w;
+        }
+    }
+  }
+  // bias partial: every wave summed its own groups
+  bs += __shfl_xor(bs, 32, 64);
+  __syncthreads();
+  if (h == 0) R[wave * 32 + li] = bs;
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
+        part[((size_t)blockIdx.x * 256 + 32 * t + row) * 32 + li] = acc[t][e];
+      }
+    if (h == 0) bpart[blockIdx.x * 32 + li] = (R[li] + R[32 + li]) + (R[64 + li] + R[96 + li]);
+  }
+}
+
 // 3840-frame minibatch: 1280 blocks of 3 frames.  Alone 768 blocks of 5 frames were the fastest (225 us against 233 for 1024, and 25 MB of partials
 // instead of 42), but beside the rollout the blocks of a grid that is resident all at once end 180-267 us after the first start (the CUs that also host
 // actor blocks run theirs slower; tools/block_trace.py) and the kernel waits for the slowest: with a second, dynamically dispatched wave of shorter
@@ -408,9 +683,11 @@ int conv1_wgrad_frames_splits(int S) {
   return (S + fpb - 1) / fpb;
 }
 int conv1_wgrad_frames_splits_bound(int maxS) { return maxS < C1W_BLOCKS ? maxS : C1W_BLOCKS; }
-void launch_conv1_wgrad_frames(const uint8_t* obs, const int32_t* idx, const float* dy, float* part, float* bpart, int S, hipStream_t st, bool split) {
+void launch_conv1_wgrad_frames(const uint8_t* obs, const int32_t* idx, const float* dy, float* part, float* bpart, int S, hipStream_t st, bool split,
+                               bool exact) {
   const int nz = conv1_wgrad_frames_splits(S);
   const int fpb = (S + nz - 1) / nz;
-  if (split) hipLaunchKernelGGL(conv1_wgrad_frames_split_kernel, dim3(nz), dim3(256), 0, st, obs, idx, dy, part, bpart, S, fpb);
+  if (exact) hipLaunchKernelGGL(conv1_wgrad_exact_kernel, dim3(nz), dim3(256), 0, st, obs, idx, dy, part, bpart, S, fpb);
+  else if (split) hipLaunchKernelGGL(conv1_wgrad_frames_split_kernel, dim3(nz), dim3(256), 0, st, obs, idx, dy, part, bpart, S, fpb);
   else hipLaunchKernelGGL(conv1_wgrad_frames_kernel, dim3(nz), dim3(256), 0, st, obs, idx, dy, part, bpart, S, fpb);
 }

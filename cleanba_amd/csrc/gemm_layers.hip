@@ -1510,7 +1510,8 @@ int nature_forward(const NatureLayout& L, const float* P, const uint8_t* obs, co
     Conv1Fwd<T128x32k16> p{obs, idx, P + L.w[0], P + L.b[0], ws.act1, B * 400, ws.mask1};
     plaunch(ws, K_CONV1_FWD, p, 1, st);
   } else {
-    prof_launch(ws, K_CONV1_FWD, st, "conv1_fwd_planes_kernel", "", [&] { launch_conv1_fwd_frames(obs, idx, P + L.w[0], P + L.b[0], ws.act1, ws.mask1, B, st); });
+    prof_launch(ws, K_CONV1_FWD, st, ws.conv1_exact_fwd ? "conv1_fwd_exact_kernel" : "conv1_fwd_planes_kernel", "",
+                [&] { launch_conv1_fwd_frames(obs, idx, P + L.w[0], P + L.b[0], ws.act1, ws.mask1, B, st, ws.conv1_exact_fwd); });
   }
   if (small) {
     ConvFwd<T64x64k16, 4, 4, 2, 32, 64, 20, 20, 9, 9> p2{ws.act1, P + L.w[1], P + L.b[1], ws.act2, B * 81, ws.mask2};
@@ -1666,8 +1667,9 @@ void nature_backward(const NatureLayout& L, const float* P, const uint8_t* obs, 
   {
     const int nz = conv1_wgrad_frames_splits(B);
     if (!fits(4, nz)) return;
-    prof_launch(ws, K_CONV1_WGRAD, st, ws.bwd_split == 2 ? "conv1_wgrad_frames_split_kernel" : "conv1_wgrad_frames_kernel", "",
-                [&] { launch_conv1_wgrad_frames(obs, idx, ws.dact1, wp + rg.w[4], bp + rg.b[4], B, st, ws.bwd_split == 2); });
+    const bool c1x = ws.conv1_exact_wgrad && B > 512 && ws.bwd_split != 2;
+    prof_launch(ws, K_CONV1_WGRAD, st, c1x ? "conv1_wgrad_exact_kernel" : ws.bwd_split == 2 ? "conv1_wgrad_frames_split_kernel" : "conv1_wgrad_frames_kernel", "",
+                [&] { launch_conv1_wgrad_frames(obs, idx, ws.dact1, wp + rg.w[4], bp + rg.b[4], B, st, ws.bwd_split == 2, c1x); });
     conv_red.add(wp + rg.w[4], nz, 256 * 32, 32, 1, grads + L.w[0], nullptr, 1.0f / 255.0f);
     conv_red.add(bp + rg.b[4], nz, 32, 32, 0, grads + L.b[0], nullptr);
     if (!ws.tail_ev) conv_red.absorb(tail_red);

@@ -30,7 +30,7 @@ class Config(C.Structure):
                 ("adam_b1", C.c_float), ("adam_b2", C.c_float), ("adam_eps", C.c_float), ("rms_decay", C.c_float),
                 ("rms_eps", C.c_float), ("actor_dense_ksplit", C.c_int32), ("forward_bf16", C.c_int32), ("grad_accum_steps", C.c_int32), ("async_batch_size", C.c_int32),
                 ("backward_split", C.c_int32), ("num_channels", C.c_int32), ("channels", C.c_int32 * 4), ("num_hiddens", C.c_int32),
-                ("hiddens", C.c_int32 * 4), ("reserved", C.c_int32 * 3)]
+                ("hiddens", C.c_int32 * 4), ("conv1_fp32_chain", C.c_int32), ("reserved", C.c_int32 * 2)]
 
 
 class EnvState(C.Structure):

@@ -70,7 +70,14 @@ typedef struct {
   int32_t channels[4];        /* built for the reference default (16, 32, 32) and cbm_ctx_create REJECTS anything else rather than silently training */
   int32_t num_hiddens;        /* a different network; hiddens: ONE hidden layer of 64, 128, ... 512 units (default 256; flat parameter layout and    */
   int32_t hiddens[4];         /* cbm_param_count_hidden follow it).  Both ignored for CBM_NET_NATURE (the legacy script has no such flags).          */
-  int32_t reserved[3];
+  int32_t conv1_fp32_chain;   /* Nature-CNN, passes of more than 512 frames (the learner's minibatches).  0 (default): conv1 forward and weight
+                                 gradient form EXACT products on the bf16 matrix cores — a pixel (integer 0..255) is exact in bf16, the fp32 operand
+                                 (w/255, dY) is split into three 8-bit terms that sum to it exactly, accumulation in fp32: no operand bit is dropped,
+                                 results differ from the fp32 chain by the order of roundings only (logits / values within 1e-5 of the oracle, measured
+                                 1e-6; tests/test_gpu_conv1_exact.py).  Bit 0 set: the forward as the k-ascending fp32 fmaf chain on
+                                 v_mfma_f32_32x32x2_f32, bit-identical to the oracle (what rounds 1-5 shipped); bit 1 set: the weight gradient on fp32
+                                 MFMA; 3 = both.  The actor step (<= 512 frames) always uses the chain: sampled actions stay bit-exact either way. */
+  int32_t reserved[2];
 } cbm_config;
 
 /* Fills cfg with the reference defaults for `algo` (ppo:34-118 / impala:34-110). */
