@@ -53,6 +53,10 @@ ALG_BYTES_PER_ENV_STEP = 345.8e3
 # not XLA, not this build).  What is launched: the rollout's forward + 4 epochs x the twelve GEMMs of KERNELS (+ the A+1-wide heads forward).
 FWD_FLOPS_PER_FRAME = 2.0 * (400 * 32 * 256 + 81 * 64 * 512 + 49 * 64 * 576 + 512 * 3136 + 512 * (A + 1))
 EXEC_FLOPS_PER_ENV_STEP = FWD_FLOPS_PER_FRAME + EPOCHS * (sum(f for _, f in KERNELS.values()) / MB + 2.0 * 512 * (A + 1))
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak
+# conv1 on the bf16 matrix cores (cbm_config.conv1_fp32_chain = 0) is HBM-bound; ALGORITHMIC bytes per launch at minibatch MB:
+#   forward: frames in (28,224 B) + fp32 activations out (400 x 32 x 4) + ReLU words (400 x 4); weight gradient: frames + dY in (its 32 KB partial per block is overhead)
+CONV1_EXACT_BYTES = {0: MB * (28224 + 400 * 32 * 4 + 400 * 4), 11: MB * (28224 + 400 * 32 * 4)}
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/pmc_traffic.py)
 
 
@@ -189,6 +193,7 @@ def run_dp(a, world, rank, local_rank):
     cfg.device = int(os.environ.get("CBM_FORCE_DEVICE", local_rank))
     cfg.local_num_envs, cfg.num_actor_slots, cfg.num_steps, cfg.num_actions = E, 1, T, A
     cfg.backward_split = a.bwd_split
+    cfg.conv1_fp32_chain = a.conv1_fp32_chain
     ctx = HipEngine(cfg)
     rdv = None
     if world > 1:
@@ -290,7 +295,13 @@ def run_dp(a, world, rank, local_rank):
                 "dtype": "f32" if not a.bwd_split else f"f32 forward / split-bf16 x{a.bwd_split} backward GEMMs (extension, not the headline)", "data": "synthetic",
                 "config": {"workload": "PPO a0-l0-d%d: Nature-CNN fp32, local_num_envs=%d, rollout_len=%d, 4 epochs x 4 minibatches, A=18, "
                                        "device synthetic %s env, concurrency on" % (world, E, T, "Atari-57-mix" if a.env_id.startswith("Atari57") else "Breakout-shaped"),
-                           "global_batch": T * E * world, "parallelism": f"dp{world}"},
+                           "global_batch": T * E * world, "parallelism": f"dp{world}",
+                           "conv1_fp32_chain": a.conv1_fp32_chain,
+                           "conv1_learner": ("fp32 throughout.  conv1 of the learner's minibatches forms its products EXACTLY on the bf16 matrix cores: a uint8 pixel is exact in "
+                                             "bf16, the fp32 operand (w/255 forward, dY weight gradient) is split into three 8-bit terms that sum to it exactly, fp32 accumulate "
+                                             "(no operand bit dropped; logits within 1e-6 of the fp32 fmaf chain, bar 1e-5: tests/test_gpu_conv1_exact.py).  The same run on the "
+                                             "fp32-MFMA chain kernels (rounds 1-5, bit-identical to the oracle) is secondary.ppo_nature_conv1_fp32_chain")
+                                            if not (a.conv1_fp32_chain & 3) else "fp32-MFMA fmaf chains (bit 0: forward, bit 1: weight gradient), bit-identical to the oracle"},
                 "per_gpu": {"value": round(sps / world, 1), "rank0_local_ms_per_step": round(dt_local / a.steps * 1e3, 3)},
                 "roofline": roofline(ctx, a, dt, prof_steps)}
         if a.dry_run:
@@ -347,17 +358,25 @@ def roofline(ctx, a, dt, prof_steps):
         launched = ctx.profile_kernel_name(k)                 # "<kernel symbol> <functor type>" of what the library launched for this id
         ent = traffic_tab.get(str(k), {})
         tr = ent.get("traffic_bytes") if _same_kernel(launched, ent.get("kernel_full", "")) else None   # PMC numbers of another kernel are not reported
-        rows[k] = {"kernel": name, "launched": launched, "avg_us": round(avg_s * 1e6, 1), "launches": int(cnt[k]), "achieved": round(tf, 2),
+        rows[k] = {"kernel": name, "launched": launched, "avg_us": round(avg_s * 1e6, 1), "launches": int(cnt[k]), "bound": "mfma", "achieved": round(tf, 2),
+                   "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                    "frac": round(tf / FP32_MFMA_PEAK_TFLOPS, 4), "time_share": round(ms[k] / 1e3 / (dt * prof_steps / a.steps), 4), "flops_per_launch": flops,
                    "traffic": tr, "hbm_gbps": None if tr is None else round(tr / avg_s / 1e9, 1),
                    "hbm_frac": None if tr is None else round(tr / avg_s / 1e9 / HBM_PEAK_GBPS, 4)}
+        if k in CONV1_EXACT_BYTES and "_exact_kernel" in (launched or ""):
+            # conv1 as exact uint8 x three-term-bf16 products on the bf16 matrix cores: 3/16 of the fp32 kernel's matrix time, so the layer's BYTES bound it
+            gbps = CONV1_EXACT_BYTES[k] / avg_s / 1e9
+            rows[k].update({"bound": "hbm", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBPS, 4),
+                            "bytes_per_launch": CONV1_EXACT_BYTES[k], "executed_bf16_mfma_tflops": round(3 * tf, 1),
+                            "executed_frac_of_bf16_mfma_peak": round(3 * tf / BF16_MFMA_PEAK_TFLOPS, 4),
+                            "algorithmic_tflops": round(tf, 2)})
     if not rows:
         return None
     dom = max(rows, key=lambda k: rows[k]["time_share"])
     r = rows[dom]
     whole_tf = ALG_FLOPS_PER_ENV_STEP * (a.steps * T * E) / dt / 1e12
     exec_tf = EXEC_FLOPS_PER_ENV_STEP * (a.steps * T * E) / dt / 1e12
-    out = {"bound": "mfma", "kernel": r["kernel"], "achieved": r["achieved"], "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": r["frac"],
+    out = {"bound": r["bound"], "kernel": r["kernel"], "achieved": r["achieved"], "peak": r["peak"], "unit": r["unit"], "frac": r["frac"],
            "traffic": r["traffic"], "hbm_gbps": r["hbm_gbps"], "hbm_frac": r["hbm_frac"], "launches": r["launches"], "avg_us": r["avg_us"],
            "flops_per_launch": r["flops_per_launch"], "time_share": r["time_share"],
            "selection": "largest measured time share; source = HIP events on the learner stream around every launch of kernel ids 0-11 during the "
@@ -367,11 +386,15 @@ def roofline(ctx, a, dt, prof_steps):
                         "free for actor blocks — 10-30 %% longer, because under the profiler the two queues interleave differently (actor kernels stretch to 4x "
                         "their isolated time).  The unprofiled event times are the ones that add up to the measured step, so they are what this object reports" % (prof_steps, a.steps),
            "event_steps": prof_steps,
-           "min_frac": min(v["frac"] for k, v in rows.items() if k != 4),   # (id 4, the 32-wide heads wgrad, is 0.2 % of the flops)
+           "min_frac": min(v["frac"] for k, v in rows.items() if k != 4),   # each kernel against ITS bound (id 4, the 32-wide heads wgrad, is 0.2 % of the flops)
+           "min_frac_mfma_bound": min([v["frac"] for k, v in rows.items() if k != 4 and v["bound"] == "mfma"] or [None]),
            "whole_step": {"executed_flops_per_env_step": round(EXEC_FLOPS_PER_ENV_STEP), "executed_achieved": round(exec_tf, 2),
                           "executed_frac": round(exec_tf / FP32_MFMA_PEAK_TFLOPS, 4),
                           "algorithmic_flops_per_env_step": ALG_FLOPS_PER_ENV_STEP, "achieved": round(whole_tf, 2), "frac": round(whole_tf / FP32_MFMA_PEAK_TFLOPS, 4),
                           "algorithmic_hbm_gbps": round(ALG_BYTES_PER_ENV_STEP * (a.steps * T * E) / dt / 1e9, 1),
+                          "conv1_note": "executed_* / achieved count conv1's forward and weight gradient at their ALGORITHMIC flops (2 x 25.2 GFLOP per minibatch); with "
+                                        "conv1_fp32_chain = 0 those two run as three exact bf16-MFMA products each (kernels[] rows with bound = hbm), so the fraction of the "
+                                        "fp32 MFMA peak is a throughput yardstick across rounds, not a utilisation of the fp32 pipe",
                           "note": "executed_*: the flops of the launched kernels (rollout forward + 4 epochs x the twelve GEMMs; no conv1 input gradient exists) "
                                   "x env-steps / wall time — the yardstick to compare rounds on; achieved / frac: SURVEY 8d's 243.2 MFLOP per env-step "
                                   "(backward priced as 2 x forward, i.e. including that non-existent conv1 dgrad) and 345.8 KB per env-step"},
@@ -436,6 +459,9 @@ def secondary_values():
              "BASELINE configs[2]: IMPALA a0-l0-d1, V-trace, Nature-CNN bf16-MFMA forward / fp32 returns, 120 envs x 128 steps"),
             ("impala_fp32_t128", "impala", ["--network", "nature"], T, 5, 63, "IMPALA a0-l0-d1 fp32, 120 envs x 128 steps"),
             ("impala_fp32_t20", "impala", ["--network", "nature"], 20, 40, 300, "IMPALA a0-l0-d1 fp32 at the script's default num_steps = 20 (40 warm + 300 timed updates of ~2.5 ms)"),
+            ("ppo_nature_conv1_fp32_chain", "ppo", ["--network", "nature", "--conv1-fp32-chain", "3"], T, 2, 18,
+             "configs[1] with conv1's forward and weight gradient on the fp32-MFMA fmaf-chain kernels (cbm_config.conv1_fp32_chain = 3: every learner-size kernel "
+             "bit-identical to the CPU oracle; what rounds 1-5 measured as the headline)"),
             ("ppo_nature_backward_split2", "ppo", ["--network", "nature", "--backward-split", "2"], T, 2, 18,
              "EXTENSION, not the headline: configs[1] with the backward GEMMs as two-term split-bf16 products on bf16 MFMA, fp32 accumulate "
              "(cbm_config.backward_split = 2; gradients within 1.2e-6 of the fp32-MFMA path); the forward stays fp32 MFMA, bit-exact"),
@@ -742,6 +768,8 @@ def main():
     ap.add_argument("--no-allreduce-ab", action="store_true", help="with N > 1 ranks: skip the RCCL / native all-reduce A/B after the timed steps")
     ap.add_argument("--no-baseline-config", action="store_true", help="with 4 / 8 ranks: skip the BASELINE configs[3] / configs[4] topology line after the dp line")
     ap.add_argument("--dry-run", action="store_true", help="CPU plumbing run of the same multi-rank code on the oracle engine over gloo (tiny sizes; never a measurement)")
+    ap.add_argument("--conv1-fp32-chain", type=int, default=0, choices=[0, 1, 2, 3],
+                    help="cbm_config.conv1_fp32_chain: 0 = learner-size conv1 as exact products on the bf16 matrix cores (default), 3 = the fp32-MFMA chain kernels")
     ap.add_argument("--bwd-split", type=int, default=0, choices=[0, 2, 3],
                     help="build-only extension (NOT the headline): backward GEMMs on split-bf16 MFMA, see cbm_config.backward_split")
     a = ap.parse_args()

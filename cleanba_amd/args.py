@@ -61,6 +61,9 @@ class Args:
                                # of the local_num_envs envs; env-id-indexed GAE, per-minibatch advantage normalisation.  0 = off (cleanba_ppo.py)
     backward_split: int = 0  # build-only extension: 0 = backward GEMMs on fp32 MFMA (reference precision); 2 / 3 = fp32 operands split exactly into
                              # 2 / 3 bf16 terms, products on bf16 MFMA, fp32 accumulate (gradient error ~1e-6 / ~1e-7 of the fp32 path's); Nature-CNN
+    conv1_fp32_chain: int = 0  # Nature-CNN, learner minibatches (> 512 frames): 0 = conv1 forward / weight gradient as exact uint8 x three-term-bf16 products on the
+                               # bf16 matrix cores, fp32 accumulate (default; logits within 1e-6 of the chain); 3 = both as fp32-MFMA fmaf chains, bit-identical to the
+                               # CPU oracle (rounds 1-5); 1 / 2 = only the forward / only the weight gradient on the chain
     bf16_forward: bool = False  # build-only extension (reference is fp32): conv2/conv3/dense forward on bf16 MFMA, fp32 accumulate + fp32 returns (Nature-CNN)
     same_env_seed_all_ranks: bool = False  # testing aid: every process steps identical envs (then dp-N == dp-1 bitwise)
 

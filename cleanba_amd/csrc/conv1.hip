@@ -272,6 +272,7 @@ static __device__ __forceinline__ void c1_split3(float v, uint32_t& t1, uint32_t
   t3 = __float_as_uint(r2);            // at most 8 significant bits left: its lower half is zero
 }
 #define C1X_WBYTES (3 * 16 * 2 * 32 * 16)
+template <bool MASK>
 __global__ __launch_bounds__(256, 2) void conv1_fwd_exact_kernel(const uint8_t* obs, const int32_t* idx, const float* W, const float* bias,
                                                                  float* out, uint32_t* mask, int S, int frames_per_block) {
   __shared__ __attribute__((aligned(16))) unsigned char smem_x[C1X_WBYTES + FR + 16];
@@ -318,9 +319,12 @@ __global__ __launch_bounds__(256, 2) void conv1_fwd_exact_kernel(const uint8_t* 
 #pragma unroll
   for (int e = 0; e < 16; ++e) bch[e] = bias[(e & 3) + 8 * (e >> 2) + 4 * h];
   put_frame();
+  if (s_lo + 1 < s_hi) load_frame(obs + (size_t)(idx ? idx[s_lo + 1] : s_lo + 1) * FR);
   __syncthreads();
+  // Per frame: multiply (LDS = frame s) | barrier | frame s+1: registers -> LDS, then the loads of frame s+2 | epilogue stores of frame s | barrier.
+  // The LDS writes wait for loads that are a whole frame old, and no store of THIS frame has been issued yet: vmcnt is one in-order counter for
+  // loads and stores, and with the stores in front of the LDS writes every frame waited for its own 51 KB of stores to be acknowledged.
   for (int s = s_lo; s < s_hi; ++s) {
-    if (s + 1 < s_hi) load_frame(obs + (size_t)(idx ? idx[s + 1] : s + 1) * FR);   // lands while this frame is multiplied
     const int first = (wave + (s - s_lo)) & 3;
     const bool four = first == 0;
     int base[4];
@@ -353,30 +357,32 @@ __global__ __launch_bounds__(256, 2) void conv1_fwd_exact_kernel(const uint8_t* 
 #pragma unroll
           for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[tm], xb[t], acc[t], 0, 0, 0);
       }
+      __syncthreads();                 // every wave is done with this frame's bytes
+      if (s + 1 < s_hi) put_frame();
+      if (s + 2 < s_hi) load_frame(obs + (size_t)(idx ? idx[s + 2] : s + 2) * FR);
       // epilogue: the fp32 kernel's (D[channel][position]: a lane holds 16 channels of one position)
 #pragma unroll
+      // No branch around the stores: the lanes of the half-empty 13th tile computed position 399 (base[] clamps) and store it again — same address, same
+      // bits — and both lane halves store the position's ReLU word.  With a branch hipcc cannot count the stores in flight and waits for ALL of them
+      // (vmcnt(0)) in front of the next frame's LDS writes, whose loads were issued a whole frame earlier.
       for (int t = 0; t < NT; ++t) {
-        const int m = (first + 4 * t) * 32 + li;
-        if (m < 400) {
-          float* o = out + ((size_t)s * 400 + m) * 32 + 4 * h;
-          uint32_t bits = 0;
+        const int m = min((first + 4 * t) * 32 + li, 399);
+        float* o = out + ((size_t)s * 400 + m) * 32 + 4 * h;
+        uint32_t bits = 0;
 #pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            float4 v;
-            v.x = relu_(acc[t][4 * g] + bch[4 * g]); v.y = relu_(acc[t][4 * g + 1] + bch[4 * g + 1]);
-            v.z = relu_(acc[t][4 * g + 2] + bch[4 * g + 2]); v.w = relu_(acc[t][4 * g + 3] + bch[4 * g + 3]);
-            *reinterpret_cast<float4*>(o + 8 * g) = v;               // channels 8g + 4h .. + 3
-            bits |= ((v.x > 0.0f ? 1u : 0u) | (v.y > 0.0f ? 2u : 0u) | (v.z > 0.0f ? 4u : 0u) | (v.w > 0.0f ? 8u : 0u)) << (8 * g + 4 * h);
-          }
-          bits |= (uint32_t)__shfl_xor((int)bits, 32, 64);
-          if (mask && lane < 32) mask[(size_t)s * 400 + m] = bits;
+        for (int g = 0; g < 4; ++g) {
+          float4 v;
+          v.x = relu_(acc[t][4 * g] + bch[4 * g]); v.y = relu_(acc[t][4 * g + 1] + bch[4 * g + 1]);
+          v.z = relu_(acc[t][4 * g + 2] + bch[4 * g + 2]); v.w = relu_(acc[t][4 * g + 3] + bch[4 * g + 3]);
+          *reinterpret_cast<float4*>(o + 8 * g) = v;               // channels 8g + 4h .. + 3
+          bits |= ((v.x > 0.0f ? 1u : 0u) | (v.y > 0.0f ? 2u : 0u) | (v.z > 0.0f ? 4u : 0u) | (v.w > 0.0f ? 8u : 0u)) << (8 * g + 4 * h);
         }
+        bits |= (uint32_t)__shfl_xor((int)bits, 32, 64);
+        if (MASK) mask[(size_t)s * 400 + m] = bits;
       }
     };
     if (four) frame_tiles(std::integral_constant<int, 4>{});
     else frame_tiles(std::integral_constant<int, 3>{});
-    __syncthreads();                 // every wave is done with this frame's bytes
-    if (s + 1 < s_hi) put_frame();
     __syncthreads();
   }
 }
@@ -394,7 +400,8 @@ void launch_conv1_fwd_frames(const uint8_t* obs, const int32_t* idx, const float
   if (S < blocks) blocks = S;
   const int fpb = (S + blocks - 1) / blocks;
   blocks = (S + fpb - 1) / fpb;
-  if (exact) hipLaunchKernelGGL(conv1_fwd_exact_kernel, dim3(blocks), dim3(256), 0, st, obs, idx, W, bias, out, mask, S, fpb);
+  if (exact && mask) hipLaunchKernelGGL(conv1_fwd_exact_kernel<true>, dim3(blocks), dim3(256), 0, st, obs, idx, W, bias, out, mask, S, fpb);
+  else if (exact) hipLaunchKernelGGL(conv1_fwd_exact_kernel<false>, dim3(blocks), dim3(256), 0, st, obs, idx, W, bias, out, mask, S, fpb);
   else hipLaunchKernelGGL(conv1_fwd_planes_kernel, dim3(blocks), dim3(256), 0, st, obs, idx, W, bias, out, mask, S, fpb);
 }
 
@@ -583,16 +590,16 @@ __global__ __launch_bounds__(256, 2) void conv1_wgrad_exact_kernel(const uint8_t
     if (s + 1 < s_hi) load_frame(obs + (size_t)(idx ? idx[s + 1] : s + 1) * FR);   // lands while this frame is multiplied
     const int g0 = (wave + 4 - ((s - s_lo) & 3)) & 3;          // this wave's groups: g0, g0 + 4, ... (the wave with seven of them rotates)
     const float* g = dy + ((size_t)s * 400 + 8 * h) * 32 + li;  // position 8h of group 0, channel li
-    float bc[8], bn[8];
+    // dY rows of this wave's groups: TWO groups in flight (a group's eight values are split into their bf16 terms first, then the same registers take
+    // the group after next) — with one group ahead the loop ran at the latency of these loads (122 us per 3840 frames)
+    float bA[8], bB[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) bc[j] = g[(g0 * 16 + j) * 32];
+    for (int j = 0; j < 8; ++j) bA[j] = g[(g0 * 16 + j) * 32];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bB[j] = g[((g0 + 4) * 16 + j) * 32];          // g0 + 4 <= 7 < 25
     __syncthreads();
-#pragma unroll 1
-    for (int grp = g0; grp < 25; grp += 4) {
-      if (grp + 4 < 25) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) bn[j] = g[((grp + 4) * 16 + j) * 32];
-      }
+    const int glast = g0 + 4 * ((24 - g0) >> 2);      // this wave's last group
+    auto group = [&](float (&bc)[8], int grp) __attribute__((always_inline)) {
       const int p0 = grp * 16 + 8 * h, oh0 = p0 / 20, ow0 = p0 - oh0 * 20;
       const unsigned short* fl = FB + kb + oh0 * 336 + ow0 * 4;
       const int wrap = 20 - ow0;                      // positions j >= wrap sit in the next output row
@@ -606,6 +613,14 @@ __global__ __launch_bounds__(256, 2) void conv1_wgrad_exact_kernel(const uint8_t
         b1[j] = __builtin_amdgcn_perm(y1, x1, 0x07060302u);
         b2[j] = __builtin_amdgcn_perm(y2, x2, 0x07060302u);
         b3[j] = __builtin_amdgcn_perm(y3, x3, 0x07060302u);
+      }
+      {   // unconditional (the group index is clamped): hipcc then knows how many loads are in flight and waits for exactly the older eight
+        const int gn = min(grp + 8, glast);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bc[j] = g[(gn * 16 + j) * 32];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
         const int off0 = 8 * j + (2 * j >= wrap ? 336 - 80 : 0), off1 = 8 * j + 4 + (2 * j + 1 >= wrap ? 336 - 80 : 0);
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
@@ -619,9 +634,14 @@ __global__ __launch_bounds__(256, 2) void conv1_wgrad_exact_kernel(const uint8_t
       for (int t = 0; t < 8; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(c1_bf16x8, a[t]), __builtin_bit_cast(c1_bf16x8, b2), acc[t], 0, 0, 0);
 #pragma unroll
       for (int t = 0; t < 8; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(c1_bf16x8, a[t]), __builtin_bit_cast(c1_bf16x8, b1), acc[t], 0, 0, 0);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) bc[j] = bn[j];
+    };
+    int grp = g0;
+#pragma unroll 1
+    for (; grp + 4 < 25; grp += 8) {
+      group(bA, grp);
+      group(bB, grp + 4);
     }
+    if (grp < 25) group(bA, grp);
   }
   // the four waves' sums: (1 -> 0, 3 -> 2), then 2 -> 0; a wave's 8 x 16 values per lane go through LDS as 32 pieces of 16 bytes, lane-contiguous
   float* R = reinterpret_cast<float*>(FB);

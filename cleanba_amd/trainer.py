@@ -67,6 +67,7 @@ def make_config(args, algo):
         cfg.hiddens[i] = int(v)
     cfg.forward_bf16 = int(bool(getattr(args, "bf16_forward", False)))
     cfg.backward_split = int(getattr(args, "backward_split", 0) or 0)
+    cfg.conv1_fp32_chain = int(getattr(args, "conv1_fp32_chain", 0) or 0)
     cfg.actor_dense_ksplit = 14 if args.network == "nature" else 11  # K segments of the flatten->dense when M <= 1024 rows
     cfg.local_num_envs = args.local_num_envs
     cfg.num_actor_slots = args.num_actor_threads * len(args.actor_device_ids)

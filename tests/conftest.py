@@ -17,7 +17,7 @@ def pytest_configure(config):
 # starts several processes on the one GPU last — a failure in a multi-process functional test must never stand in front of the parity suite.
 # Inside a file, tests marked `slow` go last.  Files not named here keep their alphabetical place between the parity block and the
 # multi-process block.
-_GPU_ORDER_FIRST = ["test_golden.py", "test_gpu_parity.py", "test_gpu_fullsize_oracle.py", "test_gpu_resnet.py", "test_gpu_resnet_hidden.py",
+_GPU_ORDER_FIRST = ["test_golden.py", "test_gpu_parity.py", "test_gpu_fullsize_oracle.py", "test_gpu_conv1_exact.py", "test_gpu_resnet.py", "test_gpu_resnet_hidden.py",
                     "test_gpu_e2e.py", "test_gpu_fullsize.py", "test_gpu_overlap.py"]
 _GPU_ORDER_LAST = ["test_gpu_split.py", "test_gpu_native_comm.py", "test_gpu_bench_launcher.py"]
 

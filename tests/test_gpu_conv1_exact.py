@@ -1,0 +1,144 @@
+"""conv1 of the learner's minibatches on the bf16 matrix cores (cbm_config.conv1_fp32_chain = 0, the default; csrc/conv1.hip conv1_fwd_exact_kernel /
+conv1_wgrad_exact_kernel) against the CPU oracle.
+
+What the kernels compute: a pixel is an integer 0..255 — exact in bf16 — and the fp32 operand (w/255 in the forward, dY in the weight gradient) is cut
+into three bf16 terms that sum to it exactly, so every product is exact and only the ORDER of the fp32 roundings differs from the oracle's k-ascending
+fmaf chain (reference: x / 255.0 then nn.Conv(32, (8, 8), strides=(4, 4)), naturecnn:151-158; XLA fixes no summation order either).  Bars:
+  * forward: logits / values within north_star's 1e-5 of the oracle (measured ~1e-6), loss statistics rtol 1e-5; conv1_fp32_chain = 3 on the same inputs
+    stays BIT-identical to the oracle (the chain kernels are still there, and this proves which kernel ran);
+  * weight gradient: behind the chain forward (conv1_fp32_chain = 1: same ReLU masks as the oracle) every gradient tensor within 1e-5 of its max,
+    like tests/test_gpu_fullsize_oracle.py;
+  * both exact: a pre-activation within ~1e-7 of zero can land on the other side of the ReLU than in the oracle; each such flip moves single elements
+    of the conv gradients by ~1e-4 of the tensor's max (one term of a sum whose random-sign terms add up to ~sqrt(n) of them).  That is a property of
+    comparing ANY two fp32 summation orders through a ReLU (XLA against the oracle included), not of these kernels — the two tests above pin the
+    kernels; this one bounds the flips: dense / heads gradients 1e-5, conv gradients 1e-3 of the tensor's max, relative L2 error 1e-4.
+Sizes: 3840 frames through a shuffled gather index (configs[1]'s minibatch), 1031 (odd: the last block of either kernel holds one frame), 513 (the
+smallest pass that takes the learner-size kernels)."""
+import os
+
+import numpy as np
+import pytest
+
+import cleanba_amd.lib as L
+from helpers import make_frames, make_params
+
+pytestmark = pytest.mark.gpu
+A, E, T = 18, 120, 128
+
+
+def bits(x):
+    return np.ascontiguousarray(x, np.float32).view(np.uint32)
+
+
+def _ctx(chain):
+    os.environ.pop("CBM_CONV1_EXACT", None)          # the A/B override of tools/ must not decide what these tests run
+    cfg = L.default_config(L.ALGO_PPO)
+    cfg.local_num_envs, cfg.num_actor_slots, cfg.num_steps = E, 1, T
+    cfg.conv1_fp32_chain = chain
+    return L.Context(cfg)
+
+
+def _loss_grad(ctx, P, pool, idx, MB, seed):
+    rng = np.random.default_rng(seed)
+    actions = rng.integers(0, A, MB).astype(np.int32)
+    old_lp = (-np.log(A) + 0.2 * rng.normal(size=MB)).astype(np.float32)
+    adv = rng.normal(size=MB).astype(np.float32)
+    tgt = rng.normal(size=MB).astype(np.float32)
+    d = [L.DevBuf(ctx, x) for x in (P, pool, actions, old_lp, adv, tgt)]
+    dI = L.DevBuf(ctx, idx) if idx is not None else None
+    dS = L.DevBuf(ctx, nbytes=32, dtype=np.float32)
+    dG = L.DevBuf(ctx, nbytes=P.size * 4, dtype=np.float32)
+    dLg = L.DevBuf(ctx, nbytes=MB * A * 4, dtype=np.float32, shape=(MB, A))
+    dV = L.DevBuf(ctx, nbytes=MB * 4, dtype=np.float32)
+    L._chk(ctx.lib.cbm_ppo_loss_grad(ctx.h, L._p(d[0].ptr), L._p(d[1].ptr), L._p(dI.ptr) if dI else None, MB, L._p(d[2].ptr), L._p(d[3].ptr),
+                                     L._p(d[4].ptr), L._p(d[5].ptr), L._p(dS.ptr), L._p(dG.ptr), L._p(dLg.ptr), L._p(dV.ptr)))
+    return (dLg.download().copy(), dV.download().copy(), dS.download()[:5].copy(), dG.download().copy()), (actions, old_lp, adv, tgt)
+
+
+def _case(MB, seed):
+    pool = make_frames(MB, seed)
+    P = make_params(A, seed + 1)
+    idx = np.random.default_rng(seed + 2).permutation(MB).astype(np.int32) if MB == 3840 else None
+    return P, pool, idx
+
+
+def _per_tensor(oracle, g, ref):
+    out = {}
+    for name, (o, shp) in oracle.nature_layout(A).items():
+        n = int(np.prod(shp))
+        r = ref[o:o + n]
+        out[name] = (float(np.abs(g[o:o + n] - r).max() / max(np.abs(r).max(), 1e-30)),
+                     float(np.linalg.norm(g[o:o + n] - r) / max(np.linalg.norm(r), 1e-30)))
+    return out
+
+
+@pytest.mark.parametrize("MB", [513, 1031, 3840])
+def test_exact_forward_logits_within_1e5_of_oracle_and_chain_mode_bit_exact(oracle, MB):
+    oracle.set_threads(max(1, min(os.cpu_count() or 1, 64)))
+    P, pool, idx = _case(MB, 500 + MB)
+    (lg, v, st, _), (actions, old_lp, adv, tgt) = (None, None, None, None), (None,) * 4
+    ctx = _ctx(0)
+    try:
+        (lg, v, st, _), (actions, old_lp, adv, tgt) = _loss_grad(ctx, P, pool, idx, MB, 7)
+    finally:
+        ctx.close()
+    ctx = _ctx(3)
+    try:
+        (lg3, v3, st3, _), _ = _loss_grad(ctx, P, pool, idx, MB, 7)
+    finally:
+        ctx.close()
+    stats_o, _, logits_o, value_o = oracle.ppo_loss_grad(P, A, pool, idx, actions, old_lp, adv, tgt)
+    assert (bits(lg3) == bits(logits_o)).all() and (bits(v3) == bits(value_o)).all(), "conv1_fp32_chain = 3 must stay bit-identical to the oracle"
+    el, ev = float(np.abs(lg - logits_o).max()), float(np.abs(v - value_o).max())
+    print(f"exact conv1 forward, {MB} frames: max|logits - oracle| {el:.2e} (max|logits| {np.abs(logits_o).max():.2f}), values {ev:.2e}; "
+          f"logits bit-identical on {100 * (bits(lg) == bits(logits_o)).mean():.1f} % of the entries")
+    assert el <= 1e-5 and ev <= 1e-5
+    assert not (bits(lg) == bits(logits_o)).all(), "the default context ran the chain kernel: the exact path was not exercised"
+    np.testing.assert_allclose(st, stats_o, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("MB", [1031, 3840])
+def test_exact_weight_gradient_behind_the_chain_forward_matches_oracle(oracle, MB):
+    oracle.set_threads(max(1, min(os.cpu_count() or 1, 64)))
+    P, pool, idx = _case(MB, 600 + MB)
+    ctx = _ctx(1)
+    try:
+        (lg, v, st, g), (actions, old_lp, adv, tgt) = _loss_grad(ctx, P, pool, idx, MB, 8)
+    finally:
+        ctx.close()
+    stats_o, grads_o, logits_o, value_o = oracle.ppo_loss_grad(P, A, pool, idx, actions, old_lp, adv, tgt)
+    assert (bits(lg) == bits(logits_o)).all()
+    err = _per_tensor(oracle, g, grads_o)
+    print(f"exact conv1 weight gradient behind the chain forward, {MB} frames: per-tensor max error / max|ref|:", {k: f"{e[0]:.1e}" for k, e in err.items()})
+    assert np.isfinite(g).all()
+    for name, (emax, _) in err.items():
+        assert emax <= 1e-5, (name, emax)
+
+
+def test_both_exact_against_oracle_bounds_the_relu_flips(oracle):
+    MB = 3840
+    oracle.set_threads(max(1, min(os.cpu_count() or 1, 64)))
+    P, pool, idx = _case(MB, 700)
+    ctx = _ctx(0)
+    try:
+        (lg, v, st, g), (actions, old_lp, adv, tgt) = _loss_grad(ctx, P, pool, idx, MB, 9)
+    finally:
+        ctx.close()
+    ctx = _ctx(2)                      # exact forward, chain weight gradient: same forward, so only the conv1 weight-gradient kernel differs
+    try:
+        (lg2, _, _, g2), _ = _loss_grad(ctx, P, pool, idx, MB, 9)
+    finally:
+        ctx.close()
+    assert (bits(lg2) == bits(lg)).all()
+    stats_o, grads_o, logits_o, value_o = oracle.ppo_loss_grad(P, A, pool, idx, actions, old_lp, adv, tgt)
+    assert np.abs(lg - logits_o).max() <= 1e-5 and np.abs(v - value_o).max() <= 1e-5
+    np.testing.assert_allclose(st, stats_o, rtol=1e-5, atol=1e-6)
+    err = _per_tensor(oracle, g, grads_o)
+    print("both exact, 3840 frames: per-tensor max error / max|ref| (relative L2):", {k: f"{e[0]:.1e} ({e[1]:.1e})" for k, e in err.items()})
+    for name, (emax, el2) in err.items():
+        bar = 1e-3 if name.startswith("conv") else 1e-5
+        assert emax <= bar and el2 <= 1e-4, (name, emax, el2)
+    same_fwd = _per_tensor(oracle, g, g2)
+    print("exact vs chain weight gradient behind the SAME (exact) forward:", {k: f"{e[0]:.1e}" for k, e in same_fwd.items() if e[0] > 0})
+    for name, (emax, _) in same_fwd.items():
+        assert emax <= (1e-5 if name.startswith("conv1") else 0.0), (name, emax)

@@ -26,7 +26,8 @@ def big():
     cfg = L.default_config(L.ALGO_PPO)
     cfg.local_num_envs, cfg.num_actor_slots, cfg.num_steps = E, 1, T
     cfg.vf_coef, cfg.ent_coef = 0.0, 0.0
-    c = L.Context(cfg)
+    cfg.conv1_fp32_chain = 3        # learner-size conv1 on the fp32 chain kernels: this file's bitwise identities (learner-size == actor-size kernels, split ==
+    c = L.Context(cfg)              # whole) are properties of ONE summation order; the default exact-product conv1 is held to the oracle in test_gpu_conv1_exact.py
     yield c
     c.close()
 

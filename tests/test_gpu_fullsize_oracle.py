@@ -65,6 +65,7 @@ def test_ppo_minibatch_3840_of_15360_shuffled(oracle):
     _all_cores(oracle)
     cfg = L.default_config(L.ALGO_PPO)
     cfg.local_num_envs, cfg.num_actor_slots, cfg.num_steps = E, 1, T
+    cfg.conv1_fp32_chain = 3       # the fmaf-chain conv1 kernels: bit-identical forward (the default exact-product conv1 on the same sizes: test_gpu_conv1_exact.py)
     ctx = L.Context(cfg)
     try:
         rng = np.random.default_rng(101)
@@ -92,11 +93,12 @@ def test_ppo_minibatch_3840_of_15360_shuffled(oracle):
         ctx.close()
 
 
-def _impala_case(oracle, T1, Bm, bf16, seed):
+def _impala_case(oracle, T1, Bm, bf16, seed, chain=0):
     _all_cores(oracle)
     cfg = L.default_config(L.ALGO_IMPALA)
     cfg.local_num_envs, cfg.num_actor_slots, cfg.num_steps, cfg.num_minibatches = 4 * Bm, 1, T1 - 1, 4
     cfg.forward_bf16 = int(bf16)
+    cfg.conv1_fp32_chain = chain
     ctx = L.Context(cfg)
     try:
         rng = np.random.default_rng(seed)
@@ -122,11 +124,35 @@ def _impala_case(oracle, T1, Bm, bf16, seed):
 
 @pytest.mark.parametrize("T1,Bm", [(21, 30), (129, 30)])
 def test_impala_minibatch_full_size_fp32(oracle, T1, Bm):
-    ctx, stats, stats_o, g, grads_o, _ = _impala_case(oracle, T1, Bm, False, 200 + T1)
+    ctx, stats, stats_o, g, grads_o, _ = _impala_case(oracle, T1, Bm, False, 200 + T1, chain=3)
     try:
         np.testing.assert_allclose(stats, stats_o, rtol=1e-5, atol=1e-5)
         worst = _check_grads(oracle, g, grads_o)
         print(f"impala {T1}x{Bm}: worst per-tensor gradient error / max|ref|:", {k: f"{v:.1e}" for k, v in worst.items()})
+    finally:
+        ctx.close()
+
+
+@pytest.mark.parametrize("T1,Bm", [(21, 30), (129, 30)])
+def test_impala_minibatch_full_size_default_exact_conv1(oracle, T1, Bm):
+    """The same minibatches with the DEFAULT conv1 (exact products on the bf16 matrix cores, cbm_config.conv1_fp32_chain = 0): the losses keep the 1e-5
+    bar; the forward now rounds in another order than the oracle's chain, so a pre-activation within ~1e-7 of zero can take the other side of a ReLU, and
+    every such flip moves single gradient elements by about one term of their sum (IMPALA's losses are SUMS over the minibatch, not means: a term is
+    ~1e-3 of a conv tensor's max).  tests/test_gpu_conv1_exact.py pins the two kernels themselves at 1e-5 (same masks); here the flips are bounded:
+    conv tensors 1e-2 of the tensor's max and 1e-3 in relative L2 norm, dense / heads 1e-4 (measured figures printed)."""
+    ctx, stats, stats_o, g, grads_o, _ = _impala_case(oracle, T1, Bm, False, 200 + T1, chain=0)
+    try:
+        np.testing.assert_allclose(stats, stats_o, rtol=1e-5, atol=1e-5)
+        out = {}
+        for name, (o, shp) in oracle.nature_layout(A).items():
+            n = int(np.prod(shp))
+            ref, got = grads_o[o:o + n], g[o:o + n]
+            emax = float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-7))
+            el2 = float(np.linalg.norm(got - ref) / max(np.linalg.norm(ref), 1e-30))
+            out[name] = (emax, el2)
+        print(f"impala {T1}x{Bm}, exact conv1: per-tensor max error / max|ref| (relative L2):", {k: f"{v[0]:.1e} ({v[1]:.1e})" for k, v in out.items()})
+        for name, (emax, el2) in out.items():
+            assert np.isfinite(emax) and emax <= (1e-2 if name.startswith("conv") else 1e-4) and el2 <= 1e-3, (name, emax, el2)
     finally:
         ctx.close()
 
@@ -171,7 +197,8 @@ def test_impala_e120_bf16_forward_is_configs2(oracle):
 
 
 @pytest.mark.slow
-def test_full_ppo_update_e120_t128_matches_oracle_engine(oracle):
+@pytest.mark.parametrize("chain", [3, 0])
+def test_full_ppo_update_e120_t128_matches_oracle_engine(oracle, chain):
     """One whole configs[1] update — bootstrap value, GAE, adv-norm, 4 epoch permutations, 16 x (3840-frame minibatch forward + loss +
     backward + clipped Adam) — on the rollout the GPU produced, replayed by the oracle engine from the same ring contents."""
     import sys
@@ -180,6 +207,7 @@ def test_full_ppo_update_e120_t128_matches_oracle_engine(oracle):
     _all_cores(oracle)
     cfg = L.default_config(L.ALGO_PPO)
     cfg.local_num_envs, cfg.num_actor_slots, cfg.num_steps = E, 1, T
+    cfg.conv1_fp32_chain = chain     # 3: every learner-size kernel on the oracle's summation order; 0: the default, conv1 as exact products on the bf16 matrix cores
     ctx = L.Context(cfg)
     eng = OracleEngine(cfg)
     try:
@@ -223,9 +251,11 @@ def test_full_ppo_update_e120_t128_matches_oracle_engine(oracle):
         # Bars: median 1e-7, all but 1 in 10 000 within 5e-6, none further than north_star's 1e-5.
         d = np.abs(p - po)
         print("whole update: |p - p_oracle| median %.2e, 99.99 %% quantile %.2e, max %.2e; relative to max|p| %.2e" % (np.median(d), np.quantile(d, 0.9999), d.max(), d.max() / np.abs(po).max()))
+        # chain = 0 (exact-product conv1): same statistics bar; the parameters additionally carry the ReLU flips of pre-activations within ~1e-7 of zero
+        # (tests/test_gpu_conv1_exact.py) through Adam's 1/(sqrt(v) + eps): measured median 0, 99.99 % quantile 5.2e-6, max 2.0e-5 -> bars 1e-7 / 1e-5 / 5e-5
         assert np.median(d) <= 1e-7, np.median(d)
-        assert np.quantile(d, 0.9999) <= 5e-6, np.quantile(d, 0.9999)
-        assert d.max() <= 1e-5, d.max()
+        assert np.quantile(d, 0.9999) <= (5e-6 if chain == 3 else 1e-5), np.quantile(d, 0.9999)
+        assert d.max() <= (1e-5 if chain == 3 else 5e-5), d.max()
     finally:
         ctx.close()
         eng.close()
