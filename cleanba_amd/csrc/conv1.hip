@@ -272,6 +272,12 @@ static __device__ __forceinline__ void c1_split3(float v, uint32_t& t1, uint32_t
   t3 = __float_as_uint(r2);            // at most 8 significant bits left: its lower half is zero
 }
 #define C1X_WBYTES (3 * 16 * 2 * 32 * 16)
+#ifndef C1X_ABL   // timing builds only (results wrong on purpose): 1 frame turn-over in front of the epilogue stores, 2 no epilogue, 4 no byte -> bf16 conversion,
+#define C1X_ABL 0 //   8 one weight fragment set for all K steps (still read each step: same address), 16 no MFMAs
+#endif
+#ifndef C1W_ABL   // timing builds only: 1 dY one group ahead, 2 no split of dY, 4 no A-fragment gathers, 8 no MFMAs, 16 no closing reduction, 32 frame converted once per block
+#define C1W_ABL 0
+#endif
 template <bool MASK>
 __global__ __launch_bounds__(256, 2) void conv1_fwd_exact_kernel(const uint8_t* obs, const int32_t* idx, const float* W, const float* bias,
                                                                  float* out, uint32_t* mask, int S, int frames_per_block) {
@@ -321,9 +327,7 @@ __global__ __launch_bounds__(256, 2) void conv1_fwd_exact_kernel(const uint8_t* 
   put_frame();
   if (s_lo + 1 < s_hi) load_frame(obs + (size_t)(idx ? idx[s_lo + 1] : s_lo + 1) * FR);
   __syncthreads();
-  // Per frame: multiply (LDS = frame s) | barrier | frame s+1: registers -> LDS, then the loads of frame s+2 | epilogue stores of frame s | barrier.
-  // The LDS writes wait for loads that are a whole frame old, and no store of THIS frame has been issued yet: vmcnt is one in-order counter for
-  // loads and stores, and with the stores in front of the LDS writes every frame waited for its own 51 KB of stores to be acknowledged.
+  // Per frame: multiply (LDS = frame s) + epilogue stores | barrier | frame s+1: registers -> LDS, then the loads of frame s+2 | barrier.
   for (int s = s_lo; s < s_hi; ++s) {
     const int first = (wave + (s - s_lo)) & 3;
     const bool four = first == 0;
@@ -346,20 +350,35 @@ __global__ __launch_bounds__(256, 2) void conv1_fwd_exact_kernel(const uint8_t* 
         const int foff = (q >> 2) * 7056 + (q & 3) * 168;
         c1_bf16x8 wf[3], xb[NT];
 #pragma unroll
-        for (int tm = 0; tm < 3; ++tm) wf[tm] = __builtin_bit_cast(c1_bf16x8, Wl[((tm * 16 + q) * 2 + h) * 32 + li]);
+        for (int tm = 0; tm < 3; ++tm) wf[tm] = __builtin_bit_cast(c1_bf16x8, Wl[((tm * 16 + ((C1X_ABL & 8) ? 0 : q)) * 2 + h) * 32 + li]);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
           const uint32_t* px = reinterpret_cast<const uint32_t*>(F + base[t] + foff);
-          xb[t] = c1_px8_bf16(px[0], px[1]);
+          if (C1X_ABL & 4) { c1_u32x4 r = {px[0], px[1], px[0], px[1]}; xb[t] = __builtin_bit_cast(c1_bf16x8, r); }
+          else xb[t] = c1_px8_bf16(px[0], px[1]);
         }
 #pragma unroll
         for (int tm = 2; tm >= 0; --tm)          // small terms first; consecutive MFMAs go to different accumulators
 #pragma unroll
-          for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[tm], xb[t], acc[t], 0, 0, 0);
+          for (int t = 0; t < NT; ++t) {
+            if (C1X_ABL & 16) { acc[t][tm] += (float)xb[t][tm] * (float)wf[tm][t]; continue; }
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[tm], xb[t], acc[t], 0, 0, 0);
+          }
       }
-      __syncthreads();                 // every wave is done with this frame's bytes
-      if (s + 1 < s_hi) put_frame();
-      if (s + 2 < s_hi) load_frame(obs + (size_t)(idx ? idx[s + 2] : s + 2) * FR);
+      if (C1X_ABL & 1) {               // timing build: frame turn-over in FRONT of the epilogue stores (the LDS writes then never wait behind this frame's stores
+        __syncthreads();               // on the in-order vmcnt; measured 14 us SLOWER per 3840 frames: the accumulators sit through a barrier and the stores start later)
+        if (s + 1 < s_hi) put_frame();
+        if (s + 2 < s_hi) load_frame(obs + (size_t)(idx ? idx[s + 2] : s + 2) * FR);
+      }
+      if (C1X_ABL & 2) {
+        float sabl = 0.0f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) sabl += acc[t][e];
+        if (sabl == 1.2345e-33f) out[0] = sabl;
+        return;
+      }
       // epilogue: the fp32 kernel's (D[channel][position]: a lane holds 16 channels of one position)
 #pragma unroll
       // No branch around the stores: the lanes of the half-empty 13th tile computed position 399 (base[] clamps) and store it again — same address, same
@@ -383,6 +402,11 @@ __global__ __launch_bounds__(256, 2) void conv1_fwd_exact_kernel(const uint8_t* 
     };
     if (four) frame_tiles(std::integral_constant<int, 4>{});
     else frame_tiles(std::integral_constant<int, 3>{});
+    if (!(C1X_ABL & 1)) {
+      __syncthreads();                 // every wave is done with this frame's bytes
+      if (s + 1 < s_hi) put_frame();
+      if (s + 2 < s_hi) load_frame(obs + (size_t)(idx ? idx[s + 2] : s + 2) * FR);   // two frames ahead: lands while the next frame is multiplied
+    }
     __syncthreads();
   }
 }
@@ -582,6 +606,7 @@ __global__ __launch_bounds__(256, 2) void conv1_wgrad_exact_kernel(const uint8_t
 #pragma unroll
     for (int j = 0; j < 7; ++j) {
       const int v = tid + 256 * j;
+      if ((C1W_ABL & 32) && s != s_lo) break;
       if (v < FR / 16) {
         *reinterpret_cast<c1_u32x4*>(FB + 16 * v) = __builtin_bit_cast(c1_u32x4, c1_px8_bf16(pw[j][0], pw[j][1]));
         *reinterpret_cast<c1_u32x4*>(FB + 16 * v + 8) = __builtin_bit_cast(c1_u32x4, c1_px8_bf16(pw[j][2], pw[j][3]));
@@ -608,14 +633,17 @@ __global__ __launch_bounds__(256, 2) void conv1_wgrad_exact_kernel(const uint8_t
       for (int j = 0; j < 4; ++j) {
         uint32_t x1, x2, x3, y1, y2, y3;
         bs += bc[2 * j] + bc[2 * j + 1];
+        if (C1W_ABL & 2) { x1 = x2 = x3 = __float_as_uint(bc[2 * j]); y1 = y2 = y3 = __float_as_uint(bc[2 * j + 1]); }
+        else {
         c1_split3(bc[2 * j], x1, x2, x3);
         c1_split3(bc[2 * j + 1], y1, y2, y3);
+        }
         b1[j] = __builtin_amdgcn_perm(y1, x1, 0x07060302u);
         b2[j] = __builtin_amdgcn_perm(y2, x2, 0x07060302u);
         b3[j] = __builtin_amdgcn_perm(y3, x3, 0x07060302u);
       }
       {   // unconditional (the group index is clamped): hipcc then knows how many loads are in flight and waits for exactly the older eight
-        const int gn = min(grp + 8, glast);
+        const int gn = (C1W_ABL & 1) ? grp : min(grp + 8, glast);
 #pragma unroll
         for (int j = 0; j < 8; ++j) bc[j] = g[(gn * 16 + j) * 32];
       }
@@ -625,15 +653,25 @@ __global__ __launch_bounds__(256, 2) void conv1_wgrad_exact_kernel(const uint8_t
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
           const int ko = (t >> 1) * 7056 + (t & 1) * 336;
-          a[t][j] = (uint32_t)fl[ko + off0] | ((uint32_t)fl[ko + off1] << 16);
+          if (C1W_ABL & 4) a[t][j] = (uint32_t)(ko + off0 + grp) * 0x00010001u + (uint32_t)lane;
+          else a[t][j] = (uint32_t)fl[ko + off0] | ((uint32_t)fl[ko + off1] << 16);
         }
       }
 #pragma unroll
-      for (int t = 0; t < 8; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(c1_bf16x8, a[t]), __builtin_bit_cast(c1_bf16x8, b3), acc[t], 0, 0, 0);
+      for (int t = 0; t < 8; ++t) {
+        if (C1W_ABL & 8) { acc[t][0] += __uint_as_float(a[t][0] ^ b3[1]); continue; }
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(c1_bf16x8, a[t]), __builtin_bit_cast(c1_bf16x8, b3), acc[t], 0, 0, 0);
+      }
 #pragma unroll
-      for (int t = 0; t < 8; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(c1_bf16x8, a[t]), __builtin_bit_cast(c1_bf16x8, b2), acc[t], 0, 0, 0);
+      for (int t = 0; t < 8; ++t) {
+        if (C1W_ABL & 8) { acc[t][0] += __uint_as_float(a[t][0] ^ b2[1]); continue; }
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(c1_bf16x8, a[t]), __builtin_bit_cast(c1_bf16x8, b2), acc[t], 0, 0, 0);
+      }
 #pragma unroll
-      for (int t = 0; t < 8; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(c1_bf16x8, a[t]), __builtin_bit_cast(c1_bf16x8, b1), acc[t], 0, 0, 0);
+      for (int t = 0; t < 8; ++t) {
+        if (C1W_ABL & 8) { acc[t][0] += __uint_as_float(a[t][0] ^ b1[1]); continue; }
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(c1_bf16x8, a[t]), __builtin_bit_cast(c1_bf16x8, b1), acc[t], 0, 0, 0);
+      }
     };
     int grp = g0;
 #pragma unroll 1
@@ -646,7 +684,7 @@ __global__ __launch_bounds__(256, 2) void conv1_wgrad_exact_kernel(const uint8_t
   // the four waves' sums: (1 -> 0, 3 -> 2), then 2 -> 0; a wave's 8 x 16 values per lane go through LDS as 32 pieces of 16 bytes, lane-contiguous
   float* R = reinterpret_cast<float*>(FB);
 #pragma unroll 1
-  for (int round = 0; round < 2; ++round) {
+  for (int round = 0; round < ((C1W_ABL & 16) ? 0 : 2); ++round) {
     __syncthreads();
     const bool writer = round == 0 ? (wave & 1) : wave == 2;
     const bool reader = round == 0 ? !(wave & 1) : wave == 0;

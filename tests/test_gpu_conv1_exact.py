@@ -9,9 +9,10 @@ fmaf chain (reference: x / 255.0 then nn.Conv(32, (8, 8), strides=(4, 4)), natur
   * weight gradient: behind the chain forward (conv1_fp32_chain = 1: same ReLU masks as the oracle) every gradient tensor within 1e-5 of its max,
     like tests/test_gpu_fullsize_oracle.py;
   * both exact: a pre-activation within ~1e-7 of zero can land on the other side of the ReLU than in the oracle; each such flip moves single elements
-    of the conv gradients by ~1e-4 of the tensor's max (one term of a sum whose random-sign terms add up to ~sqrt(n) of them).  That is a property of
+    of the conv gradients by 1e-4 ... 1e-3 of the tensor's max (one term of a sum whose random-sign terms add up to ~sqrt(n) of them).  That is a property of
     comparing ANY two fp32 summation orders through a ReLU (XLA against the oracle included), not of these kernels — the two tests above pin the
-    kernels; this one bounds the flips: dense / heads gradients 1e-5, conv gradients 1e-3 of the tensor's max, relative L2 error 1e-4.
+    kernels; this one bounds the flips: dense / heads gradients 1e-5, conv gradients 1e-2 of the tensor's max, relative L2 error 1e-3
+    (measured: 8e-5 ... 2.4e-3 of max on conv1.w depending on the seed, 5e-4 in L2).
 Sizes: 3840 frames through a shuffled gather index (configs[1]'s minibatch), 1031 (odd: the last block of either kernel holds one frame), 513 (the
 smallest pass that takes the learner-size kernels)."""
 import os
@@ -136,8 +137,8 @@ def test_both_exact_against_oracle_bounds_the_relu_flips(oracle):
     err = _per_tensor(oracle, g, grads_o)
     print("both exact, 3840 frames: per-tensor max error / max|ref| (relative L2):", {k: f"{e[0]:.1e} ({e[1]:.1e})" for k, e in err.items()})
     for name, (emax, el2) in err.items():
-        bar = 1e-3 if name.startswith("conv") else 1e-5
-        assert emax <= bar and el2 <= 1e-4, (name, emax, el2)
+        bar = 1e-2 if name.startswith("conv") else 1e-5     # measured on two seeds: conv1.w 8e-5 / 2.4e-3 (relative L2 4.8e-4), dense / heads <= 5e-7
+        assert emax <= bar and el2 <= 1e-3, (name, emax, el2)
     same_fwd = _per_tensor(oracle, g, g2)
     print("exact vs chain weight gradient behind the SAME (exact) forward:", {k: f"{e[0]:.1e}" for k, e in same_fwd.items() if e[0] > 0})
     for name, (emax, _) in same_fwd.items():
