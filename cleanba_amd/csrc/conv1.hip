@@ -724,6 +724,180 @@ __global__ __launch_bounds__(256, 2) void conv1_wgrad_exact_kernel(const uint8_t
   }
 }
 
+// Same kernel on a DE-INTERLEAVED LDS frame (timing builds showed the eight 16-bit gathers per A fragment — 64 LDS instructions per group of 16
+// positions — to cost 36 of the kernel's 127 us).  A tap (kh, kw) of output position (oh, ow) is pixel x[c][4 oh + kh][4 (ow + (kw >> 2)) + (kw & 3)]: with
+// the frame stored by BYTE LANE, FBd[c][row][b = column & 3][d = column >> 2] (rows padded from 21 to 24), the positions ow .. ow+3 of one output row are
+// four CONSECUTIVE bf16 for every tap, 8-byte aligned when ow is a multiple of 4; taps with kw >= 4 start one element later (a 32-bit funnel shift of
+// the 8 + 4 bytes read, v_alignbit with a per-lane shift).  A group of 16 positions = two halves of (4 columns) x (2 output rows): 10 row pairs x 5
+// column blocks = the frame's 25 groups exactly.  Per A fragment: 2 x (ds_read_b64 + ds_read_b32), bank-conflict-free, + 4 v_alignbit, instead of
+// 8 x ds_read_u16 + 4 packs.  The conversion pass loads the frame as row-aligned quads of dwords (5 per 84-byte row + the 21st dword) so that a
+// quad's byte lane b is four consecutive d: one ds_write_b64 per lane.
+typedef uint32_t c1_u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef uint32_t c1_u32x2 __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(256, 2) void conv1_wgrad_exact_dl_kernel(const uint8_t* obs, const int32_t* idx, const float* dy, float* part,
+                                                                      float* bpart, int S, int frames_per_block) {
+  __shared__ __attribute__((aligned(16))) unsigned short FB[C1WX_LDS / 2];   // FBd[4][84][4][24] bf16 = 64,512 B; 64 KB for the closing reduction
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int s_lo = blockIdx.x * frames_per_block, s_hi = min(S, s_lo + frames_per_block);
+  if (s_lo >= s_hi) return;
+  const int kb = ((li >> 3) * 4 + (li & 3)) * 24;   // tap (kh' = li >> 3, kw = li & 7): row kh', byte lane kw & 3; k-tile t adds (t >> 1) * 84 * 96 + (t & 1) * 384
+  const uint32_t sh = (li & 4) ? 16u : 0u;          // kw >= 4: one element later
+  f32x16 acc[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[t][e] = 0.0f;
+  float bs = 0.0f;
+  // conversion items: quads (c*84 + row, k = 0..4) -> dwords d = 4k .. 4k+3 of the row; singles (c*84 + row) -> dword d = 20
+  c1_u32x4 pq[7];
+  uint32_t p1[2];
+  auto load_frame = [&](const uint8_t* frame) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      const int it = min(tid + 256 * i, 1679), cr = it / 5, k = it - cr * 5;
+      pq[i] = *reinterpret_cast<const c1_u32x4_a4*>(frame + cr * 84 + 16 * k);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) p1[i] = *reinterpret_cast<const uint32_t*>(frame + min(tid + 256 * i, 335) * 84 + 80);
+  };
+  load_frame(obs + (size_t)(idx ? idx[s_lo] : s_lo) * FR);
+  for (int s = s_lo; s < s_hi; ++s) {
+    __syncthreads();  // previous frame fully consumed
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      const int it = tid + 256 * i, cr = it / 5, k = it - cr * 5;
+      if (it < 1680) {
+        unsigned short* dst = FB + cr * 96 + 4 * k;
+        const uint32_t d0 = pq[i][0], d1 = pq[i][1], d2 = pq[i][2], d3 = pq[i][3];
+        c1_u32x2 v;
+        v[0] = c1_pack_hi16((float)(d0 & 255u), (float)(d1 & 255u)); v[1] = c1_pack_hi16((float)(d2 & 255u), (float)(d3 & 255u));
+        *reinterpret_cast<c1_u32x2*>(dst) = v;
+        v[0] = c1_pack_hi16((float)((d0 >> 8) & 255u), (float)((d1 >> 8) & 255u)); v[1] = c1_pack_hi16((float)((d2 >> 8) & 255u), (float)((d3 >> 8) & 255u));
+        *reinterpret_cast<c1_u32x2*>(dst + 24) = v;
+        v[0] = c1_pack_hi16((float)((d0 >> 16) & 255u), (float)((d1 >> 16) & 255u)); v[1] = c1_pack_hi16((float)((d2 >> 16) & 255u), (float)((d3 >> 16) & 255u));
+        *reinterpret_cast<c1_u32x2*>(dst + 48) = v;
+        v[0] = c1_pack_hi16((float)(d0 >> 24), (float)(d1 >> 24)); v[1] = c1_pack_hi16((float)(d2 >> 24), (float)(d3 >> 24));
+        *reinterpret_cast<c1_u32x2*>(dst + 72) = v;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int cr = tid + 256 * i;
+      if (cr < 336) {
+        unsigned short* dst = FB + cr * 96 + 20;
+        const uint32_t d = p1[i];
+        dst[0] = (unsigned short)(__float_as_uint((float)(d & 255u)) >> 16);
+        dst[24] = (unsigned short)(__float_as_uint((float)((d >> 8) & 255u)) >> 16);
+        dst[48] = (unsigned short)(__float_as_uint((float)((d >> 16) & 255u)) >> 16);
+        dst[72] = (unsigned short)(__float_as_uint((float)(d >> 24)) >> 16);
+      }
+    }
+    if (s + 1 < s_hi) load_frame(obs + (size_t)(idx ? idx[s + 1] : s + 1) * FR);   // lands while this frame is multiplied
+    const int g0 = (wave + 4 - ((s - s_lo) & 3)) & 3;          // this wave's groups: g0, g0 + 4, ... (the wave with seven of them rotates)
+    const int glast = g0 + 4 * ((24 - g0) >> 2);
+    const float* g = dy + (size_t)s * 400 * 32 + li;
+    // half hh = 2 grp + h: row pair hh / 5, column block hh % 5 -> positions (2 rp, 4 blk + j) for j < 4, (2 rp + 1, 4 blk + j - 4) for j >= 4
+    auto half_pos = [&](int grp, int& rp, int& blk) __attribute__((always_inline)) { const int hh = 2 * grp + h; rp = hh / 5; blk = hh - rp * 5; };
+    auto load_dy = [&](float (&bc)[8], int grp) __attribute__((always_inline)) {
+      int rp, blk;
+      half_pos(grp, rp, blk);
+      const float* q = g + (rp * 40 + 4 * blk) * 32;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { bc[j] = q[j * 32]; bc[4 + j] = q[(20 + j) * 32]; }
+    };
+    float bA[8], bB[8];
+    load_dy(bA, g0);
+    load_dy(bB, g0 + 4);          // g0 + 4 <= 7 < 25
+    __syncthreads();
+    auto group = [&](float (&bc)[8], int grp) __attribute__((always_inline)) {
+      int rp, blk;
+      half_pos(grp, rp, blk);
+      const unsigned short* fl = FB + kb + rp * (8 * 96) + 4 * blk;
+      c1_u32x4 b1, b2, b3;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        uint32_t x1, x2, x3, y1, y2, y3;
+        bs += bc[2 * j] + bc[2 * j + 1];
+        c1_split3(bc[2 * j], x1, x2, x3);
+        c1_split3(bc[2 * j + 1], y1, y2, y3);
+        b1[j] = __builtin_amdgcn_perm(y1, x1, 0x07060302u);
+        b2[j] = __builtin_amdgcn_perm(y2, x2, 0x07060302u);
+        b3[j] = __builtin_amdgcn_perm(y3, x3, 0x07060302u);
+      }
+      load_dy(bc, min(grp + 8, glast));       // unconditional (clamped): hipcc then knows how many loads are in flight
+#pragma unroll
+      for (int th = 0; th < 8; th += 2) {     // two k-tiles at a time (8 fragment registers instead of 32: the kernel sits at the 256-register limit)
+        c1_u32x4 a[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const unsigned short* ft = fl + ((th + t) >> 1) * (84 * 96) + ((th + t) & 1) * 384;
+#pragma unroll
+          for (int r = 0; r < 2; ++r) {         // the half's two output rows: 4 image rows = 384 elements apart
+            const c1_u32x2 lo2 = *reinterpret_cast<const c1_u32x2*>(ft + r * 384);
+            const uint32_t hi1 = *reinterpret_cast<const uint32_t*>(ft + r * 384 + 4);
+            a[t][2 * r] = __builtin_amdgcn_alignbit(lo2[1], lo2[0], sh);
+            a[t][2 * r + 1] = __builtin_amdgcn_alignbit(hi1, lo2[1], sh);
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) acc[th + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(c1_bf16x8, a[t]), __builtin_bit_cast(c1_bf16x8, b3), acc[th + t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) acc[th + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(c1_bf16x8, a[t]), __builtin_bit_cast(c1_bf16x8, b2), acc[th + t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) acc[th + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(c1_bf16x8, a[t]), __builtin_bit_cast(c1_bf16x8, b1), acc[th + t], 0, 0, 0);
+      }
+    };
+    int grp = g0;
+#pragma unroll 1
+    for (; grp + 4 < 25; grp += 8) {
+      group(bA, grp);
+      group(bB, grp + 4);
+    }
+    if (grp < 25) group(bA, grp);
+  }
+  // the four waves' sums: (1 -> 0, 3 -> 2), then 2 -> 0 (as in conv1_wgrad_exact_kernel)
+  float* R = reinterpret_cast<float*>(FB);
+#pragma unroll 1
+  for (int round = 0; round < 2; ++round) {
+    __syncthreads();
+    const bool writer = round == 0 ? (wave & 1) : wave == 2;
+    const bool reader = round == 0 ? !(wave & 1) : wave == 0;
+    float* slot = R + (round == 0 ? (wave >> 1) : 0) * 8192 + lane * 4;
+    if (writer) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *reinterpret_cast<float4*>(slot + (t * 4 + q) * 256) = make_float4(acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]);
+    }
+    __syncthreads();
+    if (reader) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 v = *reinterpret_cast<const float4*>(slot + (t * 4 + q) * 256);
+          acc[t][4 * q] += v.x; acc[t][4 * q + 1] += v.y; acc[t][4 * q + 2] += v.z; acc[t][4 * q + 3] += v.w;
+        }
+    }
+  }
+  bs += __shfl_xor(bs, 32, 64);
+  __syncthreads();
+  if (h == 0) R[wave * 32 + li] = bs;
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
+        part[((size_t)blockIdx.x * 256 + 32 * t + row) * 32 + li] = acc[t][e];
+      }
+    if (h == 0) bpart[blockIdx.x * 32 + li] = (R[li] + R[32 + li]) + (R[64 + li] + R[96 + li]);
+  }
+}
+
 // 3840-frame minibatch: 1280 blocks of 3 frames.  Alone 768 blocks of 5 frames were the fastest (225 us against 233 for 1024, and 25 MB of partials
 // instead of 42), but beside the rollout the blocks of a grid that is resident all at once end 180-267 us after the first start (the CUs that also host
 // actor blocks run theirs slower; tools/block_trace.py) and the kernel waits for the slowest: with a second, dynamically dispatched wave of shorter
@@ -745,7 +919,9 @@ void launch_conv1_wgrad_frames(const uint8_t* obs, const int32_t* idx, const flo
                                bool exact) {
   const int nz = conv1_wgrad_frames_splits(S);
   const int fpb = (S + nz - 1) / nz;
-  if (exact) hipLaunchKernelGGL(conv1_wgrad_exact_kernel, dim3(nz), dim3(256), 0, st, obs, idx, dy, part, bpart, S, fpb);
+  static const bool dl = [] { const char* e = getenv("CBM_C1W_DL"); return !(e && e[0] == '0'); }();   // (=0: the row-major LDS frame with 16-bit gathers, A/B timing)
+  if (exact && dl) hipLaunchKernelGGL(conv1_wgrad_exact_dl_kernel, dim3(nz), dim3(256), 0, st, obs, idx, dy, part, bpart, S, fpb);
+  else if (exact) hipLaunchKernelGGL(conv1_wgrad_exact_kernel, dim3(nz), dim3(256), 0, st, obs, idx, dy, part, bpart, S, fpb);
   else if (split) hipLaunchKernelGGL(conv1_wgrad_frames_split_kernel, dim3(nz), dim3(256), 0, st, obs, idx, dy, part, bpart, S, fpb);
   else hipLaunchKernelGGL(conv1_wgrad_frames_kernel, dim3(nz), dim3(256), 0, st, obs, idx, dy, part, bpart, S, fpb);
 }
