@@ -251,6 +251,7 @@ __global__ __launch_bounds__(256, 2) void conv1_fwd_planes_kernel(const uint8_t*
 //        per wave with `first` rotating from frame to frame; products formed transposed (weights = the MFMA's A operand) so that the epilogue is the fp32
 //        kernel's: a lane holds 16 channels of one position -> four 16-byte stores and the position's ReLU word.
 typedef uint32_t c1_u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t c1_u32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 c1_bf16x8 __attribute__((ext_vector_type(8)));
 static __device__ __forceinline__ uint32_t c1_pack_hi16(float lo, float hi) {   // the two upper halves (bf16 by truncation; exact for integers < 256)
   return __builtin_amdgcn_perm(__float_as_uint(hi), __float_as_uint(lo), 0x07060302u);
@@ -733,7 +734,6 @@ __global__ __launch_bounds__(256, 2) void conv1_wgrad_exact_kernel(const uint8_t
 // 8 x ds_read_u16 + 4 packs.  The conversion pass loads the frame as row-aligned quads of dwords (5 per 84-byte row + the 21st dword) so that a
 // quad's byte lane b is four consecutive d: one ds_write_b64 per lane.
 typedef uint32_t c1_u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
-typedef uint32_t c1_u32x2 __attribute__((ext_vector_type(2)));
 __global__ __launch_bounds__(256, 2) void conv1_wgrad_exact_dl_kernel(const uint8_t* obs, const int32_t* idx, const float* dy, float* part,
                                                                       float* bpart, int S, int frames_per_block) {
   __shared__ __attribute__((aligned(16))) unsigned short FB[C1WX_LDS / 2];   // FBd[4][84][4][24] bf16 = 64,512 B; 64 KB for the closing reduction
@@ -826,9 +826,10 @@ __global__ __launch_bounds__(256, 2) void conv1_wgrad_exact_dl_kernel(const uint
         b3[j] = __builtin_amdgcn_perm(y3, x3, 0x07060302u);
       }
       load_dy(bc, min(grp + 8, glast));       // unconditional (clamped): hipcc then knows how many loads are in flight
-#pragma unroll
-      for (int th = 0; th < 8; th += 2) {     // two k-tiles at a time (8 fragment registers instead of 32: the kernel sits at the 256-register limit)
-        c1_u32x4 a[2];
+      // two k-tiles at a time (the kernel sits at the 256-register limit), the next pair's fragments requested before this pair's six MFMAs.
+      // (sched_group_barrier hints that interleave single MFMAs with the next pair's LDS reads / shifts — and the same for the forward's conversions —
+      // were measured: no gain, 110.3 vs 108.6 us and 90.2 vs 89.9; MFMA, VALU and LDS time add up on this chip whatever the order.)
+      auto gather = [&](int th, c1_u32x4 (&a)[2]) __attribute__((always_inline)) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
           const unsigned short* ft = fl + ((th + t) >> 1) * (84 * 96) + ((th + t) & 1) * 384;
@@ -840,12 +841,19 @@ __global__ __launch_bounds__(256, 2) void conv1_wgrad_exact_dl_kernel(const uint
             a[t][2 * r + 1] = __builtin_amdgcn_alignbit(hi1, lo2[1], sh);
           }
         }
+      };
+      c1_u32x4 af[2][2];
+      gather(0, af[0]);
 #pragma unroll
-        for (int t = 0; t < 2; ++t) acc[th + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(c1_bf16x8, a[t]), __builtin_bit_cast(c1_bf16x8, b3), acc[th + t], 0, 0, 0);
+      for (int th = 0; th < 8; th += 2) {
+        const int cur = (th >> 1) & 1, nxt = cur ^ 1;
+        if (th + 2 < 8) gather(th + 2, af[nxt]);
 #pragma unroll
-        for (int t = 0; t < 2; ++t) acc[th + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(c1_bf16x8, a[t]), __builtin_bit_cast(c1_bf16x8, b2), acc[th + t], 0, 0, 0);
+        for (int t = 0; t < 2; ++t) acc[th + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(c1_bf16x8, af[cur][t]), __builtin_bit_cast(c1_bf16x8, b3), acc[th + t], 0, 0, 0);
 #pragma unroll
-        for (int t = 0; t < 2; ++t) acc[th + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(c1_bf16x8, a[t]), __builtin_bit_cast(c1_bf16x8, b1), acc[th + t], 0, 0, 0);
+        for (int t = 0; t < 2; ++t) acc[th + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(c1_bf16x8, af[cur][t]), __builtin_bit_cast(c1_bf16x8, b2), acc[th + t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) acc[th + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(c1_bf16x8, af[cur][t]), __builtin_bit_cast(c1_bf16x8, b1), acc[th + t], 0, 0, 0);
       }
     };
     int grp = g0;
