@@ -580,8 +580,10 @@ __global__ __launch_bounds__(256, 2) void conv1_wgrad_frames_split_kernel(const 
 // fourth group and ALL eight k-tiles of dW[256][32] for it (128 accumulator registers), so the split of dY (5.5 VALU instructions per element) and
 // the row-wrap address arithmetic are paid once per 24 MFMAs; the four waves' sums are added through LDS when the block ends (two rounds).
 // Partials part[z][k][n] in pixel units, as the fp32 kernel writes them (the reduce applies 1/255).
+// This is the FIRST form (row-major bf16 frame in LDS, eight 16-bit gathers per fragment: 122-130 us per 3840 frames), kept for A/B runs (CBM_C1W_DL=0);
+// what ships is conv1_wgrad_exact_kernel below (de-interleaved LDS frame, 105-110 us).
 #define C1WX_LDS 65536
-__global__ __launch_bounds__(256, 2) void conv1_wgrad_exact_kernel(const uint8_t* obs, const int32_t* idx, const float* dy, float* part,
+__global__ __launch_bounds__(256, 2) void conv1_wgrad_exact_rowmajor_kernel(const uint8_t* obs, const int32_t* idx, const float* dy, float* part,
                                                                    float* bpart, int S, int frames_per_block) {
   __shared__ __attribute__((aligned(16))) unsigned short FB[C1WX_LDS / 2];   // one frame as bf16 (56,448 B); 64 KB for the closing reduction
   const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, h = lane >> 5;
@@ -725,7 +727,7 @@ __global__ __launch_bounds__(256, 2) void conv1_wgrad_exact_kernel(const uint8_t
   }
 }
 
-// Same kernel on a DE-INTERLEAVED LDS frame (timing builds showed the eight 16-bit gathers per A fragment — 64 LDS instructions per group of 16
+// The shipped exact weight gradient: the same work split on a DE-INTERLEAVED LDS frame (timing builds showed the eight 16-bit gathers per A fragment — 64 LDS instructions per group of 16
 // positions — to cost 36 of the kernel's 127 us).  A tap (kh, kw) of output position (oh, ow) is pixel x[c][4 oh + kh][4 (ow + (kw >> 2)) + (kw & 3)]: with
 // the frame stored by BYTE LANE, FBd[c][row][b = column & 3][d = column >> 2] (rows padded from 21 to 24), the positions ow .. ow+3 of one output row are
 // four CONSECUTIVE bf16 for every tap, 8-byte aligned when ow is a multiple of 4; taps with kw >= 4 start one element later (a 32-bit funnel shift of
@@ -734,7 +736,7 @@ __global__ __launch_bounds__(256, 2) void conv1_wgrad_exact_kernel(const uint8_t
 // 8 x ds_read_u16 + 4 packs.  The conversion pass loads the frame as row-aligned quads of dwords (5 per 84-byte row + the 21st dword) so that a
 // quad's byte lane b is four consecutive d: one ds_write_b64 per lane.
 typedef uint32_t c1_u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
-__global__ __launch_bounds__(256, 2) void conv1_wgrad_exact_dl_kernel(const uint8_t* obs, const int32_t* idx, const float* dy, float* part,
+__global__ __launch_bounds__(256, 2) void conv1_wgrad_exact_kernel(const uint8_t* obs, const int32_t* idx, const float* dy, float* part,
                                                                       float* bpart, int S, int frames_per_block) {
   __shared__ __attribute__((aligned(16))) unsigned short FB[C1WX_LDS / 2];   // FBd[4][84][4][24] bf16 = 64,512 B; 64 KB for the closing reduction
   const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, h = lane >> 5;
@@ -864,7 +866,7 @@ __global__ __launch_bounds__(256, 2) void conv1_wgrad_exact_dl_kernel(const uint
     }
     if (grp < 25) group(bA, grp);
   }
-  // the four waves' sums: (1 -> 0, 3 -> 2), then 2 -> 0 (as in conv1_wgrad_exact_kernel)
+  // the four waves' sums: (1 -> 0, 3 -> 2), then 2 -> 0 (as in conv1_wgrad_exact_rowmajor_kernel)
   float* R = reinterpret_cast<float*>(FB);
 #pragma unroll 1
   for (int round = 0; round < 2; ++round) {
@@ -928,8 +930,8 @@ void launch_conv1_wgrad_frames(const uint8_t* obs, const int32_t* idx, const flo
   const int nz = conv1_wgrad_frames_splits(S);
   const int fpb = (S + nz - 1) / nz;
   static const bool dl = [] { const char* e = getenv("CBM_C1W_DL"); return !(e && e[0] == '0'); }();   // (=0: the row-major LDS frame with 16-bit gathers, A/B timing)
-  if (exact && dl) hipLaunchKernelGGL(conv1_wgrad_exact_dl_kernel, dim3(nz), dim3(256), 0, st, obs, idx, dy, part, bpart, S, fpb);
-  else if (exact) hipLaunchKernelGGL(conv1_wgrad_exact_kernel, dim3(nz), dim3(256), 0, st, obs, idx, dy, part, bpart, S, fpb);
+  if (exact && dl) hipLaunchKernelGGL(conv1_wgrad_exact_kernel, dim3(nz), dim3(256), 0, st, obs, idx, dy, part, bpart, S, fpb);
+  else if (exact) hipLaunchKernelGGL(conv1_wgrad_exact_rowmajor_kernel, dim3(nz), dim3(256), 0, st, obs, idx, dy, part, bpart, S, fpb);
   else if (split) hipLaunchKernelGGL(conv1_wgrad_frames_split_kernel, dim3(nz), dim3(256), 0, st, obs, idx, dy, part, bpart, S, fpb);
   else hipLaunchKernelGGL(conv1_wgrad_frames_kernel, dim3(nz), dim3(256), 0, st, obs, idx, dy, part, bpart, S, fpb);
 }

@@ -13,9 +13,12 @@
 tag=$1; R=$PWD; out=$R/gpurun_out/$tag; mkdir -p $out
 export TMPDIR=/tmp PYTHONPATH=$R GIT_REV=$(cat $R/.build_rev 2>/dev/null || echo unknown)
 echo "library revision: $GIT_REV" > $out/REVISION.txt
-t0=$(date +%s); timeout 900 python bench.py > $out/bench_line.json 2> $out/bench.err; echo "python bench.py (no flags): $(( $(date +%s) - t0 )) s wall" > $out/bench_wall.txt
+# counters first: bench.py reports a kernel's `traffic` from profiles/pmc_traffic.json and only for the kernel symbols recorded there, so the table of THIS
+# library revision has to be in place before the line is taken (a kernel renamed since the last collection would read null)
 bash tools/pmc_collect.sh $tag > $out/pmc_collect.log 2>&1
 mv $out/kernel_stats.md $out/bench_kernel_stats.md
+python -c "import json,sys; d=json.load(open(sys.argv[1])); assert len(d) >= 12, len(d)" $out/pmc_traffic.json && cp $out/pmc_traffic.json profiles/pmc_traffic.json
+t0=$(date +%s); timeout 900 python bench.py > $out/bench_line.json 2> $out/bench.err; echo "python bench.py (no flags): $(( $(date +%s) - t0 )) s wall" > $out/bench_wall.txt
 prof() { # name, command...
   local n=$1; shift
   cd /tmp; timeout 400 rocprofv3 --kernel-trace --stats -d $out/tr_$n -o t -- "$@" > $out/$n.log 2>&1; cd $R
