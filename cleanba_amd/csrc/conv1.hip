@@ -264,7 +264,8 @@ static __device__ __forceinline__ c1_bf16x8 c1_px8_bf16(uint32_t w0, uint32_t w1
   r[3] = c1_pack_hi16((float)((w1 >> 16) & 255u), (float)(w1 >> 24));
   return __builtin_bit_cast(c1_bf16x8, r);
 }
-// three bf16 terms of an fp32 value by truncation: t1 + t2 + t3 == v exactly
+// three bf16 terms of an fp32 value by truncation: t1 + t2 + t3 == v exactly (for |v| >= 2^-103 or 0: below that the last remainder is subnormal and its
+// upper 16 bits drop less than 2^-133; tests/test_conv1_exact_split.py restates this in numpy)
 static __device__ __forceinline__ void c1_split3(float v, uint32_t& t1, uint32_t& t2, uint32_t& t3) {
   t1 = __float_as_uint(v) & 0xffff0000u;
   const float r1 = v - __uint_as_float(t1);
