@@ -737,14 +737,18 @@ __global__ __launch_bounds__(256, 2) void conv1_wgrad_exact_rowmajor_kernel(cons
 // 8 x ds_read_u16 + 4 packs.  The conversion pass loads the frame as row-aligned quads of dwords (5 per 84-byte row + the 21st dword) so that a
 // quad's byte lane b is four consecutive d: one ds_write_b64 per lane.
 typedef uint32_t c1_u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+#ifndef C1W_RS    // elements per (row, byte lane) of the de-interleaved frame: 21 used, a multiple of 4 (8-byte aligned fragments); 24 = 64,512 B, 28 = 75,264 B
+#define C1W_RS 24
+#endif
+static constexpr int RS = C1W_RS, RSR = 4 * C1W_RS;   // RSR: elements per image row (four byte lanes)
 __global__ __launch_bounds__(256, 2) void conv1_wgrad_exact_kernel(const uint8_t* obs, const int32_t* idx, const float* dy, float* part,
                                                                       float* bpart, int S, int frames_per_block) {
-  __shared__ __attribute__((aligned(16))) unsigned short FB[C1WX_LDS / 2];   // FBd[4][84][4][24] bf16 = 64,512 B; 64 KB for the closing reduction
+  __shared__ __attribute__((aligned(16))) unsigned short FB[(4 * 84 * RSR > C1WX_LDS / 2 ? 4 * 84 * RSR : C1WX_LDS / 2)];   // FBd[4][84][4][RS] bf16; at least 64 KB for the closing reduction
   const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int s_lo = blockIdx.x * frames_per_block, s_hi = min(S, s_lo + frames_per_block);
   if (s_lo >= s_hi) return;
-  const int kb = ((li >> 3) * 4 + (li & 3)) * 24;   // tap (kh' = li >> 3, kw = li & 7): row kh', byte lane kw & 3; k-tile t adds (t >> 1) * 84 * 96 + (t & 1) * 384
+  const int kb = ((li >> 3) * 4 + (li & 3)) * RS;   // tap (kh' = li >> 3, kw = li & 7): row kh', byte lane kw & 3; k-tile t adds (t >> 1) * 84 * RSR + (t & 1) * 4 * RSR
   const uint32_t sh = (li & 4) ? 16u : 0u;          // kw >= 4: one element later
   f32x16 acc[8];
 #pragma unroll
@@ -771,29 +775,29 @@ __global__ __launch_bounds__(256, 2) void conv1_wgrad_exact_kernel(const uint8_t
     for (int i = 0; i < 7; ++i) {
       const int it = tid + 256 * i, cr = it / 5, k = it - cr * 5;
       if (it < 1680) {
-        unsigned short* dst = FB + cr * 96 + 4 * k;
+        unsigned short* dst = FB + cr * RSR + 4 * k;
         const uint32_t d0 = pq[i][0], d1 = pq[i][1], d2 = pq[i][2], d3 = pq[i][3];
         c1_u32x2 v;
         v[0] = c1_pack_hi16((float)(d0 & 255u), (float)(d1 & 255u)); v[1] = c1_pack_hi16((float)(d2 & 255u), (float)(d3 & 255u));
         *reinterpret_cast<c1_u32x2*>(dst) = v;
         v[0] = c1_pack_hi16((float)((d0 >> 8) & 255u), (float)((d1 >> 8) & 255u)); v[1] = c1_pack_hi16((float)((d2 >> 8) & 255u), (float)((d3 >> 8) & 255u));
-        *reinterpret_cast<c1_u32x2*>(dst + 24) = v;
+        *reinterpret_cast<c1_u32x2*>(dst + RS) = v;
         v[0] = c1_pack_hi16((float)((d0 >> 16) & 255u), (float)((d1 >> 16) & 255u)); v[1] = c1_pack_hi16((float)((d2 >> 16) & 255u), (float)((d3 >> 16) & 255u));
-        *reinterpret_cast<c1_u32x2*>(dst + 48) = v;
+        *reinterpret_cast<c1_u32x2*>(dst + 2 * RS) = v;
         v[0] = c1_pack_hi16((float)(d0 >> 24), (float)(d1 >> 24)); v[1] = c1_pack_hi16((float)(d2 >> 24), (float)(d3 >> 24));
-        *reinterpret_cast<c1_u32x2*>(dst + 72) = v;
+        *reinterpret_cast<c1_u32x2*>(dst + 3 * RS) = v;
       }
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int cr = tid + 256 * i;
       if (cr < 336) {
-        unsigned short* dst = FB + cr * 96 + 20;
+        unsigned short* dst = FB + cr * RSR + 20;
         const uint32_t d = p1[i];
         dst[0] = (unsigned short)(__float_as_uint((float)(d & 255u)) >> 16);
-        dst[24] = (unsigned short)(__float_as_uint((float)((d >> 8) & 255u)) >> 16);
-        dst[48] = (unsigned short)(__float_as_uint((float)((d >> 16) & 255u)) >> 16);
-        dst[72] = (unsigned short)(__float_as_uint((float)(d >> 24)) >> 16);
+        dst[RS] = (unsigned short)(__float_as_uint((float)((d >> 8) & 255u)) >> 16);
+        dst[2 * RS] = (unsigned short)(__float_as_uint((float)((d >> 16) & 255u)) >> 16);
+        dst[3 * RS] = (unsigned short)(__float_as_uint((float)(d >> 24)) >> 16);
       }
     }
     if (s + 1 < s_hi) load_frame(obs + (size_t)(idx ? idx[s + 1] : s + 1) * FR);   // lands while this frame is multiplied
@@ -816,7 +820,7 @@ __global__ __launch_bounds__(256, 2) void conv1_wgrad_exact_kernel(const uint8_t
     auto group = [&](float (&bc)[8], int grp) __attribute__((always_inline)) {
       int rp, blk;
       half_pos(grp, rp, blk);
-      const unsigned short* fl = FB + kb + rp * (8 * 96) + 4 * blk;
+      const unsigned short* fl = FB + kb + rp * (8 * RSR) + 4 * blk;
       c1_u32x4 b1, b2, b3;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -835,11 +839,11 @@ __global__ __launch_bounds__(256, 2) void conv1_wgrad_exact_kernel(const uint8_t
       auto gather = [&](int th, c1_u32x4 (&a)[2]) __attribute__((always_inline)) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-          const unsigned short* ft = fl + ((th + t) >> 1) * (84 * 96) + ((th + t) & 1) * 384;
+          const unsigned short* ft = fl + ((th + t) >> 1) * (84 * RSR) + ((th + t) & 1) * (4 * RSR);
 #pragma unroll
-          for (int r = 0; r < 2; ++r) {         // the half's two output rows: 4 image rows = 384 elements apart
-            const c1_u32x2 lo2 = *reinterpret_cast<const c1_u32x2*>(ft + r * 384);
-            const uint32_t hi1 = *reinterpret_cast<const uint32_t*>(ft + r * 384 + 4);
+          for (int r = 0; r < 2; ++r) {         // the half's two output rows: 4 image rows = 4 * RSR elements apart
+            const c1_u32x2 lo2 = *reinterpret_cast<const c1_u32x2*>(ft + r * 4 * RSR);
+            const uint32_t hi1 = *reinterpret_cast<const uint32_t*>(ft + r * 4 * RSR + 4);
             a[t][2 * r] = __builtin_amdgcn_alignbit(lo2[1], lo2[0], sh);
             a[t][2 * r + 1] = __builtin_amdgcn_alignbit(hi1, lo2[1], sh);
           }
