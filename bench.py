@@ -109,7 +109,8 @@ def cpu_baseline(n_envs=16, n_steps=32, updates=3, full_updates=3):
         oracle.set_threads(threads)
         stamps = []
         argv = ["--local-num-envs", str(n_envs), "--num-actor-threads", "1", "--num-steps", str(n_steps), "--env-backend", "host", "--network", "nature",
-                "--total-timesteps", str((updates + 1) * n_envs * n_steps), "--log-frequency", "100000", "--concurrency"]
+                "--total-timesteps", str((updates + 1) * n_envs * n_steps), "--log-frequency", "100000", "--concurrency",
+                "--conv1-fp32-chain", "3"]     # the CPU restatement of the fp32 fmaf chain — not the oracle's emulation of the bf16 matrix instruction, which is a checker's tool
         cwd = os.getcwd()
         os.chdir(os.environ.get("TMPDIR", "/tmp"))
         try:

@@ -74,6 +74,25 @@ def set_threads(n):
     lib().cbo_set_threads(int(n))
 
 
+def set_conv1_exact(on):
+    """conv1 of passes of more than 512 frames as the product's default computes it (cbm_config.conv1_fp32_chain bit 0 clear): exact uint8 x three-term-bf16
+    products summed by the measured rule of v_mfma_f32_32x32x16_bf16 (cbm_oracle.c: cbo_mfma_bf16_group8) instead of the k-ascending fmaf chain.  Global, like
+    set_threads; returns the previous setting."""
+    prev = bool(lib().cbo_get_conv1_exact())
+    lib().cbo_set_conv1_exact(int(bool(on)))
+    return prev
+
+
+def mfma_bf16_32x32x16(A, B, Cm):
+    """D = A[32,16] x B[16,32] + C[32,32] as ONE v_mfma_f32_32x32x16_bf16 computes it; A / B are bf16 bit patterns (uint16)."""
+    A = np.ascontiguousarray(A, np.uint16).reshape(32, 16)
+    B = np.ascontiguousarray(B, np.uint16).reshape(16, 32)
+    Cm = np.ascontiguousarray(Cm, np.float32).reshape(32, 32)
+    D = np.zeros((32, 32), np.float32)
+    lib().cbo_mfma_bf16_32x32x16(_p(A), _p(B), _p(Cm), _p(D))
+    return D
+
+
 # ---------------------------------------------------------------- PRNG
 def threefry2x32(key, ctr):
     out = np.zeros(2, np.uint32)

@@ -62,6 +62,9 @@ class OracleEngine:
         self.cfg = cfg
         assert int(getattr(cfg, "network", 0)) == 0, "OracleEngine restates the Nature-CNN trainer (the ResNet torso is checked per call: oracle.resnet_*)"
         self.ppo = cfg.algo == 0
+        # conv1 of learner-size passes the way the configuration asks for it: cbm_config.conv1_fp32_chain bit 0 clear (the default) = exact products summed by the
+        # measured rule of the bf16 matrix instruction (oracle.set_conv1_exact), set = the fmaf chain.  Process-wide, like oracle.set_threads.
+        oracle.set_conv1_exact((int(getattr(cfg, "conv1_fp32_chain", 3)) & 1) == 0)
         self.A, self.E, self.S = cfg.num_actions, cfg.local_num_envs, cfg.num_actor_slots
         self.T = cfg.num_steps
         self.asyncB = int(getattr(cfg, "async_batch_size", 0) or 0)
