@@ -44,3 +44,13 @@ def oracle():
     import oracle as o
     o.build()
     return o
+
+
+@pytest.fixture(autouse=True)
+def _oracle_conv1_chain_unless_a_test_asks(request):
+    """oracle.set_conv1_exact is process-wide (like set_threads) and tests/oracle_engine.py switches it to follow an engine's configuration: every test starts
+    from the fmaf chain again, so that a test which compares against the chain oracle never inherits another test's setting."""
+    o = sys.modules.get("oracle")
+    if o is not None and getattr(o, "_lib", None) is not None:
+        o.set_conv1_exact(False)
+    yield

@@ -4,7 +4,11 @@ Usage: python native_comm_worker.py <rank> <nranks> <port> <out.npz>"""
 import os
 import sys
 
+import faulthandler
+
 import numpy as np
+
+faulthandler.dump_traceback_later(int(os.environ.get("CBM_WORKER_WATCHDOG_S", "180")), exit=True)   # a stalled rank says WHERE it stalled, then gets out of the way
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
