@@ -195,10 +195,12 @@ def run_dp(a, world, rank, local_rank):
     cfg.local_num_envs, cfg.num_actor_slots, cfg.num_steps, cfg.num_actions = E, 1, T, A
     cfg.backward_split = a.bwd_split
     cfg.conv1_fp32_chain = a.conv1_fp32_chain
-    ctx = HipEngine(cfg)
+    # rendezvous (imports torch for the TCPStore) BEFORE the first HIP context of the process, like cleanba_amd.trainer: importing torch into a process whose
+    # HIP runtime is already live has stalled inside torch's extension load (tests/native_comm_worker.py, round 6)
     rdv = None
     if world > 1:
         rdv = topology.Rendezvous(world, rank, os.environ.get("MASTER_ADDR", "127.0.0.1"), os.environ.get("MASTER_PORT", "29500"))
+    ctx = HipEngine(cfg)
     if world > 1 or ctx.wants_comm_at_world_one():
         topology.setup_learner_comm(ctx, rdv, list(range(world)), rank)      # RCCL communicator over all ranks (pmap's device list, ppo:656-660)
     comm = ctx.comm_size() > 0

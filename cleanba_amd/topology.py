@@ -70,7 +70,8 @@ class Layout:
 class Rendezvous:
     """Host control plane of a multi-process run: torch's TCPStore (a C++ key-value server on rank 0; no process group, no GPU).  Carries
     the RCCL unique id, the IPC handles and the 'landed' notifications.  `get` polls so that a failed peer (which posts 'abort') or a
-    vanished server ends the wait instead of hanging it."""
+    vanished server ends the wait instead of hanging it.  Construct it BEFORE the process creates its first HIP context: the constructor imports torch, and
+    importing torch into a process whose HIP runtime is already live has been seen to stall inside torch's extension load (round 6, two rank processes)."""
 
     _base = {}   # (addr, port, world, rank) -> TCPStore: one connection (and, on rank 0, one server) per process, whatever the number of runs
     _runs = {}   # (store key, prefix) -> how many Rendezvous objects of this process used that prefix so far

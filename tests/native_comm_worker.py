@@ -17,10 +17,13 @@ rank, n, port, out = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.a
 import cleanba_amd.lib as L  # noqa: E402
 from cleanba_amd import topology  # noqa: E402
 
+# The rendezvous FIRST (it imports torch for the TCPStore), the HIP context after it — the trainer's order.  With the context first, both ranks of this test
+# were found stalled inside `import torch` (torch/__init__.py loading its extension module with the HIP runtime already live in the process) on three of
+# ten fresh boxes: the stack dumps of the watchdog above showed it (round 6).
+rdv = topology.Rendezvous(n, rank, "127.0.0.1", port, timeout_s=120.0)
 cfg = L.default_config(L.ALGO_PPO)
 cfg.local_num_envs, cfg.num_actor_slots, cfg.num_steps = 8, 1, 8
 ctx = L.Context(cfg)
-rdv = topology.Rendezvous(n, rank, "127.0.0.1", port, timeout_s=120.0)
 blob = ctx.comm_native_export()
 rdv.put(f"blob/{rank}", blob)
 ctx.comm_native_init([blob if r == rank else bytes(rdv.get(f"blob/{r}")) for r in range(n)], rank)

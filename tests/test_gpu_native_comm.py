@@ -46,10 +46,9 @@ def test_native_allreduce_is_the_rank_ordered_sum(tmp_path, n):
             ok = ok and p.returncode == 0
         return ok, logs
 
-    # Round 6: twice in eight runs the FIRST native-communicator use on a fresh box did not finish (both rank processes silent for ten minutes, nothing in
-    # their logs; the in-kernel 60 s flag timeout did not fire, so the stall is on the host side: rendezvous / IPC mapping / first code-object load — the
-    # workers now dump their Python stacks after 180 s and exit).  Root cause not found; the second attempt on the then-warm box has always passed.  One retry,
-    # reported loudly, so that this cold-start stall cannot stand in front of the parity result of the whole suite (pytest -x).
+    # Round 6: on three of ten fresh boxes the two rank processes of this test did not finish.  The workers' watchdog (stack dump after 180 s) showed both inside
+    # `import torch` — topology.Rendezvous importing torch for its TCPStore AFTER the worker had created its HIP context; the worker (and bench.py's run_dp) now
+    # build the rendezvous first, the trainer's order.  The retry stays as a net: a cold-start stall must not stand in front of the suite's parity result (pytest -x).
     ok, logs = attempt()
     if not ok:
         print("FIRST ATTEMPT of the native all-reduce rank processes failed; retrying once.  Logs of the first attempt:\n" + "\n=====\n".join(lg[-3000:] for lg in logs))
